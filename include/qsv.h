@@ -1,0 +1,155 @@
+/*
+ * libqsv -- MI355X (gfx950) statevector + Pauli-expectation backend for the QUEASARS circuit-evaluation path.
+ *
+ * C ABI.  Plain pointers and sizes only; no Python, torch or C++ types cross this boundary.
+ *
+ * The reference (DLR-RB/QUEASARS, pure Python) has no FFI for this path: its boundary is the Python protocol
+ *     BaseCircuitEvaluator.evaluate_circuits(circuits, parameter_values) -> list[float]   and   .n_qubits
+ *     (reference: queasars/circuit_evaluation/circuit_evaluation.py:62-87)
+ * whose implementations hand (circuit, operator, parameter values) "pubs" to a Qiskit primitive
+ *     OperatorCircuitEvaluator.evaluate_circuits        (circuit_evaluation.py:200-215, estimator branch)
+ *     OperatorSamplerCircuitEvaluator.evaluate_circuits (circuit_evaluation.py:147-157, sampler branch)
+ *     measure_quasi_distributions                       (circuit_evaluation.py:29-59)
+ * Each entry point below says which of those calls it replaces.  INTEGRATION.md shows the ctypes stub a
+ * QUEASARS maintainer would add.
+ *
+ * Conventions
+ *   - little endian qubits: qubit q is bit q of a basis-state index (reference: queasars/utility/pauli_strings.py:38-40)
+ *   - a Pauli term is (x_mask, z_mask, coeff): factor on qubit q is I/X/Z/Y for (x,z) bit pair 00/10/01/11
+ *   - gates: id, u(theta,phi,lam) and cu3(theta,phi,lam) with Qiskit's matrix definitions
+ *     (reference: queasars/minimum_eigensolvers/evqe/quantum_circuit/quantum_gate.py:78-79, :96-102, :157-165)
+ *   - every function returns 0 on success, a negative QSV_E_* code otherwise; qsv_last_error() gives text
+ *   - the caller owns every host array it passes in or receives results in; the library owns all device memory
+ *   - a handle may be used from several host threads; calls on one handle are serialised internally
+ */
+#ifndef QSV_H
+#define QSV_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct qsv_handle qsv_t;
+
+enum { QSV_OP_ID = 0, QSV_OP_U = 1, QSV_OP_CU3 = 2 };
+enum { QSV_F64 = 0, QSV_F32 = 1 };
+enum { QSV_NO_CONTROL = 0xFF };
+
+enum {
+    QSV_OK = 0,
+    QSV_E_ARG = -1,      /* bad argument */
+    QSV_E_DEVICE = -2,   /* HIP runtime error (no device, out of memory, launch failure) */
+    QSV_E_STATE = -3,    /* call order (e.g. expectation requested before an operator was set) */
+    QSV_E_UNSUPPORTED = -4
+};
+
+/* One decomposed circuit instruction.  An angle is params[p_x] when p_x >= 0, else the literal. 40 bytes. */
+typedef struct qsv_op {
+    uint8_t kind;    /* QSV_OP_* */
+    uint8_t target;  /* qubit the 2x2 matrix acts on */
+    uint8_t control; /* control qubit for cu3, QSV_NO_CONTROL otherwise */
+    uint8_t flags;   /* reserved, 0 */
+    int32_t p_theta, p_phi, p_lambda;
+    double theta, phi, lambda;
+} qsv_op;
+
+/* Tuning knobs of the pass scheduler (0 = library default). */
+typedef struct qsv_plan_config {
+    int32_t tile_bits; /* k: qubits resident on chip per pass (per workgroup tile of 2^k amplitudes) */
+    int32_t reg_bits;  /* r: qubits held in each thread's registers at a time (2^r amplitudes per thread) */
+    int32_t low_bits;  /* c: lowest qubits always kept in the tile so global accesses stay coalesced */
+    int32_t group;     /* circuits evaluated per launch group (0 = size the group to the Infinity Cache) */
+} qsv_plan_config;
+
+/* Counters of the most recent qsv_eval_* call (timings need qsv_set_profiling(h, 1)). */
+typedef struct qsv_profile {
+    uint64_t n_evals;          /* circuit evaluations in the call */
+    uint64_t n_pass_launches;  /* launches of the gate-pass kernel */
+    uint64_t n_state_passes;   /* sum over launches of states swept (launch x circuits in its group) */
+    uint64_t n_gates;          /* non-identity gates applied */
+    double pass_ms;            /* device time of all gate-pass launches (HIP events on the library's stream) */
+    double expect_ms;          /* device time of expectation / reduction kernels */
+    double total_ms;           /* device time of the whole call, first launch to last */
+} qsv_profile;
+
+/* ---- lifetime ---------------------------------------------------------------------------------- */
+
+/* Create an evaluator for n_qubits on HIP device `device`.  Replaces constructing a Qiskit primitive. */
+int qsv_create(int n_qubits, int dtype, int device, const qsv_plan_config* cfg /* may be NULL */, qsv_t** out);
+void qsv_destroy(qsv_t* h);
+/* Text of the last error on this handle (or of the last failed qsv_create when h is NULL). */
+const char* qsv_last_error(const qsv_t* h);
+/* Launch on an existing HIP stream (hipStream_t passed as void*); NULL = the library's own stream. */
+int qsv_set_stream(qsv_t* h, void* hip_stream);
+int qsv_n_qubits(const qsv_t* h);
+
+/* ---- operator ---------------------------------------------------------------------------------- */
+
+/*
+ * Set the observable H = sum_k (coeff_re[k] + i coeff_im[k]) P_k.
+ * Replaces passing `operator` in each pub (circuit_evaluation.py:204-208).  An operator whose terms are all
+ * I/Z takes the diagonal fast path (one table D[i] = sum_k c_k (-1)^popcount(i & z_k) built once on device).
+ */
+int qsv_set_operator(qsv_t* h, int n_terms, const uint64_t* x_mask, const uint64_t* z_mask,
+                     const double* coeff_re, const double* coeff_im);
+
+/* ---- circuits ---------------------------------------------------------------------------------- */
+
+/* Register a circuit structure once; evaluations then send only parameter values. */
+int qsv_circuit_create(qsv_t* h, int n_ops, const qsv_op* ops, int n_params, int* out_circuit_id);
+int qsv_circuit_destroy(qsv_t* h, int circuit_id);
+
+/*
+ * Expectation values real(<psi_i|H|psi_i>) of n_evals (circuit, parameter vector) pairs, |psi_i> prepared from
+ * |0..0>.  params holds the vectors back to back, vector i at params[param_offsets[i] .. param_offsets[i+1]).
+ * Replaces `estimator.run(pubs, precision=0).result()` + `real(res.data.evs)` (circuit_evaluation.py:210-215).
+ */
+int qsv_eval_circuits(qsv_t* h, int n_evals, const int* circuit_ids, const int64_t* param_offsets,
+                      const double* params, double* out_expectations);
+
+/* Same, with the op lists passed inline (circuit i = ops[op_offsets[i] .. op_offsets[i+1])). */
+int qsv_eval_batch(qsv_t* h, int n_evals, const int64_t* op_offsets, const qsv_op* ops,
+                   const int64_t* param_offsets, const double* params, double* out_expectations);
+
+/* Final state of one circuit as interleaved (re, im) doubles, 2 * 2^n values (debug / parity checks). */
+int qsv_statevector(qsv_t* h, int circuit_id, const double* params, int n_params, double* out_re_im);
+
+/* |amplitude|^2 of every basis state, 2^n doubles.  Exact counterpart of the sampler's distribution. */
+int qsv_probabilities(qsv_t* h, int circuit_id, const double* params, int n_params, double* out_probs);
+
+/*
+ * Draw `shots` basis states from the circuit's output distribution on the device (seeded inverse-CDF sampling).
+ * Replaces `sampler.run(pubs, shots)` + `get_counts()` in measure_quasi_distributions (circuit_evaluation.py:50-59).
+ */
+int qsv_sample(qsv_t* h, int circuit_id, const double* params, int n_params, int shots, uint64_t seed,
+               uint64_t* out_states);
+
+/* ---- measurement support ----------------------------------------------------------------------- */
+
+int qsv_set_profiling(qsv_t* h, int enabled);
+int qsv_get_profile(const qsv_t* h, qsv_profile* out);
+
+/*
+ * Roofline microbenchmark: apply one u (control < 0) or cu3 gate with the given angles
+ * to the resident 2^n state `reps` times and report the average device time per sweep in milliseconds.
+ */
+int qsv_bench_gate(qsv_t* h, int target, int control, double theta, double phi, double lambda, int reps,
+                   double* out_ms_per_sweep);
+
+/*
+ * Build (without touching any device) the pass plan the scheduler produces for a circuit and copy its encoded
+ * words out; *n_words receives the size needed.  Used by the CPU-side tests to check the scheduler.
+ */
+int qsv_plan_build(int n_qubits, int dtype, int n_ops, const qsv_op* ops, const qsv_plan_config* cfg,
+                   uint32_t* out_words, size_t capacity_words, size_t* n_words);
+
+/* Library version string. */
+const char* qsv_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QSV_H */

@@ -1,0 +1,72 @@
+"""Builds libqsv.so (HIP kernels + C ABI) in-tree with hipcc for gfx950.
+
+The shared object is written next to this file so that it travels with the repository snapshot to the
+GPU box; it is git-ignored.  There is no CPU fallback: if the build or the load fails the package raises.
+"""
+
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+from pathlib import Path
+
+PKG_DIR = Path(__file__).resolve().parent
+CSRC = PKG_DIR / "csrc"
+LIB_PATH = PKG_DIR / "libqsv.so"
+SOURCES = ["kernels.hip", "qsv_api.hip", "plan.cpp"]
+HEADERS = ["kernels.hpp", "plan.hpp", "../../include/qsv.h"]
+ARCH = "gfx950"
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and Path(cand).exists():
+            return cand
+    raise RuntimeError("hipcc not found; libqsv cannot be built")
+
+
+def needs_build() -> bool:
+    if not LIB_PATH.exists():
+        return True
+    built = LIB_PATH.stat().st_mtime
+    return any((CSRC / f).resolve().stat().st_mtime > built for f in SOURCES + HEADERS)
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    """Compile every HIP source for gfx950 into queasars_amd/libqsv.so and return its path."""
+    if not force and not needs_build():
+        return LIB_PATH
+    obj_dir = PKG_DIR / "build"
+    obj_dir.mkdir(exist_ok=True)
+    hipcc = _hipcc()
+    common = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+    procs = []
+    objs = []
+    for src in SOURCES:
+        obj = obj_dir / (src + ".o")
+        objs.append(str(obj))
+        cmd = [hipcc, *common, "-c", str(CSRC / src), "-o", str(obj)]
+        if src.endswith(".cpp"):
+            cmd.insert(1, "-x")
+            cmd.insert(2, "hip")
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for src, proc in procs:
+        out, _ = proc.communicate()
+        if proc.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{out}")
+        if verbose and out.strip():
+            print(out)
+    tmp = LIB_PATH.with_suffix(".so.tmp")
+    link = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(tmp), *objs]
+    res = subprocess.run(link, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if res.returncode != 0:
+        raise RuntimeError(f"link failed:\n{res.stdout}")
+    os.replace(tmp, LIB_PATH)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

@@ -1,0 +1,62 @@
+// Device-side data structures and kernel launch wrappers shared between kernels.hip and qsv_api.cpp.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace qsv {
+
+// One evaluation (circuit + parameter vector) inside a launch group.
+struct EvalDesc {
+    uint32_t plan_base;   // word offset of the circuit plan in the plan arena
+    uint32_t mat_base;    // offset (in doubles) of this evaluation's gate matrices in the matrix buffer
+    uint32_t state_slot;  // which resident state buffer the evaluation uses
+    uint32_t out_index;   // row of `partials` / entry of the result vector
+};
+
+enum PassMode : uint32_t {
+    kModeSynthFirst = 1u,  // pass 0 synthesises |0..0> instead of reading the state
+    kModeFinalStore = 2u,  // the last pass writes the state back
+    kModeFinalDiag = 4u,   // the last pass reduces sum_i |a_i|^2 D[i] into `partials`
+};
+
+struct PassArgs {
+    const uint32_t* plan;  // plan arena
+    const double* mats;    // 8 doubles per gate: m00 m01 m10 m11 as (re, im)
+    const EvalDesc* evals; // blockIdx.y indexes this array
+    void* states;          // slot s starts at s * state_stride amplitudes
+    const double* diag;    // D[i] for the diagonal fast path (may be null)
+    double* partials;      // [out_index][blocks_per_state]
+    uint64_t state_stride;
+    uint32_t pass_index;
+    uint32_t mode;
+    uint32_t blocks_per_state;
+};
+
+// dtype: 0 = fp64, 1 = fp32.  r = register bits (1..5).  Returns hipSuccess or the launch error.
+hipError_t launch_pass(int dtype, int r, dim3 grid, int threads, size_t lds_bytes, hipStream_t stream,
+                       const PassArgs& args);
+hipError_t configure_pass_kernels(int dtype, int r, size_t lds_bytes);
+
+hipError_t launch_diag_table(int n_qubits, int n_terms, const uint64_t* z_mask, const double* coeff, double* table,
+                             hipStream_t stream);
+
+// out[e] = sum_b partials[e * blocks + b]   (fixed-order tree: bitwise reproducible)
+hipError_t launch_reduce_partials(const double* partials, uint32_t blocks, int n_evals, double* out,
+                                  hipStream_t stream);
+
+// General Pauli terms.  term_partials[((slot * n_terms) + term) * nb + block] = (re, im) of
+// sum_{i in block's share} conj(a_i) a_{i^x} (-1)^{popcount((i^x) & z)}.
+hipError_t launch_pauli_terms(int dtype, const void* states, uint64_t state_stride, int n_qubits, int n_slots,
+                              int n_terms, const uint64_t* x_mask, const uint64_t* z_mask, int nb,
+                              double* term_partials, hipStream_t stream);
+// out[out_index[slot]] = real( sum_k coeff_k i^{ny_k} sum_b term_partials[slot][k][b] )
+hipError_t launch_pauli_combine(const double* term_partials, int n_slots, int n_terms, int nb, const uint64_t* x_mask,
+                                const uint64_t* z_mask, const double* coeff_re, const double* coeff_im,
+                                const EvalDesc* evals, double* out, hipStream_t stream);
+
+hipError_t launch_probabilities(int dtype, const void* state, uint64_t dim, double* probs, hipStream_t stream);
+hipError_t launch_state_to_f64(int dtype, const void* state, uint64_t dim, double* out_re_im, hipStream_t stream);
+
+}  // namespace qsv

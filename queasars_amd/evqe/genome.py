@@ -1,0 +1,379 @@
+"""EVQE genome -> plain-data circuits: the input side of the hot path and its workload generator.
+
+This is a restatement, written from the behaviour of the reference, of just enough of the genome to
+(i) generate the same random populations the reference generates for a seed and (ii) lower an individual
+to the ``id / u / cu3`` op list the simulator consumes.  Reference behaviour followed:
+
+* gate kinds and what each one lowers to:
+  queasars/minimum_eigensolvers/evqe/quantum_circuit/quantum_gate.py:12-20, :78-79, :96-102, :125-126, :157-165
+* random layer construction (which RNG calls happen, in which order):
+  queasars/minimum_eigensolvers/evqe/quantum_circuit/circuit_layer.py:37-125; validity :157-189
+* individuals / populations and their seeding chain:
+  queasars/minimum_eigensolvers/evqe/evolutionary_algorithm/individual.py:34-65, :239-250, :288-322
+  queasars/minimum_eigensolvers/evqe/evolutionary_algorithm/population.py:32-77
+  queasars/utility/random.py:15
+* parameter naming ``layer{L}_q{Q}_{theta|phi|lambda}`` (quantum_gate.py:98-100, circuit_layer.py:201) and
+  the fact that Qiskit binds a flat value list in *name-sorted* parameter order, both for a bound layer
+  (circuit_layer.py:233-235, ``assign_parameters`` with a sequence) and for the evaluated circuit
+  (circuit_evaluation.py:204-208).  :func:`sorted_parameter_rank` reproduces that order, so the
+  :class:`~queasars_amd.ir.CircuitIR` this module emits carries explicit indices.
+
+Random-number consumption matches the reference call for call because the same ``random.Random`` methods
+are invoked on same-sized sequences in the same order.
+"""
+
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from enum import Enum
+from random import Random
+from typing import Iterable, Optional, Sequence
+
+from queasars_amd.ir import CircuitIR, ParamRef
+
+_ANGLE_NAMES = ("theta", "phi", "lambda")
+
+
+def new_random_seed(random_generator: Random) -> int:
+    """Seed chaining helper (reference: queasars/utility/random.py:15)."""
+    return random_generator.randint(0, 2147483647)
+
+
+class EVQEGateType(Enum):
+    IDENTITY = 0
+    ROTATION = 1
+    CONTROL = 2
+    CONTROLLED_ROTATION = 3
+
+
+@dataclass(frozen=True)
+class EVQEGate:
+    """One genome slot.  ``partner_index`` is the controlled qubit for CONTROL, the control qubit for
+    CONTROLLED_ROTATION, and -1 otherwise."""
+
+    kind: EVQEGateType
+    qubit_index: int
+    partner_index: int = -1
+
+    def gate_type(self) -> EVQEGateType:
+        return self.kind
+
+    def n_parameters(self) -> int:
+        return 3 if self.kind in (EVQEGateType.ROTATION, EVQEGateType.CONTROLLED_ROTATION) else 0
+
+    # reference-style accessors
+    @property
+    def control_qubit_index(self) -> int:
+        if self.kind is not EVQEGateType.CONTROLLED_ROTATION:
+            raise AttributeError("only controlled rotations have a control qubit")
+        return self.partner_index
+
+    @property
+    def controlled_qubit_index(self) -> int:
+        if self.kind is not EVQEGateType.CONTROL:
+            raise AttributeError("only control markers have a controlled qubit")
+        return self.partner_index
+
+
+def IdentityGate(qubit_index: int) -> EVQEGate:
+    return EVQEGate(EVQEGateType.IDENTITY, qubit_index)
+
+
+def RotationGate(qubit_index: int) -> EVQEGate:
+    return EVQEGate(EVQEGateType.ROTATION, qubit_index)
+
+
+def ControlGate(qubit_index: int, controlled_qubit_index: int) -> EVQEGate:
+    return EVQEGate(EVQEGateType.CONTROL, qubit_index, controlled_qubit_index)
+
+
+def ControlledRotationGate(qubit_index: int, control_qubit_index: int) -> EVQEGate:
+    return EVQEGate(EVQEGateType.CONTROLLED_ROTATION, qubit_index, control_qubit_index)
+
+
+class EVQECircuitLayerException(Exception):
+    pass
+
+
+class EVQEIndividualException(Exception):
+    pass
+
+
+def parameter_names(layer_id: int, gates: Sequence[EVQEGate]) -> list[str]:
+    """Names in genome order: gate by gate (qubit order), theta, phi, lambda."""
+    names = []
+    for gate in gates:
+        if gate.n_parameters():
+            names.extend(f"layer{layer_id}_q{gate.qubit_index}_{a}" for a in _ANGLE_NAMES)
+    return names
+
+
+def sorted_parameter_rank(names: Iterable[str]) -> dict[str, int]:
+    """name -> position in Qiskit's ``circuit.parameters`` (plain string sort of the names)."""
+    return {name: rank for rank, name in enumerate(sorted(names))}
+
+
+@dataclass(frozen=True)
+class EVQECircuitLayer:
+    n_qubits: int
+    gates: tuple[EVQEGate, ...]
+
+    def __post_init__(self) -> None:
+        if not self.is_valid():
+            raise EVQECircuitLayerException("The created layer is invalid!")
+
+    @property
+    def n_parameters(self) -> int:
+        return sum(g.n_parameters() for g in self.gates)
+
+    @property
+    def n_controlled_gates(self) -> int:
+        return sum(1 for g in self.gates if g.kind is EVQEGateType.CONTROLLED_ROTATION)
+
+    def is_valid(self) -> bool:
+        if len(self.gates) != self.n_qubits:
+            return False
+        for position, gate in enumerate(self.gates):
+            if gate.qubit_index != position:
+                return False
+            if gate.kind in (EVQEGateType.CONTROL, EVQEGateType.CONTROLLED_ROTATION):
+                if not 0 <= gate.partner_index < self.n_qubits:
+                    return False
+                other = self.gates[gate.partner_index]
+                wanted = (
+                    EVQEGateType.CONTROL if gate.kind is EVQEGateType.CONTROLLED_ROTATION else EVQEGateType.CONTROLLED_ROTATION
+                )
+                if other.kind is not wanted or other.partner_index != position:
+                    return False
+        return True
+
+    @staticmethod
+    def random_layer(
+        n_qubits: int, previous_layer: Optional["EVQECircuitLayer"] = None, random_seed: Optional[int] = None
+    ) -> "EVQECircuitLayer":
+        if n_qubits < 1:
+            raise EVQECircuitLayerException("A circuit layer may not have fewer than one qubit!")
+        if previous_layer is not None and previous_layer.n_qubits != n_qubits:
+            raise EVQECircuitLayerException(
+                f"The previous_layer has {previous_layer.n_qubits} qubits which differs from the {n_qubits} "
+                + "for the layer which shall be randomly generated! The amount of qubits for both layers must match!"
+            )
+        rng = Random(random_seed)
+        slots: list[EVQEGate] = [IdentityGate(q) for q in range(n_qubits)]
+        to_pair: list[int] = []
+        free_kinds = [EVQEGateType.ROTATION, EVQEGateType.CONTROLLED_ROTATION]
+        for q in range(n_qubits):
+            forced = previous_layer is not None and previous_layer.gates[q].kind in (
+                EVQEGateType.ROTATION,
+                EVQEGateType.IDENTITY,
+            )
+            if forced:
+                # a single-qubit gate directly after a single-qubit gate adds no expressivity: no RNG draw
+                to_pair.append(q)
+            elif rng.choice(free_kinds) is EVQEGateType.CONTROLLED_ROTATION:
+                to_pair.append(q)
+            else:
+                slots[q] = RotationGate(q)
+        while len(to_pair) >= 2:
+            target, control = rng.sample(to_pair, 2)
+            candidate = ControlledRotationGate(target, control)
+            marker = ControlGate(control, target)
+            if previous_layer is None or (candidate not in previous_layer.gates and marker not in previous_layer.gates):
+                slots[target], slots[control] = candidate, marker
+                to_pair.remove(target)
+                to_pair.remove(control)
+        if len(to_pair) == 1:
+            q = to_pair[0]
+            repeats_rotation = previous_layer is not None and previous_layer.gates[q].kind is EVQEGateType.ROTATION
+            slots[q] = IdentityGate(q) if repeats_rotation else RotationGate(q)
+        return EVQECircuitLayer(n_qubits=n_qubits, gates=tuple(slots))
+
+    def lower(self, circuit: CircuitIR, layer_id: int, angle_of: dict[str, object]) -> None:
+        """Append this layer's ops; ``angle_of`` maps a parameter name to a float or a ParamRef."""
+        prefix = f"layer{layer_id}_"
+        for gate in self.gates:
+            q = gate.qubit_index
+            if gate.kind is EVQEGateType.IDENTITY:
+                circuit.id(q)
+            elif gate.kind is EVQEGateType.ROTATION:
+                circuit.u(angle_of[f"{prefix}q{q}_theta"], angle_of[f"{prefix}q{q}_phi"], angle_of[f"{prefix}q{q}_lambda"], q)
+            elif gate.kind is EVQEGateType.CONTROLLED_ROTATION:
+                circuit.cu3(
+                    angle_of[f"{prefix}q{q}_theta"],
+                    angle_of[f"{prefix}q{q}_phi"],
+                    angle_of[f"{prefix}q{q}_lambda"],
+                    gate.partner_index,
+                    q,
+                )
+            # CONTROL markers emit nothing (quantum_gate.py:125-126)
+
+
+@dataclass(frozen=True)
+class EVQEIndividual:
+    n_qubits: int
+    layers: tuple[EVQECircuitLayer, ...]
+    parameter_values: tuple[float, ...]
+
+    def __post_init__(self) -> None:
+        if not self.is_valid():
+            raise EVQEIndividualException("The created individual is not valid!")
+
+    def is_valid(self) -> bool:
+        if len(self.layers) == 0:
+            return False
+        if any((not layer.is_valid()) or layer.n_qubits != self.n_qubits for layer in self.layers):
+            return False
+        return len(self.parameter_values) == sum(layer.n_parameters for layer in self.layers)
+
+    @property
+    def layer_parameter_indices(self) -> dict[int, tuple[int, ...]]:
+        out, start = {}, 0
+        for i, layer in enumerate(self.layers):
+            out[i] = tuple(range(start, start + layer.n_parameters))
+            start += layer.n_parameters
+        return out
+
+    @staticmethod
+    def random_individual(
+        n_qubits: int, n_layers: int, randomize_parameter_values: bool, random_seed: Optional[int] = None
+    ) -> "EVQEIndividual":
+        rng = Random(random_seed)
+        layers: list[EVQECircuitLayer] = []
+        for _ in range(n_layers):
+            layers.append(
+                EVQECircuitLayer.random_layer(
+                    n_qubits=n_qubits,
+                    previous_layer=layers[-1] if layers else None,
+                    random_seed=new_random_seed(rng),
+                )
+            )
+        n_parameters = sum(layer.n_parameters for layer in layers)
+        if randomize_parameter_values:
+            values = tuple(2 * math.pi * rng.random() for _ in range(n_parameters))
+        else:
+            values = (0,) * n_parameters
+        return EVQEIndividual(n_qubits=n_qubits, layers=tuple(layers), parameter_values=values)
+
+    @staticmethod
+    def change_parameter_values(individual: "EVQEIndividual", parameter_values: tuple[float, ...]) -> "EVQEIndividual":
+        if len(parameter_values) != len(individual.parameter_values):
+            raise EVQEIndividualException("The number of parameter values given does not match the individual!")
+        return EVQEIndividual(individual.n_qubits, individual.layers, tuple(parameter_values))
+
+    @staticmethod
+    def change_layer_parameter_values(
+        individual: "EVQEIndividual", layer_id: int, parameter_values: tuple[float, ...]
+    ) -> "EVQEIndividual":
+        layer_id %= len(individual.layers)
+        indices = individual.layer_parameter_indices[layer_id]
+        if len(parameter_values) != len(indices):
+            raise EVQEIndividualException(
+                "The amount of given parameter_values does not match the amount needed by the circuit layer!"
+            )
+        values = list(individual.parameter_values)
+        for i, v in zip(indices, parameter_values):
+            values[i] = v
+        return EVQEIndividual(individual.n_qubits, individual.layers, tuple(values))
+
+    @staticmethod
+    def add_random_layers(
+        individual: "EVQEIndividual", n_layers: int, randomize_parameter_values: bool, random_seed: Optional[int] = None
+    ) -> "EVQEIndividual":
+        if n_layers < 1:
+            raise EVQEIndividualException("n_layers must be at least 1!")
+        rng = Random(random_seed)
+        new_layers = [
+            # every appended layer is drawn against the individual's current last layer (individual.py:161-167)
+            EVQECircuitLayer.random_layer(
+                n_qubits=individual.n_qubits, random_seed=new_random_seed(rng), previous_layer=individual.layers[-1]
+            )
+            for _ in range(n_layers)
+        ]
+        n_new = sum(layer.n_parameters for layer in new_layers)
+        new_values = tuple(2 * math.pi * rng.random() for _ in range(n_new)) if randomize_parameter_values else (0,) * n_new
+        return EVQEIndividual(
+            individual.n_qubits, (*individual.layers, *new_layers), (*individual.parameter_values, *new_values)
+        )
+
+    @staticmethod
+    def remove_layers(individual: "EVQEIndividual", n_layers: int) -> "EVQEIndividual":
+        if not 0 < n_layers:
+            raise EVQEIndividualException("n_layers must be at least 1!")
+        if not n_layers < len(individual.layers):
+            raise EVQEIndividualException(
+                "Removed too many layers (one layer must remain)! Choose a smaller n_layer value"
+            )
+        keep = len(individual.layers) - n_layers
+        n_values = sum(layer.n_parameters for layer in individual.layers[:keep])
+        return EVQEIndividual(individual.n_qubits, individual.layers[:keep], individual.parameter_values[:n_values])
+
+    @staticmethod
+    def get_genetic_distance(individual_1: "EVQEIndividual", individual_2: "EVQEIndividual") -> int:
+        l1, l2 = len(individual_1.layers), len(individual_2.layers)
+        shared = sum(1 for a, b in zip(individual_1.layers, individual_2.layers) if a == b)
+        return math.ceil(0.5 * (l1 + l2)) - shared
+
+    def get_parameter_values(self) -> tuple[float, ...]:
+        return self.parameter_values
+
+    def get_layer_parameter_values(self, layer_id: int) -> tuple[float, ...]:
+        layer_id %= len(self.layers)
+        return tuple(self.parameter_values[i] for i in self.layer_parameter_indices[layer_id])
+
+    def get_n_controlled_gates(self) -> int:
+        return sum(layer.n_controlled_gates for layer in self.layers)
+
+    def get_parameterized_quantum_circuit(self) -> CircuitIR:
+        return self.get_partially_parameterized_quantum_circuit(set(range(len(self.layers))))
+
+    def get_partially_parameterized_quantum_circuit(self, parameterized_layers: set[int]) -> CircuitIR:
+        """Lower to ops.  Layers in ``parameterized_layers`` keep free parameters (indices follow the
+        name-sorted order over all free parameters); every other layer is bound to this individual's
+        values, the k-th value going to that layer's k-th *name-sorted* parameter, exactly as
+        ``assign_parameters`` with a sequence does in the reference (circuit_layer.py:233-235)."""
+        chosen = {layer_id % len(self.layers) for layer_id in parameterized_layers}
+        free_names: list[str] = []
+        for i in sorted(chosen):
+            free_names.extend(parameter_names(i, self.layers[i].gates))
+        free_rank = sorted_parameter_rank(free_names)
+        circuit = CircuitIR(self.n_qubits)
+        for i, layer in enumerate(self.layers):
+            names = parameter_names(i, layer.gates)
+            if i in chosen:
+                angle_of = {name: ParamRef(free_rank[name]) for name in names}
+            else:
+                values = self.get_layer_parameter_values(i)
+                rank = sorted_parameter_rank(names)
+                angle_of = {name: float(values[rank[name]]) for name in names}
+            layer.lower(circuit, i, angle_of)
+        return circuit
+
+
+@dataclass
+class EVQEPopulation:
+    individuals: tuple[EVQEIndividual, ...]
+    species_representatives: Optional[list[EVQEIndividual]] = None
+    species_members: Optional[dict[EVQEIndividual, list[int]]] = None
+    species_membership: Optional[dict[int, EVQEIndividual]] = None
+
+    @staticmethod
+    def random_population(
+        n_qubits: int,
+        n_layers: int,
+        n_individuals: int,
+        randomize_parameter_values: bool,
+        random_seed: Optional[int] = None,
+    ) -> "EVQEPopulation":
+        rng = Random(random_seed)
+        return EVQEPopulation(
+            individuals=tuple(
+                EVQEIndividual.random_individual(
+                    n_qubits=n_qubits,
+                    n_layers=n_layers,
+                    randomize_parameter_values=randomize_parameter_values,
+                    random_seed=new_random_seed(rng),
+                )
+                for _ in range(n_individuals)
+            )
+        )

@@ -1,0 +1,140 @@
+"""Shared test helpers: workload construction and access to the oracles (tests only)."""
+
+from __future__ import annotations
+
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+from oracle import statevector_oracle as so
+from queasars_amd.evqe import EVQEPopulation
+from queasars_amd.ir import CircuitIR, PauliOperator
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def random_pauli_operator(n_qubits: int, n_terms: int, seed: int, alphabet: str = "IXYZ") -> PauliOperator:
+    """T distinct random Pauli strings (no all-identity string), coefficients uniform(-1, 1)."""
+    rng = np.random.default_rng(seed)
+    labels: list[str] = []
+    seen = set()
+    while len(labels) < n_terms:
+        label = "".join(rng.choice(list(alphabet), size=n_qubits))
+        if set(label) == {"I"} or label in seen:
+            if 4**n_qubits - 1 <= len(seen):
+                break
+            continue
+        seen.add(label)
+        labels.append(label)
+    coeffs = rng.uniform(-1.0, 1.0, size=len(labels))
+    return PauliOperator(labels, coeffs)
+
+
+def random_ising_operator(n_qubits: int, seed: int) -> PauliOperator:
+    """H = sum_{i<j} J_ij Z_i Z_j + sum_i h_i Z_i, J, h ~ N(0, 1)."""
+    rng = np.random.default_rng(seed)
+    terms = []
+    for i in range(n_qubits):
+        for j in range(i + 1, n_qubits):
+            terms.append(("ZZ", [i, j], float(rng.normal())))
+    for i in range(n_qubits):
+        terms.append(("Z", [i], float(rng.normal())))
+    return PauliOperator.from_sparse_list(terms, n_qubits)
+
+
+def population_circuits(n_qubits: int, n_layers: int, n_individuals: int, seed: int, randomize: bool = True):
+    pop = EVQEPopulation.random_population(n_qubits, n_layers, n_individuals, randomize, seed)
+    circuits = [ind.get_parameterized_quantum_circuit() for ind in pop.individuals]
+    params = [list(ind.parameter_values) for ind in pop.individuals]
+    return pop, circuits, params
+
+
+def oracle_state(circuit: CircuitIR, params) -> np.ndarray:
+    return so.simulate(circuit.n_qubits, circuit.bound_ops(params))
+
+
+def oracle_expectation(circuit: CircuitIR, params, operator: PauliOperator) -> float:
+    state = oracle_state(circuit, params)
+    return so.pauli_expectation(state, operator.x_mask.tolist(), operator.z_mask.tolist(), operator.coeffs.tolist()).real
+
+
+def inverse_circuit(circuit: CircuitIR, params) -> CircuitIR:
+    """Bound circuit that undoes ``circuit``: gates reversed, u(t,p,l)^-1 = u(-t,-l,-p)."""
+    inv = CircuitIR(circuit.n_qubits)
+    for kind, target, control, theta, phi, lam in reversed(circuit.bound_ops(params)):
+        if kind == 0:
+            inv.id(target)
+        elif kind == 1:
+            inv.u(-theta, -lam, -phi, target)
+        else:
+            inv.cu3(-theta, -lam, -phi, control, target)
+    return inv
+
+
+def bound_copy(circuit: CircuitIR, params) -> CircuitIR:
+    out = CircuitIR(circuit.n_qubits)
+    for kind, target, control, theta, phi, lam in circuit.bound_ops(params):
+        if kind == 0:
+            out.id(target)
+        elif kind == 1:
+            out.u(theta, phi, lam, target)
+        else:
+            out.cu3(theta, phi, lam, control, target)
+    return out
+
+
+class COracle:
+    def __init__(self, lib):
+        self.lib = lib
+        lib.qsvo_simulate.restype = C.c_int
+        lib.qsvo_evaluate.restype = C.c_double
+        lib.qsvo_diagonal_expectation_table.restype = C.c_double
+        lib.qsvo_max_threads.restype = C.c_int
+
+    @staticmethod
+    def _arrays(circuit: CircuitIR, params):
+        ops = circuit.bound_ops(params)
+        kinds = np.asarray([o[0] for o in ops], dtype=np.int32)
+        targets = np.asarray([o[1] for o in ops], dtype=np.int32)
+        controls = np.asarray([o[2] for o in ops], dtype=np.int32)
+        angles = np.asarray([[o[3], o[4], o[5]] for o in ops], dtype=np.float64).reshape(-1)
+        return kinds, targets, controls, angles
+
+    def simulate(self, circuit: CircuitIR, params) -> np.ndarray:
+        kinds, targets, controls, angles = self._arrays(circuit, params)
+        state = np.zeros(2 << circuit.n_qubits, dtype=np.float64)
+        rc = self.lib.qsvo_simulate(
+            circuit.n_qubits, len(kinds), kinds.ctypes, targets.ctypes, controls.ctypes, angles.ctypes, state.ctypes, 1
+        )
+        assert rc == 0, rc
+        return state.view(np.complex128)
+
+    def diagonal_table(self, operator: PauliOperator) -> np.ndarray:
+        table = np.zeros(1 << operator.num_qubits, dtype=np.float64)
+        z = np.ascontiguousarray(operator.z_mask)
+        c = np.ascontiguousarray(operator.coeffs.real)
+        self.lib.qsvo_diagonal_table(operator.num_qubits, len(operator), z.ctypes, c.ctypes, table.ctypes)
+        return table
+
+    def evaluate(self, circuit: CircuitIR, params, operator: PauliOperator, table=None, scratch=None) -> float:
+        kinds, targets, controls, angles = self._arrays(circuit, params)
+        if scratch is None:
+            scratch = np.zeros(2 << circuit.n_qubits, dtype=np.float64)
+        x = np.ascontiguousarray(operator.x_mask)
+        z = np.ascontiguousarray(operator.z_mask)
+        cre = np.ascontiguousarray(operator.coeffs.real)
+        cim = np.ascontiguousarray(operator.coeffs.imag)
+        return self.lib.qsvo_evaluate(
+            circuit.n_qubits, len(kinds), kinds.ctypes, targets.ctypes, controls.ctypes, angles.ctypes, len(operator),
+            x.ctypes, z.ctypes, cre.ctypes, cim.ctypes, table.ctypes if table is not None else None, scratch.ctypes,
+        )
+
+
+def load_c_oracle() -> COracle:
+    so_path = ROOT / "oracle" / "libqsv_oracle.so"
+    src = ROOT / "oracle" / "qsv_oracle.c"
+    if not so_path.exists() or so_path.stat().st_mtime < src.stat().st_mtime:
+        subprocess.run(["make", "-C", str(ROOT / "oracle")], check=True, capture_output=True)
+    return COracle(C.CDLL(str(so_path)))

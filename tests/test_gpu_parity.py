@@ -1,0 +1,178 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the oracle.  Run on the MI355X box with -m gpu.
+
+Tolerances: fp64 expectation values within 1e-10 of the oracle (BASELINE.json north_star); amplitudes within
+1e-12; fp32 states within 2e-5 per amplitude.
+"""
+
+import numpy as np
+import pytest
+
+import helpers
+from oracle import statevector_oracle as so
+from queasars_amd.circuit_evaluation import OperatorCircuitEvaluator, StatevectorDevice
+from queasars_amd.ir import CircuitIR, ParamRef, PauliOperator
+
+pytestmark = pytest.mark.gpu
+
+EXP_TOL = 1e-10
+AMP_TOL = 1e-12
+
+
+@pytest.mark.parametrize("n_qubits,n_layers", [(1, 2), (2, 3), (3, 2), (5, 3), (7, 2), (8, 2), (10, 3), (12, 4), (13, 3), (14, 4), (16, 2)])
+def test_statevector_matches_oracle(n_qubits, n_layers):
+    _, circuits, params = helpers.population_circuits(n_qubits, n_layers, 4, seed=11)
+    dev = StatevectorDevice(n_qubits)
+    for c, p in zip(circuits, params):
+        got = dev.statevector(c, p)
+        ref = helpers.oracle_state(c, p)
+        assert np.abs(got - ref).max() < AMP_TOL
+
+
+@pytest.mark.parametrize("cfg", [dict(tile_bits=10, reg_bits=3, low_bits=3), dict(tile_bits=11, reg_bits=4, low_bits=4), dict(tile_bits=9, reg_bits=2, low_bits=2), dict(tile_bits=12, reg_bits=5, low_bits=4)])
+def test_statevector_other_geometries(cfg):
+    n_qubits = 14
+    _, circuits, params = helpers.population_circuits(n_qubits, 3, 3, seed=5)
+    dev = StatevectorDevice(n_qubits, **cfg)
+    for c, p in zip(circuits, params):
+        assert np.abs(dev.statevector(c, p) - helpers.oracle_state(c, p)).max() < AMP_TOL
+
+
+def test_config1_plumbing_general_paulis():
+    """BASELINE config 1: n=8, P=4, L=2, 20 random Pauli strings."""
+    n = 8
+    _, circuits, params = helpers.population_circuits(n, 2, 4, seed=0)
+    op = helpers.random_pauli_operator(n, 20, seed=1234)
+    ev = OperatorCircuitEvaluator(op)
+    got = ev.evaluate_circuits(circuits, params)
+    ref = [helpers.oracle_expectation(c, p, op) for c, p in zip(circuits, params)]
+    assert np.abs(np.asarray(got) - np.asarray(ref)).max() < EXP_TOL
+
+
+@pytest.mark.parametrize("n_qubits", [4, 9, 12, 15])
+def test_diagonal_expectation_matches_oracle(n_qubits):
+    _, circuits, params = helpers.population_circuits(n_qubits, 3, 6, seed=3)
+    op = helpers.random_ising_operator(n_qubits, seed=2020)
+    ev = OperatorCircuitEvaluator(op)
+    got = ev.evaluate_circuits(circuits, params)
+    ref = [helpers.oracle_expectation(c, p, op) for c, p in zip(circuits, params)]
+    assert np.abs(np.asarray(got) - np.asarray(ref)).max() < EXP_TOL
+
+
+@pytest.mark.parametrize("n_qubits", [3, 10, 13])
+def test_general_expectation_matches_oracle(n_qubits):
+    _, circuits, params = helpers.population_circuits(n_qubits, 2, 5, seed=9)
+    op = helpers.random_pauli_operator(n_qubits, 12, seed=77)
+    ev = OperatorCircuitEvaluator(op)
+    got = ev.evaluate_circuits(circuits, params)
+    ref = [helpers.oracle_expectation(c, p, op) for c, p in zip(circuits, params)]
+    assert np.abs(np.asarray(got) - np.asarray(ref)).max() < EXP_TOL
+
+
+def test_zero_angles_known_answer():
+    """u(0,0,0) = cu3(0,0,0) = I: the state stays |0..0>, <H> = sum of the I/Z-only coefficients."""
+    n = 6
+    _, circuits, params = helpers.population_circuits(n, 2, 3, seed=0, randomize=False)
+    op = PauliOperator(["ZIIIII", "IZZIII", "XIIIII", "IIYIIZ", "IIIIII"], [0.5, -1.25, 3.0, 2.0, 0.75])
+    ev = OperatorCircuitEvaluator(op)
+    got = ev.evaluate_circuits(circuits, params)
+    assert np.allclose(got, 0.5 - 1.25 + 0.75, atol=1e-14)
+
+
+def test_bit_flip_known_answer():
+    """u(pi, 0, pi) = X on qubit q gives basis state 1 << q."""
+    n = 9
+    dev = StatevectorDevice(n)
+    for q in range(n):
+        c = CircuitIR(n).u(np.pi, 0.0, np.pi, q)
+        probs = dev.probabilities(c, [])
+        assert abs(probs[1 << q] - 1.0) < 1e-14 and abs(probs.sum() - 1.0) < 1e-14
+
+
+def test_reference_test_hamiltonian_known_answer():
+    """min x^2 - y^2 Ising form: <0000|H|0000> = 0 and the minimum -9 sits at x=0, y=3."""
+    op = PauliOperator.from_sparse_list(
+        [("Z", [0], -1.5), ("Z", [1], -3.0), ("ZZ", [0, 1], 1.0), ("Z", [2], 1.5), ("Z", [3], 3.0), ("ZZ", [2, 3], -1.0)], 4
+    )
+    ev = OperatorCircuitEvaluator(op)
+    ident = CircuitIR(4).id(0)
+    assert abs(ev.evaluate_circuits([ident], [[]])[0]) < 1e-14
+    flip_y = CircuitIR(4).u(np.pi, 0.0, np.pi, 2).u(np.pi, 0.0, np.pi, 3)  # y = 3, x = 0
+    assert abs(ev.evaluate_circuits([flip_y], [[]])[0] - (-9.0)) < 1e-13
+
+
+def test_partially_parameterized_and_param_indices():
+    n = 10
+    pop, _, _ = helpers.population_circuits(n, 3, 3, seed=21)
+    op = helpers.random_ising_operator(n, seed=1)
+    ev = OperatorCircuitEvaluator(op)
+    for ind in pop.individuals:
+        full = ind.get_parameterized_quantum_circuit()
+        ref = helpers.oracle_expectation(full, list(ind.parameter_values), op)
+        for layer in range(len(ind.layers)):
+            part = ind.get_partially_parameterized_quantum_circuit({layer})
+            vals = list(ind.get_layer_parameter_values(layer))
+            got = ev.evaluate_circuits([part, part], [vals, vals])
+            assert abs(got[0] - ref) < EXP_TOL and got[0] == got[1]
+
+
+def test_results_ordered_by_input_index_and_batch_invariance():
+    n = 11
+    _, circuits, params = helpers.population_circuits(n, 2, 9, seed=4)
+    op = helpers.random_ising_operator(n, seed=8)
+    ev = OperatorCircuitEvaluator(op)
+    together = ev.evaluate_circuits(circuits, params)
+    one_by_one = [ev.evaluate_circuits([c], [p])[0] for c, p in zip(circuits, params)]
+    assert together == one_by_one  # bitwise: fixed-order reductions
+    rev = ev.evaluate_circuits(circuits[::-1], params[::-1])
+    assert rev[::-1] == together
+
+
+def test_initial_state_circuit():
+    n = 5
+    _, circuits, params = helpers.population_circuits(n, 2, 2, seed=13)
+    op = helpers.random_pauli_operator(n, 6, seed=3)
+    init = CircuitIR(n).u(0.3, 0.1, -0.2, 0).cu3(1.0, 0.2, 0.3, 0, 3)
+    ev = OperatorCircuitEvaluator(op, initial_state_circuit=init)
+    got = ev.evaluate_circuits(circuits, params)
+    for g, c, p in zip(got, circuits, params):
+        ops = init.bound_ops([]) + c.bound_ops(p)
+        state = so.simulate(n, ops)
+        ref = so.pauli_expectation(state, op.x_mask.tolist(), op.z_mask.tolist(), op.coeffs.tolist()).real
+        assert abs(g - ref) < EXP_TOL
+
+
+def test_fp32_state_close_to_fp64():
+    n = 12
+    _, circuits, params = helpers.population_circuits(n, 3, 2, seed=2)
+    dev = StatevectorDevice(n, dtype="fp32")
+    for c, p in zip(circuits, params):
+        assert np.abs(dev.statevector(c, p) - helpers.oracle_state(c, p)).max() < 2e-5
+
+
+# ---- size-independent properties at the benchmark sizes --------------------------------------------------
+
+
+@pytest.mark.parametrize("n_qubits", [20, 24])
+def test_round_trip_and_norm_at_full_size(n_qubits, c_oracle):
+    """circuit followed by its inverse returns |0..0>; <I> = 1; expectation is linear in the coefficients."""
+    _, circuits, params = helpers.population_circuits(n_qubits, 4, 2, seed=0)
+    ident = PauliOperator(["I" * n_qubits], [1.0])
+    dev = StatevectorDevice(n_qubits)
+    ev_id = OperatorCircuitEvaluator(ident, statevector_device=dev)
+    assert np.allclose(ev_id.evaluate_circuits(circuits, params), 1.0, atol=1e-12)
+    c, p = circuits[0], params[0]
+    round_trip = helpers.bound_copy(c, p).compose(helpers.inverse_circuit(c, p))
+    probs = dev.probabilities(round_trip, [])
+    assert abs(probs[0] - 1.0) < 1e-11 and abs(probs.sum() - 1.0) < 1e-11
+    # linearity: <a H1 + b H2> = a <H1> + b <H2>
+    h1 = helpers.random_ising_operator(n_qubits, seed=1)
+    h2 = helpers.random_ising_operator(n_qubits, seed=2)
+    combo = PauliOperator(h1.labels + h2.labels, np.concatenate([0.3 * h1.coeffs, -1.7 * h2.coeffs]))
+    e1 = OperatorCircuitEvaluator(h1, statevector_device=dev).evaluate_circuits(circuits, params)
+    e2 = OperatorCircuitEvaluator(h2, statevector_device=dev).evaluate_circuits(circuits, params)
+    e12 = OperatorCircuitEvaluator(combo, statevector_device=dev).evaluate_circuits(circuits, params)
+    assert np.abs(np.asarray(e12) - (0.3 * np.asarray(e1) - 1.7 * np.asarray(e2))).max() < 1e-9
+    if n_qubits == 20:
+        # direct check against the C oracle at the benchmark size
+        ref = [c_oracle.evaluate(ci, pi, h1) for ci, pi in zip(circuits, params)]
+        assert np.abs(np.asarray(e1) - np.asarray(ref)).max() < EXP_TOL
