@@ -62,6 +62,8 @@ typedef struct qsv_plan_config {
     int32_t reg_bits;  /* r: qubits held in each thread's registers at a time (2^r amplitudes per thread) */
     int32_t low_bits;  /* c: lowest qubits always kept in the tile so global accesses stay coalesced */
     int32_t group;     /* circuits evaluated per launch group (0 = size the group to the Infinity Cache) */
+    int32_t exchange;  /* LDS transpose: 1 whole complex element per access, 2 re/im planes both resident,
+                          3 re then im through one plane buffer (half the LDS); fp32 always uses 1 */
 } qsv_plan_config;
 
 /* Counters of the most recent qsv_eval_* call (timings need qsv_set_profiling(h, 1)). */
@@ -70,6 +72,7 @@ typedef struct qsv_profile {
     uint64_t n_pass_launches;  /* launches of the gate-pass kernel */
     uint64_t n_state_passes;   /* sum over launches of states swept (launch x circuits in its group) */
     uint64_t n_gates;          /* non-identity gates applied */
+    uint64_t state_bytes;      /* bytes of state amplitudes the gate-pass launches read + wrote */
     double pass_ms;            /* device time of all gate-pass launches (HIP events on the library's stream) */
     double expect_ms;          /* device time of expectation / reduction kernels */
     double total_ms;           /* device time of the whole call, first launch to last */
@@ -138,6 +141,13 @@ int qsv_get_profile(const qsv_t* h, qsv_profile* out);
  */
 int qsv_bench_gate(qsv_t* h, int target, int control, double theta, double phi, double lambda, int reps,
                    double* out_ms_per_sweep);
+
+/*
+ * Same for an arbitrary bound gate list (every angle literal): the ops are scheduled into passes WITHOUT folding
+ * and applied read-modify-write to the resident state `reps` times.  Reports milliseconds per repetition and the
+ * number of passes one repetition takes.
+ */
+int qsv_bench_ops(qsv_t* h, int n_ops, const qsv_op* ops, int reps, double* out_ms_per_rep, int* out_n_passes);
 
 /*
  * Build (without touching any device) the pass plan the scheduler produces for a circuit and copy its encoded

@@ -31,7 +31,13 @@ class QsvOp(C.Structure):
 
 
 class QsvPlanConfig(C.Structure):
-    _fields_ = [("tile_bits", C.c_int32), ("reg_bits", C.c_int32), ("low_bits", C.c_int32), ("group", C.c_int32)]
+    _fields_ = [
+        ("tile_bits", C.c_int32),
+        ("reg_bits", C.c_int32),
+        ("low_bits", C.c_int32),
+        ("group", C.c_int32),
+        ("exchange", C.c_int32),
+    ]
 
 
 class QsvProfile(C.Structure):
@@ -40,6 +46,7 @@ class QsvProfile(C.Structure):
         ("n_pass_launches", C.c_uint64),
         ("n_state_passes", C.c_uint64),
         ("n_gates", C.c_uint64),
+        ("state_bytes", C.c_uint64),
         ("pass_ms", C.c_double),
         ("expect_ms", C.c_double),
         ("total_ms", C.c_double),
@@ -68,6 +75,7 @@ SIGNATURES = {
     "qsv_set_profiling": (C.c_int, [_P, C.c_int]),
     "qsv_get_profile": (C.c_int, [_P, C.POINTER(QsvProfile)]),
     "qsv_bench_gate": (C.c_int, [_P, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.POINTER(C.c_double)]),
+    "qsv_bench_ops": (C.c_int, [_P, C.c_int, _P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "qsv_plan_build": (
         C.c_int,
         [C.c_int, C.c_int, C.c_int, _P, C.POINTER(QsvPlanConfig), _P, C.c_size_t, C.POINTER(C.c_size_t)],

@@ -71,13 +71,14 @@ class StatevectorDevice:
         reg_bits: int = 0,
         low_bits: int = 0,
         group: int = 0,
+        exchange: int = 0,
     ):
         if dtype not in ("fp64", "fp32"):
             raise ValueError("dtype must be 'fp64' or 'fp32'")
-        self._args = (int(n_qubits), dtype, int(device), int(tile_bits), int(reg_bits), int(low_bits), int(group))
+        self._args = (int(n_qubits), dtype, int(device), int(tile_bits), int(reg_bits), int(low_bits), int(group), int(exchange))
         self._lib = _lib.load()
         self._handle = C.c_void_p()
-        cfg = _lib.QsvPlanConfig(tile_bits, reg_bits, low_bits, group)
+        cfg = _lib.QsvPlanConfig(tile_bits, reg_bits, low_bits, group, exchange)
         rc = self._lib.qsv_create(
             int(n_qubits), _lib.QSV_F64 if dtype == "fp64" else _lib.QSV_F32, int(device), C.byref(cfg), C.byref(self._handle)
         )
@@ -233,10 +234,17 @@ class StatevectorDevice:
         self._check(self._lib.qsv_bench_gate(self._handle, target, control, theta, phi, lam, reps, C.byref(ms)))
         return ms.value
 
+    def bench_ops(self, circuit: CircuitIR, reps: int = 20) -> tuple[float, int]:
+        """(milliseconds per repetition, passes per repetition) of a bound circuit applied read-modify-write."""
+        ops = circuit.packed()
+        ms, n_passes = C.c_double(0.0), C.c_int(0)
+        self._check(self._lib.qsv_bench_ops(self._handle, len(ops), _lib.as_ptr(ops), reps, C.byref(ms), C.byref(n_passes)))
+        return ms.value, n_passes.value
+
 
 def _rebuild_device(args, operator):
-    n_qubits, dtype, device, tile_bits, reg_bits, low_bits, group = args
-    dev = StatevectorDevice(n_qubits, dtype, device, tile_bits, reg_bits, low_bits, group)
+    n_qubits, dtype, device, tile_bits, reg_bits, low_bits, group, exchange = args
+    dev = StatevectorDevice(n_qubits, dtype, device, tile_bits, reg_bits, low_bits, group, exchange)
     if operator is not None:
         dev.set_operator(operator)
     return dev

@@ -13,6 +13,8 @@
 #include "kernels.hpp"
 #include "plan.hpp"
 
+#include <hip/hip_runtime.h>
+
 namespace qsv {
 
 template <typename real>
@@ -33,141 +35,393 @@ __device__ __forceinline__ void register_offsets(const uint32_t* __restrict__ rc
     for (int e = 1; e < (1 << R); ++e) ro[e] = ro[e & (e - 1)] ^ rc[__builtin_ctz(e)];
 }
 
-template <typename real, int R, int J>
-__device__ __forceinline__ void butterfly(cx<real> (&amp)[1 << R], const real (&m)[8], uint32_t cr, bool on) {
-    if (on) {
+// Visit the 2^R register indices in Gray-code order: consecutive indices differ in one bit, so the running offset
+// needs one XOR with one column (a scalar) per step and no 2^R-entry offset table has to stay live in SGPRs.
+//   for (int i = 0; i < NR; ++i) { off = gray_step<R>(i, off, cols); use(gray_index(i), off); }
+__device__ __forceinline__ constexpr int gray_index(int i) { return i ^ (i >> 1); }
+__device__ __forceinline__ uint32_t gray_step(int i, uint32_t off, const uint32_t* __restrict__ reg_cols) {
+    return i == 0 ? off : off ^ reg_cols[__builtin_ctz(i)];
+}
+
+// Spread a tile number around the tile's bit positions: the fixed (non-tile) index bits of that tile.
+__device__ __forceinline__ uint64_t tile_base(uint32_t tile, const uint32_t* __restrict__ pos, int k) {
+    uint64_t base = tile;
+    for (int j = 0; j < k; ++j) {
+        const uint32_t p = pos[j];
+        base = ((base >> p) << (p + 1)) | (base & ((uint64_t(1) << p) - 1));
+    }
+    return base;
+}
+
+// 2x2 butterfly with a u-type matrix (m00 is real: 14 multiply-adds per amplitude pair instead of 16).
+// m = {m00, Re m01, Im m01, Re m10, Im m10, Re m11, Im m11}.  J = target register bit, C = control register bit
+// (-1: none): both compile-time, so a controlled gate touches exactly the 2^(R-2) pairs it must and there is no
+// per-pair branching.  The operation order lets every result be written by its last FMA straight into the
+// register that held the input it replaces (a1 is consumed first, then a0), so no v_mov_b64 is needed -- on
+// gfx950 a 64-bit move costs as much issue time as a v_fma_f64.
+template <typename real, int R, int J, int C>
+__device__ __forceinline__ void butterfly(cx<real> (&amp)[1 << R], const real (&m)[7]) {
+    constexpr int tbit = 1 << J;
+    constexpr int cbit = C >= 0 ? (1 << (C >= 0 ? C : 0)) : 0;
 #pragma unroll
-        for (int e0 = 0; e0 < (1 << R); ++e0) {
-            if (e0 & (1 << J)) continue;
-            if ((uint32_t(e0) & cr) == cr) {
-                constexpr int bit = 1 << J;
-                const cx<real> a0 = amp[e0], a1 = amp[e0 | bit];
-                amp[e0].re = m[0] * a0.re - m[1] * a0.im + m[2] * a1.re - m[3] * a1.im;
-                amp[e0].im = m[0] * a0.im + m[1] * a0.re + m[2] * a1.im + m[3] * a1.re;
-                amp[e0 | bit].re = m[4] * a0.re - m[5] * a0.im + m[6] * a1.re - m[7] * a1.im;
-                amp[e0 | bit].im = m[4] * a0.im + m[5] * a0.re + m[6] * a1.im + m[7] * a1.re;
-            }
-        }
+    for (int e0 = 0; e0 < (1 << R); ++e0) {
+        if ((e0 & tbit) || (e0 & cbit) != cbit) continue;
+        const real a0r = amp[e0].re, a0i = amp[e0].im, a1r = amp[e0 | tbit].re, a1i = amp[e0 | tbit].im;
+        real u = m[1] * a1r;   // a1 part of the new a0
+        real w = m[1] * a1i;
+        real p = m[5] * a1r;   // a1 part of the new a1
+        real q = m[5] * a1i;
+        u = fma(-m[2], a1i, u);
+        w = fma(m[2], a1r, w);
+        p = fma(-m[6], a1i, p);
+        q = fma(m[6], a1r, q);   // last use of the old a1
+        p = fma(m[3], a0r, p);
+        q = fma(m[3], a0i, q);
+        amp[e0 | tbit].re = fma(-m[4], a0i, p);
+        amp[e0 | tbit].im = fma(m[4], a0r, q);
+        amp[e0].re = fma(m[0], a0r, u);
+        amp[e0].im = fma(m[0], a0i, w);
     }
 }
 
-template <typename real, int R, int J>
+// sel = J * (R + 1) + (C + 1)
+template <typename real, int R, int SEL>
 struct ButterflyDispatch {
-    static __device__ __forceinline__ void run(int j, cx<real> (&amp)[1 << R], const real (&m)[8], uint32_t cr, bool on) {
-        if (j == J)
-            butterfly<real, R, J>(amp, m, cr, on);
-        else
-            ButterflyDispatch<real, R, J - 1>::run(j, amp, m, cr, on);
+    static __device__ __forceinline__ void run(int sel, cx<real> (&amp)[1 << R], const real (&m)[7]) {
+        if (sel == SEL) {
+            constexpr int J = SEL / (R + 1), C = SEL % (R + 1) - 1;
+            if constexpr (C != J) butterfly<real, R, J, C>(amp, m);
+        } else {
+            ButterflyDispatch<real, R, SEL - 1>::run(sel, amp, m);
+        }
     }
 };
 template <typename real, int R>
 struct ButterflyDispatch<real, R, -1> {
-    static __device__ __forceinline__ void run(int, cx<real> (&)[1 << R], const real (&)[8], uint32_t, bool) {}
+    static __device__ __forceinline__ void run(int, cx<real> (&)[1 << R], const real (&)[7]) {}
 };
 
-template <typename real, int R>
-__global__ void __launch_bounds__(256) pass_kernel(const PassArgs a) {
-    using cxr = cx<real>;
-    extern __shared__ __align__(16) unsigned char lds_raw[];
-    cxr* lds = reinterpret_cast<cxr*>(lds_raw);
+// Read-only inputs are separate `const __restrict__` kernel parameters (not members of a by-value struct): that is
+// what lets hipcc prove they cannot alias the state stores and fetch plan words and matrices with SCALAR loads.
+struct PassScalars {
+    uint64_t state_stride;
+    uint32_t pass_index;
+    uint32_t mode;
+    uint32_t tiles_per_block;
+};
 
-    const EvalDesc ev = a.evals[blockIdx.y];
-    const uint32_t* __restrict__ cp = a.plan + ev.plan_base;
+// XMODE selects how a tile is transposed through LDS:
+//   0  one complex element per access (ds_*_b128 for fp64, ds_*_b64 for fp32); LDS = 2^k * sizeof(complex)
+//   1  real and imaginary planes, both resident (ds_*_b64 for fp64);           LDS = 2^k * sizeof(complex)
+//   2  real plane then imaginary plane through ONE plane buffer;                LDS = 2^k * sizeof(real)
+// Mode 2 halves the LDS footprint (32 KiB at k = 12, fp64) so three or four 512-thread workgroups fit a CU.
+// Occupancy is what sets the v_fma_f64 issue rate on gfx950 (measured with scripts/ubench/valu_rate.hip:
+// 13 / 7.2 / 5.8 / 4.7 cycles per instruction at 1 / 2 / 4 / 8 waves per SIMD), so the kernel is compiled for
+// 6 waves per SIMD (<= 80 VGPRs) in mode 2; at 8 (<= 64 VGPRs) hipcc spills the amplitudes.
+// PIPE = true: software pipelining inside the workgroup.  Identical workgroups run in lock-step (all load, then
+// all compute, then all store), so memory time ADDS to compute time unless each wave keeps its own next tile's
+// loads in flight while it computes: the next tile's amplitudes (and diagonal values) are prefetched into a second
+// register set before the current tile's gates run.
+template <int XMODE, bool PIPE>
+struct Occupancy {
+    static constexpr int waves_per_simd = PIPE ? 4 : (XMODE == 2 ? 6 : 4);
+};
+
+template <typename real, int R, int XMODE, bool PIPE>
+__global__ void __launch_bounds__(512, (Occupancy<XMODE, PIPE>::waves_per_simd))
+    pass_kernel(const uint32_t* __restrict__ plan_arena, const double* __restrict__ mats_all,
+                const EvalDesc* __restrict__ evals, cx<real>* __restrict__ states, const double* __restrict__ diag,
+                double* __restrict__ partials, const PassScalars a) {
+    using cxr = cx<real>;
+    constexpr int NR = 1 << R;
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+
+    const EvalDesc ev = evals[blockIdx.y];
+    const uint32_t* __restrict__ cp = plan_arena + ev.plan_base;
     const uint32_t n_passes = cp[0];
     if (a.pass_index >= n_passes) return;
-    const uint32_t* __restrict__ pp = cp + cp[2 + a.pass_index];
+    const uint32_t n_real = cp[1], n_qubits = cp[2];
+    const uint32_t* __restrict__ pp = cp + cp[kCircuitHeaderWords + a.pass_index];
     const uint32_t hdr = pp[0];
     const int k = hdr & 0xff, t = (hdr >> 16) & 0xff, n_rounds = hdr >> 24;
     const uint32_t tid = threadIdx.x;
+    const bool all_active = blockDim.x == (1u << t);
     const bool active = tid < (1u << t);
+    const uint32_t wave_base = __builtin_amdgcn_readfirstlane(tid & ~63u);
 
-    // fixed (non-tile) index bits of this workgroup: spread blockIdx.x around the tile positions
-    uint64_t base = blockIdx.x;
-    for (int j = 0; j < k; ++j) {
-        const uint32_t p = pp[kPassHeaderWords + j];
-        base = ((base >> p) << (p + 1)) | (base & ((uint64_t(1) << p) - 1));
-    }
-
-    const uint32_t* __restrict__ gl = pp + kPassHeaderWords + k;
+    const uint32_t* __restrict__ pos = pp + kPassHeaderWords;
+    const uint32_t* __restrict__ gl = pos + k;
     const uint32_t* __restrict__ gs = gl + (t + R);
-    const uint32_t* __restrict__ rp = gs + (t + R);
+    const uint32_t* __restrict__ rounds0 = gs + (t + R);
+    const double* __restrict__ mats0 = mats_all + ev.mat_base + size_t(pp[1]) * 8;
+    const double* __restrict__ vecs = mats_all + ev.mat_base + size_t(n_real) * 8;
 
-    cxr* __restrict__ st = reinterpret_cast<cxr*>(a.states) + uint64_t(ev.state_slot) * a.state_stride + base;
-    cxr amp[1 << R];
+    const bool synth = a.pass_index == 0 && (a.mode & kModeSynthFirst);
+    const bool last = a.pass_index + 1 == n_passes;
+    const bool do_store = !last || (a.mode & kModeFinalStore);
+    const bool do_diag = last && (a.mode & kModeFinalDiag);
+    cxr* __restrict__ st0 = states + uint64_t(ev.state_slot) * a.state_stride;
 
-    {
-        const uint32_t tg = xor_columns(gl, t, tid);
-        uint32_t ro[1 << R];
-        register_offsets<R>(gl + t, ro);
-        if (a.pass_index == 0 && (a.mode & kModeSynthFirst)) {
-#pragma unroll
-            for (int e = 0; e < (1 << R); ++e) {
-                amp[e].re = (base == 0 && (tg ^ ro[e]) == 0) ? real(1) : real(0);
-                amp[e].im = real(0);
-            }
-        } else if (active) {
-#pragma unroll
-            for (int e = 0; e < (1 << R); ++e) amp[e] = st[tg ^ ro[e]];
-        }
-    }
+    const uint32_t tg = xor_columns(gl, t, tid), sg = xor_columns(gs, t, tid);
 
+    const uint32_t n_tiles = a.tiles_per_block;
+    const uint32_t tile0 = blockIdx.x * n_tiles;
+    cxr amp[NR], nxt[PIPE ? NR : 1];
+    double dcur[PIPE ? NR : 1], dnxt[PIPE ? NR : 1];
+    double acc = 0.0;
     bool lds_dirty = false;
-    for (int m = 0; m < n_rounds; ++m) {
-        const uint32_t rh = rp[0];
-        const int n_gates = rh & 0xffff;
-        rp += 1;
-        if ((rh >> 16) & 1u) {
-            const uint32_t* __restrict__ wc = rp;
-            const uint32_t* __restrict__ rc = rp + (t + R);
-            rp += 2 * (t + R);
-            if (lds_dirty) __syncthreads();  // everyone has finished reading the previous exchange
-            if (active) {
-                const uint32_t wt = xor_columns(wc, t, tid);
-                uint32_t wo[1 << R];
-                register_offsets<R>(wc + t, wo);
+    uint64_t base = tile_base(tile0, pos, k);
+    if constexpr (PIPE) {
+        if (!synth && active) {
+            uint32_t off = tg;
 #pragma unroll
-                for (int e = 0; e < (1 << R); ++e) lds[wt ^ wo[e]] = amp[e];
+            for (int i = 0; i < NR; ++i) {
+                off = gray_step(i, off, gl + t);
+                amp[gray_index(i)] = st0[base + off];
             }
-            __syncthreads();
-            if (active) {
-                const uint32_t rt = xor_columns(rc, t, tid);
-                uint32_t ro[1 << R];
-                register_offsets<R>(rc + t, ro);
-#pragma unroll
-                for (int e = 0; e < (1 << R); ++e) amp[e] = lds[rt ^ ro[e]];
-            }
-            lds_dirty = true;
         }
-        for (int g = 0; g < n_gates; ++g, rp += kGateWords) {
-            const uint32_t w0 = rp[0], cr = rp[1], ct = rp[2], cg = rp[3];
-            if ((uint32_t(base) & cg) != cg) continue;  // control is one of this workgroup's fixed bits and is 0
-            const double* __restrict__ mp = a.mats + ev.mat_base + size_t(w0 >> 8) * 8;
-            real mm[8];
+        if (do_diag && active) {
+            uint32_t off = sg;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) mm[i] = real(mp[i]);
-            const bool on = active && ((tid & ct) == ct);
-            ButterflyDispatch<real, R, R - 1>::run(int(w0 & 0xff), amp, mm, cr, on);
+            for (int i = 0; i < NR; ++i) {
+                off = gray_step(i, off, gs + t);
+                dcur[PIPE ? gray_index(i) : 0] = diag[base + off];
+            }
         }
     }
 
-    const bool last = (a.pass_index + 1 == n_passes);
-    const uint32_t sg = xor_columns(gs, t, tid);
-    uint32_t so[1 << R];
-    register_offsets<R>(gs + t, so);
-    if ((!last || (a.mode & kModeFinalStore)) && active) {
+    for (uint32_t j = 0; j < n_tiles; ++j) {
+        const bool has_next = j + 1 < n_tiles;
+        const uint64_t base_next = has_next ? tile_base(tile0 + j + 1, pos, k) : 0;
+        if constexpr (PIPE) {
+            if (has_next && active) {
+                if (!synth) {
+                    uint32_t off = tg;
 #pragma unroll
-        for (int e = 0; e < (1 << R); ++e) st[sg ^ so[e]] = amp[e];
-    }
-    if (last && (a.mode & kModeFinalDiag)) {
-        double acc = 0.0;
-        if (active) {
-            const double* __restrict__ d = a.diag + base;
+                    for (int i = 0; i < NR; ++i) {
+                        off = gray_step(i, off, gl + t);
+                        nxt[PIPE ? gray_index(i) : 0] = st0[base_next + off];
+                    }
+                }
+                if (do_diag) {
+                    uint32_t off = sg;
 #pragma unroll
-            for (int e = 0; e < (1 << R); ++e) {
-                const double re = double(amp[e].re), im = double(amp[e].im);
-                acc += (re * re + im * im) * d[sg ^ so[e]];
+                    for (int i = 0; i < NR; ++i) {
+                        off = gray_step(i, off, gs + t);
+                        dnxt[PIPE ? gray_index(i) : 0] = diag[base_next + off];
+                    }
+                }
             }
         }
+        if (synth) {
+            // initial product state: amplitude(i) = prod_q v_q[bit q of i]; v_q = vecs[4q .. 4q+3] = (v0, v1)
+            uint32_t reg_mask = 0;
+#pragma unroll
+            for (int v = 0; v < R; ++v) reg_mask |= gl[t + v];
+            const uint64_t g0 = base | tg;
+            double fr = 1.0, fi = 0.0;
+            for (uint32_t q = 0; q < n_qubits; ++q) {
+                if ((reg_mask >> q) & 1u) continue;
+                const bool one = (g0 >> q) & 1u;
+                // both factors are uniform (scalar loads); the lane picks one
+                const double v0r = vecs[4 * q], v0i = vecs[4 * q + 1], v1r = vecs[4 * q + 2], v1i = vecs[4 * q + 3];
+                const double vr = one ? v1r : v0r, vi = one ? v1i : v0i;
+                const double nr = fr * vr - fi * vi;
+                fi = fr * vi + fi * vr;
+                fr = nr;
+            }
+            amp[0].re = real(fr);
+            amp[0].im = real(fi);
+#pragma unroll
+            for (int v = 0; v < R; ++v) {
+                const uint32_t q = __builtin_ctz(gl[t + v]);
+                const real v0r = real(vecs[4 * q]), v0i = real(vecs[4 * q + 1]);
+                const real v1r = real(vecs[4 * q + 2]), v1i = real(vecs[4 * q + 3]);
+#pragma unroll
+                for (int e = 0; e < (1 << v); ++e) {
+                    const cxr x = amp[e];
+                    amp[e | (1 << v)].re = x.re * v1r - x.im * v1i;
+                    amp[e | (1 << v)].im = x.re * v1i + x.im * v1r;
+                    amp[e].re = x.re * v0r - x.im * v0i;
+                    amp[e].im = x.re * v0i + x.im * v0r;
+                }
+            }
+        } else if (!PIPE && active) {
+            uint32_t off = tg;
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                off = gray_step(i, off, gl + t);
+                amp[gray_index(i)] = st0[base + off];
+            }
+        }
+
+        const uint32_t* __restrict__ rp = rounds0;
+        const double* __restrict__ mp = mats0;
+        for (int m = 0; m < n_rounds; ++m) {
+            const uint32_t rh = rp[0];
+            const int n_gates = rh & 0xffff;
+            rp += 1;
+            if ((rh >> 16) & 1u) {
+                const uint32_t* __restrict__ wc = rp;
+                const uint32_t* __restrict__ rc = rp + (t + R);
+                rp += 2 * (t + R);
+                {
+                    const uint32_t wt = xor_columns(wc, t, tid), rt = xor_columns(rc, t, tid);
+                    const uint32_t* __restrict__ wrc = wc + t;
+                    const uint32_t* __restrict__ rrc = rc + t;
+                    if (lds_dirty) __syncthreads();  // everyone has finished reading the previous exchange
+                    if constexpr (XMODE == 0) {
+                        cxr* lds = reinterpret_cast<cxr*>(lds_raw);
+                        if (active) {
+                            uint32_t off = wt;
+#pragma unroll
+                            for (int i = 0; i < NR; ++i) {
+                                off = gray_step(i, off, wrc);
+                                lds[off] = amp[gray_index(i)];
+                            }
+                        }
+                        __syncthreads();
+                        if (active) {
+                            uint32_t off = rt;
+#pragma unroll
+                            for (int i = 0; i < NR; ++i) {
+                                off = gray_step(i, off, rrc);
+                                amp[gray_index(i)] = lds[off];
+                            }
+                        }
+                    } else if constexpr (XMODE == 1) {
+                        real* pre = reinterpret_cast<real*>(lds_raw);
+                        real* pim = pre + (size_t(1) << k);
+                        if (active) {
+                            uint32_t off = wt;
+#pragma unroll
+                            for (int i = 0; i < NR; ++i) {
+                                off = gray_step(i, off, wrc);
+                                pre[off] = amp[gray_index(i)].re;
+                                pim[off] = amp[gray_index(i)].im;
+                            }
+                        }
+                        __syncthreads();
+                        if (active) {
+                            uint32_t off = rt;
+#pragma unroll
+                            for (int i = 0; i < NR; ++i) {
+                                off = gray_step(i, off, rrc);
+                                amp[gray_index(i)].re = pre[off];
+                                amp[gray_index(i)].im = pim[off];
+                            }
+                        }
+                    } else {
+                        real* pl = reinterpret_cast<real*>(lds_raw);
+                        if (active) {
+                            uint32_t off = wt;
+#pragma unroll
+                            for (int i = 0; i < NR; ++i) {
+                                off = gray_step(i, off, wrc);
+                                pl[off] = amp[gray_index(i)].re;
+                            }
+                        }
+                        __syncthreads();
+                        if (active) {
+                            uint32_t off = rt;
+#pragma unroll
+                            for (int i = 0; i < NR; ++i) {
+                                off = gray_step(i, off, rrc);
+                                amp[gray_index(i)].re = pl[off];
+                            }
+                        }
+                        __syncthreads();
+                        if (active) {
+                            uint32_t off = wt;
+#pragma unroll
+                            for (int i = 0; i < NR; ++i) {
+                                off = gray_step(i, off, wrc);
+                                pl[off] = amp[gray_index(i)].im;
+                            }
+                        }
+                        __syncthreads();
+                        if (active) {
+                            uint32_t off = rt;
+#pragma unroll
+                            for (int i = 0; i < NR; ++i) {
+                                off = gray_step(i, off, rrc);
+                                amp[gray_index(i)].im = pl[off];
+                            }
+                        }
+                    }
+                    lds_dirty = true;
+                }
+            }
+            // gate stream: descriptor and matrix of gate g+1 are fetched (scalar loads) while gate g runs
+            uint32_t w0 = rp[0], ct = rp[1], cg = rp[2];
+            double m0 = mp[0], m1 = mp[2], m2 = mp[3], m3 = mp[4], m4 = mp[5], m5 = mp[6], m6 = mp[7];
+            for (int g = 0; g < n_gates; ++g) {
+                rp += kGateWords;
+                mp += 8;
+                const uint32_t nw0 = rp[0], nct = rp[1], ncg = rp[2];
+                const double n0 = mp[0], n1 = mp[2], n2 = mp[3], n3 = mp[4], n4 = mp[5], n5 = mp[6], n6 = mp[7];
+                if ((uint32_t(base) & cg) == cg) {  // else: the control is a fixed bit of this tile and it is 0
+                    const uint32_t creg = (w0 >> 8) & 0xffu;
+                    const int sel = int(w0 & 0xffu) * (R + 1) + (creg == 0xffu ? 0 : int(creg) + 1);
+                    if (all_active && (ct & 63u) == 0) {
+                        // the control (if any) is a wave-index bit: whole waves either run the gate or skip it
+                        if ((wave_base & ct) == ct) {
+                            const real mm[7] = {real(m0), real(m1), real(m2), real(m3), real(m4), real(m5), real(m6)};
+                            ButterflyDispatch<real, R, R*(R + 1) - 1>::run(sel, amp, mm);
+                        }
+                    } else {
+                        // per-lane control: lanes whose control bit is 0 apply the identity
+                        const bool on = active && ((tid & ct) == ct);
+                        const real mm[7] = {on ? real(m0) : real(1), on ? real(m1) : real(0), on ? real(m2) : real(0),
+                                            on ? real(m3) : real(0), on ? real(m4) : real(0), on ? real(m5) : real(1),
+                                            on ? real(m6) : real(0)};
+                        ButterflyDispatch<real, R, R*(R + 1) - 1>::run(sel, amp, mm);
+                    }
+                }
+                w0 = nw0; ct = nct; cg = ncg;
+                m0 = n0; m1 = n1; m2 = n2; m3 = n3; m4 = n4; m5 = n5; m6 = n6;
+            }
+        }
+
+        if (do_store && active) {
+            uint32_t off = sg;
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                off = gray_step(i, off, gs + t);
+                st0[base + off] = amp[gray_index(i)];
+            }
+        }
+        if (do_diag && active) {
+            if constexpr (PIPE) {
+#pragma unroll
+                for (int e = 0; e < NR; ++e) {
+                    const double re = double(amp[e].re), im = double(amp[e].im);
+                    acc += (re * re + im * im) * dcur[PIPE ? e : 0];
+                }
+            } else {
+                const double* __restrict__ d = diag + base;
+                uint32_t off = sg;
+#pragma unroll
+                for (int i = 0; i < NR; ++i) {
+                    off = gray_step(i, off, gs + t);
+                    const double re = double(amp[gray_index(i)].re), im = double(amp[gray_index(i)].im);
+                    acc += (re * re + im * im) * d[off];
+                }
+            }
+        }
+        if constexpr (PIPE) {
+            if (has_next) {
+#pragma unroll
+                for (int e = 0; e < NR; ++e) {
+                    if (!synth) amp[e] = nxt[PIPE ? e : 0];
+                    if (do_diag) dcur[PIPE ? e : 0] = dnxt[PIPE ? e : 0];
+                }
+            }
+        }
+        base = base_next;
+    }
+
+    if (do_diag) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
         double* red = reinterpret_cast<double*>(lds_raw);
@@ -178,61 +432,142 @@ __global__ void __launch_bounds__(256) pass_kernel(const PassArgs a) {
             double total = 0.0;
             const int n_waves = (blockDim.x + 63) >> 6;
             for (int w = 0; w < n_waves; ++w) total += red[w];
-            a.partials[size_t(ev.out_index) * a.blocks_per_state + blockIdx.x] = total;
+            partials[size_t(ev.out_index) * gridDim.x + blockIdx.x] = total;
         }
     }
 }
 
-template <typename real, int R>
+template <typename real, int R, int XMODE>
 static hipError_t launch_pass_t(dim3 grid, int threads, size_t lds_bytes, hipStream_t stream, const PassArgs& args) {
     // the block reduction at the end needs one double per wave
     const size_t lds = lds_bytes < 64 ? 64 : lds_bytes;
-    hipLaunchKernelGGL((pass_kernel<real, R>), grid, dim3(threads), lds, stream, args);
+    const PassScalars sc{args.state_stride, args.pass_index, args.mode, args.tiles_per_block};
+    cx<real>* st = reinterpret_cast<cx<real>*>(args.states);
+    if (args.pipeline && args.tiles_per_block > 1)
+        hipLaunchKernelGGL((pass_kernel<real, R, XMODE, true>), grid, dim3(threads), lds, stream, args.plan, args.mats,
+                           args.evals, st, args.diag, args.partials, sc);
+    else
+        hipLaunchKernelGGL((pass_kernel<real, R, XMODE, false>), grid, dim3(threads), lds, stream, args.plan,
+                           args.mats, args.evals, st, args.diag, args.partials, sc);
     return hipGetLastError();
 }
 
-template <typename real>
-static hipError_t launch_pass_r(int r, dim3 grid, int threads, size_t lds_bytes, hipStream_t stream,
-                                const PassArgs& args) {
+template <typename real, int R, int XMODE>
+static hipError_t configure_t(size_t lds_bytes) {
+    const int bytes = int(lds_bytes < 64 ? 64 : lds_bytes);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pass_kernel<real, R, XMODE, false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&pass_kernel<real, R, XMODE, true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
+// op = 0: launch, op = 1: configure
+template <typename real, int XMODE>
+static hipError_t pass_dispatch_r(int op, int r, dim3 grid, int threads, size_t lds_bytes, hipStream_t stream,
+                                  const PassArgs* args) {
     switch (r) {
-        case 1: return launch_pass_t<real, 1>(grid, threads, lds_bytes, stream, args);
-        case 2: return launch_pass_t<real, 2>(grid, threads, lds_bytes, stream, args);
-        case 3: return launch_pass_t<real, 3>(grid, threads, lds_bytes, stream, args);
-        case 4: return launch_pass_t<real, 4>(grid, threads, lds_bytes, stream, args);
-        case 5: return launch_pass_t<real, 5>(grid, threads, lds_bytes, stream, args);
+        case 1: return op ? configure_t<real, 1, XMODE>(lds_bytes) : launch_pass_t<real, 1, XMODE>(grid, threads, lds_bytes, stream, *args);
+        case 2: return op ? configure_t<real, 2, XMODE>(lds_bytes) : launch_pass_t<real, 2, XMODE>(grid, threads, lds_bytes, stream, *args);
+        case 3: return op ? configure_t<real, 3, XMODE>(lds_bytes) : launch_pass_t<real, 3, XMODE>(grid, threads, lds_bytes, stream, *args);
+        case 4: return op ? configure_t<real, 4, XMODE>(lds_bytes) : launch_pass_t<real, 4, XMODE>(grid, threads, lds_bytes, stream, *args);
         default: return hipErrorInvalidValue;
     }
 }
 
-hipError_t launch_pass(int dtype, int r, dim3 grid, int threads, size_t lds_bytes, hipStream_t stream,
-                       const PassArgs& args) {
-    if (threads > 256) return hipErrorInvalidValue;
-    return dtype == 0 ? launch_pass_r<double>(r, grid, threads, lds_bytes, stream, args)
-                      : launch_pass_r<float>(r, grid, threads, lds_bytes, stream, args);
-}
-
-template <typename real, int R>
-static hipError_t configure_t(size_t lds_bytes) {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&pass_kernel<real, R>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes < 64 ? 64 : lds_bytes));
-}
-
-hipError_t configure_pass_kernels(int dtype, int r, size_t lds_bytes) {
-#define QSV_CFG(real)                                   \
-    switch (r) {                                        \
-        case 1: return configure_t<real, 1>(lds_bytes); \
-        case 2: return configure_t<real, 2>(lds_bytes); \
-        case 3: return configure_t<real, 3>(lds_bytes); \
-        case 4: return configure_t<real, 4>(lds_bytes); \
-        case 5: return configure_t<real, 5>(lds_bytes); \
-        default: return hipErrorInvalidValue;           \
-    }
+static hipError_t pass_dispatch(int op, int dtype, int r, int xmode, dim3 grid, int threads, size_t lds_bytes,
+                                hipStream_t stream, const PassArgs* args) {
+    if (threads > 512) return hipErrorInvalidValue;
     if (dtype == 0) {
-        QSV_CFG(double)
-    } else {
-        QSV_CFG(float)
+        switch (xmode) {
+            case 0: return pass_dispatch_r<double, 0>(op, r, grid, threads, lds_bytes, stream, args);
+            case 1: return pass_dispatch_r<double, 1>(op, r, grid, threads, lds_bytes, stream, args);
+            case 2: return pass_dispatch_r<double, 2>(op, r, grid, threads, lds_bytes, stream, args);
+            default: return hipErrorInvalidValue;
+        }
     }
-#undef QSV_CFG
+    switch (xmode) {
+        case 0: return pass_dispatch_r<float, 0>(op, r, grid, threads, lds_bytes, stream, args);
+        case 2: return pass_dispatch_r<float, 2>(op, r, grid, threads, lds_bytes, stream, args);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_pass(int dtype, int r, int xmode, dim3 grid, int threads, size_t lds_bytes, hipStream_t stream,
+                       const PassArgs& args) {
+    return pass_dispatch(0, dtype, r, xmode, grid, threads, lds_bytes, stream, &args);
+}
+
+hipError_t configure_pass_kernels(int dtype, int r, int xmode, size_t lds_bytes) {
+    return pass_dispatch(1, dtype, r, xmode, dim3(1), 64, lds_bytes, nullptr, nullptr);
+}
+
+// ---- angles -> matrices ---------------------------------------------------------------------------------
+struct Angles {
+    double theta, phi, lam;
+};
+
+__device__ __forceinline__ Angles read_angles(const uint32_t* __restrict__ e, const double* __restrict__ params) {
+    const int32_t pt = int32_t(e[0]), pf = int32_t(e[1]), pl = int32_t(e[2]);
+    Angles a;
+    a.theta = pt >= 0 ? params[pt] : __hiloint2double(int(e[4]), int(e[3]));
+    a.phi = pf >= 0 ? params[pf] : __hiloint2double(int(e[6]), int(e[5]));
+    a.lam = pl >= 0 ? params[pl] : __hiloint2double(int(e[8]), int(e[7]));
+    return a;
+}
+
+// Qiskit UGate: [[cos(t/2), -e^{i lam} sin(t/2)], [e^{i phi} sin(t/2), e^{i(phi+lam)} cos(t/2)]]
+__device__ __forceinline__ void u_matrix(const Angles& a, double* m) {
+    double s, c, sl, cl, sp, cp, spl, cpl;
+    sincos(a.theta * 0.5, &s, &c);
+    sincos(a.lam, &sl, &cl);
+    sincos(a.phi, &sp, &cp);
+    sincos(a.phi + a.lam, &spl, &cpl);
+    m[0] = c;        m[1] = 0.0;
+    m[2] = -cl * s;  m[3] = -sl * s;
+    m[4] = cp * s;   m[5] = sp * s;
+    m[6] = cpl * c;  m[7] = spl * c;
+}
+
+__global__ void __launch_bounds__(256) prepare_kernel(const uint32_t* __restrict__ plan,
+                                                      const EvalDesc* __restrict__ evals,
+                                                      const double* __restrict__ params, double* __restrict__ mats) {
+    const EvalDesc ev = evals[blockIdx.x];
+    const uint32_t* __restrict__ cp = plan + ev.plan_base;
+    const uint32_t n_real = cp[1], n_qubits = cp[2];
+    const uint32_t* __restrict__ table = cp + cp[3];
+    const uint32_t* __restrict__ fold = cp + cp[4];
+    const double* __restrict__ p = params + ev.param_base;
+    double* __restrict__ out = mats + ev.mat_base;
+    for (uint32_t j = threadIdx.x; j < n_real; j += blockDim.x) {
+        double m[8];
+        u_matrix(read_angles(table + size_t(j) * kAngleEntryWords, p), m);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) out[size_t(j) * 8 + i] = m[i];
+    }
+    for (uint32_t q = threadIdx.x; q < n_qubits; q += blockDim.x) {
+        const uint32_t first = fold[2 * q], count = fold[2 * q + 1];
+        double v0r = 1.0, v0i = 0.0, v1r = 0.0, v1i = 0.0;
+        for (uint32_t i = 0; i < count; ++i) {
+            double m[8];
+            u_matrix(read_angles(table + size_t(first + i) * kAngleEntryWords, p), m);
+            const double a0r = v0r, a0i = v0i, a1r = v1r, a1i = v1i;
+            v0r = m[0] * a0r - m[1] * a0i + m[2] * a1r - m[3] * a1i;
+            v0i = m[0] * a0i + m[1] * a0r + m[2] * a1i + m[3] * a1r;
+            v1r = m[4] * a0r - m[5] * a0i + m[6] * a1r - m[7] * a1i;
+            v1i = m[4] * a0i + m[5] * a0r + m[6] * a1i + m[7] * a1r;
+        }
+        double* o = out + size_t(n_real) * 8 + size_t(q) * 4;
+        o[0] = v0r; o[1] = v0i; o[2] = v1r; o[3] = v1i;
+    }
+    // zero the padding the pass kernel's one-gate-ahead prefetch may read
+    for (uint32_t i = threadIdx.x; i < 16; i += blockDim.x) out[size_t(n_real) * 8 + size_t(n_qubits) * 4 + i] = 0.0;
+}
+
+hipError_t launch_prepare(const uint32_t* plan, const EvalDesc* evals, const double* params, double* mats, int n_evals,
+                          hipStream_t stream) {
+    hipLaunchKernelGGL(prepare_kernel, dim3(n_evals), dim3(256), 0, stream, plan, evals, params, mats);
+    return hipGetLastError();
 }
 
 // ---- diagonal table ------------------------------------------------------------------------------------

@@ -10,9 +10,13 @@ namespace qsv {
 // One evaluation (circuit + parameter vector) inside a launch group.
 struct EvalDesc {
     uint32_t plan_base;   // word offset of the circuit plan in the plan arena
-    uint32_t mat_base;    // offset (in doubles) of this evaluation's gate matrices in the matrix buffer
+    uint32_t mat_base;    // offset (in doubles) of this evaluation's matrix region: 8 doubles per scheduled gate,
+                          // then 4 doubles per qubit (the initial product-state factors), then padding
     uint32_t state_slot;  // which resident state buffer the evaluation uses
     uint32_t out_index;   // row of `partials` / entry of the result vector
+    uint32_t param_base;  // offset (in doubles) of this evaluation's parameter vector in the parameter buffer
+    uint32_t n_params;
+    uint32_t reserved0, reserved1;
 };
 
 enum PassMode : uint32_t {
@@ -23,21 +27,30 @@ enum PassMode : uint32_t {
 
 struct PassArgs {
     const uint32_t* plan;  // plan arena
-    const double* mats;    // 8 doubles per gate: m00 m01 m10 m11 as (re, im)
+    const double* mats;    // matrix regions (see EvalDesc::mat_base); 8 doubles per gate: m00 m01 m10 m11 as (re, im)
     const EvalDesc* evals; // blockIdx.y indexes this array
     void* states;          // slot s starts at s * state_stride amplitudes
     const double* diag;    // D[i] for the diagonal fast path (may be null)
-    double* partials;      // [out_index][blocks_per_state]
+    double* partials;      // [out_index][gridDim.x]
     uint64_t state_stride;
     uint32_t pass_index;
     uint32_t mode;
-    uint32_t blocks_per_state;
+    uint32_t tiles_per_block;  // consecutive tiles each workgroup sweeps
+    uint32_t pipeline;         // 1: prefetch the next tile into a second register set while computing (needs > 1 tile)
 };
 
-// dtype: 0 = fp64, 1 = fp32.  r = register bits (1..5).  Returns hipSuccess or the launch error.
-hipError_t launch_pass(int dtype, int r, dim3 grid, int threads, size_t lds_bytes, hipStream_t stream,
+// doubles an evaluation's matrix region occupies for a circuit with n_real scheduled gates on n qubits
+inline uint32_t mat_region_doubles(uint32_t n_real, uint32_t n_qubits) { return 8 * n_real + 4 * n_qubits + 16; }
+
+// Angles -> gate matrices and initial product-state factors, one workgroup per evaluation.
+hipError_t launch_prepare(const uint32_t* plan, const EvalDesc* evals, const double* params, double* mats, int n_evals,
+                          hipStream_t stream);
+
+// dtype: 0 = fp64, 1 = fp32.  r = register bits (1..4).  xmode = LDS exchange mode (see kernels.hip).
+// Returns hipSuccess or the launch error.
+hipError_t launch_pass(int dtype, int r, int xmode, dim3 grid, int threads, size_t lds_bytes, hipStream_t stream,
                        const PassArgs& args);
-hipError_t configure_pass_kernels(int dtype, int r, size_t lds_bytes);
+hipError_t configure_pass_kernels(int dtype, int r, int xmode, size_t lds_bytes);
 
 hipError_t launch_diag_table(int n_qubits, int n_terms, const uint64_t* z_mask, const double* coeff, double* table,
                              hipStream_t stream);

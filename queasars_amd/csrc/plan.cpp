@@ -12,9 +12,10 @@ namespace qsv {
 
 Geometry make_geometry(int n, const PlanConfig& cfg) {
     if (n < 1 || n > 32) throw std::invalid_argument("n_qubits must be in [1, 32]");
-    if (cfg.reg_bits < 1 || cfg.reg_bits > 5) throw std::invalid_argument("reg_bits must be in [1, 5]");
-    if (cfg.tile_bits < cfg.reg_bits + 1 || cfg.tile_bits > cfg.reg_bits + 10)
-        throw std::invalid_argument("tile_bits must be in [reg_bits+1, reg_bits+10]");
+    if (cfg.reg_bits < 1 || cfg.reg_bits > 4) throw std::invalid_argument("reg_bits must be in [1, 4]");
+    if (cfg.tile_bits < cfg.reg_bits + 1 || cfg.tile_bits > cfg.reg_bits + 9)
+        throw std::invalid_argument("tile_bits must be in [reg_bits+1, reg_bits+9]");
+    if (cfg.xmode < 0 || cfg.xmode > 2) throw std::invalid_argument("xmode must be 0, 1 or 2");
     if (cfg.low_bits < 0 || cfg.low_bits > 8) throw std::invalid_argument("low_bits must be in [0, 8]");
     Geometry g;
     g.n = n;
@@ -30,7 +31,7 @@ Geometry make_geometry(int n, const PlanConfig& cfg) {
     g.threads_active = 1 << g.t;
     g.threads_launch = std::max(64, g.threads_active);
     g.blocks_per_state = 1u << (n - g.k);
-    g.lds_bytes = (size_t(1) << g.k) * size_t(cfg.elem_bytes);
+    g.lds_bytes = (size_t(1) << g.k) * size_t(cfg.amp_bytes) / (cfg.xmode == 2 ? 2 : 1);
     return g;
 }
 
@@ -42,13 +43,17 @@ struct Layout {
     std::vector<int> reg;  // reg[v] = tile bit under register bit v (ascending)
 };
 
-Layout make_layout(int k, const std::vector<int>& regbits_sorted) {
+// `last` lists tile bits that should become the HIGHEST thread bits (wave-index bits): controls of the round's
+// gates, so that the control predicate is uniform per wave and a wave whose control bit is 0 skips the gate.
+Layout make_layout(int k, const std::vector<int>& regbits_sorted, const std::vector<int>& last = {}) {
     Layout l;
     l.reg = regbits_sorted;
-    std::vector<char> is_reg(k, 0);
-    for (int b : regbits_sorted) is_reg[b] = 1;
+    std::vector<char> skip(k, 0);
+    for (int b : regbits_sorted) skip[b] = 1;
+    for (int b : last) skip[b] = 1;
     for (int b = 0; b < k; ++b)
-        if (!is_reg[b]) l.thr.push_back(b);
+        if (!skip[b]) l.thr.push_back(b);
+    for (int b : last) l.thr.push_back(b);
     return l;
 }
 
@@ -142,9 +147,9 @@ SwizzleChoice choose_swizzle(const Layout& a, const Layout& b, int k, int elem_b
     std::vector<int> key;
     key.push_back(k);
     key.push_back(elem_bytes);
-    key.insert(key.end(), a.reg.begin(), a.reg.end());
+    key.insert(key.end(), a.thr.begin(), a.thr.end());
     key.push_back(-1);
-    key.insert(key.end(), b.reg.begin(), b.reg.end());
+    key.insert(key.end(), b.thr.begin(), b.thr.end());
     {
         std::lock_guard<std::mutex> lock(mu);
         auto it = memo.find(key);
@@ -222,7 +227,7 @@ struct Blocker {
 
 struct RoundPlan {
     std::vector<int> regbits;  // tile bits, ascending
-    std::vector<int> gates;    // indices into the circuit's gate list, program order
+    std::vector<int> gates;    // indices into the real-gate list, program order
 };
 
 struct PassPlan {
@@ -230,16 +235,51 @@ struct PassPlan {
     std::vector<RoundPlan> rounds;
 };
 
+void push_angle_entry(std::vector<uint32_t>& w, const AngleSource& a) {
+    w.push_back(uint32_t(a.p_theta));
+    w.push_back(uint32_t(a.p_phi));
+    w.push_back(uint32_t(a.p_lambda));
+    for (double v : {a.theta, a.phi, a.lambda}) {
+        uint64_t bits;
+        std::memcpy(&bits, &v, 8);
+        w.push_back(uint32_t(bits & 0xffffffffu));
+        w.push_back(uint32_t(bits >> 32));
+    }
+}
+
 }  // namespace
 
-CircuitPlan build_plan(int n, const std::vector<GateIn>& gates, const PlanConfig& cfg) {
+CircuitPlan build_plan(int n, const std::vector<GateIn>& all_gates, const std::vector<AngleSource>& op_angles,
+                       const PlanConfig& cfg) {
     const Geometry geo = make_geometry(n, cfg);
     const int k = geo.k, r = geo.r, t = geo.t, c = geo.c;
-    for (const GateIn& g : gates) {
+    for (const GateIn& g : all_gates) {
         if (g.target < 0 || g.target >= n || g.control >= n || g.control == g.target)
             throw std::invalid_argument("gate qubit index out of range");
+        if (g.op < 0 || size_t(g.op) >= op_angles.size()) throw std::invalid_argument("gate op index out of range");
+    }
+    CircuitPlan out;
+
+    // ---- 1. fold leading gates into the initial product state --------------------------------------------
+    enum : char { kZero = 0, kProduct = 1, kEntangled = 2 };
+    std::vector<char> qstate(n, kZero);
+    std::vector<std::vector<int>> folds(n);  // per qubit: op indices of folded u gates, program order
+    std::vector<GateIn> gates;               // the real gates
+    for (const GateIn& g : all_gates) {
+        if (cfg.fold && g.control < 0 && qstate[g.target] != kEntangled) {
+            folds[g.target].push_back(g.op);
+            qstate[g.target] = kProduct;
+            out.stats.n_folded_gates += 1;
+        } else if (cfg.fold && g.control >= 0 && qstate[g.control] == kZero) {
+            out.stats.n_dropped_gates += 1;  // control is exactly |0>: identity
+        } else {
+            gates.push_back(g);
+            qstate[g.target] = kEntangled;
+            if (g.control >= 0) qstate[g.control] = kEntangled;
+        }
     }
 
+    // ---- 2. passes and rounds ----------------------------------------------------------------------------
     std::vector<int> default_regs;
     for (int b = k - r; b < k; ++b) default_regs.push_back(b);
 
@@ -249,7 +289,6 @@ CircuitPlan build_plan(int n, const std::vector<GateIn>& gates, const PlanConfig
 
     while (n_done < gates.size() || passes.empty()) {
         PassPlan pass;
-        // ---- choose the tile --------------------------------------------------------------------
         std::vector<char> in_tile(n, 0);
         int tile_count = 0;
         if (k == n) {
@@ -280,7 +319,6 @@ CircuitPlan build_plan(int n, const std::vector<GateIn>& gates, const PlanConfig
                     blk.defer(g);
             }
         }
-        // pad the tile with the lowest unused qubits
         for (int q = 0; q < n && tile_count < k; ++q)
             if (!in_tile[q]) {
                 in_tile[q] = 1;
@@ -293,7 +331,6 @@ CircuitPlan build_plan(int n, const std::vector<GateIn>& gates, const PlanConfig
                 pass.pos.push_back(q);
             }
 
-        // ---- split the selected gates into rounds ---------------------------------------------------
         std::vector<char> placed(selected.size(), 0);
         size_t n_placed = 0;
         bool first = true;
@@ -325,7 +362,6 @@ CircuitPlan build_plan(int n, const std::vector<GateIn>& gates, const PlanConfig
                     blk.defer(g);
                 }
             }
-            // pad the register set, highest tile bits first (keeps lanes on the low bits)
             for (int b = k - 1; b >= 0 && reg_count < r; --b)
                 if (!is_reg[b]) {
                     is_reg[b] = 1;
@@ -336,7 +372,6 @@ CircuitPlan build_plan(int n, const std::vector<GateIn>& gates, const PlanConfig
             pass.rounds.push_back(std::move(round));
             first = false;
         }
-        // the last layout doubles as the global store layout
         bool low_in_regs = false;
         for (int b : pass.rounds.back().regbits) low_in_regs |= (b < c);
         if (low_in_regs) {
@@ -348,28 +383,50 @@ CircuitPlan build_plan(int n, const std::vector<GateIn>& gates, const PlanConfig
             done[s] = 1;
             ++n_done;
         }
-        if (selected.empty() && n_done < gates.size())
-            throw std::logic_error("scheduler made no progress");  // cannot happen: the first pending gate always fits
+        if (selected.empty() && n_done < gates.size()) throw std::logic_error("scheduler made no progress");
         passes.push_back(std::move(pass));
     }
 
-    // ---- encode --------------------------------------------------------------------------------------
-    CircuitPlan out;
+    // ---- 3. encode ---------------------------------------------------------------------------------------
     std::vector<uint32_t>& w = out.words;
-    w.push_back(uint32_t(passes.size()));
-    w.push_back(uint32_t(gates.size()));
+    w.assign(kCircuitHeaderWords, 0);
+    w[0] = uint32_t(passes.size());
+    w[1] = uint32_t(gates.size());
+    w[2] = uint32_t(n);
     const size_t off_table = w.size();
     w.resize(w.size() + passes.size(), 0);
+    std::vector<int> schedule;  // real-gate indices in schedule order
 
     for (size_t pi = 0; pi < passes.size(); ++pi) {
         const PassPlan& pass = passes[pi];
         w[off_table + pi] = uint32_t(w.size());
         w.push_back(uint32_t(k) | uint32_t(r) << 8 | uint32_t(t) << 16 | uint32_t(pass.rounds.size()) << 24);
-        w.push_back(0);
+        w.push_back(uint32_t(schedule.size()));
         for (int q : pass.pos) w.push_back(uint32_t(q));
+        auto tile_bit = [&](int q) {
+            auto it = std::lower_bound(pass.pos.begin(), pass.pos.end(), q);
+            return (it != pass.pos.end() && *it == q) ? int(it - pass.pos.begin()) : -1;
+        };
 
+        // Layouts.  The first and the last one touch global memory, so their lanes stay on the lowest tile bits;
+        // layouts in between put the round's control bits on the highest thread bits (wave-uniform predicates).
         std::vector<Layout> layouts;
-        for (const RoundPlan& rd : pass.rounds) layouts.push_back(make_layout(k, rd.regbits));
+        for (size_t m = 0; m < pass.rounds.size(); ++m) {
+            const RoundPlan& rd = pass.rounds[m];
+            std::vector<int> ctrl_bits;
+            if (m > 0 && m + 1 < pass.rounds.size()) {
+                for (int gi : rd.gates) {
+                    if (gates[gi].control < 0) continue;
+                    const int cb = tile_bit(gates[gi].control);
+                    if (cb < 0 || std::find(rd.regbits.begin(), rd.regbits.end(), cb) != rd.regbits.end()) continue;
+                    if (std::find(ctrl_bits.begin(), ctrl_bits.end(), cb) == ctrl_bits.end()) ctrl_bits.push_back(cb);
+                }
+                std::sort(ctrl_bits.begin(), ctrl_bits.end());
+                const size_t wave_bits = t > 6 ? size_t(t - 6) : 0;
+                if (ctrl_bits.size() > wave_bits) ctrl_bits.resize(wave_bits);
+            }
+            layouts.push_back(make_layout(k, rd.regbits, ctrl_bits));
+        }
         auto push_global_cols = [&](const Layout& l) {
             for (int b : l.thr) w.push_back(1u << pass.pos[b]);
             for (int b : l.reg) w.push_back(1u << pass.pos[b]);
@@ -396,32 +453,47 @@ CircuitPlan build_plan(int n, const std::vector<GateIn>& gates, const PlanConfig
             for (size_t u = 0; u < lay.thr.size(); ++u) thr_index_of[lay.thr[u]] = int(u);
             for (int gi : rd.gates) {
                 const GateIn& g = gates[gi];
-                // which tile bit is this qubit?
-                auto tile_bit = [&](int q) {
-                    auto it = std::lower_bound(pass.pos.begin(), pass.pos.end(), q);
-                    return (it != pass.pos.end() && *it == q) ? int(it - pass.pos.begin()) : -1;
-                };
                 const int tb = tile_bit(g.target);
-                uint32_t cr = 0, ct = 0, cg = 0;
+                uint32_t creg = 0xFF, ct = 0, cg = 0;
                 if (g.control >= 0) {
                     const int cb = tile_bit(g.control);
                     if (cb < 0)
                         cg = 1u << g.control;
                     else if (reg_index_of[cb] >= 0)
-                        cr = 1u << reg_index_of[cb];
+                        creg = uint32_t(reg_index_of[cb]);
                     else
                         ct = 1u << thr_index_of[cb];
                 }
-                w.push_back(uint32_t(reg_index_of[tb]) | uint32_t(g.mat) << 8);
-                w.push_back(cr);
+                w.push_back(uint32_t(reg_index_of[tb]) | creg << 8);
                 w.push_back(ct);
                 w.push_back(cg);
-                out.stats.n_gates += 1;
+                w.push_back(uint32_t(g.op));
+                schedule.push_back(gi);
             }
             out.stats.n_rounds += 1;
         }
     }
+    // angle table: scheduled gates first, then the fold entries; fold index per qubit
+    w[3] = uint32_t(w.size());
+    for (int gi : schedule) push_angle_entry(w, op_angles[size_t(gates[size_t(gi)].op)]);
+    std::vector<std::pair<uint32_t, uint32_t>> fold_index(size_t(n), {0u, 0u});
+    uint32_t entry = uint32_t(schedule.size());
+    for (int q = 0; q < n; ++q) {
+        fold_index[size_t(q)] = {entry, uint32_t(folds[size_t(q)].size())};
+        for (int op : folds[size_t(q)]) {
+            push_angle_entry(w, op_angles[size_t(op)]);
+            ++entry;
+        }
+    }
+    w[4] = uint32_t(w.size());
+    w[5] = entry - uint32_t(schedule.size());
+    for (const auto& fi : fold_index) {
+        w.push_back(fi.first);
+        w.push_back(fi.second);
+    }
+    w.resize(w.size() + kPlanPadWords, 0);
     out.stats.n_passes = int(passes.size());
+    out.stats.n_real_gates = int(gates.size());
     return out;
 }
 

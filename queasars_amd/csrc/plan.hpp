@@ -1,14 +1,22 @@
 // Host-side pass scheduler for the tiled statevector kernel.  Pure C++ (no HIP): it is exercised on the CPU by
 // tests/test_plan.py through qsv_plan_build().
 //
-// Model.  A circuit is a list of single-target gates (u: no control, cu3: one control) on n qubits.  The state is
-// swept in PASSES.  A pass picks k qubits (the TILE); every workgroup owns one tile of 2^k amplitudes (the other
-// n-k index bits are fixed per workgroup) and keeps it on chip for the whole pass.  Inside a pass the tile lives
-// in registers: each of 2^t threads holds 2^r amplitudes (k = t + r).  A ROUND chooses which r tile bits are
-// "register bits"; a gate is applied in a round in which its TARGET is a register bit (a 2x2 butterfly between
-// two registers of one thread).  The CONTROL of a cu3 never has to be a register bit, nor even in the tile:
-// it is a predicate on the register index, on the thread index or on the workgroup's fixed bits.  Between rounds
-// the tile is transposed through LDS (an EXCHANGE) so that a different set of tile bits becomes register bits.
+// Model.  A circuit is a list of single-target gates (u: no control, cu3: one control) on n qubits, applied to
+// |0..0>.
+//
+// 1. FOLDING.  Leading gates are absorbed into the initial state: a qubit that no real gate has touched yet is
+//    still a tensor factor of the state, so a u gate on it only changes that factor, and a cu3 whose control has
+//    never been targeted (it is still exactly |0>) is the identity.  What remains after folding are the REAL
+//    gates; the state they act on first is the product state  (x)_q v_q,  which pass 0 synthesises on the fly
+//    instead of reading anything from memory.
+//
+// 2. PASSES.  The real gates are swept over the state in passes.  A pass picks k qubits (the TILE); every tile of
+//    2^k amplitudes (the other n-k index bits fixed) stays on chip for the whole pass.  Inside a pass the tile
+//    lives in registers: each of 2^t threads holds 2^r amplitudes (k = t + r).  A ROUND chooses which r tile bits
+//    are "register bits"; a gate is applied in a round in which its TARGET is a register bit (a 2x2 butterfly
+//    between two registers of one thread).  The CONTROL of a cu3 never has to be a register bit, nor even in the
+//    tile: it is a predicate on the register index, on the thread index or on the tile's fixed bits.  Between
+//    rounds the tile is transposed through LDS (an EXCHANGE) so that other tile bits become register bits.
 //
 // All index maps (thread/register -> global offset, thread/register -> LDS offset) are GF(2)-linear, so each is
 // shipped to the device as one column per thread bit and per register bit; the kernel XORs columns together.
@@ -22,15 +30,18 @@ namespace qsv {
 
 struct PlanConfig {
     int tile_bits = 12;  // k for n >= k
-    int reg_bits = 4;    // r
+    int reg_bits = 3;    // r
     int low_bits = 4;    // c: tile always contains qubits 0..c-1 (coalescing)
-    int elem_bytes = 16; // size of one complex amplitude in LDS (16 = fp64, 8 = fp32)
+    int elem_bytes = 16; // bytes of one LDS access of the exchange (16: complex fp64; 8: complex fp32 or one fp64 plane)
+    int amp_bytes = 16;  // bytes of one complex amplitude (16 = fp64, 8 = fp32)
+    int xmode = 0;       // LDS exchange mode (kernels.hip): 0 whole element, 1 two resident planes, 2 one plane buffer
+    bool fold = true;    // absorb leading gates into the synthesised initial product state
 };
 
 struct GateIn {
     int target;
     int control;  // -1 if none
-    int mat;      // index of the gate's 2x2 matrix in the per-evaluation matrix buffer
+    int op;       // index of the originating qsv_op (angle source)
 };
 
 // Resolved geometry for a given n (same for every circuit on the handle).
@@ -38,7 +49,7 @@ struct Geometry {
     int n = 0, k = 0, r = 0, t = 0, c = 0;
     int threads_active = 0;  // 2^t
     int threads_launch = 0;  // max(64, 2^t)
-    uint32_t blocks_per_state = 0;  // 2^(n-k)
+    uint32_t blocks_per_state = 0;  // tiles per state = 2^(n-k)
     size_t lds_bytes = 0;
 };
 Geometry make_geometry(int n_qubits, const PlanConfig& cfg);
@@ -47,29 +58,49 @@ struct PlanStats {
     int n_passes = 0;
     int n_rounds = 0;
     int n_exchanges = 0;
-    int n_gates = 0;
+    int n_real_gates = 0;
+    int n_folded_gates = 0;   // u gates absorbed into the initial product state
+    int n_dropped_gates = 0;  // cu3 gates whose control is still |0>: identity
     int lds_conflict_cycles = 0;  // extra LDS cycles per wave-instruction summed over exchanges (0 = conflict free)
 };
 
 struct CircuitPlan {
-    std::vector<uint32_t> words;  // encoded plan, see plan.cpp for the layout
+    std::vector<uint32_t> words;  // encoded plan (layout below)
     PlanStats stats;
 };
 
-// Word layout constants shared with the kernel (kernels.hip includes this header).
-// circuit: [0] n_passes  [1] n_mats  [2 .. 2+n_passes) pass offsets (words, relative to the circuit base)
-// pass:    [0] k | r<<8 | t<<16 | n_rounds<<24      [1] reserved
+// ---- encoded layout (uint32 words; offsets relative to the circuit plan's first word) -------------------------
+// circuit: [0] n_passes  [1] n_real (scheduled gates)  [2] n_qubits  [3] offset of the ANGLE TABLE
+//          [4] offset of the FOLD INDEX  [5] n_fold_entries  [6..8) reserved
+//          [8 .. 8+n_passes) pass offsets
+// pass:    [0] k | r<<8 | t<<16 | n_rounds<<24      [1] index of the pass's first scheduled gate
 //          [2 .. 2+k) tile bit j -> qubit position (ascending)
 //          then (t+r) global columns for the load layout, (t+r) for the store layout (amplitude offsets)
 //          then the rounds
 // round:   [0] n_gates | has_exchange<<16
 //          if has_exchange: (t+r) LDS write columns (previous layout), (t+r) LDS read columns (this layout),
 //                           both in ELEMENT units under the same swizzle
-//          then 4 words per gate: [0] target register bit | mat<<8   [1] ctrl mask over register index
-//                                 [2] ctrl mask over thread index     [3] ctrl mask over the global index
+//          then 4 words per gate: [0] target register bit | control register bit<<8 (0xFF: none)
+//                                 [1] ctrl mask over the thread index   [2] ctrl mask over the global index
+//                                 [3] index of the originating op (informational; the kernel does not read it)
+//          Gates are numbered in the order they appear here (the SCHEDULE ORDER); the matrix of scheduled gate s
+//          of an evaluation lives at mats[mat_base + 8 s].
+// ANGLE TABLE: 9 words per entry {p_theta, p_phi, p_lambda (int32; <0 = literal), theta, phi, lambda (3 doubles)}:
+//          first the n_real scheduled gates in schedule order, then the fold entries.
+// FOLD INDEX: per qubit q two words {first fold entry (index into the angle table), count}: the u gates folded
+//          into qubit q's initial factor, in program order.
+constexpr uint32_t kCircuitHeaderWords = 8;
 constexpr uint32_t kPassHeaderWords = 2;
 constexpr uint32_t kGateWords = 4;
+constexpr uint32_t kAngleEntryWords = 9;
+constexpr uint32_t kPlanPadWords = 16;  // readable padding after every plan (the kernel prefetches one gate ahead)
 
-CircuitPlan build_plan(int n_qubits, const std::vector<GateIn>& gates, const PlanConfig& cfg);
+struct AngleSource {
+    int32_t p_theta, p_phi, p_lambda;
+    double theta, phi, lambda;
+};
+
+CircuitPlan build_plan(int n_qubits, const std::vector<GateIn>& gates, const std::vector<AngleSource>& op_angles,
+                       const PlanConfig& cfg);
 
 }  // namespace qsv

@@ -21,9 +21,8 @@ namespace {
 thread_local std::string g_create_error;
 
 struct Circuit {
-    std::vector<qsv_op> ops;        // as registered (identity ops kept for parameter bookkeeping)
-    std::vector<int> gate_op;       // gate index -> index into ops
     int n_params = 0;
+    int n_gates = 0;                // non-identity ops
     CircuitPlan plan;
     bool uploaded = false;
     uint32_t plan_base = 0;         // word offset in the device arena
@@ -62,7 +61,10 @@ struct qsv_handle {
     DeviceBuffer d_arena;  // plans (uint32 words)
     size_t arena_used_words = 0;
     DeviceBuffer d_states;
-    DeviceBuffer d_batch;     // [EvalDesc x B][mats]
+    DeviceBuffer d_batch;     // [EvalDesc x B][parameter vectors]
+    DeviceBuffer d_mats;      // per evaluation: gate matrices in schedule order + product-state factors
+    int tiles_per_block = 1;
+    int pipeline = 0;
     DeviceBuffer d_partials;  // [B][blocks_per_state]
     DeviceBuffer d_out;       // [B]
     DeviceBuffer d_scratch;   // probabilities / converted state
@@ -106,15 +108,6 @@ int ensure(qsv_t* h, DeviceBuffer& b, size_t bytes) {
     return QSV_OK;
 }
 
-void gate_matrix(double theta, double phi, double lam, double* m) {
-    // Qiskit UGate: [[cos(t/2), -e^{i lam} sin(t/2)], [e^{i phi} sin(t/2), e^{i(phi+lam)} cos(t/2)]]
-    const double c = std::cos(theta * 0.5), s = std::sin(theta * 0.5);
-    m[0] = c;                      m[1] = 0.0;
-    m[2] = -std::cos(lam) * s;     m[3] = -std::sin(lam) * s;
-    m[4] = std::cos(phi) * s;      m[5] = std::sin(phi) * s;
-    m[6] = std::cos(phi + lam) * c; m[7] = std::sin(phi + lam) * c;
-}
-
 int validate_ops(qsv_t* h, int n, int n_ops, const qsv_op* ops, int n_params) {
     if (n_ops < 0 || (n_ops > 0 && !ops)) return fail(h, QSV_E_ARG, "ops is null");
     for (int i = 0; i < n_ops; ++i) {
@@ -130,43 +123,54 @@ int validate_ops(qsv_t* h, int n, int n_ops, const qsv_op* ops, int n_params) {
     return QSV_OK;
 }
 
-std::vector<GateIn> gates_of(const qsv_op* ops, int n_ops, std::vector<int>* gate_op) {
+std::vector<GateIn> gates_of(const qsv_op* ops, int n_ops, std::vector<AngleSource>* angles) {
     std::vector<GateIn> gates;
+    angles->clear();
     for (int i = 0; i < n_ops; ++i) {
+        angles->push_back(AngleSource{ops[i].p_theta, ops[i].p_phi, ops[i].p_lambda, ops[i].theta, ops[i].phi,
+                                      ops[i].lambda});
         if (ops[i].kind == QSV_OP_ID) continue;
         GateIn g;
         g.target = ops[i].target;
         g.control = ops[i].kind == QSV_OP_CU3 ? int(ops[i].control) : -1;
-        g.mat = int(gates.size());
+        g.op = i;
         gates.push_back(g);
-        if (gate_op) gate_op->push_back(i);
     }
     return gates;
 }
 
 PlanConfig resolve_config(const qsv_plan_config* cfg, int dtype) {
     PlanConfig pc;
-    pc.elem_bytes = dtype == QSV_F64 ? 16 : 8;
+    pc.amp_bytes = dtype == QSV_F64 ? 16 : 8;
+    if (dtype != QSV_F64) pc.xmode = 0;  // fp32: one 8-byte complex element per LDS access
+    if (const char* e = getenv("QSV_XMODE")) pc.xmode = atoi(e);
     if (const char* e = getenv("QSV_TILE_BITS")) pc.tile_bits = atoi(e);
     if (const char* e = getenv("QSV_REG_BITS")) pc.reg_bits = atoi(e);
     if (const char* e = getenv("QSV_LOW_BITS")) pc.low_bits = atoi(e);
+    if (const char* e = getenv("QSV_FOLD")) pc.fold = atoi(e) != 0;
     if (cfg) {
         if (cfg->tile_bits > 0) pc.tile_bits = cfg->tile_bits;
         if (cfg->reg_bits > 0) pc.reg_bits = cfg->reg_bits;
         if (cfg->low_bits > 0) pc.low_bits = cfg->low_bits;
+        if (cfg->exchange > 0) pc.xmode = cfg->exchange - 1;
     }
+    if (dtype != QSV_F64 && pc.xmode != 0) pc.xmode = 0;
+    pc.elem_bytes = (dtype == QSV_F64 && pc.xmode == 0) ? 16 : 8;
     return pc;
 }
 
-int register_circuit(qsv_t* h, int n_ops, const qsv_op* ops, int n_params, int* out_id) {
+int register_circuit(qsv_t* h, int n_ops, const qsv_op* ops, int n_params, int* out_id, bool fold = true) {
     int rc = validate_ops(h, h->n, n_ops, ops, n_params);
     if (rc) return rc;
     Circuit c;
-    c.ops.assign(ops, ops + n_ops);
     c.n_params = n_params;
-    std::vector<GateIn> gates = gates_of(ops, n_ops, &c.gate_op);
+    std::vector<AngleSource> angles;
+    std::vector<GateIn> gates = gates_of(ops, n_ops, &angles);
+    c.n_gates = int(gates.size());
     try {
-        c.plan = build_plan(h->n, gates, h->cfg);
+        PlanConfig pc = h->cfg;
+        pc.fold = pc.fold && fold;
+        c.plan = build_plan(h->n, gates, angles, pc);
     } catch (const std::exception& e) {
         return fail(h, QSV_E_ARG, std::string("plan: ") + e.what());
     }
@@ -232,43 +236,100 @@ struct EventPair {
     hipEvent_t a, b;
 };
 
-// Fill matrices of one evaluation into `mats` (8 doubles per gate).
-int fill_matrices(qsv_t* h, const Circuit& c, const double* params, int64_t n_params, double* mats) {
-    if (n_params < c.n_params)
-        return fail(h, QSV_E_ARG, "circuit needs " + std::to_string(c.n_params) + " parameter values, got " +
-                                      std::to_string(n_params));
-    for (size_t g = 0; g < c.gate_op.size(); ++g) {
-        const qsv_op& o = c.ops[c.gate_op[g]];
-        const double theta = o.p_theta >= 0 ? params[o.p_theta] : o.theta;
-        const double phi = o.p_phi >= 0 ? params[o.p_phi] : o.phi;
-        const double lam = o.p_lambda >= 0 ? params[o.p_lambda] : o.lambda;
-        gate_matrix(theta, phi, lam, mats + 8 * g);
+struct Staged {
+    const EvalDesc* d_evals = nullptr;
+    const double* d_params = nullptr;
+};
+
+// Stage descriptors + parameter vectors of a batch on the device and turn angles into matrices there.
+// `params_of(i)` yields (pointer, count) of evaluation i's parameter vector.
+template <typename ParamsOf>
+int stage_batch(qsv_t* h, const std::vector<Circuit*>& circs, ParamsOf params_of, Staged* out) {
+    const size_t n_evals = circs.size();
+    int rc;
+    // a growing arena invalidates earlier uploads: repeat until every plan of the batch is resident
+    for (int attempt = 0; attempt < 16; ++attempt) {
+        bool all = true;
+        for (Circuit* c : circs)
+            if ((rc = upload_plan(h, *c))) return rc;
+        for (Circuit* c : circs) all = all && c->uploaded;
+        if (all) break;
+        if (attempt == 15) return fail(h, QSV_E_DEVICE, "plan arena could not hold the batch");
     }
+    size_t total_params = 0, total_mats = 0;
+    for (size_t i = 0; i < n_evals; ++i) {
+        const auto pr = params_of(i);
+        if (pr.second < circs[i]->n_params)
+            return fail(h, QSV_E_ARG, "circuit needs " + std::to_string(circs[i]->n_params) + " parameter values, got " +
+                                          std::to_string(pr.second));
+        total_params += size_t(pr.second);
+        total_mats += mat_region_doubles(uint32_t(circs[i]->plan.stats.n_real_gates), uint32_t(h->n));
+    }
+    if (total_params >= (size_t(1) << 31) || total_mats >= (size_t(1) << 31))
+        return fail(h, QSV_E_ARG, "batch too large");
+    const size_t desc_bytes = ((sizeof(EvalDesc) * n_evals + 63) / 64) * 64;
+    const size_t bytes = desc_bytes + (total_params + 1) * sizeof(double);
+    if ((rc = ensure_host_batch(h, bytes))) return rc;
+    if ((rc = ensure(h, h->d_batch, bytes))) return rc;
+    if ((rc = ensure(h, h->d_mats, total_mats * sizeof(double)))) return rc;
+    EvalDesc* hd = static_cast<EvalDesc*>(h->h_batch);
+    double* hp = reinterpret_cast<double*>(static_cast<char*>(h->h_batch) + desc_bytes);
+    size_t pcur = 0, mcur = 0;
+    for (size_t i = 0; i < n_evals; ++i) {
+        const Circuit& c = *circs[i];
+        const auto pr = params_of(i);
+        hd[i] = EvalDesc{c.plan_base, uint32_t(mcur), uint32_t(i % size_t(h->group)), uint32_t(i), uint32_t(pcur),
+                         uint32_t(pr.second), 0, 0};
+        if (pr.second) std::memcpy(hp + pcur, pr.first, size_t(pr.second) * sizeof(double));
+        pcur += size_t(pr.second);
+        mcur += mat_region_doubles(uint32_t(c.plan.stats.n_real_gates), uint32_t(h->n));
+        h->prof.n_gates += uint64_t(c.n_gates);
+    }
+    QSV_HIP(h, hipMemcpyAsync(h->d_batch.ptr, h->h_batch, bytes, hipMemcpyHostToDevice, h->stream));
+    out->d_evals = static_cast<const EvalDesc*>(h->d_batch.ptr);
+    out->d_params = reinterpret_cast<const double*>(static_cast<const char*>(h->d_batch.ptr) + desc_bytes);
+    QSV_HIP(h, launch_prepare(static_cast<const uint32_t*>(h->d_arena.ptr), out->d_evals, out->d_params,
+                              static_cast<double*>(h->d_mats.ptr), int(n_evals), h->stream));
     return QSV_OK;
 }
 
-// Run the gate passes of `count` evaluations whose descriptors sit at d_evals (device) / evals (host mirror).
-// mode_final: kModeFinalStore and/or kModeFinalDiag.
-int run_group(qsv_t* h, const EvalDesc* d_evals, const double* d_mats, const std::vector<const Circuit*>& circs,
-              size_t first, size_t count, uint32_t mode_final) {
+unsigned chunks_per_state(const qsv_t* h) {
+    const unsigned tpb = unsigned(std::min<uint32_t>(uint32_t(h->tiles_per_block), h->geo.blocks_per_state));
+    return h->geo.blocks_per_state / tpb;
+}
+
+// Run the gate passes of evaluations [first, first+count) of a staged batch.
+int run_group(qsv_t* h, const Staged& st, const std::vector<Circuit*>& circs, size_t first, size_t count,
+              uint32_t mode) {
     int max_passes = 0;
     for (size_t i = 0; i < count; ++i) max_passes = std::max(max_passes, circs[first + i]->plan.stats.n_passes);
     PassArgs a{};
     a.plan = static_cast<const uint32_t*>(h->d_arena.ptr);
-    a.mats = d_mats;
-    a.evals = d_evals + first;
+    a.mats = static_cast<const double*>(h->d_mats.ptr);
+    a.evals = st.d_evals + first;
     a.states = h->d_states.ptr;
     a.diag = static_cast<const double*>(h->d_diag.ptr);
     a.partials = static_cast<double*>(h->d_partials.ptr);
     a.state_stride = uint64_t(1) << h->n;
-    a.mode = kModeSynthFirst | mode_final;
-    a.blocks_per_state = h->geo.blocks_per_state;
-    dim3 grid(h->geo.blocks_per_state, unsigned(count));
+    a.mode = mode;
+    const unsigned chunks = chunks_per_state(h);
+    a.tiles_per_block = h->geo.blocks_per_state / chunks;
+    a.pipeline = uint32_t(h->pipeline);
+    dim3 grid(chunks, unsigned(count));
     for (int p = 0; p < max_passes; ++p) {
         a.pass_index = uint32_t(p);
-        QSV_HIP(h, launch_pass(h->dtype, h->geo.r, grid, h->geo.threads_launch, h->geo.lds_bytes, h->stream, a));
+        QSV_HIP(h, launch_pass(h->dtype, h->geo.r, h->cfg.xmode, grid, h->geo.threads_launch, h->geo.lds_bytes, h->stream, a));
         h->prof.n_pass_launches += 1;
         h->prof.n_state_passes += count;
+    }
+    // state bytes moved: pass 0 synthesises (write only), the last pass only reads when the expectation is fused
+    const uint64_t sweep = (uint64_t(1) << h->n) * h->amp_bytes;
+    for (size_t i = 0; i < count; ++i) {
+        const int np = circs[first + i]->plan.stats.n_passes;
+        uint64_t halves = 2 * uint64_t(np);          // every pass: one read + one write ...
+        if (mode & kModeSynthFirst) halves -= 1;     // ... except that a synthesising pass 0 does not read
+        if (!(mode & kModeFinalStore)) halves -= 1;  // ... and the fused last pass does not write
+        h->prof.state_bytes += halves * sweep;
     }
     return QSV_OK;
 }
@@ -280,46 +341,11 @@ int eval_impl(qsv_t* h, int n_evals, const std::vector<Circuit*>& circs, const i
     h->prof = qsv_profile{};
     h->prof.n_evals = uint64_t(n_evals);
 
-    // ---- stage descriptors + matrices --------------------------------------------------------------
-    size_t total_gates = 0;
-    for (int i = 0; i < n_evals; ++i) total_gates += circs[i]->gate_op.size();
-    const size_t desc_bytes = ((sizeof(EvalDesc) * size_t(n_evals) + 63) / 64) * 64;
-    const size_t mats_bytes = total_gates * 8 * sizeof(double);
-    int rc = ensure_host_batch(h, desc_bytes + mats_bytes);
-    if (rc) return rc;
-    if ((rc = ensure(h, h->d_batch, desc_bytes + mats_bytes))) return rc;
-    if ((rc = ensure(h, h->d_partials, size_t(n_evals) * h->geo.blocks_per_state * sizeof(double)))) return rc;
+    int rc;
+    const unsigned chunks = chunks_per_state(h);
+    if ((rc = ensure(h, h->d_partials, size_t(n_evals) * chunks * sizeof(double)))) return rc;
     if ((rc = ensure(h, h->d_out, size_t(n_evals) * sizeof(double)))) return rc;
     if ((rc = ensure_host_out(h, size_t(n_evals)))) return rc;
-    // a growing arena invalidates earlier uploads: repeat until every plan of the batch is resident
-    for (int attempt = 0; attempt < 16; ++attempt) {
-        bool all = true;
-        for (int i = 0; i < n_evals; ++i) {
-            if ((rc = upload_plan(h, *circs[i]))) return rc;
-        }
-        for (int i = 0; i < n_evals; ++i) all = all && circs[i]->uploaded;
-        if (all) break;
-        if (attempt == 15) return fail(h, QSV_E_DEVICE, "plan arena could not hold the batch");
-    }
-
-    EvalDesc* hd = static_cast<EvalDesc*>(h->h_batch);
-    double* hm = reinterpret_cast<double*>(static_cast<char*>(h->h_batch) + desc_bytes);
-    size_t mat_cursor = 0;
-    const int G = h->group;
-    for (int i = 0; i < n_evals; ++i) {
-        const Circuit& c = *circs[i];
-        hd[i].plan_base = c.plan_base;
-        hd[i].mat_base = uint32_t(mat_cursor);
-        hd[i].state_slot = uint32_t(i % G);
-        hd[i].out_index = uint32_t(i);
-        rc = fill_matrices(h, c, params + param_offsets[i], param_offsets[i + 1] - param_offsets[i], hm + mat_cursor);
-        if (rc) return rc;
-        mat_cursor += c.gate_op.size() * 8;
-        h->prof.n_gates += c.gate_op.size();
-    }
-    QSV_HIP(h, hipMemcpyAsync(h->d_batch.ptr, h->h_batch, desc_bytes + mats_bytes, hipMemcpyHostToDevice, h->stream));
-    const EvalDesc* d_evals = static_cast<const EvalDesc*>(h->d_batch.ptr);
-    const double* d_mats = reinterpret_cast<const double*>(static_cast<const char*>(h->d_batch.ptr) + desc_bytes);
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<EventPair> pass_events, exp_events;
@@ -342,11 +368,17 @@ int eval_impl(qsv_t* h, int n_evals, const std::vector<Circuit*>& circs, const i
         QSV_HIP(h, hipEventRecord(ev0, h->stream));
     }
 
-    std::vector<const Circuit*> ccircs(circs.begin(), circs.end());
-    for (size_t first = 0; first < size_t(n_evals); first += size_t(G)) {
-        const size_t count = std::min(size_t(G), size_t(n_evals) - first);
+    Staged st;
+    rc = stage_batch(h, circs, [&](size_t i) {
+        return std::make_pair(params + param_offsets[i], int64_t(param_offsets[i + 1] - param_offsets[i]));
+    }, &st);
+    if (rc) return rc;
+
+    const size_t G = size_t(h->group);
+    for (size_t first = 0; first < size_t(n_evals); first += G) {
+        const size_t count = std::min(G, size_t(n_evals) - first);
         QSV_HIP(h, stamp(pass_events, true));
-        rc = run_group(h, d_evals, d_mats, ccircs, first, count, h->diagonal ? kModeFinalDiag : kModeFinalStore);
+        rc = run_group(h, st, circs, first, count, kModeSynthFirst | (h->diagonal ? kModeFinalDiag : kModeFinalStore));
         QSV_HIP(h, stamp(pass_events, false));
         if (rc) return rc;
         if (!h->diagonal) {
@@ -359,15 +391,15 @@ int eval_impl(qsv_t* h, int n_evals, const std::vector<Circuit*>& circs, const i
                                             h->pauli_nb, static_cast<const uint64_t*>(h->d_x.ptr),
                                             static_cast<const uint64_t*>(h->d_z.ptr),
                                             static_cast<const double*>(h->d_cre.ptr),
-                                            static_cast<const double*>(h->d_cim.ptr), d_evals + first,
+                                            static_cast<const double*>(h->d_cim.ptr), st.d_evals + first,
                                             static_cast<double*>(h->d_out.ptr), h->stream));
             QSV_HIP(h, stamp(exp_events, false));
         }
     }
     if (h->diagonal) {
         QSV_HIP(h, stamp(exp_events, true));
-        QSV_HIP(h, launch_reduce_partials(static_cast<const double*>(h->d_partials.ptr), h->geo.blocks_per_state,
-                                          n_evals, static_cast<double*>(h->d_out.ptr), h->stream));
+        QSV_HIP(h, launch_reduce_partials(static_cast<const double*>(h->d_partials.ptr), chunks, n_evals,
+                                          static_cast<double*>(h->d_out.ptr), h->stream));
         QSV_HIP(h, stamp(exp_events, false));
     }
     if (h->profiling) QSV_HIP(h, hipEventRecord(ev1, h->stream));
@@ -383,17 +415,17 @@ int eval_impl(qsv_t* h, int n_evals, const std::vector<Circuit*>& circs, const i
         for (auto& p : pass_events) {
             QSV_HIP(h, hipEventElapsedTime(&ms, p.a, p.b));
             h->prof.pass_ms += ms;
-            hipEventDestroy(p.a);
-            hipEventDestroy(p.b);
+            (void)hipEventDestroy(p.a);
+            (void)hipEventDestroy(p.b);
         }
         for (auto& p : exp_events) {
             QSV_HIP(h, hipEventElapsedTime(&ms, p.a, p.b));
             h->prof.expect_ms += ms;
-            hipEventDestroy(p.a);
-            hipEventDestroy(p.b);
+            (void)hipEventDestroy(p.a);
+            (void)hipEventDestroy(p.b);
         }
-        hipEventDestroy(ev0);
-        hipEventDestroy(ev1);
+        (void)hipEventDestroy(ev0);
+        (void)hipEventDestroy(ev1);
     }
     return QSV_OK;
 }
@@ -402,24 +434,14 @@ int eval_impl(qsv_t* h, int n_evals, const std::vector<Circuit*>& circs, const i
 int run_single_to_state(qsv_t* h, int circuit_id, const double* params, int n_params) {
     auto it = h->circuits.find(circuit_id);
     if (it == h->circuits.end()) return fail(h, QSV_E_ARG, "unknown circuit id");
-    Circuit& c = it->second;
-    int rc = upload_plan(h, c);
+    std::vector<Circuit*> cc{&it->second};
+    Staged st;
+    int rc = stage_batch(h, cc, [&](size_t) { return std::make_pair(params, int64_t(n_params)); }, &st);
     if (rc) return rc;
-    const size_t desc_bytes = 64;
-    const size_t mats_bytes = c.gate_op.size() * 8 * sizeof(double);
-    if ((rc = ensure_host_batch(h, desc_bytes + mats_bytes))) return rc;
-    if ((rc = ensure(h, h->d_batch, desc_bytes + mats_bytes))) return rc;
-    if ((rc = ensure(h, h->d_partials, size_t(h->geo.blocks_per_state) * sizeof(double)))) return rc;
-    EvalDesc* hd = static_cast<EvalDesc*>(h->h_batch);
-    double* hm = reinterpret_cast<double*>(static_cast<char*>(h->h_batch) + desc_bytes);
-    hd[0] = EvalDesc{c.plan_base, 0, 0, 0};
-    if ((rc = fill_matrices(h, c, params, n_params, hm))) return rc;
-    QSV_HIP(h, hipMemcpyAsync(h->d_batch.ptr, h->h_batch, desc_bytes + mats_bytes, hipMemcpyHostToDevice, h->stream));
-    std::vector<const Circuit*> cc{&c};
-    return run_group(h, static_cast<const EvalDesc*>(h->d_batch.ptr),
-                     reinterpret_cast<const double*>(static_cast<const char*>(h->d_batch.ptr) + desc_bytes), cc, 0, 1,
-                     kModeFinalStore);
+    if ((rc = ensure(h, h->d_partials, size_t(chunks_per_state(h)) * sizeof(double)))) return rc;
+    return run_group(h, st, cc, 0, 1, kModeSynthFirst | kModeFinalStore);
 }
+
 
 }  // namespace
 
@@ -439,7 +461,7 @@ int qsv_create(int n_qubits, int dtype, int device, const qsv_plan_config* cfg, 
     } catch (const std::exception& e) {
         return fail(nullptr, QSV_E_ARG, e.what());
     }
-    if (geo.threads_launch > 256) return fail(nullptr, QSV_E_ARG, "tile_bits - reg_bits must be <= 8");
+    if (geo.threads_launch > 512) return fail(nullptr, QSV_E_ARG, "tile_bits - reg_bits must be <= 9");
     int n_dev = 0;
     hipError_t e = hipGetDeviceCount(&n_dev);
     if (e != hipSuccess || n_dev == 0)
@@ -454,7 +476,7 @@ int qsv_create(int n_qubits, int dtype, int device, const qsv_plan_config* cfg, 
     h->device = device;
     h->cfg = pc;
     h->geo = geo;
-    h->amp_bytes = size_t(pc.elem_bytes);
+    h->amp_bytes = size_t(pc.amp_bytes);
     const size_t state_bytes = (size_t(1) << n_qubits) * h->amp_bytes;
     int group = cfg && cfg->group > 0 ? cfg->group : 0;
     if (const char* env = getenv("QSV_GROUP")) group = atoi(env);
@@ -465,6 +487,8 @@ int qsv_create(int n_qubits, int dtype, int device, const qsv_plan_config* cfg, 
         group = int(std::max<size_t>(1, std::min<size_t>(1024, budget / state_bytes)));
     }
     h->group = group;
+    if (const char* env = getenv("QSV_TILES_PER_BLOCK")) h->tiles_per_block = std::max(1, atoi(env));
+    if (const char* env = getenv("QSV_PIPELINE")) h->pipeline = atoi(env) != 0;
     auto bail = [&](hipError_t err, const char* what) {
         std::string msg = std::string(what) + ": " + hipGetErrorString(err);
         qsv_destroy(h);
@@ -474,21 +498,21 @@ int qsv_create(int n_qubits, int dtype, int device, const qsv_plan_config* cfg, 
     h->own_stream = true;
     if ((e = hipMalloc(&h->d_states.ptr, state_bytes * size_t(group))) != hipSuccess) return bail(e, "hipMalloc(states)");
     h->d_states.bytes = state_bytes * size_t(group);
-    if ((e = configure_pass_kernels(dtype, geo.r, geo.lds_bytes)) != hipSuccess) return bail(e, "hipFuncSetAttribute");
+    if ((e = configure_pass_kernels(dtype, geo.r, pc.xmode, geo.lds_bytes)) != hipSuccess) return bail(e, "hipFuncSetAttribute");
     *out = h;
     return QSV_OK;
 }
 
 void qsv_destroy(qsv_t* h) {
     if (!h) return;
-    hipSetDevice(h->device);
-    if (h->stream) hipStreamSynchronize(h->stream);
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (DeviceBuffer* b : {&h->d_x, &h->d_z, &h->d_cre, &h->d_cim, &h->d_diag, &h->d_term_partials, &h->d_arena,
-                            &h->d_states, &h->d_batch, &h->d_partials, &h->d_out, &h->d_scratch})
-        if (b->ptr) hipFree(b->ptr);
-    if (h->h_batch) hipHostFree(h->h_batch);
-    if (h->h_out) hipHostFree(h->h_out);
-    if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
+                            &h->d_states, &h->d_batch, &h->d_mats, &h->d_partials, &h->d_out, &h->d_scratch})
+        if (b->ptr) (void)hipFree(b->ptr);
+    if (h->h_batch) (void)hipHostFree(h->h_batch);
+    if (h->h_out) (void)hipHostFree(h->h_out);
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
 
@@ -500,7 +524,7 @@ int qsv_set_stream(qsv_t* h, void* hip_stream) {
     QSV_HIP(h, hipSetDevice(h->device));
     QSV_HIP(h, hipStreamSynchronize(h->stream));
     if (h->own_stream) {
-        hipStreamDestroy(h->stream);
+        (void)hipStreamDestroy(h->stream);
         h->own_stream = false;
     }
     if (hip_stream) {
@@ -683,12 +707,75 @@ int qsv_get_profile(const qsv_t* h, qsv_profile* out) {
     return QSV_OK;
 }
 
+static int bench_ops_locked(qsv_t* h, int n_ops, const qsv_op* ops, int reps, double* out_ms_per_rep,
+                            int* out_n_passes) {
+    if (!out_ms_per_rep || reps < 1) return fail(h, QSV_E_ARG, "bad arguments");
+    QSV_HIP(h, hipSetDevice(h->device));
+    int id = 0;
+    // no folding: the gates must really be applied to the resident state
+    int rc = register_circuit(h, n_ops, ops, 0, &id, /*fold=*/false);
+    if (rc) return rc;
+    Circuit& c = h->circuits.find(id)->second;
+    auto cleanup = [&]() { h->circuits.erase(id); };
+    std::vector<Circuit*> cc{&c};
+    Staged st;
+    static const double dummy = 0.0;
+    if ((rc = stage_batch(h, cc, [&](size_t) { return std::make_pair(&dummy, int64_t(0)); }, &st))) {
+        cleanup();
+        return rc;
+    }
+    PassArgs a{};
+    a.plan = static_cast<const uint32_t*>(h->d_arena.ptr);
+    a.mats = static_cast<const double*>(h->d_mats.ptr);
+    a.evals = st.d_evals;
+    a.states = h->d_states.ptr;
+    a.state_stride = uint64_t(1) << h->n;
+    a.mode = kModeFinalStore;  // read-modify-write of the resident state, no synthesis
+    const unsigned chunks = chunks_per_state(h);
+    a.tiles_per_block = h->geo.blocks_per_state / chunks;
+    a.pipeline = uint32_t(h->pipeline);
+    dim3 grid(chunks, 1);
+    const int n_passes = c.plan.stats.n_passes;
+    auto sweep = [&]() -> hipError_t {
+        for (int p = 0; p < n_passes; ++p) {
+            a.pass_index = uint32_t(p);
+            hipError_t e = launch_pass(h->dtype, h->geo.r, h->cfg.xmode, grid, h->geo.threads_launch, h->geo.lds_bytes, h->stream, a);
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
+    };
+    hipEvent_t e0, e1;
+    QSV_HIP(h, hipEventCreate(&e0));
+    QSV_HIP(h, hipEventCreate(&e1));
+    QSV_HIP(h, sweep());  // untimed: code object load, plan in cache
+    QSV_HIP(h, hipEventRecord(e0, h->stream));
+    for (int i = 0; i < reps; ++i) QSV_HIP(h, sweep());
+    QSV_HIP(h, hipEventRecord(e1, h->stream));
+    QSV_HIP(h, hipStreamSynchronize(h->stream));
+    float ms = 0.f;
+    QSV_HIP(h, hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *out_ms_per_rep = double(ms) / reps;
+    if (out_n_passes) *out_n_passes = n_passes;
+    cleanup();
+    return QSV_OK;
+}
+
+int qsv_bench_ops(qsv_t* h, int n_ops, const qsv_op* ops, int reps, double* out_ms_per_rep, int* out_n_passes) {
+    if (!h) return QSV_E_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    for (int i = 0; i < n_ops; ++i)
+        if (ops && ops[i].kind != QSV_OP_ID && (ops[i].p_theta >= 0 || ops[i].p_phi >= 0 || ops[i].p_lambda >= 0))
+            return fail(h, QSV_E_ARG, "qsv_bench_ops needs bound (literal) angles");
+    return bench_ops_locked(h, n_ops, ops, reps, out_ms_per_rep, out_n_passes);
+}
+
 int qsv_bench_gate(qsv_t* h, int target, int control, double theta, double phi, double lambda, int reps,
                    double* out_ms_per_sweep) {
     if (!h) return QSV_E_ARG;
     std::lock_guard<std::mutex> lock(h->mu);
-    if (!out_ms_per_sweep || reps < 1) return fail(h, QSV_E_ARG, "bad arguments");
-    QSV_HIP(h, hipSetDevice(h->device));
+    if (target < 0 || target >= h->n || control >= h->n) return fail(h, QSV_E_ARG, "qubit out of range");
     qsv_op op{};
     op.kind = control >= 0 ? QSV_OP_CU3 : QSV_OP_U;
     op.target = uint8_t(target);
@@ -697,49 +784,7 @@ int qsv_bench_gate(qsv_t* h, int target, int control, double theta, double phi, 
     op.theta = theta;
     op.phi = phi;
     op.lambda = lambda;
-    int id = 0;
-    int rc = register_circuit(h, 1, &op, 0, &id);
-    if (rc) return rc;
-    Circuit& c = h->circuits.find(id)->second;
-    auto cleanup = [&]() { h->circuits.erase(id); };
-    if ((rc = upload_plan(h, c))) { cleanup(); return rc; }
-    const size_t desc_bytes = 64, mats_bytes = 64;
-    if ((rc = ensure_host_batch(h, desc_bytes + mats_bytes)) || (rc = ensure(h, h->d_batch, desc_bytes + mats_bytes))) {
-        cleanup();
-        return rc;
-    }
-    EvalDesc* hd = static_cast<EvalDesc*>(h->h_batch);
-    double* hm = reinterpret_cast<double*>(static_cast<char*>(h->h_batch) + desc_bytes);
-    hd[0] = EvalDesc{c.plan_base, 0, 0, 0};
-    gate_matrix(theta, phi, lambda, hm);
-    QSV_HIP(h, hipMemcpyAsync(h->d_batch.ptr, h->h_batch, desc_bytes + mats_bytes, hipMemcpyHostToDevice, h->stream));
-    PassArgs a{};
-    a.plan = static_cast<const uint32_t*>(h->d_arena.ptr);
-    a.mats = reinterpret_cast<const double*>(static_cast<const char*>(h->d_batch.ptr) + desc_bytes);
-    a.evals = static_cast<const EvalDesc*>(h->d_batch.ptr);
-    a.states = h->d_states.ptr;
-    a.state_stride = uint64_t(1) << h->n;
-    a.mode = kModeFinalStore;  // read-modify-write of the resident state, no synthesis
-    a.blocks_per_state = h->geo.blocks_per_state;
-    a.pass_index = 0;
-    dim3 grid(h->geo.blocks_per_state, 1);
-    hipEvent_t e0, e1;
-    QSV_HIP(h, hipEventCreate(&e0));
-    QSV_HIP(h, hipEventCreate(&e1));
-    // one untimed sweep first (code object load, plan in cache)
-    QSV_HIP(h, launch_pass(h->dtype, h->geo.r, grid, h->geo.threads_launch, h->geo.lds_bytes, h->stream, a));
-    QSV_HIP(h, hipEventRecord(e0, h->stream));
-    for (int i = 0; i < reps; ++i)
-        QSV_HIP(h, launch_pass(h->dtype, h->geo.r, grid, h->geo.threads_launch, h->geo.lds_bytes, h->stream, a));
-    QSV_HIP(h, hipEventRecord(e1, h->stream));
-    QSV_HIP(h, hipStreamSynchronize(h->stream));
-    float ms = 0.f;
-    QSV_HIP(h, hipEventElapsedTime(&ms, e0, e1));
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
-    *out_ms_per_sweep = double(ms) / reps;
-    cleanup();
-    return QSV_OK;
+    return bench_ops_locked(h, 1, &op, reps, out_ms_per_sweep, nullptr);
 }
 
 int qsv_plan_build(int n_qubits, int dtype, int n_ops, const qsv_op* ops, const qsv_plan_config* cfg,
@@ -751,8 +796,9 @@ int qsv_plan_build(int n_qubits, int dtype, int n_ops, const qsv_op* ops, const 
     if (rc) return rc;
     try {
         PlanConfig pc = resolve_config(cfg, dtype);
-        std::vector<GateIn> gates = gates_of(ops, n_ops, nullptr);
-        CircuitPlan plan = build_plan(n_qubits, gates, pc);
+        std::vector<AngleSource> angles;
+        std::vector<GateIn> gates = gates_of(ops, n_ops, &angles);
+        CircuitPlan plan = build_plan(n_qubits, gates, angles, pc);
         *n_words = plan.words.size();
         if (out_words && capacity_words >= plan.words.size())
             std::memcpy(out_words, plan.words.data(), plan.words.size() * 4);

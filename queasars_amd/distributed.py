@@ -1,0 +1,57 @@
+"""Population sharding over the GPUs of one node: one process per GPU, one fitness all-gather per evaluation.
+
+The reference farms one task per individual to a thread pool or a Dask cluster
+(queasars/minimum_eigensolvers/evqe/evolutionary_algorithm/selection.py:75-85, mutation.py:206-218).  Here the
+individuals are split into contiguous blocks by population index; each rank evaluates its block on its own GPU
+with no communication, and a single all-gather of ``P / world`` doubles per rank (``backend="nccl"`` is RCCL on
+ROCm) gives every rank all P fitness values, which is what selection needs (selection.py:85, :102).  The
+collective moves a few hundred bytes: it is latency bound, xGMI bandwidth does not matter.
+"""
+
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import numpy as np
+
+
+def shard_bounds(n_items: int, world_size: int, rank: int) -> tuple[int, int]:
+    """Contiguous block [lo, hi) of ``n_items`` owned by ``rank``; the first ``n_items % world_size`` ranks get
+    one item more."""
+    if world_size < 1 or not 0 <= rank < world_size:
+        raise ValueError("bad rank / world_size")
+    base, extra = divmod(n_items, world_size)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def evaluate_population_sharded(evaluator, circuits: Sequence, parameter_values: Sequence, group=None, device=None) -> list[float]:
+    """Evaluate this rank's block of the population and all-gather the fitness values.
+
+    ``evaluator`` is any object with ``evaluate_circuits(circuits, parameter_values)``; every rank must pass the
+    same full ``circuits`` / ``parameter_values`` lists.  Returns all values, ordered by population index, on
+    every rank.  Without an initialised process group (or with world size 1) it evaluates everything locally.
+    """
+    import torch
+    import torch.distributed as dist
+
+    n = len(circuits)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return list(evaluator.evaluate_circuits(list(circuits), list(parameter_values)))
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    lo, hi = shard_bounds(n, world, rank)
+    local = evaluator.evaluate_circuits(list(circuits[lo:hi]), list(parameter_values[lo:hi])) if hi > lo else []
+    width = -(-n // world)  # every rank contributes a fixed-size slot so one all_gather_into_tensor suffices
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    send = torch.full((width,), float("nan"), dtype=torch.float64, device=device)
+    if local:
+        send[: len(local)] = torch.as_tensor(np.asarray(local, dtype=np.float64), device=device)
+    recv = torch.empty(world * width, dtype=torch.float64, device=device)
+    dist.all_gather_into_tensor(recv, send, group=group)
+    recv = recv.cpu().numpy().reshape(world, width)
+    out: list[float] = []
+    for r in range(world):
+        rlo, rhi = shard_bounds(n, world, r)
+        out.extend(float(v) for v in recv[r, : rhi - rlo])
+    return out

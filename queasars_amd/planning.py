@@ -17,11 +17,12 @@ def build_plan_words(
     tile_bits: int = 0,
     reg_bits: int = 0,
     low_bits: int = 0,
+    exchange: int = 0,
 ) -> np.ndarray:
     """Encoded pass plan (uint32 words) the scheduler produces for ``circuit``."""
     lib = _lib.load()
     ops = circuit.packed()
-    cfg = _lib.QsvPlanConfig(tile_bits, reg_bits, low_bits, 0)
+    cfg = _lib.QsvPlanConfig(tile_bits, reg_bits, low_bits, 0, exchange)
     n_words = C.c_size_t(0)
     rc = lib.qsv_plan_build(circuit.n_qubits, dtype, len(ops), _lib.as_ptr(ops), C.byref(cfg), None, 0, C.byref(n_words))
     if rc != 0:

@@ -1,0 +1,33 @@
+"""Condense rocprofv3 CSV output (kernel trace stats + PMC passes) into a short text summary."""
+import csv
+import glob
+import sys
+from collections import defaultdict
+
+root = sys.argv[1]
+
+
+def short(name: str) -> str:
+    name = name.replace("void ", "")
+    return name[:70]
+
+
+print("== kernel stats (rocprofv3 --kernel-trace --stats) ==")
+for path in glob.glob(f"{root}/trace/**/*kernel_stats.csv", recursive=True):
+    with open(path) as f:
+        rows = list(csv.DictReader(f))
+    for r in rows:
+        print(f"{short(r['Name']):72s} calls={r['Calls']:>6s} total_ns={r['TotalDurationNs']:>12s} avg_ns={float(r['AverageNs']):>10.0f} pct={r['Percentage']}")
+
+print("\n== per-kernel PMC averages per dispatch ==")
+acc = defaultdict(lambda: defaultdict(list))
+for path in glob.glob(f"{root}/pmc_*/**/*counter_collection.csv", recursive=True):
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for kern, counters in acc.items():
+    if "pass_kernel" not in kern and "reduce" not in kern and "prepare" not in kern:
+        continue
+    print(kern)
+    for cname, vals in sorted(counters.items()):
+        print(f"    {cname:28s} n={len(vals):5d} mean={sum(vals)/len(vals):16.1f}")

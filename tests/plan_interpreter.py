@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import numpy as np
 
+CIRCUIT_HEADER_WORDS = 8
 HEADER_WORDS = 2
 GATE_WORDS = 4
 
@@ -51,14 +52,43 @@ def bank_conflicts_b128(thread_cols, is_write: bool) -> int:
     return extra
 
 
+def _angle_entry(w: np.ndarray, off: int, params) -> tuple[float, float, float]:
+    idx = [int(np.int32(w[off + i])) for i in range(3)]
+    lit = np.asarray(w[off + 3 : off + 9], dtype=np.uint32).view(np.float64)
+    return tuple(float(params[i]) if i >= 0 else float(l) for i, l in zip(idx, lit))
+
+
+def _u_matrix(theta: float, phi: float, lam: float) -> np.ndarray:
+    c, s = np.cos(theta / 2), np.sin(theta / 2)
+    return np.array([[c, -np.exp(1j * lam) * s], [np.exp(1j * phi) * s, np.exp(1j * (phi + lam)) * c]])
+
+
+def bank_conflicts_b64(thread_cols, is_write: bool) -> int:
+    """Same for 8-byte-per-lane accesses: ds_write_b64 = 4 groups of 16 contiguous lanes over 16 8-B slots,
+    ds_read_b64 = 2 groups of 32 lanes over 32 8-B slots (MI355X_MICROARCH.md, LDS table)."""
+    lanes = np.arange(64, dtype=np.uint64)
+    n_lane_bits = min(6, len(thread_cols))
+    off = _xor_columns(np.asarray(thread_cols[:n_lane_bits], dtype=np.uint64), lanes)
+    active = 1 << n_lane_bits
+    size, mod = (16, 16) if is_write else (32, 32)
+    extra = 0
+    for g in range(64 // size):
+        slots = [int(off[lane]) % mod for lane in range(g * size, (g + 1) * size) if lane < active]
+        if slots:
+            extra += max(slots.count(s) for s in set(slots)) - 1
+    return extra
+
+
 def decode(words: np.ndarray) -> dict:
     w = np.asarray(words, dtype=np.uint32)
-    n_passes, n_mats = int(w[0]), int(w[1])
+    n_passes, n_real, n_qubits = int(w[0]), int(w[1]), int(w[2])
+    angle_off, fold_off, n_fold = int(w[3]), int(w[4]), int(w[5])
     passes = []
     for p in range(n_passes):
-        o = int(w[2 + p])
+        o = int(w[CIRCUIT_HEADER_WORDS + p])
         hdr = int(w[o])
         k, r, t, n_rounds = hdr & 0xFF, (hdr >> 8) & 0xFF, (hdr >> 16) & 0xFF, hdr >> 24
+        first_gate = int(w[o + 1])
         cur = o + HEADER_WORDS
         pos = [int(x) for x in w[cur : cur + k]]
         cur += k
@@ -67,6 +97,7 @@ def decode(words: np.ndarray) -> dict:
         gs = [int(x) for x in w[cur : cur + t + r]]
         cur += t + r
         rounds = []
+        sched = first_gate
         for _ in range(n_rounds):
             rh = int(w[cur])
             cur += 1
@@ -79,25 +110,45 @@ def decode(words: np.ndarray) -> dict:
                 cur += t + r
             gates = []
             for _g in range(n_gates):
-                w0, cr, ct, cg = (int(x) for x in w[cur : cur + GATE_WORDS])
+                w0, ct, cg, op = (int(x) for x in w[cur : cur + GATE_WORDS])
                 cur += GATE_WORDS
-                gates.append({"tbit": w0 & 0xFF, "mat": w0 >> 8, "cr": cr, "ct": ct, "cg": cg})
+                creg = (w0 >> 8) & 0xFF
+                gates.append({"tbit": w0 & 0xFF, "creg": None if creg == 0xFF else creg, "ct": ct, "cg": cg, "op": op, "sched": sched})
+                sched += 1
             rounds.append({"write_cols": wc, "read_cols": rc, "gates": gates})
-        passes.append({"k": k, "r": r, "t": t, "pos": pos, "load_cols": gl, "store_cols": gs, "rounds": rounds})
-    return {"n_passes": n_passes, "n_mats": n_mats, "passes": passes}
+        passes.append({"k": k, "r": r, "t": t, "pos": pos, "load_cols": gl, "store_cols": gs, "rounds": rounds, "first_gate": first_gate})
+    fold_index = [(int(w[fold_off + 2 * q]), int(w[fold_off + 2 * q + 1])) for q in range(n_qubits)]
+    return {
+        "n_passes": n_passes, "n_real": n_real, "n_qubits": n_qubits, "angle_off": angle_off, "n_fold": n_fold,
+        "fold_index": fold_index, "passes": passes, "words": w,
+    }
 
 
-def run(words: np.ndarray, n_qubits: int, mats: np.ndarray, stats: dict | None = None) -> np.ndarray:
-    """Execute the plan from |0..0>; ``mats`` is (n_gates, 8) = m00 m01 m10 m11 as (re, im) pairs."""
+def prepare(plan: dict, params) -> tuple[np.ndarray, np.ndarray]:
+    """What prepare_kernel computes: matrices of the scheduled gates and the initial product-state factors."""
+    w, off = plan["words"], plan["angle_off"]
+    mats = np.array([_u_matrix(*_angle_entry(w, off + 9 * j, params)) for j in range(plan["n_real"])]).reshape(-1, 2, 2)
+    vecs = np.zeros((plan["n_qubits"], 2), dtype=np.complex128)
+    for q, (first, count) in enumerate(plan["fold_index"]):
+        v = np.array([1.0 + 0j, 0.0 + 0j])
+        for i in range(count):
+            v = _u_matrix(*_angle_entry(w, off + 9 * (first + i), params)) @ v
+        vecs[q] = v
+    return mats, vecs
+
+
+def run(words: np.ndarray, n_qubits: int, params, stats: dict | None = None, lds_access_bytes: int = 16) -> np.ndarray:
+    """Execute the plan from |0..0> for the given flat parameter list, the way prepare_kernel + pass_kernel do."""
     plan = decode(words)
+    assert plan["n_qubits"] == n_qubits
+    mats, vecs = prepare(plan, params)
     dim = 1 << n_qubits
     state = np.zeros(dim, dtype=np.complex128)
+    all_gates = [g for ps in plan["passes"] for rd in ps["rounds"] for g in rd["gates"]]
+    assert [g["sched"] for g in all_gates] == list(range(plan["n_real"])), "schedule order must be contiguous"
     if stats is not None:
-        stats.update({"passes": plan["n_passes"], "rounds": 0, "exchanges": 0, "gates": 0, "conflicts": 0})
-    scheduled = sorted(g["mat"] for ps in plan["passes"] for rd in ps["rounds"] for g in rd["gates"])
-    assert scheduled == list(range(plan["n_mats"])), "every gate must be scheduled exactly once"
-    if stats is not None:
-        stats["gates"] = len(scheduled)
+        stats.update({"passes": plan["n_passes"], "rounds": 0, "exchanges": 0, "gates": plan["n_real"],
+                      "folded": plan["n_fold"], "conflicts": 0, "wave_uniform_ctrl": 0, "lane_ctrl": 0})
     for pi, ps in enumerate(plan["passes"]):
         k, r, t = ps["k"], ps["r"], ps["t"]
         assert k == t + r and k <= n_qubits
@@ -117,7 +168,6 @@ def run(words: np.ndarray, n_qubits: int, mats: np.ndarray, stats: dict | None =
             flat = np.sort(gmap.reshape(-1))
             assert len(np.unique(flat)) == n_thr * n_reg, "global index map is not injective"
             assert np.all((flat & ~np.uint64(tile_mask)) == 0), "global offsets leave the tile"
-        # per-exchange index maps (same for every workgroup)
         lds_maps = []
         for rd in ps["rounds"]:
             if rd["write_cols"] is None:
@@ -130,16 +180,24 @@ def run(words: np.ndarray, n_qubits: int, mats: np.ndarray, stats: dict | None =
             lds_maps.append((wmap, rmap))
             if stats is not None:
                 stats["exchanges"] += 1
-                stats["conflicts"] += bank_conflicts_b128(rd["write_cols"][:t], True)
-                stats["conflicts"] += bank_conflicts_b128(rd["read_cols"][:t], False)
+                model = bank_conflicts_b128 if lds_access_bytes == 16 else bank_conflicts_b64
+                stats["conflicts"] += model(rd["write_cols"][:t], True)
+                stats["conflicts"] += model(rd["read_cols"][:t], False)
         if stats is not None:
             stats["rounds"] += len(ps["rounds"])
+            for rd in ps["rounds"]:
+                for g in rd["gates"]:
+                    if g["ct"]:
+                        stats["wave_uniform_ctrl" if (g["ct"] & 63) == 0 else "lane_ctrl"] += 1
 
         new_state = state.copy()
         for b in range(1 << (n_qubits - k)):
             base = _insert_zeros(b, ps["pos"])
             if pi == 0:
-                amp = np.where((g_load == 0) & (base == 0), 1.0 + 0j, 0.0 + 0j).astype(np.complex128)
+                gidx = (np.uint64(base) + g_load).astype(np.int64)
+                amp = np.ones(gidx.shape, dtype=np.complex128)
+                for q in range(n_qubits):
+                    amp = amp * np.where((gidx >> q) & 1, vecs[q, 1], vecs[q, 0])
             else:
                 amp = state[(np.uint64(base) + g_load).astype(np.int64)]
             for rd, maps in zip(ps["rounds"], lds_maps):
@@ -151,17 +209,16 @@ def run(words: np.ndarray, n_qubits: int, mats: np.ndarray, stats: dict | None =
                 for g in rd["gates"]:
                     if (base & g["cg"]) != g["cg"]:
                         continue
-                    m = mats[g["mat"]]
-                    m00, m01 = complex(m[0], m[1]), complex(m[2], m[3])
-                    m10, m11 = complex(m[4], m[5]), complex(m[6], m[7])
+                    m = mats[g["sched"]]
                     bit = 1 << g["tbit"]
+                    cbit = 0 if g["creg"] is None else 1 << g["creg"]
                     lane_on = (np.arange(n_thr) & g["ct"]) == g["ct"]
                     for e0 in range(n_reg):
-                        if e0 & bit or (e0 & g["cr"]) != g["cr"]:
+                        if e0 & bit or (e0 & cbit) != cbit:
                             continue
                         a0, a1 = amp[:, e0].copy(), amp[:, e0 | bit].copy()
-                        amp[:, e0] = np.where(lane_on, m00 * a0 + m01 * a1, a0)
-                        amp[:, e0 | bit] = np.where(lane_on, m10 * a0 + m11 * a1, a1)
+                        amp[:, e0] = np.where(lane_on, m[0, 0] * a0 + m[0, 1] * a1, a0)
+                        amp[:, e0 | bit] = np.where(lane_on, m[1, 0] * a0 + m[1, 1] * a1, a1)
             new_state[(np.uint64(base) + g_store).astype(np.int64)] = amp
         state = new_state
     return state

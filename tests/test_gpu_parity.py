@@ -28,7 +28,18 @@ def test_statevector_matches_oracle(n_qubits, n_layers):
         assert np.abs(got - ref).max() < AMP_TOL
 
 
-@pytest.mark.parametrize("cfg", [dict(tile_bits=10, reg_bits=3, low_bits=3), dict(tile_bits=11, reg_bits=4, low_bits=4), dict(tile_bits=9, reg_bits=2, low_bits=2), dict(tile_bits=12, reg_bits=5, low_bits=4)])
+@pytest.mark.parametrize(
+    "cfg",
+    [
+        dict(tile_bits=10, reg_bits=3, low_bits=3),
+        dict(tile_bits=11, reg_bits=4, low_bits=4),
+        dict(tile_bits=9, reg_bits=2, low_bits=2),
+        dict(tile_bits=12, reg_bits=4, low_bits=2),
+        dict(tile_bits=12, reg_bits=3, exchange=2),
+        dict(tile_bits=12, reg_bits=3, exchange=3),
+        dict(tile_bits=11, reg_bits=2, exchange=3, group=2),
+    ],
+)
 def test_statevector_other_geometries(cfg):
     n_qubits = 14
     _, circuits, params = helpers.population_circuits(n_qubits, 3, 3, seed=5)

@@ -1,0 +1,108 @@
+"""Pass scheduler checked on the CPU: plans from qsv_plan_build() are executed by tests/plan_interpreter.py
+(a NumPy model of the kernel) and compared with the oracle."""
+
+import numpy as np
+import pytest
+
+import helpers
+import plan_interpreter as pi
+from queasars_amd.ir import CircuitIR, ParamRef
+from queasars_amd.planning import build_plan_words
+
+GEOMETRIES = [
+    {},
+    dict(tile_bits=10, reg_bits=3, low_bits=3),
+    dict(tile_bits=11, reg_bits=4, low_bits=4),
+    dict(tile_bits=12, reg_bits=4, low_bits=2),
+    dict(tile_bits=9, reg_bits=2, low_bits=2),
+    dict(tile_bits=8, reg_bits=1, low_bits=1),
+]
+
+
+@pytest.mark.parametrize("n_qubits,n_layers", [(1, 2), (2, 3), (3, 2), (5, 4), (7, 2), (8, 3), (10, 3), (12, 4), (13, 3), (14, 3)])
+def test_default_plans_reproduce_the_circuit(n_qubits, n_layers):
+    _, circuits, params = helpers.population_circuits(n_qubits, n_layers, 3, seed=7)
+    for c, p in zip(circuits, params):
+        stats = {}
+        got = pi.run(build_plan_words(c), n_qubits, p, stats)
+        assert np.abs(got - helpers.oracle_state(c, p)).max() < 1e-13
+        assert stats["conflicts"] == 0, "LDS exchanges must be bank-conflict free"
+
+
+@pytest.mark.parametrize("cfg", GEOMETRIES[1:])
+@pytest.mark.parametrize("exchange", [1, 3])
+def test_other_geometries(cfg, exchange):
+    n_qubits = 13
+    _, circuits, params = helpers.population_circuits(n_qubits, 3, 2, seed=3)
+    for c, p in zip(circuits, params):
+        stats = {}
+        got = pi.run(build_plan_words(c, exchange=exchange, **cfg), n_qubits, p, stats, lds_access_bytes=16 if exchange == 1 else 8)
+        assert np.abs(got - helpers.oracle_state(c, p)).max() < 1e-13
+        assert stats["conflicts"] == 0
+
+
+def test_partially_parameterised_circuit_and_literals():
+    pop, _, _ = helpers.population_circuits(9, 3, 2, seed=1)
+    for ind in pop.individuals:
+        for layer in range(3):
+            c = ind.get_partially_parameterized_quantum_circuit({layer})
+            vals = list(ind.get_layer_parameter_values(layer))
+            got = pi.run(build_plan_words(c), 9, vals)
+            assert np.abs(got - helpers.oracle_state(c, vals)).max() < 1e-13
+
+
+def test_folding_rules():
+    """u gates before any entangling gate fold into the product state; cu3 with an untouched control is dropped."""
+    n = 4
+    c = CircuitIR(n)
+    c.u(0.3, 0.2, 0.1, 0).u(1.0, 0.5, 0.25, 0)          # both fold into qubit 0
+    c.cu3(0.7, 0.1, 0.2, 2, 1)                            # control 2 still |0>: identity, dropped
+    c.cu3(0.9, 0.3, 0.4, 0, 1)                            # real: control 0 is in superposition
+    c.u(0.5, 0.6, 0.7, 0)                                  # qubit 0 is entangled now: real
+    c.u(ParamRef(0), ParamRef(1), ParamRef(2), 3)          # untouched qubit: folds even this late
+    c.id(2)
+    params = [0.11, 0.22, 0.33]
+    plan = pi.decode(build_plan_words(c))
+    assert plan["n_real"] == 2 and plan["n_fold"] == 3
+    assert [cnt for _, cnt in plan["fold_index"]] == [2, 0, 0, 1]
+    got = pi.run(build_plan_words(c), n, params)
+    assert np.abs(got - helpers.oracle_state(c, params)).max() < 1e-14
+
+
+def test_empty_and_identity_only_circuits():
+    for c in (CircuitIR(3), CircuitIR(3).id(0).id(2)):
+        got = pi.run(build_plan_words(c), 3, [])
+        assert got[0] == 1 and np.count_nonzero(got) == 1
+
+
+def test_every_gate_scheduled_once_in_dependency_order():
+    n = 14
+    _, circuits, params = helpers.population_circuits(n, 4, 3, seed=11)
+    for c in circuits:
+        plan = pi.decode(build_plan_words(c, tile_bits=10, reg_bits=3, low_bits=3))
+        ops = c.packed()
+        order = [g["op"] for ps in plan["passes"] for rd in ps["rounds"] for g in rd["gates"]]
+        assert len(order) == len(set(order)) == plan["n_real"]
+        seen_at = {op: i for i, op in enumerate(order)}
+        # two real gates that touch a common qubit (other than as shared control) keep their program order
+        for i in order:
+            for j in order:
+                if i >= j:
+                    continue
+                a, b = ops[i], ops[j]
+                qa = {int(a["target"])} | ({int(a["control"])} if a["kind"] == 2 else set())
+                qb = {int(b["target"])} | ({int(b["control"])} if b["kind"] == 2 else set())
+                shared = qa & qb
+                commuting_share = shared and all(
+                    q != a["target"] and q != b["target"] for q in shared
+                )
+                if shared and not commuting_share:
+                    assert seen_at[i] < seen_at[j]
+
+
+def test_plan_build_rejects_bad_input():
+    c = CircuitIR(4).u(0.1, 0.2, 0.3, 1)
+    with pytest.raises(ValueError):
+        build_plan_words(c, tile_bits=3, reg_bits=4)
+    with pytest.raises(ValueError):
+        build_plan_words(c, reg_bits=7)
