@@ -113,6 +113,19 @@ int qsv_circuit_destroy(qsv_t* h, int circuit_id);
 int qsv_eval_circuits(qsv_t* h, int n_evals, const int* circuit_ids, const int64_t* param_offsets,
                       const double* params, double* out_expectations);
 
+/*
+ * Streaming form of qsv_eval_circuits, for callers whose parameter vectors become available (or are converted)
+ * piecemeal: qsv_eval_begin lays the batch out, each qsv_eval_push ships the packed parameter values of evaluations
+ * [first, first+count) and launches them asynchronously, qsv_eval_end waits and returns all results.  Pushes must be
+ * in order and cover whole launch groups (count a multiple of the group size, except for the last push).  The
+ * handle is locked from begin to end; end must be called even after a failed push.
+ */
+int qsv_eval_begin(qsv_t* h, int n_evals, const int* circuit_ids, const int64_t* param_counts);
+int qsv_eval_push(qsv_t* h, int first, int count, const double* values);
+int qsv_eval_end(qsv_t* h, double* out_expectations);
+/* Launch-group size of the handle (evaluations whose states are resident at the same time). */
+int qsv_group_size(const qsv_t* h);
+
 /* Same, with the op lists passed inline (circuit i = ops[op_offsets[i] .. op_offsets[i+1])). */
 int qsv_eval_batch(qsv_t* h, int n_evals, const int64_t* op_offsets, const qsv_op* ops,
                    const int64_t* param_offsets, const double* params, double* out_expectations);

@@ -34,6 +34,14 @@ typedef struct {
 static inline cplx cmul(cplx a, cplx b) { return (cplx){a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
 static inline cplx cadd(cplx a, cplx b) { return (cplx){a.re + b.re, a.im + b.im}; }
 
+void qsvo_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 int qsvo_max_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -68,6 +68,10 @@ SIGNATURES = {
     "qsv_circuit_create": (C.c_int, [_P, C.c_int, _P, C.c_int, C.POINTER(C.c_int)]),
     "qsv_circuit_destroy": (C.c_int, [_P, C.c_int]),
     "qsv_eval_circuits": (C.c_int, [_P, C.c_int, _P, _P, _P, _P]),
+    "qsv_eval_begin": (C.c_int, [_P, C.c_int, _P, _P]),
+    "qsv_eval_push": (C.c_int, [_P, C.c_int, C.c_int, _P]),
+    "qsv_eval_end": (C.c_int, [_P, _P]),
+    "qsv_group_size": (C.c_int, [_P]),
     "qsv_eval_batch": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P]),
     "qsv_statevector": (C.c_int, [_P, C.c_int, _P, C.c_int, _P]),
     "qsv_probabilities": (C.c_int, [_P, C.c_int, _P, C.c_int, _P]),

@@ -24,6 +24,7 @@ from __future__ import annotations
 import ctypes as C
 import threading
 import weakref
+from itertools import chain
 from abc import ABC, abstractmethod
 from typing import Optional, Sequence
 
@@ -89,6 +90,8 @@ class StatevectorDevice:
             raise CircuitEvaluatorException(f"qsv_create failed: {msg}")
         self._n_qubits = int(n_qubits)
         self._dtype = dtype
+        self._group = max(1, int(self._lib.qsv_group_size(self._handle)))
+        self._push_groups = 1  # launch groups per qsv_eval_push
         self._operator: Optional[PauliOperator] = None
         self._reg_lock = threading.Lock()
         self._token = object()
@@ -174,24 +177,43 @@ class StatevectorDevice:
             device._lib.qsv_circuit_destroy(device._handle, cid)
 
     def expectation_values(self, circuits: Sequence[CircuitIR], parameter_values: Sequence[Sequence[float]]) -> np.ndarray:
+        """Exact ``real(<psi_i|H|psi_i>)`` for every (circuit, parameter vector) pair, in input order.
+
+        Parameter vectors are converted to doubles one launch group at a time and pushed to the device as they
+        become ready (``qsv_eval_begin / push / end``), so the conversion of the next group overlaps the GPU work
+        on the previous one."""
         n = len(circuits)
         if len(parameter_values) != n:
             raise ValueError("circuits and parameter_values must have the same length")
         if n == 0:
             return np.zeros(0, dtype=np.float64)
         ids = np.fromiter((self.circuit_id(c) for c in circuits), dtype=np.int32, count=n)
-        offsets = np.zeros(n + 1, dtype=np.int64)
-        for i, (c, p) in enumerate(zip(circuits, parameter_values)):
-            if len(p) < c.num_parameters:
-                raise ValueError(f"circuit {i} needs {c.num_parameters} parameter values, got {len(p)}")
-            offsets[i + 1] = offsets[i] + len(p)
-        flat = np.empty(max(int(offsets[-1]), 1), dtype=np.float64)
-        for i, p in enumerate(parameter_values):
-            flat[offsets[i] : offsets[i + 1]] = p
+        counts = np.fromiter((len(p) for p in parameter_values), dtype=np.int64, count=n)
+        for i, c in enumerate(circuits):
+            if counts[i] < c.num_parameters:
+                raise ValueError(f"circuit {i} needs {c.num_parameters} parameter values, got {counts[i]}")
         out = np.empty(n, dtype=np.float64)
-        self._check(
-            self._lib.qsv_eval_circuits(self._handle, n, _lib.as_ptr(ids), _lib.as_ptr(offsets), _lib.as_ptr(flat), _lib.as_ptr(out))
-        )
+        lib, handle = self._lib, self._handle
+        self._check(lib.qsv_eval_begin(handle, n, _lib.as_ptr(ids), _lib.as_ptr(counts)))
+        rc = _lib.QSV_OK
+        try:
+            step = self._group * max(1, self._push_groups)
+            for first in range(0, n, step):
+                chunk = parameter_values[first : first + step]
+                total = int(counts[first : first + step].sum())
+                if total:
+                    values = np.fromiter(chain.from_iterable(chunk), dtype=np.float64, count=total)
+                    rc = lib.qsv_eval_push(handle, first, len(chunk), _lib.as_ptr(values))
+                else:
+                    rc = lib.qsv_eval_push(handle, first, len(chunk), None)
+                if rc != _lib.QSV_OK:
+                    break
+        finally:
+            msg = _lib.last_error(lib, handle) if rc != _lib.QSV_OK else ""
+            rc_end = lib.qsv_eval_end(handle, _lib.as_ptr(out))
+        if rc != _lib.QSV_OK:
+            raise (ValueError if rc == _lib.QSV_E_ARG else CircuitEvaluatorException)(msg)
+        self._check(rc_end)
         return out
 
     def statevector(self, circuit: CircuitIR, parameter_values: Sequence[float]) -> np.ndarray:

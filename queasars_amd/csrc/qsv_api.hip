@@ -73,6 +73,19 @@ struct qsv_handle {
     double* h_out = nullptr;  // pinned
     size_t h_out_count = 0;
 
+    // streaming evaluation (qsv_eval_begin / push / end)
+    struct Batch {
+        bool open = false;
+        std::vector<Circuit*> circs;
+        std::vector<uint32_t> param_base;  // per evaluation, in doubles
+        std::vector<uint32_t> n_params;
+        size_t desc_bytes = 0;
+        size_t pushed = 0;                 // evaluations launched so far
+        std::vector<std::pair<hipEvent_t, hipEvent_t>> pass_events, exp_events;
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    } batch;
+    std::unique_lock<std::mutex> batch_lock;  // held from begin to end
+
     // profiling
     bool profiling = false;
     qsv_profile prof{};
@@ -236,15 +249,13 @@ struct EventPair {
     hipEvent_t a, b;
 };
 
-struct Staged {
-    const EvalDesc* d_evals = nullptr;
-    const double* d_params = nullptr;
-};
+// ---- batches ---------------------------------------------------------------------------------------------
+// A batch is laid out once (descriptors, parameter offsets, matrix regions), then evaluations are PUSHED in
+// group-aligned slices: each push ships that slice's parameter values, turns them into matrices on the device and
+// launches the slice's gate passes, all asynchronously, so the host can prepare the next slice meanwhile.
 
-// Stage descriptors + parameter vectors of a batch on the device and turn angles into matrices there.
-// `params_of(i)` yields (pointer, count) of evaluation i's parameter vector.
-template <typename ParamsOf>
-int stage_batch(qsv_t* h, const std::vector<Circuit*>& circs, ParamsOf params_of, Staged* out) {
+int batch_layout(qsv_t* h, const std::vector<Circuit*>& circs, const std::vector<int64_t>& n_params) {
+    qsv_handle::Batch& b = h->batch;
     const size_t n_evals = circs.size();
     int rc;
     // a growing arena invalidates earlier uploads: repeat until every plan of the batch is resident
@@ -258,38 +269,56 @@ int stage_batch(qsv_t* h, const std::vector<Circuit*>& circs, ParamsOf params_of
     }
     size_t total_params = 0, total_mats = 0;
     for (size_t i = 0; i < n_evals; ++i) {
-        const auto pr = params_of(i);
-        if (pr.second < circs[i]->n_params)
+        if (n_params[i] < circs[i]->n_params)
             return fail(h, QSV_E_ARG, "circuit needs " + std::to_string(circs[i]->n_params) + " parameter values, got " +
-                                          std::to_string(pr.second));
-        total_params += size_t(pr.second);
+                                          std::to_string(n_params[i]));
+        total_params += size_t(n_params[i]);
         total_mats += mat_region_doubles(uint32_t(circs[i]->plan.stats.n_real_gates), uint32_t(h->n));
     }
     if (total_params >= (size_t(1) << 31) || total_mats >= (size_t(1) << 31))
         return fail(h, QSV_E_ARG, "batch too large");
-    const size_t desc_bytes = ((sizeof(EvalDesc) * n_evals + 63) / 64) * 64;
-    const size_t bytes = desc_bytes + (total_params + 1) * sizeof(double);
+    b.desc_bytes = ((sizeof(EvalDesc) * n_evals + 63) / 64) * 64;
+    const size_t bytes = b.desc_bytes + (total_params + 1) * sizeof(double);
     if ((rc = ensure_host_batch(h, bytes))) return rc;
     if ((rc = ensure(h, h->d_batch, bytes))) return rc;
     if ((rc = ensure(h, h->d_mats, total_mats * sizeof(double)))) return rc;
     EvalDesc* hd = static_cast<EvalDesc*>(h->h_batch);
-    double* hp = reinterpret_cast<double*>(static_cast<char*>(h->h_batch) + desc_bytes);
+    b.circs = circs;
+    b.param_base.resize(n_evals);
+    b.n_params.resize(n_evals);
     size_t pcur = 0, mcur = 0;
     for (size_t i = 0; i < n_evals; ++i) {
         const Circuit& c = *circs[i];
-        const auto pr = params_of(i);
         hd[i] = EvalDesc{c.plan_base, uint32_t(mcur), uint32_t(i % size_t(h->group)), uint32_t(i), uint32_t(pcur),
-                         uint32_t(pr.second), 0, 0};
-        if (pr.second) std::memcpy(hp + pcur, pr.first, size_t(pr.second) * sizeof(double));
-        pcur += size_t(pr.second);
+                         uint32_t(n_params[i]), 0, 0};
+        b.param_base[i] = uint32_t(pcur);
+        b.n_params[i] = uint32_t(n_params[i]);
+        pcur += size_t(n_params[i]);
         mcur += mat_region_doubles(uint32_t(c.plan.stats.n_real_gates), uint32_t(h->n));
         h->prof.n_gates += uint64_t(c.n_gates);
     }
-    QSV_HIP(h, hipMemcpyAsync(h->d_batch.ptr, h->h_batch, bytes, hipMemcpyHostToDevice, h->stream));
-    out->d_evals = static_cast<const EvalDesc*>(h->d_batch.ptr);
-    out->d_params = reinterpret_cast<const double*>(static_cast<const char*>(h->d_batch.ptr) + desc_bytes);
-    QSV_HIP(h, launch_prepare(static_cast<const uint32_t*>(h->d_arena.ptr), out->d_evals, out->d_params,
-                              static_cast<double*>(h->d_mats.ptr), int(n_evals), h->stream));
+    QSV_HIP(h, hipMemcpyAsync(h->d_batch.ptr, h->h_batch, b.desc_bytes, hipMemcpyHostToDevice, h->stream));
+    b.pushed = 0;
+    return QSV_OK;
+}
+
+const EvalDesc* batch_evals(const qsv_t* h) { return static_cast<const EvalDesc*>(h->d_batch.ptr); }
+
+// Ship the parameter values of evaluations [first, first+count) (packed back to back in `values`) and prepare
+// their matrices.
+int batch_ship(qsv_t* h, size_t first, size_t count, const double* values) {
+    qsv_handle::Batch& b = h->batch;
+    if (count == 0) return QSV_OK;
+    const size_t p0 = b.param_base[first];
+    const size_t p1 = size_t(b.param_base[first + count - 1]) + b.n_params[first + count - 1];
+    double* hp = reinterpret_cast<double*>(static_cast<char*>(h->h_batch) + b.desc_bytes);
+    double* dp = reinterpret_cast<double*>(static_cast<char*>(h->d_batch.ptr) + b.desc_bytes);
+    if (p1 > p0) {
+        std::memcpy(hp + p0, values, (p1 - p0) * sizeof(double));
+        QSV_HIP(h, hipMemcpyAsync(dp + p0, hp + p0, (p1 - p0) * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    }
+    QSV_HIP(h, launch_prepare(static_cast<const uint32_t*>(h->d_arena.ptr), batch_evals(h) + first, dp,
+                              static_cast<double*>(h->d_mats.ptr), int(count), h->stream));
     return QSV_OK;
 }
 
@@ -298,15 +327,14 @@ unsigned chunks_per_state(const qsv_t* h) {
     return h->geo.blocks_per_state / tpb;
 }
 
-// Run the gate passes of evaluations [first, first+count) of a staged batch.
-int run_group(qsv_t* h, const Staged& st, const std::vector<Circuit*>& circs, size_t first, size_t count,
-              uint32_t mode) {
+// Run the gate passes of evaluations [first, first+count) of the current batch (one launch group).
+int run_group(qsv_t* h, const std::vector<Circuit*>& circs, size_t first, size_t count, uint32_t mode) {
     int max_passes = 0;
     for (size_t i = 0; i < count; ++i) max_passes = std::max(max_passes, circs[first + i]->plan.stats.n_passes);
     PassArgs a{};
     a.plan = static_cast<const uint32_t*>(h->d_arena.ptr);
     a.mats = static_cast<const double*>(h->d_mats.ptr);
-    a.evals = st.d_evals + first;
+    a.evals = batch_evals(h) + first;
     a.states = h->d_states.ptr;
     a.diag = static_cast<const double*>(h->d_diag.ptr);
     a.partials = static_cast<double*>(h->d_partials.ptr);
@@ -334,100 +362,144 @@ int run_group(qsv_t* h, const Staged& st, const std::vector<Circuit*>& circs, si
     return QSV_OK;
 }
 
-int eval_impl(qsv_t* h, int n_evals, const std::vector<Circuit*>& circs, const int64_t* param_offsets,
-              const double* params, double* out) {
-    if (n_evals == 0) return QSV_OK;
+hipError_t stamp(qsv_t* h, std::vector<std::pair<hipEvent_t, hipEvent_t>>& list, bool begin) {
+    if (!h->profiling) return hipSuccess;
+    if (begin) {
+        std::pair<hipEvent_t, hipEvent_t> p{nullptr, nullptr};
+        hipError_t e = hipEventCreate(&p.first);
+        if (e != hipSuccess) return e;
+        e = hipEventCreate(&p.second);
+        if (e != hipSuccess) return e;
+        list.push_back(p);
+        return hipEventRecord(p.first, h->stream);
+    }
+    return hipEventRecord(list.back().second, h->stream);
+}
+
+int eval_begin(qsv_t* h, const std::vector<Circuit*>& circs, const std::vector<int64_t>& n_params) {
     if (h->n_terms == 0) return fail(h, QSV_E_STATE, "no operator set (call qsv_set_operator first)");
     h->prof = qsv_profile{};
-    h->prof.n_evals = uint64_t(n_evals);
-
+    h->prof.n_evals = uint64_t(circs.size());
     int rc;
-    const unsigned chunks = chunks_per_state(h);
-    if ((rc = ensure(h, h->d_partials, size_t(n_evals) * chunks * sizeof(double)))) return rc;
-    if ((rc = ensure(h, h->d_out, size_t(n_evals) * sizeof(double)))) return rc;
-    if ((rc = ensure_host_out(h, size_t(n_evals)))) return rc;
-
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    std::vector<EventPair> pass_events, exp_events;
-    auto stamp = [&](std::vector<EventPair>& list, bool begin) -> hipError_t {
-        if (!h->profiling) return hipSuccess;
-        if (begin) {
-            EventPair p{};
-            hipError_t e = hipEventCreate(&p.a);
-            if (e != hipSuccess) return e;
-            e = hipEventCreate(&p.b);
-            if (e != hipSuccess) return e;
-            list.push_back(p);
-            return hipEventRecord(p.a, h->stream);
-        }
-        return hipEventRecord(list.back().b, h->stream);
-    };
+    const size_t n_evals = circs.size();
+    if ((rc = ensure(h, h->d_partials, std::max<size_t>(1, n_evals) * chunks_per_state(h) * sizeof(double)))) return rc;
+    if ((rc = ensure(h, h->d_out, std::max<size_t>(1, n_evals) * sizeof(double)))) return rc;
+    if ((rc = ensure_host_out(h, std::max<size_t>(1, n_evals)))) return rc;
     if (h->profiling) {
-        QSV_HIP(h, hipEventCreate(&ev0));
-        QSV_HIP(h, hipEventCreate(&ev1));
-        QSV_HIP(h, hipEventRecord(ev0, h->stream));
+        QSV_HIP(h, hipEventCreate(&h->batch.ev0));
+        QSV_HIP(h, hipEventCreate(&h->batch.ev1));
+        QSV_HIP(h, hipEventRecord(h->batch.ev0, h->stream));
     }
+    return batch_layout(h, circs, n_params);
+}
 
-    Staged st;
-    rc = stage_batch(h, circs, [&](size_t i) {
-        return std::make_pair(params + param_offsets[i], int64_t(param_offsets[i + 1] - param_offsets[i]));
-    }, &st);
-    if (rc) return rc;
-
+int eval_push(qsv_t* h, size_t first, size_t count, const double* values) {
+    qsv_handle::Batch& b = h->batch;
+    if (first != b.pushed) return fail(h, QSV_E_STATE, "evaluations must be pushed in order");
+    if (first + count > b.circs.size()) return fail(h, QSV_E_ARG, "push exceeds the batch");
     const size_t G = size_t(h->group);
-    for (size_t first = 0; first < size_t(n_evals); first += G) {
-        const size_t count = std::min(G, size_t(n_evals) - first);
-        QSV_HIP(h, stamp(pass_events, true));
-        rc = run_group(h, st, circs, first, count, kModeSynthFirst | (h->diagonal ? kModeFinalDiag : kModeFinalStore));
-        QSV_HIP(h, stamp(pass_events, false));
-        if (rc) return rc;
+    if (first % G != 0 || (count % G != 0 && first + count != b.circs.size()))
+        return fail(h, QSV_E_ARG, "a push must cover whole launch groups (multiples of the group size)");
+    int rc = batch_ship(h, first, count, values);
+    if (rc) return rc;
+    const uint32_t mode = kModeSynthFirst | (h->diagonal ? kModeFinalDiag : kModeFinalStore);
+    if (h->diagonal) QSV_HIP(h, stamp(h, b.pass_events, true));
+    for (size_t g0 = first; g0 < first + count; g0 += G) {
+        const size_t gc = std::min(G, first + count - g0);
+        if (!h->diagonal) QSV_HIP(h, stamp(h, b.pass_events, true));
+        if ((rc = run_group(h, b.circs, g0, gc, mode))) return rc;
         if (!h->diagonal) {
-            QSV_HIP(h, stamp(exp_events, true));
-            QSV_HIP(h, launch_pauli_terms(h->dtype, h->d_states.ptr, uint64_t(1) << h->n, h->n, int(count), h->n_terms,
+            QSV_HIP(h, stamp(h, b.pass_events, false));
+            QSV_HIP(h, stamp(h, b.exp_events, true));
+            QSV_HIP(h, launch_pauli_terms(h->dtype, h->d_states.ptr, uint64_t(1) << h->n, h->n, int(gc), h->n_terms,
                                           static_cast<const uint64_t*>(h->d_x.ptr),
                                           static_cast<const uint64_t*>(h->d_z.ptr), h->pauli_nb,
                                           static_cast<double*>(h->d_term_partials.ptr), h->stream));
-            QSV_HIP(h, launch_pauli_combine(static_cast<const double*>(h->d_term_partials.ptr), int(count), h->n_terms,
+            QSV_HIP(h, launch_pauli_combine(static_cast<const double*>(h->d_term_partials.ptr), int(gc), h->n_terms,
                                             h->pauli_nb, static_cast<const uint64_t*>(h->d_x.ptr),
                                             static_cast<const uint64_t*>(h->d_z.ptr),
                                             static_cast<const double*>(h->d_cre.ptr),
-                                            static_cast<const double*>(h->d_cim.ptr), st.d_evals + first,
+                                            static_cast<const double*>(h->d_cim.ptr), batch_evals(h) + g0,
                                             static_cast<double*>(h->d_out.ptr), h->stream));
-            QSV_HIP(h, stamp(exp_events, false));
+            QSV_HIP(h, stamp(h, b.exp_events, false));
         }
     }
-    if (h->diagonal) {
-        QSV_HIP(h, stamp(exp_events, true));
-        QSV_HIP(h, launch_reduce_partials(static_cast<const double*>(h->d_partials.ptr), chunks, n_evals,
-                                          static_cast<double*>(h->d_out.ptr), h->stream));
-        QSV_HIP(h, stamp(exp_events, false));
-    }
-    if (h->profiling) QSV_HIP(h, hipEventRecord(ev1, h->stream));
-    QSV_HIP(h, hipMemcpyAsync(h->h_out, h->d_out.ptr, size_t(n_evals) * sizeof(double), hipMemcpyDeviceToHost,
-                              h->stream));
-    QSV_HIP(h, hipStreamSynchronize(h->stream));
-    std::memcpy(out, h->h_out, size_t(n_evals) * sizeof(double));
+    if (h->diagonal) QSV_HIP(h, stamp(h, b.pass_events, false));
+    b.pushed = first + count;
+    return QSV_OK;
+}
 
+int eval_end(qsv_t* h, double* out) {
+    qsv_handle::Batch& b = h->batch;
+    const size_t n_evals = b.circs.size();
+    if (b.pushed != n_evals) return fail(h, QSV_E_STATE, "not every evaluation of the batch was pushed");
+    if (n_evals == 0) return QSV_OK;
+    if (h->diagonal) {
+        QSV_HIP(h, stamp(h, b.exp_events, true));
+        QSV_HIP(h, launch_reduce_partials(static_cast<const double*>(h->d_partials.ptr), chunks_per_state(h),
+                                          int(n_evals), static_cast<double*>(h->d_out.ptr), h->stream));
+        QSV_HIP(h, stamp(h, b.exp_events, false));
+    }
+    if (h->profiling) QSV_HIP(h, hipEventRecord(b.ev1, h->stream));
+    QSV_HIP(h, hipMemcpyAsync(h->h_out, h->d_out.ptr, n_evals * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    QSV_HIP(h, hipStreamSynchronize(h->stream));
+    std::memcpy(out, h->h_out, n_evals * sizeof(double));
     if (h->profiling) {
         float ms = 0.f;
-        QSV_HIP(h, hipEventElapsedTime(&ms, ev0, ev1));
+        QSV_HIP(h, hipEventElapsedTime(&ms, b.ev0, b.ev1));
         h->prof.total_ms = ms;
-        for (auto& p : pass_events) {
-            QSV_HIP(h, hipEventElapsedTime(&ms, p.a, p.b));
+        for (auto& p : b.pass_events) {
+            QSV_HIP(h, hipEventElapsedTime(&ms, p.first, p.second));
             h->prof.pass_ms += ms;
-            (void)hipEventDestroy(p.a);
-            (void)hipEventDestroy(p.b);
         }
-        for (auto& p : exp_events) {
-            QSV_HIP(h, hipEventElapsedTime(&ms, p.a, p.b));
+        for (auto& p : b.exp_events) {
+            QSV_HIP(h, hipEventElapsedTime(&ms, p.first, p.second));
             h->prof.expect_ms += ms;
-            (void)hipEventDestroy(p.a);
-            (void)hipEventDestroy(p.b);
         }
-        (void)hipEventDestroy(ev0);
-        (void)hipEventDestroy(ev1);
     }
     return QSV_OK;
+}
+
+// Releases whatever a batch holds (events) and marks it closed; safe to call on error paths.
+void eval_close(qsv_t* h) {
+    qsv_handle::Batch& b = h->batch;
+    for (auto* list : {&b.pass_events, &b.exp_events}) {
+        for (auto& p : *list) {
+            if (p.first) (void)hipEventDestroy(p.first);
+            if (p.second) (void)hipEventDestroy(p.second);
+        }
+        list->clear();
+    }
+    if (b.ev0) (void)hipEventDestroy(b.ev0);
+    if (b.ev1) (void)hipEventDestroy(b.ev1);
+    b.ev0 = b.ev1 = nullptr;
+    b.circs.clear();
+    b.open = false;
+}
+
+// One-shot evaluation: begin + one push + end.
+int eval_all(qsv_t* h, const std::vector<Circuit*>& circs, const int64_t* param_offsets, const double* params,
+             double* out) {
+    if (circs.empty()) return QSV_OK;
+    std::vector<int64_t> np(circs.size());
+    for (size_t i = 0; i < circs.size(); ++i) np[i] = param_offsets[i + 1] - param_offsets[i];
+    int rc = eval_begin(h, circs, np);
+    // the caller's vectors may have gaps between them: pack what each evaluation declared
+    std::vector<double> packed;
+    if (!rc) {
+        size_t total = 0;
+        for (int64_t v : np) total += size_t(v);
+        packed.resize(total + 1);
+        size_t cur = 0;
+        for (size_t i = 0; i < circs.size(); ++i) {
+            if (np[i]) std::memcpy(packed.data() + cur, params + param_offsets[i], size_t(np[i]) * sizeof(double));
+            cur += size_t(np[i]);
+        }
+        rc = eval_push(h, 0, circs.size(), packed.data());
+    }
+    if (!rc) rc = eval_end(h, out);
+    eval_close(h);
+    return rc;
 }
 
 // Prepare the final state of one circuit in slot 0 (used by statevector / probabilities / sample).
@@ -435,11 +507,13 @@ int run_single_to_state(qsv_t* h, int circuit_id, const double* params, int n_pa
     auto it = h->circuits.find(circuit_id);
     if (it == h->circuits.end()) return fail(h, QSV_E_ARG, "unknown circuit id");
     std::vector<Circuit*> cc{&it->second};
-    Staged st;
-    int rc = stage_batch(h, cc, [&](size_t) { return std::make_pair(params, int64_t(n_params)); }, &st);
-    if (rc) return rc;
-    if ((rc = ensure(h, h->d_partials, size_t(chunks_per_state(h)) * sizeof(double)))) return rc;
-    return run_group(h, st, cc, 0, 1, kModeSynthFirst | kModeFinalStore);
+    h->prof = qsv_profile{};
+    int rc = batch_layout(h, cc, std::vector<int64_t>{int64_t(n_params)});
+    if (!rc) rc = batch_ship(h, 0, 1, params);
+    if (!rc) rc = ensure(h, h->d_partials, size_t(chunks_per_state(h)) * sizeof(double));
+    if (!rc) rc = run_group(h, cc, 0, 1, kModeSynthFirst | kModeFinalStore);
+    h->batch.circs.clear();
+    return rc;
 }
 
 
@@ -537,6 +611,7 @@ int qsv_set_stream(qsv_t* h, void* hip_stream) {
 }
 
 int qsv_n_qubits(const qsv_t* h) { return h ? h->n : QSV_E_ARG; }
+int qsv_group_size(const qsv_t* h) { return h ? h->group : QSV_E_ARG; }
 
 int qsv_set_operator(qsv_t* h, int n_terms, const uint64_t* x_mask, const uint64_t* z_mask, const double* coeff_re,
                      const double* coeff_im) {
@@ -612,7 +687,51 @@ int qsv_eval_circuits(qsv_t* h, int n_evals, const int* circuit_ids, const int64
         if (param_offsets[i + 1] < param_offsets[i]) return fail(h, QSV_E_ARG, "param_offsets must be non-decreasing");
     }
     static const double dummy = 0.0;
-    return eval_impl(h, n_evals, circs, param_offsets, params ? params : &dummy, out);
+    return eval_all(h, circs, param_offsets, params ? params : &dummy, out);
+}
+
+int qsv_eval_begin(qsv_t* h, int n_evals, const int* circuit_ids, const int64_t* param_counts) {
+    if (!h) return QSV_E_ARG;
+    std::unique_lock<std::mutex> lock(h->mu);
+    if (h->batch.open) return fail(h, QSV_E_STATE, "a batch is already open on this handle");
+    if (n_evals < 0 || (n_evals > 0 && (!circuit_ids || !param_counts))) return fail(h, QSV_E_ARG, "bad arguments");
+    QSV_HIP(h, hipSetDevice(h->device));
+    std::vector<Circuit*> circs(size_t(n_evals), nullptr);
+    std::vector<int64_t> np(size_t(n_evals), 0);
+    for (int i = 0; i < n_evals; ++i) {
+        auto it = h->circuits.find(circuit_ids[i]);
+        if (it == h->circuits.end()) return fail(h, QSV_E_ARG, "unknown circuit id " + std::to_string(circuit_ids[i]));
+        circs[size_t(i)] = &it->second;
+        if (param_counts[i] < 0) return fail(h, QSV_E_ARG, "negative parameter count");
+        np[size_t(i)] = param_counts[i];
+    }
+    int rc = eval_begin(h, circs, np);
+    if (rc) {
+        eval_close(h);
+        return rc;
+    }
+    h->batch.open = true;
+    h->batch_lock = std::move(lock);  // other threads wait until qsv_eval_end
+    return QSV_OK;
+}
+
+int qsv_eval_push(qsv_t* h, int first, int count, const double* values) {
+    if (!h) return QSV_E_ARG;
+    if (!h->batch.open) return fail(h, QSV_E_STATE, "no open batch (call qsv_eval_begin first)");
+    if (first < 0 || count < 0) return fail(h, QSV_E_ARG, "bad arguments");
+    static const double dummy = 0.0;
+    return eval_push(h, size_t(first), size_t(count), values ? values : &dummy);
+}
+
+int qsv_eval_end(qsv_t* h, double* out_expectations) {
+    if (!h) return QSV_E_ARG;
+    if (!h->batch.open) return fail(h, QSV_E_STATE, "no open batch (call qsv_eval_begin first)");
+    int rc = out_expectations || h->batch.circs.empty() ? eval_end(h, out_expectations)
+                                                        : fail(h, QSV_E_ARG, "out is null");
+    if (rc) (void)hipStreamSynchronize(h->stream);  // nothing of the failed batch may still be running
+    eval_close(h);
+    std::unique_lock<std::mutex> lock = std::move(h->batch_lock);
+    return rc;  // `lock` releases the handle here
 }
 
 int qsv_eval_batch(qsv_t* h, int n_evals, const int64_t* op_offsets, const qsv_op* ops, const int64_t* param_offsets,
@@ -648,7 +767,7 @@ int qsv_eval_batch(qsv_t* h, int n_evals, const int64_t* op_offsets, const qsv_o
         circs[size_t(i)] = &h->circuits.find(id)->second;
     }
     static const double dummy = 0.0;
-    return eval_impl(h, n_evals, circs, param_offsets, params ? params : &dummy, out);
+    return eval_all(h, circs, param_offsets, params ? params : &dummy, out);
 }
 
 int qsv_statevector(qsv_t* h, int circuit_id, const double* params, int n_params, double* out_re_im) {
@@ -718,16 +837,17 @@ static int bench_ops_locked(qsv_t* h, int n_ops, const qsv_op* ops, int reps, do
     Circuit& c = h->circuits.find(id)->second;
     auto cleanup = [&]() { h->circuits.erase(id); };
     std::vector<Circuit*> cc{&c};
-    Staged st;
     static const double dummy = 0.0;
-    if ((rc = stage_batch(h, cc, [&](size_t) { return std::make_pair(&dummy, int64_t(0)); }, &st))) {
+    if ((rc = batch_layout(h, cc, std::vector<int64_t>{0})) || (rc = batch_ship(h, 0, 1, &dummy))) {
+        h->batch.circs.clear();
         cleanup();
         return rc;
     }
+    h->batch.circs.clear();
     PassArgs a{};
     a.plan = static_cast<const uint32_t*>(h->d_arena.ptr);
     a.mats = static_cast<const double*>(h->d_mats.ptr);
-    a.evals = st.d_evals;
+    a.evals = batch_evals(h);
     a.states = h->d_states.ptr;
     a.state_stride = uint64_t(1) << h->n;
     a.mode = kModeFinalStore;  // read-modify-write of the resident state, no synthesis

@@ -1,0 +1,95 @@
+"""Population sharding + fitness all-gather over two CPU ranks (gloo).  The evaluator is mocked with the oracle:
+what is under test is the N > 1 control path of queasars_amd.distributed, not the GPU kernels."""
+
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+class _OracleEvaluator:
+    """Stands in for the GPU evaluator on CPU ranks; records which individuals this rank evaluated."""
+
+    def __init__(self, operator):
+        self.operator = operator
+        self.seen = 0
+
+    def evaluate_circuits(self, circuits, parameter_values):
+        import helpers
+
+        self.seen += len(circuits)
+        return [helpers.oracle_expectation(c, p, self.operator) for c, p in zip(circuits, parameter_values)]
+
+
+def _worker(rank: int, world: int, port: int, n_individuals: int, out_dir: str):
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+
+    import helpers
+    from queasars_amd.distributed import evaluate_population_sharded, shard_bounds
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        _, circuits, params = helpers.population_circuits(5, 2, n_individuals, seed=42)
+        op = helpers.random_ising_operator(5, seed=7)
+        evaluator = _OracleEvaluator(op)
+        values = evaluate_population_sharded(evaluator, circuits, params)
+        lo, hi = shard_bounds(n_individuals, world, rank)
+        assert evaluator.seen == hi - lo, "a rank must only evaluate its own block"
+        np.save(os.path.join(out_dir, f"rank{rank}.npy"), np.asarray(values))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_individuals", [8, 7, 1])
+def test_two_rank_sharded_evaluation(tmp_path, n_individuals):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), n_individuals, str(tmp_path)), nprocs=world, join=True)
+    import helpers
+
+    _, circuits, params = helpers.population_circuits(5, 2, n_individuals, seed=42)
+    op = helpers.random_ising_operator(5, seed=7)
+    want = np.asarray([helpers.oracle_expectation(c, p, op) for c, p in zip(circuits, params)])
+    for rank in range(world):
+        got = np.load(tmp_path / f"rank{rank}.npy")
+        assert got.shape == want.shape and np.array_equal(got, want), "every rank must hold all fitness values in order"
+
+
+def test_shard_bounds_cover_everything_once():
+    from queasars_amd.distributed import shard_bounds
+
+    for n in (0, 1, 7, 64, 256, 257):
+        for world in (1, 2, 3, 8):
+            blocks = [shard_bounds(n, world, r) for r in range(world)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(blocks, blocks[1:]))
+            sizes = [hi - lo for lo, hi in blocks]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_bounds(4, 2, 2)
+
+
+def test_single_process_falls_back_to_local_evaluation():
+    import helpers
+    from queasars_amd.distributed import evaluate_population_sharded
+
+    _, circuits, params = helpers.population_circuits(4, 2, 3, seed=1)
+    op = helpers.random_ising_operator(4, seed=2)
+    ev = _OracleEvaluator(op)
+    values = evaluate_population_sharded(ev, circuits, params)
+    assert ev.seen == 3 and len(values) == 3

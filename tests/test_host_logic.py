@@ -1,0 +1,106 @@
+"""Host-side pieces of the evaluator API that need no GPU: IR, operator format, CVaR post-processing,
+bitstring evaluator (mirrors what the reference's circuit_evaluation package does outside the primitive)."""
+
+import pickle
+
+import numpy as np
+import pytest
+
+from oracle import statevector_oracle as so
+from queasars_amd.circuit_evaluation import (
+    BitstringEvaluator,
+    BitstringEvaluatorException,
+    get_expectation_with_bitstring_evaluator,
+    get_expectation_with_operator,
+)
+from queasars_amd.circuit_evaluation.expectation_calculation import basis_state_values
+from queasars_amd.ir import NO_CONTROL, OP_CU3, OP_ID, OP_U, CircuitIR, ParamRef, PauliOperator
+
+
+class TestCircuitIR:
+    def test_builder_and_packing(self):
+        c = CircuitIR(3).id(0).u(0.1, ParamRef(1), 0.3, 2).cu3(ParamRef(0), 0.5, ParamRef(2), 0, 1)
+        ops = c.packed()
+        assert len(c) == 3 and c.num_parameters == 3 and c.count_ops() == {"id": 1, "u": 1, "cu3": 1}
+        assert list(ops["kind"]) == [OP_ID, OP_U, OP_CU3]
+        assert list(ops["target"]) == [0, 2, 1] and list(ops["control"]) == [NO_CONTROL, NO_CONTROL, 0]
+        assert list(ops["p_phi"]) == [-1, 1, -1] and ops["theta"][1] == 0.1
+        assert c.bound_ops([9.0, 8.0, 7.0]) == [(0, 0, -1, 0.0, 0.0, 0.0), (1, 2, -1, 0.1, 8.0, 0.3), (2, 1, 0, 9.0, 0.5, 7.0)]
+
+    def test_argument_errors(self):
+        with pytest.raises(ValueError):
+            CircuitIR(0)
+        with pytest.raises(ValueError):
+            CircuitIR(2).u(0, 0, 0, 2)
+        with pytest.raises(ValueError):
+            CircuitIR(2).cu3(0, 0, 0, 1, 1)
+        with pytest.raises(ValueError):
+            CircuitIR(2).u(ParamRef(0), 0, 0, 0).bound_ops([])
+        with pytest.raises(ValueError):
+            CircuitIR(2).compose(CircuitIR(3))
+
+    def test_compose_keeps_order(self):
+        a, b = CircuitIR(2).u(0.1, 0.2, 0.3, 0), CircuitIR(2).cu3(0.4, 0.5, 0.6, 0, 1)
+        assert [o[0] for o in a.compose(b).bound_ops([])] == [OP_U, OP_CU3]
+
+
+class TestPauliOperator:
+    def test_masks_follow_qiskit_label_order(self):
+        op = PauliOperator(["IZ", "XI", "YZ"], [1.0, 2.0, 3.0])
+        assert op.x_mask.tolist() == [0, 2, 2] and op.z_mask.tolist() == [1, 0, 3]
+        assert op.num_qubits == 2 and len(op) == 3 and not op.is_diagonal()
+        assert PauliOperator(["ZI", "II"]).is_diagonal()
+
+    def test_sparse_list_and_pickle(self):
+        op = PauliOperator.from_sparse_list([("ZZ", [0, 3], 0.5), ("X", [1], -1.0)], 4)
+        assert op.labels == ["ZIIZ", "IIXI"]
+        clone = pickle.loads(pickle.dumps(op))
+        assert clone.labels == op.labels and np.array_equal(clone.coeffs, op.coeffs)
+
+    def test_bad_labels(self):
+        with pytest.raises(ValueError):
+            PauliOperator([])
+        with pytest.raises(ValueError):
+            PauliOperator(["ZZ", "Z"])
+        with pytest.raises(ValueError):
+            PauliOperator(["ZQ"])
+        with pytest.raises(ValueError):
+            PauliOperator(["ZZ"], [1.0, 2.0])
+
+
+class TestSamplerPostProcessing:
+    def test_values_match_the_oracle(self):
+        rng = np.random.default_rng(0)
+        op = PauliOperator.from_sparse_list([("ZZ", [0, 2], 0.7), ("Z", [1], -1.3), ("ZZ", [1, 4], 0.2)], 5)
+        states = rng.integers(0, 32, size=20)
+        want = [so.evaluate_sparsepauli(int(s), op.z_mask.tolist(), op.coeffs.tolist()).real for s in states]
+        assert np.allclose(basis_state_values(states, op), want, atol=1e-15)
+
+    @pytest.mark.parametrize("alpha", [1.0, 0.5, 0.3, 0.05])
+    def test_cvar_matches_the_oracle(self, alpha):
+        rng = np.random.default_rng(3)
+        op = PauliOperator.from_sparse_list([("ZZ", [0, 1], 1.0), ("Z", [2], 0.5), ("Z", [0], -0.25)], 3)
+        counts = rng.integers(1, 50, size=8)
+        dist = {s: c / counts.sum() for s, c in enumerate(counts)}
+        got = get_expectation_with_operator(dist, op, alpha)
+        want = so.expectation_from_distribution(dist, op.z_mask.tolist(), op.coeffs.tolist(), alpha)
+        assert abs(got - want) < 1e-14
+
+    def test_alpha_range_and_diagonal_requirement(self):
+        op = PauliOperator(["ZI"])
+        for bad in (0.0, -0.1, 1.5):
+            with pytest.raises(ValueError):
+                get_expectation_with_operator({0: 1.0}, op, bad)
+        with pytest.raises(ValueError):
+            get_expectation_with_operator({0: 1.0}, PauliOperator(["XI"]), 1.0)
+
+    def test_bitstring_evaluator(self):
+        ev = BitstringEvaluator(3, lambda b: float(int(b, 2)))
+        assert ev.evaluate_bitstring("101") == 5.0 and ev.input_length == 3
+        with pytest.raises(BitstringEvaluatorException):
+            ev.evaluate_bitstring("10")
+        with pytest.raises(BitstringEvaluatorException):
+            ev.evaluate_bitstring("1a1")
+        dist = {0b001: 0.5, 0b110: 0.5}
+        assert get_expectation_with_bitstring_evaluator(dist, ev, 1.0) == 0.5 * 1 + 0.5 * 6
+        assert get_expectation_with_bitstring_evaluator(dist, ev, 0.5) == 1.0
