@@ -557,10 +557,18 @@ int qsv_create(int n_qubits, int dtype, int device, const qsv_plan_config* cfg, 
     if (group <= 0) {
         // keep a launch group's states inside half of the 256 MiB Infinity Cache so that consecutive passes
         // over them are served on-die
-        const size_t budget = size_t(128) << 20;
+        const size_t budget = size_t(256) << 20;
         group = int(std::max<size_t>(1, std::min<size_t>(1024, budget / state_bytes)));
     }
     h->group = group;
+    // workgroups sweep several consecutive tiles when a launch would otherwise have far more workgroups than the
+    // chip holds (less wave-dispatch and plan-parsing overhead): aim for about 1024 workgroups per launch
+    {
+        const uint64_t tiles_per_launch = uint64_t(geo.blocks_per_state) * uint64_t(group);
+        int tpb = 1;
+        while (tpb < 8 && tiles_per_launch / uint64_t(tpb * 2) >= 1024 && uint32_t(tpb * 2) <= geo.blocks_per_state) tpb *= 2;
+        h->tiles_per_block = tpb;
+    }
     if (const char* env = getenv("QSV_TILES_PER_BLOCK")) h->tiles_per_block = std::max(1, atoi(env));
     if (const char* env = getenv("QSV_PIPELINE")) h->pipeline = atoi(env) != 0;
     auto bail = [&](hipError_t err, const char* what) {
