@@ -24,7 +24,7 @@ from __future__ import annotations
 import ctypes as C
 import threading
 import weakref
-from itertools import chain
+from itertools import chain, count
 from abc import ABC, abstractmethod
 from typing import Optional, Sequence
 
@@ -54,6 +54,9 @@ class BaseCircuitEvaluator(ABC):
     @abstractmethod
     def n_qubits(self) -> int:
         """Size (in qubits) of the circuits this evaluator can evaluate."""
+
+
+_device_serial = count(1)
 
 
 class StatevectorDevice:
@@ -94,7 +97,7 @@ class StatevectorDevice:
         self._push_groups = 1  # launch groups per qsv_eval_push
         self._operator: Optional[PauliOperator] = None
         self._reg_lock = threading.Lock()
-        self._token = object()
+        self._serial = next(_device_serial)  # key of this device in CircuitIR._registered (never reused)
 
     # -- plumbing -------------------------------------------------------------------------------
     def __reduce__(self):
@@ -151,13 +154,13 @@ class StatevectorDevice:
     # -- circuits -------------------------------------------------------------------------------
     def circuit_id(self, circuit: CircuitIR) -> int:
         """Register ``circuit`` on this device once; later calls return the cached id."""
-        cid = circuit._registered.get(id(self._token))
+        cid = circuit._registered.get(self._serial)
         if cid is not None:
             return cid
         if circuit.n_qubits != self._n_qubits:
             raise ValueError(f"circuit has {circuit.n_qubits} qubits, the evaluator {self._n_qubits}")
         with self._reg_lock:
-            cid = circuit._registered.get(id(self._token))
+            cid = circuit._registered.get(self._serial)
             if cid is None:
                 ops = circuit.packed()
                 out = C.c_int(0)
@@ -165,7 +168,7 @@ class StatevectorDevice:
                     self._lib.qsv_circuit_create(self._handle, len(ops), _lib.as_ptr(ops), circuit.num_parameters, C.byref(out))
                 )
                 cid = out.value
-                circuit._registered[id(self._token)] = cid
+                circuit._registered[self._serial] = cid
                 # drop the device-side plan when the circuit object goes away
                 weakref.finalize(circuit, StatevectorDevice._release, weakref.ref(self), cid)
         return cid

@@ -723,6 +723,95 @@ __global__ void __launch_bounds__(256) state_to_f64_kernel(const cx<real>* __res
     }
 }
 
+// ---- sampling -------------------------------------------------------------------------------------------
+// Inverse-CDF sampling without materialising a 2^n-entry CDF: chunk sums (fixed-order), one inclusive scan over
+// the chunk sums, then per shot a binary search over chunks and a sequential walk inside the chosen chunk.
+constexpr uint32_t kSampleChunk = 4096;
+
+__global__ void __launch_bounds__(256) chunk_sums_kernel(const double* __restrict__ probs, uint64_t dim,
+                                                         double* __restrict__ sums) {
+    __shared__ double red[4];
+    const uint64_t lo = uint64_t(blockIdx.x) * kSampleChunk;
+    double acc = 0.0;
+    for (uint32_t i = threadIdx.x; i < kSampleChunk; i += 256) {
+        const uint64_t idx = lo + i;
+        if (idx < dim) acc += probs[idx];
+    }
+    const double total = block_sum_256(acc, red);
+    if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+
+// in-place inclusive scan of `n` chunk sums by one workgroup (n <= 2^20: a few microseconds)
+__global__ void __launch_bounds__(256) scan_sums_kernel(double* __restrict__ sums, uint32_t n) {
+    __shared__ double part[256];
+    const uint32_t per = (n + 255) / 256;
+    const uint32_t lo = threadIdx.x * per, hi = min(n, lo + per);
+    double acc = 0.0;
+    for (uint32_t i = lo; i < hi; ++i) acc += sums[i];
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double run = 0.0;
+        for (int i = 0; i < 256; ++i) {
+            const double v = part[i];
+            part[i] = run;
+            run += v;
+        }
+    }
+    __syncthreads();
+    double run = part[threadIdx.x];
+    for (uint32_t i = lo; i < hi; ++i) {
+        run += sums[i];
+        sums[i] = run;
+    }
+}
+
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+__global__ void __launch_bounds__(256) sample_kernel(const double* __restrict__ probs, uint64_t dim,
+                                                     const double* __restrict__ scanned, uint32_t n_chunks,
+                                                     int shots, uint64_t seed, uint64_t* __restrict__ out) {
+    const int shot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (shot >= shots) return;
+    const double total = scanned[n_chunks - 1];
+    const uint64_t bits = splitmix64(seed ^ splitmix64(uint64_t(shot) + 1));
+    const double u = double(bits >> 11) * (1.0 / 9007199254740992.0) * total;  // [0, total)
+    // first chunk whose inclusive prefix exceeds u
+    uint32_t lo = 0, hi = n_chunks - 1;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (scanned[mid] > u) hi = mid; else lo = mid + 1;
+    }
+    double run = lo ? scanned[lo - 1] : 0.0;
+    const uint64_t first = uint64_t(lo) * kSampleChunk;
+    const uint64_t last = min(dim, first + kSampleChunk) - 1;
+    uint64_t idx = first;
+    for (; idx < last; ++idx) {
+        run += probs[idx];
+        if (run > u) break;
+    }
+    // walk back over zero-probability states a rounding tie could have selected
+    while (idx > first && probs[idx] == 0.0) --idx;
+    out[shot] = idx;
+}
+
+hipError_t launch_sample(const double* probs, uint64_t dim, double* chunk_sums, int shots, uint64_t seed,
+                         uint64_t* out, hipStream_t stream) {
+    const uint32_t n_chunks = uint32_t((dim + kSampleChunk - 1) / kSampleChunk);
+    hipLaunchKernelGGL(chunk_sums_kernel, dim3(n_chunks), dim3(256), 0, stream, probs, dim, chunk_sums);
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(256), 0, stream, chunk_sums, n_chunks);
+    hipLaunchKernelGGL(sample_kernel, dim3((shots + 255) / 256), dim3(256), 0, stream, probs, dim, chunk_sums,
+                       n_chunks, shots, seed, out);
+    return hipGetLastError();
+}
+
+uint32_t sample_chunk_count(uint64_t dim) { return uint32_t((dim + kSampleChunk - 1) / kSampleChunk); }
+
 static unsigned stream_blocks(uint64_t dim) {
     const uint64_t want = (dim + 255) / 256;
     return unsigned(want < 4096 ? want : 4096);

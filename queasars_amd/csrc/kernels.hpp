@@ -69,6 +69,11 @@ hipError_t launch_pauli_combine(const double* term_partials, int n_slots, int n_
                                 const uint64_t* z_mask, const double* coeff_re, const double* coeff_im,
                                 const EvalDesc* evals, double* out, hipStream_t stream);
 
+// Draw `shots` basis states from `probs` (need not be normalised); chunk_sums: scratch of sample_chunk_count(dim) doubles.
+hipError_t launch_sample(const double* probs, uint64_t dim, double* chunk_sums, int shots, uint64_t seed,
+                         uint64_t* out, hipStream_t stream);
+uint32_t sample_chunk_count(uint64_t dim);
+
 hipError_t launch_probabilities(int dtype, const void* state, uint64_t dim, double* probs, hipStream_t stream);
 hipError_t launch_state_to_f64(int dtype, const void* state, uint64_t dim, double* out_re_im, hipStream_t stream);
 

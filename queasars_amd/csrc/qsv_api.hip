@@ -814,10 +814,28 @@ int qsv_probabilities(qsv_t* h, int circuit_id, const double* params, int n_para
     return QSV_OK;
 }
 
-int qsv_sample(qsv_t* h, int, const double*, int, int, uint64_t, uint64_t*) {
+int qsv_sample(qsv_t* h, int circuit_id, const double* params, int n_params, int shots, uint64_t seed,
+               uint64_t* out_states) {
     if (!h) return QSV_E_ARG;
     std::lock_guard<std::mutex> lock(h->mu);
-    return fail(h, QSV_E_UNSUPPORTED, "qsv_sample is not implemented yet");
+    if (shots < 0 || (shots > 0 && !out_states)) return fail(h, QSV_E_ARG, "bad arguments");
+    if (shots == 0) return QSV_OK;
+    QSV_HIP(h, hipSetDevice(h->device));
+    static const double dummy = 0.0;
+    int rc = run_single_to_state(h, circuit_id, params ? params : &dummy, n_params);
+    if (rc) return rc;
+    const uint64_t dim = uint64_t(1) << h->n;
+    const size_t probs_bytes = dim * 8, sums_bytes = size_t(sample_chunk_count(dim)) * 8;
+    const size_t out_off = ((probs_bytes + sums_bytes + 63) / 64) * 64;
+    if ((rc = ensure(h, h->d_scratch, out_off + size_t(shots) * 8))) return rc;
+    double* probs = static_cast<double*>(h->d_scratch.ptr);
+    double* sums = probs + dim;
+    uint64_t* d_out = reinterpret_cast<uint64_t*>(static_cast<char*>(h->d_scratch.ptr) + out_off);
+    QSV_HIP(h, launch_probabilities(h->dtype, h->d_states.ptr, dim, probs, h->stream));
+    QSV_HIP(h, launch_sample(probs, dim, sums, shots, seed, d_out, h->stream));
+    QSV_HIP(h, hipMemcpyAsync(out_states, d_out, size_t(shots) * 8, hipMemcpyDeviceToHost, h->stream));
+    QSV_HIP(h, hipStreamSynchronize(h->stream));
+    return QSV_OK;
 }
 
 int qsv_set_profiling(qsv_t* h, int enabled) {
