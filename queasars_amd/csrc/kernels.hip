@@ -363,18 +363,13 @@ __global__ void __launch_bounds__(512, (Occupancy<XMODE, PIPE>::waves_per_simd))
                 if ((uint32_t(base) & cg) == cg) {  // else: the control is a fixed bit of this tile and it is 0
                     const uint32_t creg = (w0 >> 8) & 0xffu;
                     const int sel = int(w0 & 0xffu) * (R + 1) + (creg == 0xffu ? 0 : int(creg) + 1);
+                    const real mm[7] = {real(m0), real(m1), real(m2), real(m3), real(m4), real(m5), real(m6)};
                     if (all_active && (ct & 63u) == 0) {
                         // the control (if any) is a wave-index bit: whole waves either run the gate or skip it
-                        if ((wave_base & ct) == ct) {
-                            const real mm[7] = {real(m0), real(m1), real(m2), real(m3), real(m4), real(m5), real(m6)};
-                            ButterflyDispatch<real, R, R*(R + 1) - 1>::run(sel, amp, mm);
-                        }
-                    } else {
-                        // per-lane control: lanes whose control bit is 0 apply the identity
-                        const bool on = active && ((tid & ct) == ct);
-                        const real mm[7] = {on ? real(m0) : real(1), on ? real(m1) : real(0), on ? real(m2) : real(0),
-                                            on ? real(m3) : real(0), on ? real(m4) : real(0), on ? real(m5) : real(1),
-                                            on ? real(m6) : real(0)};
+                        if ((wave_base & ct) == ct) ButterflyDispatch<real, R, R*(R + 1) - 1>::run(sel, amp, mm);
+                    } else if (active && ((tid & ct) == ct)) {
+                        // per-lane control: lanes whose control bit is 0 sit the gate out under the exec mask; the
+                        // butterfly updates registers in place, so the two paths merge without copies
                         ButterflyDispatch<real, R, R*(R + 1) - 1>::run(sel, amp, mm);
                     }
                 }

@@ -34,7 +34,7 @@ struct PlanConfig {
     int low_bits = 4;    // c: tile always contains qubits 0..c-1 (coalescing)
     int elem_bytes = 16; // bytes of one LDS access of the exchange (16: complex fp64; 8: complex fp32 or one fp64 plane)
     int amp_bytes = 16;  // bytes of one complex amplitude (16 = fp64, 8 = fp32)
-    int xmode = 0;       // LDS exchange mode (kernels.hip): 0 whole element, 1 two resident planes, 2 one plane buffer
+    int xmode = 2;       // LDS exchange mode (kernels.hip): 0 whole element, 1 two resident planes, 2 one plane buffer
     bool fold = true;    // absorb leading gates into the synthesised initial product state
 };
 

@@ -137,7 +137,7 @@ def prepare(plan: dict, params) -> tuple[np.ndarray, np.ndarray]:
     return mats, vecs
 
 
-def run(words: np.ndarray, n_qubits: int, params, stats: dict | None = None, lds_access_bytes: int = 16) -> np.ndarray:
+def run(words: np.ndarray, n_qubits: int, params, stats: dict | None = None, lds_access_bytes: int = 8) -> np.ndarray:
     """Execute the plan from |0..0> for the given flat parameter list, the way prepare_kernel + pass_kernel do."""
     plan = decode(words)
     assert plan["n_qubits"] == n_qubits
