@@ -244,3 +244,35 @@ def test_sampler_and_bitstring_evaluators_converge_to_exact_values():
         probs = so.probabilities(helpers.oracle_state(c, p))
         want = sum(pr * bin(i).count("1") for i, pr in enumerate(probs))
         assert abs(value - want) < 6 * n / np.sqrt(shots)
+
+
+# ---- JSSP operator (BASELINE config 4) ---------------------------------------------------------------------
+
+
+def test_jssp_notebook_energy_on_gpu():
+    """The notebook's 12-qubit JSSP Hamiltonian: the basis state of its best schedule has energy 22.75
+    (examples/evqe_jssp_optimization.ipynb:384-392), through the estimator and the sampler/CVaR branch."""
+    import jssp_instances as inst
+    from queasars_amd.circuit_evaluation import OperatorSamplerCircuitEvaluator
+    from queasars_amd.job_shop_scheduling import JSSPDomainWallHamiltonianEncoder
+
+    enc = JSSPDomainWallHamiltonianEncoder(inst.notebook_2x3(), makespan_limit=6, **inst.NOTEBOOK_PENALTIES)
+    op = enc.get_problem_hamiltonian()
+    starts = {}
+    for job, times in zip(enc.jssp_instance.jobs, [(0, 1, 2), (1, 3, 4)]):
+        starts.update(dict(zip(job.operations, times)))
+    bitstring = enc.bitstring_of(starts)
+    prep = CircuitIR(enc.n_qubits)
+    for q, bit in enumerate(bitstring[::-1]):
+        if bit == "1":
+            prep.u(np.pi, 0.0, np.pi, q)
+        else:
+            prep.id(q)
+    assert abs(OperatorCircuitEvaluator(op).evaluate_circuits([prep], [[]])[0] - 22.75) < 1e-10
+    sampled = OperatorSamplerCircuitEvaluator(512, op, alpha=0.5, seed=1).evaluate_circuits([prep], [[]])[0]
+    assert abs(sampled - 22.75) < 1e-9
+    # a random population agrees with the oracle on this operator too
+    _, circuits, params = helpers.population_circuits(enc.n_qubits, 2, 4, seed=3)
+    got = OperatorCircuitEvaluator(op).evaluate_circuits(circuits, params)
+    ref = [helpers.oracle_expectation(c, p, op) for c, p in zip(circuits, params)]
+    assert np.abs(np.asarray(got) - np.asarray(ref)).max() < 1e-9
