@@ -616,84 +616,85 @@ hipError_t launch_reduce_partials(const double* partials, uint32_t blocks, int n
 }
 
 // ---- general Pauli terms -------------------------------------------------------------------------------
+// Terms are grouped by x mask (host).  For a group with mask x != 0 and pivot bit b = highest set bit of x, every
+// unordered pair (i, j = i ^ x) with bit b of i clear is visited once -- so each amplitude is read once per group --
+// and contributes  2 * sgn_k(i) * coef_k * (Re or Im of conj(a_i) a_j)  for every term k of the group:
+//   <P> = sum_pairs i^{ny} (-1)^{popcount(i & z)} [ (-1)^{ny} c + conj(c) ],  c = conj(a_i) a_j
+//       = +-2 Re c (ny even) or +-2 Im c (ny odd); the sign (-1)^{floor(ny/2)} is folded into coef_k on the host.
+// The x = 0 group (diagonal terms) does not come here: it uses the diagonal table inside the last gate pass.
 template <typename real>
-__global__ void __launch_bounds__(256) pauli_terms_kernel(const cx<real>* __restrict__ states, uint64_t state_stride,
-                                                          uint64_t dim, int n_terms,
-                                                          const uint64_t* __restrict__ x_mask,
-                                                          const uint64_t* __restrict__ z_mask,
-                                                          double* __restrict__ term_partials) {
+__global__ void __launch_bounds__(256) pauli_groups_kernel(const cx<real>* __restrict__ states, uint64_t state_stride,
+                                                           uint64_t n_pairs, const PauliGroup* __restrict__ groups,
+                                                           const uint64_t* __restrict__ term_z,
+                                                           const double* __restrict__ term_coef,
+                                                           const uint32_t* __restrict__ term_odd,
+                                                           double* __restrict__ partials) {
     __shared__ double red[4];
-    const int term = blockIdx.y, slot = blockIdx.z;
-    const uint64_t x = x_mask[term], z = z_mask[term];
+    const PauliGroup g = groups[blockIdx.y];
+    const int slot = blockIdx.z;
     const cx<real>* __restrict__ st = states + uint64_t(slot) * state_stride;
-    double acc_re = 0.0, acc_im = 0.0;
+    const uint64_t low_mask = (uint64_t(1) << g.pivot) - 1;
+    double acc = 0.0;
     const uint64_t stride = uint64_t(gridDim.x) * 256;
-    for (uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x; i < dim; i += stride) {
-        const uint64_t j = i ^ x;
+    for (uint64_t p = uint64_t(blockIdx.x) * 256 + threadIdx.x; p < n_pairs; p += stride) {
+        const uint64_t i = ((p & ~low_mask) << 1) | (p & low_mask);  // bit `pivot` of i is 0
+        const uint64_t j = i ^ g.x;
         const cx<real> a = st[i], b = st[j];
-        const double sgn = (__popcll(j & z) & 1) ? -1.0 : 1.0;
-        acc_re += sgn * (double(a.re) * double(b.re) + double(a.im) * double(b.im));
-        acc_im += sgn * (double(a.re) * double(b.im) - double(a.im) * double(b.re));
+        const double re = double(a.re) * double(b.re) + double(a.im) * double(b.im);
+        const double im = double(a.re) * double(b.im) - double(a.im) * double(b.re);
+        double w_re = 0.0, w_im = 0.0;
+        for (uint32_t k = g.first; k < g.first + g.count; ++k) {
+            const double c = (__popcll(i & term_z[k]) & 1) ? -term_coef[k] : term_coef[k];
+            if (term_odd[k]) w_im += c; else w_re += c;
+        }
+        acc += w_re * re + w_im * im;
     }
-    const double tr = block_sum_256(acc_re, red);
-    const double ti = block_sum_256(acc_im, red);
-    if (threadIdx.x == 0) {
-        double* o = term_partials + ((size_t(slot) * n_terms + term) * gridDim.x + blockIdx.x) * 2;
-        o[0] = tr;
-        o[1] = ti;
-    }
+    const double total = block_sum_256(2.0 * acc, red);
+    if (threadIdx.x == 0) partials[(size_t(slot) * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = total;
 }
 
-hipError_t launch_pauli_terms(int dtype, const void* states, uint64_t state_stride, int n_qubits, int n_slots,
-                              int n_terms, const uint64_t* x_mask, const uint64_t* z_mask, int nb,
-                              double* term_partials, hipStream_t stream) {
-    const uint64_t dim = uint64_t(1) << n_qubits;
-    dim3 grid(nb, n_terms, n_slots);
+hipError_t launch_pauli_groups(int dtype, const void* states, uint64_t state_stride, int n_qubits, int n_slots,
+                               int n_groups, const PauliGroup* groups, const uint64_t* term_z,
+                               const double* term_coef, const uint32_t* term_odd, int nb, double* partials,
+                               hipStream_t stream) {
+    const uint64_t n_pairs = uint64_t(1) << (n_qubits - 1);
+    dim3 grid(nb, n_groups, n_slots);
     if (dtype == 0)
-        hipLaunchKernelGGL(pauli_terms_kernel<double>, grid, dim3(256), 0, stream,
-                           reinterpret_cast<const cx<double>*>(states), state_stride, dim, n_terms, x_mask, z_mask,
-                           term_partials);
+        hipLaunchKernelGGL(pauli_groups_kernel<double>, grid, dim3(256), 0, stream,
+                           reinterpret_cast<const cx<double>*>(states), state_stride, n_pairs, groups, term_z,
+                           term_coef, term_odd, partials);
     else
-        hipLaunchKernelGGL(pauli_terms_kernel<float>, grid, dim3(256), 0, stream,
-                           reinterpret_cast<const cx<float>*>(states), state_stride, dim, n_terms, x_mask, z_mask,
-                           term_partials);
+        hipLaunchKernelGGL(pauli_groups_kernel<float>, grid, dim3(256), 0, stream,
+                           reinterpret_cast<const cx<float>*>(states), state_stride, n_pairs, groups, term_z,
+                           term_coef, term_odd, partials);
     return hipGetLastError();
 }
 
-__global__ void __launch_bounds__(256) pauli_combine_kernel(const double* __restrict__ term_partials, int n_terms,
-                                                            int nb, const uint64_t* __restrict__ x_mask,
-                                                            const uint64_t* __restrict__ z_mask,
-                                                            const double* __restrict__ coeff_re,
-                                                            const double* __restrict__ coeff_im,
+// out[out_index[slot]] = (fixed-order sum of the slot's group partials) + (sum of its diagonal-table partials)
+__global__ void __launch_bounds__(256) pauli_combine_kernel(const double* __restrict__ partials, uint32_t per_slot,
+                                                            const double* __restrict__ diag_partials,
+                                                            uint32_t diag_per_eval,
                                                             const EvalDesc* __restrict__ evals,
                                                             double* __restrict__ out) {
     __shared__ double red[4];
     const int slot = blockIdx.x;
+    const uint32_t out_index = evals[slot].out_index;
     double acc = 0.0;
-    for (int k = threadIdx.x; k < n_terms; k += 256) {
-        const double* p = term_partials + (size_t(slot) * n_terms + k) * nb * 2;
-        double tr = 0.0, ti = 0.0;
-        for (int b = 0; b < nb; ++b) {
-            tr += p[2 * b];
-            ti += p[2 * b + 1];
-        }
-        // multiply by i^{ny}
-        const int ny = __popcll(x_mask[k] & z_mask[k]) & 3;
-        double pr = tr, pi = ti;
-        if (ny == 1) { pr = -ti; pi = tr; }
-        else if (ny == 2) { pr = -tr; pi = -ti; }
-        else if (ny == 3) { pr = ti; pi = -tr; }
-        acc += coeff_re[k] * pr - coeff_im[k] * pi;  // real part of coeff * value
+    const double* p = partials + size_t(slot) * per_slot;
+    for (uint32_t i = threadIdx.x; i < per_slot; i += 256) acc += p[i];
+    if (diag_partials) {
+        const double* d = diag_partials + size_t(out_index) * diag_per_eval;
+        for (uint32_t i = threadIdx.x; i < diag_per_eval; i += 256) acc += d[i];
     }
     const double total = block_sum_256(acc, red);
-    if (threadIdx.x == 0) out[evals[slot].out_index] = total;
+    if (threadIdx.x == 0) out[out_index] = total;
 }
 
-hipError_t launch_pauli_combine(const double* term_partials, int n_slots, int n_terms, int nb, const uint64_t* x_mask,
-                                const uint64_t* z_mask, const double* coeff_re, const double* coeff_im,
-                                const EvalDesc* evals, double* out, hipStream_t stream) {
-    hipLaunchKernelGGL(pauli_combine_kernel, dim3(n_slots), dim3(256), 0, stream, term_partials, n_terms, nb, x_mask,
-                       z_mask, coeff_re, coeff_im, evals, out);
+hipError_t launch_pauli_combine(const double* partials, uint32_t per_slot, const double* diag_partials,
+                                uint32_t diag_per_eval, int n_slots, const EvalDesc* evals, double* out,
+                                hipStream_t stream) {
+    hipLaunchKernelGGL(pauli_combine_kernel, dim3(n_slots), dim3(256), 0, stream, partials, per_slot, diag_partials,
+                       diag_per_eval, evals, out);
     return hipGetLastError();
 }
 

@@ -59,15 +59,21 @@ hipError_t launch_diag_table(int n_qubits, int n_terms, const uint64_t* z_mask, 
 hipError_t launch_reduce_partials(const double* partials, uint32_t blocks, int n_evals, double* out,
                                   hipStream_t stream);
 
-// General Pauli terms.  term_partials[((slot * n_terms) + term) * nb + block] = (re, im) of
-// sum_{i in block's share} conj(a_i) a_{i^x} (-1)^{popcount((i^x) & z)}.
-hipError_t launch_pauli_terms(int dtype, const void* states, uint64_t state_stride, int n_qubits, int n_slots,
-                              int n_terms, const uint64_t* x_mask, const uint64_t* z_mask, int nb,
-                              double* term_partials, hipStream_t stream);
-// out[out_index[slot]] = real( sum_k coeff_k i^{ny_k} sum_b term_partials[slot][k][b] )
-hipError_t launch_pauli_combine(const double* term_partials, int n_slots, int n_terms, int nb, const uint64_t* x_mask,
-                                const uint64_t* z_mask, const double* coeff_re, const double* coeff_im,
-                                const EvalDesc* evals, double* out, hipStream_t stream);
+// Off-diagonal Pauli terms grouped by x mask (see kernels.hip).
+struct PauliGroup {
+    uint64_t x;       // common x mask (never 0)
+    uint32_t first;   // first term of the group in the term arrays
+    uint32_t count;
+    uint32_t pivot;   // highest set bit of x
+    uint32_t pad;
+};
+hipError_t launch_pauli_groups(int dtype, const void* states, uint64_t state_stride, int n_qubits, int n_slots,
+                               int n_groups, const PauliGroup* groups, const uint64_t* term_z,
+                               const double* term_coef, const uint32_t* term_odd, int nb, double* partials,
+                               hipStream_t stream);
+hipError_t launch_pauli_combine(const double* partials, uint32_t per_slot, const double* diag_partials,
+                                uint32_t diag_per_eval, int n_slots, const EvalDesc* evals, double* out,
+                                hipStream_t stream);
 
 // Draw `shots` basis states from `probs` (need not be normalised); chunk_sums: scratch of sample_chunk_count(dim) doubles.
 hipError_t launch_sample(const double* probs, uint64_t dim, double* chunk_sums, int shots, uint64_t seed,

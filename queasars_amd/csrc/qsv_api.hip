@@ -48,8 +48,10 @@ struct qsv_handle {
 
     // operator
     int n_terms = 0;
-    bool diagonal = false;
-    DeviceBuffer d_x, d_z, d_cre, d_cim, d_diag, d_term_partials;
+    bool diagonal = false;        // every term is I/Z: the whole expectation is fused into the last gate pass
+    bool has_diag_part = false;   // some terms are I/Z (their diagonal table exists)
+    int n_groups = 0;             // x-mask groups of the off-diagonal terms
+    DeviceBuffer d_z, d_cre, d_diag, d_term_partials, d_groups, d_term_odd;
     int pauli_nb = 0;
 
     // circuits
@@ -402,7 +404,8 @@ int eval_push(qsv_t* h, size_t first, size_t count, const double* values) {
         return fail(h, QSV_E_ARG, "a push must cover whole launch groups (multiples of the group size)");
     int rc = batch_ship(h, first, count, values);
     if (rc) return rc;
-    const uint32_t mode = kModeSynthFirst | (h->diagonal ? kModeFinalDiag : kModeFinalStore);
+    const uint32_t mode = kModeSynthFirst | (h->diagonal ? kModeFinalDiag : kModeFinalStore) |
+                          (h->has_diag_part ? kModeFinalDiag : 0u);
     if (h->diagonal) QSV_HIP(h, stamp(h, b.pass_events, true));
     for (size_t g0 = first; g0 < first + count; g0 += G) {
         const size_t gc = std::min(G, first + count - g0);
@@ -411,15 +414,16 @@ int eval_push(qsv_t* h, size_t first, size_t count, const double* values) {
         if (!h->diagonal) {
             QSV_HIP(h, stamp(h, b.pass_events, false));
             QSV_HIP(h, stamp(h, b.exp_events, true));
-            QSV_HIP(h, launch_pauli_terms(h->dtype, h->d_states.ptr, uint64_t(1) << h->n, h->n, int(gc), h->n_terms,
-                                          static_cast<const uint64_t*>(h->d_x.ptr),
-                                          static_cast<const uint64_t*>(h->d_z.ptr), h->pauli_nb,
-                                          static_cast<double*>(h->d_term_partials.ptr), h->stream));
-            QSV_HIP(h, launch_pauli_combine(static_cast<const double*>(h->d_term_partials.ptr), int(gc), h->n_terms,
-                                            h->pauli_nb, static_cast<const uint64_t*>(h->d_x.ptr),
-                                            static_cast<const uint64_t*>(h->d_z.ptr),
-                                            static_cast<const double*>(h->d_cre.ptr),
-                                            static_cast<const double*>(h->d_cim.ptr), batch_evals(h) + g0,
+            QSV_HIP(h, launch_pauli_groups(h->dtype, h->d_states.ptr, uint64_t(1) << h->n, h->n, int(gc), h->n_groups,
+                                           static_cast<const PauliGroup*>(h->d_groups.ptr),
+                                           static_cast<const uint64_t*>(h->d_z.ptr),
+                                           static_cast<const double*>(h->d_cre.ptr),
+                                           static_cast<const uint32_t*>(h->d_term_odd.ptr), h->pauli_nb,
+                                           static_cast<double*>(h->d_term_partials.ptr), h->stream));
+            QSV_HIP(h, launch_pauli_combine(static_cast<const double*>(h->d_term_partials.ptr),
+                                            uint32_t(h->n_groups) * uint32_t(h->pauli_nb),
+                                            h->has_diag_part ? static_cast<const double*>(h->d_partials.ptr) : nullptr,
+                                            chunks_per_state(h), int(gc), batch_evals(h) + g0,
                                             static_cast<double*>(h->d_out.ptr), h->stream));
             QSV_HIP(h, stamp(h, b.exp_events, false));
         }
@@ -589,7 +593,7 @@ void qsv_destroy(qsv_t* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    for (DeviceBuffer* b : {&h->d_x, &h->d_z, &h->d_cre, &h->d_cim, &h->d_diag, &h->d_term_partials, &h->d_arena,
+    for (DeviceBuffer* b : {&h->d_z, &h->d_cre, &h->d_diag, &h->d_term_partials, &h->d_groups, &h->d_term_odd, &h->d_arena,
                             &h->d_states, &h->d_batch, &h->d_mats, &h->d_partials, &h->d_out, &h->d_scratch})
         if (b->ptr) (void)hipFree(b->ptr);
     if (h->h_batch) (void)hipHostFree(h->h_batch);
@@ -626,42 +630,79 @@ int qsv_set_operator(qsv_t* h, int n_terms, const uint64_t* x_mask, const uint64
     if (!h) return QSV_E_ARG;
     std::lock_guard<std::mutex> lock(h->mu);
     if (n_terms < 1 || !x_mask || !z_mask || !coeff_re) return fail(h, QSV_E_ARG, "operator needs at least one term");
-    const uint64_t limit = h->n >= 64 ? ~uint64_t(0) : ((uint64_t(1) << h->n) - 1);
-    bool diagonal = true;
-    for (int k = 0; k < n_terms; ++k) {
+    (void)coeff_im;  // <P_k> is real for every Pauli string, so real(<H>) only needs the real parts
+    const uint64_t limit = (uint64_t(1) << h->n) - 1;
+    for (int k = 0; k < n_terms; ++k)
         if ((x_mask[k] | z_mask[k]) & ~limit) return fail(h, QSV_E_ARG, "Pauli term acts on a qubit >= n_qubits");
-        if (x_mask[k]) diagonal = false;
-    }
     QSV_HIP(h, hipSetDevice(h->device));
-    std::vector<double> zeros;
-    if (!coeff_im) {
-        zeros.assign(size_t(n_terms), 0.0);
-        coeff_im = zeros.data();
+    // ---- split into the diagonal part (x = 0) and x-mask groups of the rest -------------------------------
+    std::vector<uint64_t> diag_z, off_z;
+    std::vector<double> diag_c, off_c;
+    std::vector<uint32_t> off_odd;
+    std::vector<PauliGroup> groups;
+    std::vector<int> order;
+    for (int k = 0; k < n_terms; ++k) {
+        if (x_mask[k] == 0) {
+            diag_z.push_back(z_mask[k]);
+            diag_c.push_back(coeff_re[k]);
+        } else {
+            order.push_back(k);
+        }
+    }
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return x_mask[a] < x_mask[b]; });
+    for (int k : order) {
+        const uint64_t x = x_mask[k];
+        if (groups.empty() || groups.back().x != x) {
+            PauliGroup g{};
+            g.x = x;
+            g.first = uint32_t(off_z.size());
+            g.count = 0;
+            g.pivot = uint32_t(63 - __builtin_clzll(x));
+            groups.push_back(g);
+        }
+        groups.back().count += 1;
+        const int ny = __builtin_popcountll(x & z_mask[k]);
+        off_z.push_back(z_mask[k]);
+        off_odd.push_back(uint32_t(ny & 1));
+        off_c.push_back(((ny >> 1) & 1) ? -coeff_re[k] : coeff_re[k]);  // (-1)^{floor(ny/2)}
     }
     int rc;
-    const size_t mb = size_t(n_terms) * 8;
-    if ((rc = ensure(h, h->d_x, mb)) || (rc = ensure(h, h->d_z, mb)) || (rc = ensure(h, h->d_cre, mb)) ||
-        (rc = ensure(h, h->d_cim, mb)))
-        return rc;
-    QSV_HIP(h, hipMemcpyAsync(h->d_x.ptr, x_mask, mb, hipMemcpyHostToDevice, h->stream));
-    QSV_HIP(h, hipMemcpyAsync(h->d_z.ptr, z_mask, mb, hipMemcpyHostToDevice, h->stream));
-    QSV_HIP(h, hipMemcpyAsync(h->d_cre.ptr, coeff_re, mb, hipMemcpyHostToDevice, h->stream));
-    QSV_HIP(h, hipMemcpyAsync(h->d_cim.ptr, coeff_im, mb, hipMemcpyHostToDevice, h->stream));
-    h->n_terms = n_terms;
-    h->diagonal = diagonal;
-    if (diagonal) {
-        // the imaginary parts of the coefficients cannot contribute to real(<H>) of a diagonal operator
+    const bool all_diag = groups.empty();
+    if (!diag_z.empty()) {
+        DeviceBuffer tmp_z, tmp_c;
+        const size_t mb = diag_z.size() * 8;
+        if ((rc = ensure(h, tmp_z, mb)) || (rc = ensure(h, tmp_c, mb))) return rc;
+        QSV_HIP(h, hipMemcpyAsync(tmp_z.ptr, diag_z.data(), mb, hipMemcpyHostToDevice, h->stream));
+        QSV_HIP(h, hipMemcpyAsync(tmp_c.ptr, diag_c.data(), mb, hipMemcpyHostToDevice, h->stream));
         if ((rc = ensure(h, h->d_diag, (size_t(1) << h->n) * sizeof(double)))) return rc;
-        QSV_HIP(h, launch_diag_table(h->n, n_terms, static_cast<const uint64_t*>(h->d_z.ptr),
-                                     static_cast<const double*>(h->d_cre.ptr), static_cast<double*>(h->d_diag.ptr),
+        QSV_HIP(h, launch_diag_table(h->n, int(diag_z.size()), static_cast<const uint64_t*>(tmp_z.ptr),
+                                     static_cast<const double*>(tmp_c.ptr), static_cast<double*>(h->d_diag.ptr),
                                      h->stream));
-    } else {
-        const uint64_t dim = uint64_t(1) << h->n;
-        h->pauli_nb = int(std::max<uint64_t>(1, std::min<uint64_t>(256, dim / 1024)));
-        if ((rc = ensure(h, h->d_term_partials, size_t(h->group) * size_t(n_terms) * size_t(h->pauli_nb) * 2 * 8)))
-            return rc;
+        QSV_HIP(h, hipStreamSynchronize(h->stream));
+        (void)hipFree(tmp_z.ptr);
+        (void)hipFree(tmp_c.ptr);
     }
-    QSV_HIP(h, hipStreamSynchronize(h->stream));
+    if (!all_diag) {
+        const size_t nt = off_z.size();
+        if ((rc = ensure(h, h->d_z, nt * 8)) || (rc = ensure(h, h->d_cre, nt * 8)) ||
+            (rc = ensure(h, h->d_term_odd, nt * 4)) || (rc = ensure(h, h->d_groups, groups.size() * sizeof(PauliGroup))))
+            return rc;
+        QSV_HIP(h, hipMemcpyAsync(h->d_z.ptr, off_z.data(), nt * 8, hipMemcpyHostToDevice, h->stream));
+        QSV_HIP(h, hipMemcpyAsync(h->d_cre.ptr, off_c.data(), nt * 8, hipMemcpyHostToDevice, h->stream));
+        QSV_HIP(h, hipMemcpyAsync(h->d_term_odd.ptr, off_odd.data(), nt * 4, hipMemcpyHostToDevice, h->stream));
+        QSV_HIP(h, hipMemcpyAsync(h->d_groups.ptr, groups.data(), groups.size() * sizeof(PauliGroup),
+                                  hipMemcpyHostToDevice, h->stream));
+        const uint64_t n_pairs = uint64_t(1) << (h->n - 1);
+        // enough workgroups per group to fill the chip once the group count is accounted for
+        const uint64_t want = std::max<uint64_t>(1, 2048 / std::max<size_t>(1, groups.size()));
+        h->pauli_nb = int(std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(want, 1024), n_pairs / 256 + 1)));
+        if ((rc = ensure(h, h->d_term_partials, size_t(h->group) * groups.size() * size_t(h->pauli_nb) * 8))) return rc;
+        QSV_HIP(h, hipStreamSynchronize(h->stream));
+    }
+    h->n_terms = n_terms;
+    h->diagonal = all_diag;
+    h->has_diag_part = !diag_z.empty();
+    h->n_groups = int(groups.size());
     return QSV_OK;
 }
 
