@@ -122,13 +122,14 @@ struct PassScalars {
 // all compute, then all store), so memory time ADDS to compute time unless each wave keeps its own next tile's
 // loads in flight while it computes: the next tile's amplitudes (and diagonal values) are prefetched into a second
 // register set before the current tile's gates run.
-template <int XMODE, bool PIPE>
+template <int R, int XMODE, bool PIPE>
 struct Occupancy {
-    static constexpr int waves_per_simd = PIPE ? 4 : (XMODE == 2 ? 6 : 4);
+    // 2^R amplitudes = 4 * 2^R VGPRs: R = 3 fits the 80-VGPR budget of 6 waves per SIMD, R = 4 needs the 128 of 4
+    static constexpr int waves_per_simd = (PIPE || R >= 4) ? 4 : (XMODE == 2 ? 6 : 4);
 };
 
 template <typename real, int R, int XMODE, bool PIPE>
-__global__ void __launch_bounds__(512, (Occupancy<XMODE, PIPE>::waves_per_simd))
+__global__ void __launch_bounds__(512, (Occupancy<R, XMODE, PIPE>::waves_per_simd))
     pass_kernel(const uint32_t* __restrict__ plan_arena, const double* __restrict__ mats_all,
                 const EvalDesc* __restrict__ evals, cx<real>* __restrict__ states, const double* __restrict__ diag,
                 double* __restrict__ partials, const PassScalars a) {

@@ -28,6 +28,7 @@ Geometry make_geometry(int n, const PlanConfig& cfg) {
     }
     g.t = g.k - g.r;
     g.c = std::min(cfg.low_bits, g.t);
+    g.cl = std::max(0, std::min(cfg.lane_bits, g.c));
     g.threads_active = 1 << g.t;
     g.threads_launch = std::max(64, g.threads_active);
     g.blocks_per_state = 1u << (n - g.k);
@@ -252,7 +253,7 @@ void push_angle_entry(std::vector<uint32_t>& w, const AngleSource& a) {
 CircuitPlan build_plan(int n, const std::vector<GateIn>& all_gates, const std::vector<AngleSource>& op_angles,
                        const PlanConfig& cfg) {
     const Geometry geo = make_geometry(n, cfg);
-    const int k = geo.k, r = geo.r, t = geo.t, c = geo.c;
+    const int k = geo.k, r = geo.r, t = geo.t, c = geo.c, cl = geo.cl;
     for (const GateIn& g : all_gates) {
         if (g.target < 0 || g.target >= n || g.control >= n || g.control == g.target)
             throw std::invalid_argument("gate qubit index out of range");
@@ -345,7 +346,7 @@ CircuitPlan build_plan(int n, const std::vector<GateIn>& all_gates, const std::v
                 const int tb = tile_bit_of[g.target];
                 bool ok = blk.allows(g);
                 // the first layout doubles as the global load layout: its lanes must sit on the low tile bits
-                if (ok && first && tb < c) ok = false;
+                if (ok && first && tb < cl) ok = false;
                 if (ok && !is_reg[tb]) {
                     if (reg_count < r) {
                         is_reg[tb] = 1;
@@ -363,7 +364,7 @@ CircuitPlan build_plan(int n, const std::vector<GateIn>& all_gates, const std::v
                 }
             }
             for (int b = k - 1; b >= 0 && reg_count < r; --b)
-                if (!is_reg[b]) {
+                if (!is_reg[b] && !(first && b < cl)) {
                     is_reg[b] = 1;
                     ++reg_count;
                 }
@@ -373,7 +374,7 @@ CircuitPlan build_plan(int n, const std::vector<GateIn>& all_gates, const std::v
             first = false;
         }
         bool low_in_regs = false;
-        for (int b : pass.rounds.back().regbits) low_in_regs |= (b < c);
+        for (int b : pass.rounds.back().regbits) low_in_regs |= (b < cl);
         if (low_in_regs) {
             RoundPlan tail;
             tail.regbits = default_regs;

@@ -32,6 +32,8 @@ struct PlanConfig {
     int tile_bits = 12;  // k for n >= k
     int reg_bits = 3;    // r
     int low_bits = 4;    // c: tile always contains qubits 0..c-1 (coalescing)
+    int lane_bits = 2;   // of those, the lowest `lane_bits` must sit on lanes in the layouts that touch global memory
+                         // (64-byte runs per 4 lanes keep full bandwidth; measured)
     int elem_bytes = 16; // bytes of one LDS access of the exchange (16: complex fp64; 8: complex fp32 or one fp64 plane)
     int amp_bytes = 16;  // bytes of one complex amplitude (16 = fp64, 8 = fp32)
     int xmode = 2;       // LDS exchange mode (kernels.hip): 0 whole element, 1 two resident planes, 2 one plane buffer
@@ -46,7 +48,7 @@ struct GateIn {
 
 // Resolved geometry for a given n (same for every circuit on the handle).
 struct Geometry {
-    int n = 0, k = 0, r = 0, t = 0, c = 0;
+    int n = 0, k = 0, r = 0, t = 0, c = 0, cl = 0;
     int threads_active = 0;  // 2^t
     int threads_launch = 0;  // max(64, 2^t)
     uint32_t blocks_per_state = 0;  // tiles per state = 2^(n-k)

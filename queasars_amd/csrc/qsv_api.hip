@@ -162,6 +162,7 @@ PlanConfig resolve_config(const qsv_plan_config* cfg, int dtype) {
     if (const char* e = getenv("QSV_TILE_BITS")) pc.tile_bits = atoi(e);
     if (const char* e = getenv("QSV_REG_BITS")) pc.reg_bits = atoi(e);
     if (const char* e = getenv("QSV_LOW_BITS")) pc.low_bits = atoi(e);
+    if (const char* e = getenv("QSV_LANE_BITS")) pc.lane_bits = atoi(e);
     if (const char* e = getenv("QSV_FOLD")) pc.fold = atoi(e) != 0;
     if (cfg) {
         if (cfg->tile_bits > 0) pc.tile_bits = cfg->tile_bits;
