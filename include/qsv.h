@@ -143,6 +143,16 @@ int qsv_probabilities(qsv_t* h, int circuit_id, const double* params, int n_para
 int qsv_sample(qsv_t* h, int circuit_id, const double* params, int n_params, int shots, uint64_t seed,
                uint64_t* out_states);
 
+/*
+ * The same for a batch: evaluation i draws `shots` samples into out_states[i * shots ..] from its own random stream
+ * derived from (seed, i).  When the operator set on the handle is diagonal (I/Z terms only) and out_values is not
+ * NULL, out_values[i * shots + s] receives the operator's value on that sample, sum_k c_k (-1)^popcount(state & z_k)
+ * -- what `_evaluate_sparsepauli` computes per measured state in get_expectation_with_operator
+ * (reference: queasars/circuit_evaluation/expectation_calculation.py:64-66) -- so the host only sorts for the CVaR.
+ */
+int qsv_sample_batch(qsv_t* h, int n_evals, const int* circuit_ids, const int64_t* param_offsets, const double* params,
+                     int shots, uint64_t seed, uint64_t* out_states, double* out_values /* may be NULL */);
+
 /* ---- measurement support ----------------------------------------------------------------------- */
 
 int qsv_set_profiling(qsv_t* h, int enabled);

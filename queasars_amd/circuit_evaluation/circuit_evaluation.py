@@ -234,15 +234,37 @@ class StatevectorDevice:
         return out
 
     def sample(self, circuit: CircuitIR, parameter_values: Sequence[float], shots: int, seed: int) -> np.ndarray:
-        cid = self.circuit_id(circuit)
-        p = np.ascontiguousarray(parameter_values, dtype=np.float64)
-        out = np.empty(int(shots), dtype=np.uint64)
+        return self.sample_batch([circuit], [parameter_values], shots, seed)[0][0]
+
+    def sample_batch(
+        self, circuits: Sequence[CircuitIR], parameter_values: Sequence[Sequence[float]], shots: int, seed: int, with_values: bool = False
+    ) -> tuple[np.ndarray, Optional[np.ndarray]]:
+        """``shots`` measured basis states per (circuit, parameter vector) pair, sampled on the device:
+        ``states[i, s]``.  With ``with_values`` (diagonal operator set on the device) also ``values[i, s]``, the
+        operator's value on each sample, gathered from the device-resident diagonal table."""
+        n = len(circuits)
+        if len(parameter_values) != n:
+            raise ValueError("circuits and parameter_values must have the same length")
+        states = np.empty((n, int(shots)), dtype=np.uint64)
+        values = np.empty((n, int(shots)), dtype=np.float64) if with_values else None
+        if n == 0 or shots == 0:
+            return states, values
+        ids = np.fromiter((self.circuit_id(c) for c in circuits), dtype=np.int32, count=n)
+        counts = np.fromiter((len(p) for p in parameter_values), dtype=np.int64, count=n)
+        for i, c in enumerate(circuits):
+            if counts[i] < c.num_parameters:
+                raise ValueError(f"circuit {i} needs {c.num_parameters} parameter values, got {counts[i]}")
+        offsets = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(counts, out=offsets[1:])
+        flat = np.fromiter(chain.from_iterable(parameter_values), dtype=np.float64, count=int(offsets[-1]))
+        flat = flat if flat.size else np.zeros(1)
         self._check(
-            self._lib.qsv_sample(
-                self._handle, cid, _lib.as_ptr(p) if p.size else None, p.size, int(shots), C.c_uint64(seed & (2**64 - 1)), _lib.as_ptr(out)
+            self._lib.qsv_sample_batch(
+                self._handle, n, _lib.as_ptr(ids), _lib.as_ptr(offsets), _lib.as_ptr(flat), int(shots),
+                C.c_uint64(seed & (2**64 - 1)), _lib.as_ptr(states), _lib.as_ptr(values) if with_values else None,
             )
         )
-        return out
+        return states, values
 
     # -- measurement support ----------------------------------------------------------------------
     def set_profiling(self, enabled: bool) -> None:
@@ -354,16 +376,31 @@ def measure_quasi_distributions(
     shots: int,
     seed: Optional[int] = None,
 ) -> list[dict[int, float]]:
-    """``{state: count / shots}`` per circuit, sampled on the device (reference [29-59])."""
+    """``{state: count / shots}`` per circuit, sampled on the device in one batched call (reference [29-59])."""
+    pairs = [(c, p) for c, p in zip(circuits, parameter_values) if c is not None and p is not None]
     rng = np.random.default_rng(seed)
+    states, _ = sampler.sample_batch([c for c, _ in pairs], [p for _, p in pairs], shots, int(rng.integers(0, 2**63 - 1)))
     out = []
-    for circuit, params in zip(circuits, parameter_values):
-        if circuit is None or params is None:
-            continue
-        states = sampler.sample(circuit, params, shots, int(rng.integers(0, 2**63 - 1)))
-        values, counts = np.unique(states, return_counts=True)
+    for row in states:
+        values, counts = np.unique(row, return_counts=True)
         out.append({int(s): int(c) / shots for s, c in zip(values, counts)})
     return out
+
+
+def _cvar_of_samples(values: np.ndarray, alpha: float) -> float:
+    """Expectation / CVaR_alpha of equally weighted samples: what `_get_expectation` computes on the measured
+    distribution (reference: expectation_calculation.py:14-32), evaluated on the sorted sample values."""
+    shots = values.size
+    if np.isclose(alpha, 1):
+        return float(values.mean())
+    ordered = np.sort(values)
+    # gather probability mass alpha in ascending order of value: whole samples, then a fraction of the next one
+    mass = alpha * shots
+    whole = int(np.floor(mass + 1e-12))
+    total = float(ordered[:whole].sum())
+    if whole < shots and mass - whole > 1e-12:
+        total += (mass - whole) * float(ordered[whole])
+    return total / mass
 
 
 class OperatorSamplerCircuitEvaluator(BaseCircuitEvaluator):
@@ -395,14 +432,24 @@ class OperatorSamplerCircuitEvaluator(BaseCircuitEvaluator):
         self._initial_state_circuit = initial_state_circuit
         self._rng = np.random.default_rng(seed)
         self._device = statevector_device or StatevectorDevice(operator.num_qubits, dtype=dtype, device=device)
+        self._device.set_operator(operator)
+
+    @property
+    def statevector_device(self) -> StatevectorDevice:
+        return self._device
 
     def evaluate_circuits(self, circuits: list[CircuitIR], parameter_values: list[list[float]]) -> list[float]:
+        """Samples every circuit on the device and gathers each sample's operator value from the device-resident
+        diagonal table, so the host only sorts ``shots`` numbers per circuit for the CVaR."""
         if self._initial_state_circuit is not None:
             circuits = [self._initial_state_circuit.compose(c) for c in circuits]
-        dists = measure_quasi_distributions(
-            circuits, parameter_values, self._device, self._shots, seed=int(self._rng.integers(0, 2**63 - 1))
+        pairs = [(c, p) for c, p in zip(circuits, parameter_values) if c is not None and p is not None]
+        if self._device._operator is not self._operator:
+            self._device.set_operator(self._operator)
+        _, values = self._device.sample_batch(
+            [c for c, _ in pairs], [p for _, p in pairs], self._shots, int(self._rng.integers(0, 2**63 - 1)), with_values=True
         )
-        return [get_expectation_with_operator(d, self._operator, self._alpha) for d in dists]
+        return [_cvar_of_samples(row, self._alpha) for row in values]
 
     @property
     def n_qubits(self) -> int:

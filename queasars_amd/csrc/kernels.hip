@@ -701,8 +701,10 @@ hipError_t launch_pauli_combine(const double* partials, uint32_t per_slot, const
 
 // ---- state read-out ------------------------------------------------------------------------------------
 template <typename real>
-__global__ void __launch_bounds__(256) probabilities_kernel(const cx<real>* __restrict__ st, uint64_t dim,
-                                                            double* __restrict__ probs) {
+__global__ void __launch_bounds__(256) probabilities_kernel(const cx<real>* __restrict__ st_all, uint64_t dim,
+                                                            double* __restrict__ probs_all) {
+    const cx<real>* __restrict__ st = st_all + uint64_t(blockIdx.y) * dim;
+    double* __restrict__ probs = probs_all + uint64_t(blockIdx.y) * dim;
     const uint64_t stride = uint64_t(gridDim.x) * 256;
     for (uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x; i < dim; i += stride) {
         const double re = double(st[i].re), im = double(st[i].im);
@@ -725,9 +727,10 @@ __global__ void __launch_bounds__(256) state_to_f64_kernel(const cx<real>* __res
 // the chunk sums, then per shot a binary search over chunks and a sequential walk inside the chosen chunk.
 constexpr uint32_t kSampleChunk = 4096;
 
-__global__ void __launch_bounds__(256) chunk_sums_kernel(const double* __restrict__ probs, uint64_t dim,
-                                                         double* __restrict__ sums) {
+__global__ void __launch_bounds__(256) chunk_sums_kernel(const double* __restrict__ probs_all, uint64_t dim,
+                                                         double* __restrict__ sums_all, uint32_t n_chunks) {
     __shared__ double red[4];
+    const double* __restrict__ probs = probs_all + uint64_t(blockIdx.y) * dim;
     const uint64_t lo = uint64_t(blockIdx.x) * kSampleChunk;
     double acc = 0.0;
     for (uint32_t i = threadIdx.x; i < kSampleChunk; i += 256) {
@@ -735,14 +738,15 @@ __global__ void __launch_bounds__(256) chunk_sums_kernel(const double* __restric
         if (idx < dim) acc += probs[idx];
     }
     const double total = block_sum_256(acc, red);
-    if (threadIdx.x == 0) sums[blockIdx.x] = total;
+    if (threadIdx.x == 0) sums_all[size_t(blockIdx.y) * n_chunks + blockIdx.x] = total;
 }
 
-// in-place inclusive scan of `n` chunk sums by one workgroup (n <= 2^20: a few microseconds)
-__global__ void __launch_bounds__(256) scan_sums_kernel(double* __restrict__ sums, uint32_t n) {
+// in-place inclusive scan of `n` chunk sums by one workgroup per slot (n <= 2^20: a few microseconds)
+__global__ void __launch_bounds__(256) scan_sums_kernel(double* __restrict__ sums_all, uint32_t n) {
     __shared__ double part[256];
+    double* __restrict__ sums = sums_all + size_t(blockIdx.x) * n;
     const uint32_t per = (n + 255) / 256;
-    const uint32_t lo = threadIdx.x * per, hi = min(n, lo + per);
+    const uint32_t lo = min(n, threadIdx.x * per), hi = min(n, lo + per);
     double acc = 0.0;
     for (uint32_t i = lo; i < hi; ++i) acc += sums[i];
     part[threadIdx.x] = acc;
@@ -770,13 +774,21 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
     return x ^ (x >> 31);
 }
 
-__global__ void __launch_bounds__(256) sample_kernel(const double* __restrict__ probs, uint64_t dim,
-                                                     const double* __restrict__ scanned, uint32_t n_chunks,
-                                                     int shots, uint64_t seed, uint64_t* __restrict__ out) {
+// blockIdx.y = slot; slot s samples with stream seed splitmix64(seed + stream_of[s]) and writes shots of
+// evaluation out_index[s]; when `diag` is given each sample's diagonal value D[state] is gathered too.
+__global__ void __launch_bounds__(256) sample_kernel(const double* __restrict__ probs_all, uint64_t dim,
+                                                     const double* __restrict__ scanned_all, uint32_t n_chunks,
+                                                     int shots, uint64_t seed, uint32_t first_eval,
+                                                     const double* __restrict__ diag, uint64_t* __restrict__ out,
+                                                     double* __restrict__ out_values) {
     const int shot = blockIdx.x * blockDim.x + threadIdx.x;
     if (shot >= shots) return;
+    const uint32_t slot = blockIdx.y, eval = first_eval + slot;
+    const double* __restrict__ probs = probs_all + uint64_t(slot) * dim;
+    const double* __restrict__ scanned = scanned_all + size_t(slot) * n_chunks;
     const double total = scanned[n_chunks - 1];
-    const uint64_t bits = splitmix64(seed ^ splitmix64(uint64_t(shot) + 1));
+    const uint64_t stream = splitmix64(seed + 0xD1B54A32D192ED03ull * (uint64_t(eval) + 1));
+    const uint64_t bits = splitmix64(stream ^ splitmix64(uint64_t(shot) + 1));
     const double u = double(bits >> 11) * (1.0 / 9007199254740992.0) * total;  // [0, total)
     // first chunk whose inclusive prefix exceeds u
     uint32_t lo = 0, hi = n_chunks - 1;
@@ -794,16 +806,19 @@ __global__ void __launch_bounds__(256) sample_kernel(const double* __restrict__ 
     }
     // walk back over zero-probability states a rounding tie could have selected
     while (idx > first && probs[idx] == 0.0) --idx;
-    out[shot] = idx;
+    const size_t o = size_t(eval) * size_t(shots) + size_t(shot);
+    out[o] = idx;
+    if (out_values) out_values[o] = diag[idx];
 }
 
-hipError_t launch_sample(const double* probs, uint64_t dim, double* chunk_sums, int shots, uint64_t seed,
-                         uint64_t* out, hipStream_t stream) {
+hipError_t launch_sample(const double* probs, uint64_t dim, int n_slots, double* chunk_sums, int shots, uint64_t seed,
+                         uint32_t first_eval, const double* diag, uint64_t* out, double* out_values,
+                         hipStream_t stream) {
     const uint32_t n_chunks = uint32_t((dim + kSampleChunk - 1) / kSampleChunk);
-    hipLaunchKernelGGL(chunk_sums_kernel, dim3(n_chunks), dim3(256), 0, stream, probs, dim, chunk_sums);
-    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(256), 0, stream, chunk_sums, n_chunks);
-    hipLaunchKernelGGL(sample_kernel, dim3((shots + 255) / 256), dim3(256), 0, stream, probs, dim, chunk_sums,
-                       n_chunks, shots, seed, out);
+    hipLaunchKernelGGL(chunk_sums_kernel, dim3(n_chunks, n_slots), dim3(256), 0, stream, probs, dim, chunk_sums, n_chunks);
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(n_slots), dim3(256), 0, stream, chunk_sums, n_chunks);
+    hipLaunchKernelGGL(sample_kernel, dim3((shots + 255) / 256, n_slots), dim3(256), 0, stream, probs, dim, chunk_sums,
+                       n_chunks, shots, seed, first_eval, diag, out, out_values);
     return hipGetLastError();
 }
 
@@ -814,12 +829,14 @@ static unsigned stream_blocks(uint64_t dim) {
     return unsigned(want < 4096 ? want : 4096);
 }
 
-hipError_t launch_probabilities(int dtype, const void* state, uint64_t dim, double* probs, hipStream_t stream) {
+hipError_t launch_probabilities(int dtype, const void* state, uint64_t dim, int n_slots, double* probs,
+                                hipStream_t stream) {
+    const dim3 grid(stream_blocks(dim), n_slots);
     if (dtype == 0)
-        hipLaunchKernelGGL(probabilities_kernel<double>, dim3(stream_blocks(dim)), dim3(256), 0, stream,
+        hipLaunchKernelGGL(probabilities_kernel<double>, grid, dim3(256), 0, stream,
                            reinterpret_cast<const cx<double>*>(state), dim, probs);
     else
-        hipLaunchKernelGGL(probabilities_kernel<float>, dim3(stream_blocks(dim)), dim3(256), 0, stream,
+        hipLaunchKernelGGL(probabilities_kernel<float>, grid, dim3(256), 0, stream,
                            reinterpret_cast<const cx<float>*>(state), dim, probs);
     return hipGetLastError();
 }

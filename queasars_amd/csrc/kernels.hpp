@@ -75,12 +75,16 @@ hipError_t launch_pauli_combine(const double* partials, uint32_t per_slot, const
                                 uint32_t diag_per_eval, int n_slots, const EvalDesc* evals, double* out,
                                 hipStream_t stream);
 
-// Draw `shots` basis states from `probs` (need not be normalised); chunk_sums: scratch of sample_chunk_count(dim) doubles.
-hipError_t launch_sample(const double* probs, uint64_t dim, double* chunk_sums, int shots, uint64_t seed,
-                         uint64_t* out, hipStream_t stream);
+// For each of n_slots probability vectors (slot s at probs + s * dim, need not be normalised) draw `shots` basis
+// states; evaluation (first_eval + s) gets its own random stream and writes out[(first_eval + s) * shots ..].
+// chunk_sums: scratch of n_slots * sample_chunk_count(dim) doubles.  With diag != null, out_values receives D[state].
+hipError_t launch_sample(const double* probs, uint64_t dim, int n_slots, double* chunk_sums, int shots, uint64_t seed,
+                         uint32_t first_eval, const double* diag, uint64_t* out, double* out_values,
+                         hipStream_t stream);
 uint32_t sample_chunk_count(uint64_t dim);
 
-hipError_t launch_probabilities(int dtype, const void* state, uint64_t dim, double* probs, hipStream_t stream);
+hipError_t launch_probabilities(int dtype, const void* state, uint64_t dim, int n_slots, double* probs,
+                                hipStream_t stream);
 hipError_t launch_state_to_f64(int dtype, const void* state, uint64_t dim, double* out_re_im, hipStream_t stream);
 
 }  // namespace qsv

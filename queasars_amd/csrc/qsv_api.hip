@@ -850,34 +850,92 @@ int qsv_probabilities(qsv_t* h, int circuit_id, const double* params, int n_para
     if (rc) return rc;
     const uint64_t dim = uint64_t(1) << h->n;
     if ((rc = ensure(h, h->d_scratch, dim * 8))) return rc;
-    QSV_HIP(h, launch_probabilities(h->dtype, h->d_states.ptr, dim, static_cast<double*>(h->d_scratch.ptr), h->stream));
+    QSV_HIP(h, launch_probabilities(h->dtype, h->d_states.ptr, dim, 1, static_cast<double*>(h->d_scratch.ptr), h->stream));
     QSV_HIP(h, hipMemcpyAsync(out_probs, h->d_scratch.ptr, dim * 8, hipMemcpyDeviceToHost, h->stream));
     QSV_HIP(h, hipStreamSynchronize(h->stream));
     return QSV_OK;
+}
+
+// Sampler branch for a whole batch: run the circuits group by group, turn each resident state into probabilities,
+// draw `shots` samples per evaluation on the device and (for a diagonal operator) gather each sample's value D[state].
+static int sample_batch_locked(qsv_t* h, const std::vector<Circuit*>& circs, const int64_t* param_offsets,
+                               const double* params, int shots, uint64_t seed, uint64_t* out_states,
+                               double* out_values) {
+    const size_t n_evals = circs.size();
+    if (n_evals == 0 || shots == 0) return QSV_OK;
+    if (out_values && !(h->has_diag_part && h->diagonal))
+        return fail(h, QSV_E_STATE, "sample values need a diagonal operator (call qsv_set_operator with I/Z terms only)");
+    std::vector<int64_t> np(n_evals);
+    std::vector<double> packed;
+    size_t total = 0;
+    for (size_t i = 0; i < n_evals; ++i) {
+        np[i] = param_offsets[i + 1] - param_offsets[i];
+        if (np[i] < 0) return fail(h, QSV_E_ARG, "param_offsets must be non-decreasing");
+        total += size_t(np[i]);
+    }
+    packed.resize(total + 1);
+    for (size_t i = 0, cur = 0; i < n_evals; cur += size_t(np[i]), ++i)
+        if (np[i]) std::memcpy(packed.data() + cur, params + param_offsets[i], size_t(np[i]) * sizeof(double));
+    h->prof = qsv_profile{};
+    int rc = batch_layout(h, circs, np);
+    if (rc) return rc;
+    const uint64_t dim = uint64_t(1) << h->n;
+    const size_t G = size_t(h->group);
+    const size_t probs_bytes = G * dim * 8, sums_bytes = G * size_t(sample_chunk_count(dim)) * 8;
+    const size_t states_off = ((probs_bytes + sums_bytes + 63) / 64) * 64;
+    const size_t values_off = states_off + n_evals * size_t(shots) * 8;
+    if ((rc = ensure(h, h->d_scratch, values_off + (out_values ? n_evals * size_t(shots) * 8 : 0)))) return rc;
+    if ((rc = ensure(h, h->d_partials, std::max<size_t>(1, n_evals) * chunks_per_state(h) * sizeof(double)))) return rc;
+    double* probs = static_cast<double*>(h->d_scratch.ptr);
+    double* sums = probs + G * dim;
+    uint64_t* d_states = reinterpret_cast<uint64_t*>(static_cast<char*>(h->d_scratch.ptr) + states_off);
+    double* d_values = out_values ? reinterpret_cast<double*>(static_cast<char*>(h->d_scratch.ptr) + values_off) : nullptr;
+    rc = batch_ship(h, 0, n_evals, packed.data());
+    for (size_t g0 = 0; !rc && g0 < n_evals; g0 += G) {
+        const size_t gc = std::min(G, n_evals - g0);
+        if ((rc = run_group(h, circs, g0, gc, kModeSynthFirst | kModeFinalStore))) break;
+        QSV_HIP(h, launch_probabilities(h->dtype, h->d_states.ptr, dim, int(gc), probs, h->stream));
+        QSV_HIP(h, launch_sample(probs, dim, int(gc), sums, shots, seed, uint32_t(g0),
+                                 static_cast<const double*>(h->d_diag.ptr), d_states, d_values, h->stream));
+    }
+    h->batch.circs.clear();
+    if (rc) return rc;
+    QSV_HIP(h, hipMemcpyAsync(out_states, d_states, n_evals * size_t(shots) * 8, hipMemcpyDeviceToHost, h->stream));
+    if (out_values)
+        QSV_HIP(h, hipMemcpyAsync(out_values, d_values, n_evals * size_t(shots) * 8, hipMemcpyDeviceToHost, h->stream));
+    QSV_HIP(h, hipStreamSynchronize(h->stream));
+    return QSV_OK;
+}
+
+int qsv_sample_batch(qsv_t* h, int n_evals, const int* circuit_ids, const int64_t* param_offsets, const double* params,
+                     int shots, uint64_t seed, uint64_t* out_states, double* out_values) {
+    if (!h) return QSV_E_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    if (n_evals < 0 || shots < 0 || (n_evals > 0 && shots > 0 && (!circuit_ids || !param_offsets || !out_states)))
+        return fail(h, QSV_E_ARG, "bad arguments");
+    QSV_HIP(h, hipSetDevice(h->device));
+    std::vector<Circuit*> circs(size_t(n_evals), nullptr);
+    for (int i = 0; i < n_evals; ++i) {
+        auto it = h->circuits.find(circuit_ids[i]);
+        if (it == h->circuits.end()) return fail(h, QSV_E_ARG, "unknown circuit id " + std::to_string(circuit_ids[i]));
+        circs[size_t(i)] = &it->second;
+    }
+    static const double dummy = 0.0;
+    return sample_batch_locked(h, circs, param_offsets, params ? params : &dummy, shots, seed, out_states, out_values);
 }
 
 int qsv_sample(qsv_t* h, int circuit_id, const double* params, int n_params, int shots, uint64_t seed,
                uint64_t* out_states) {
     if (!h) return QSV_E_ARG;
     std::lock_guard<std::mutex> lock(h->mu);
-    if (shots < 0 || (shots > 0 && !out_states)) return fail(h, QSV_E_ARG, "bad arguments");
-    if (shots == 0) return QSV_OK;
+    if (shots < 0 || n_params < 0 || (shots > 0 && !out_states)) return fail(h, QSV_E_ARG, "bad arguments");
     QSV_HIP(h, hipSetDevice(h->device));
+    auto it = h->circuits.find(circuit_id);
+    if (it == h->circuits.end()) return fail(h, QSV_E_ARG, "unknown circuit id");
+    std::vector<Circuit*> circs{&it->second};
+    const int64_t offsets[2] = {0, n_params};
     static const double dummy = 0.0;
-    int rc = run_single_to_state(h, circuit_id, params ? params : &dummy, n_params);
-    if (rc) return rc;
-    const uint64_t dim = uint64_t(1) << h->n;
-    const size_t probs_bytes = dim * 8, sums_bytes = size_t(sample_chunk_count(dim)) * 8;
-    const size_t out_off = ((probs_bytes + sums_bytes + 63) / 64) * 64;
-    if ((rc = ensure(h, h->d_scratch, out_off + size_t(shots) * 8))) return rc;
-    double* probs = static_cast<double*>(h->d_scratch.ptr);
-    double* sums = probs + dim;
-    uint64_t* d_out = reinterpret_cast<uint64_t*>(static_cast<char*>(h->d_scratch.ptr) + out_off);
-    QSV_HIP(h, launch_probabilities(h->dtype, h->d_states.ptr, dim, probs, h->stream));
-    QSV_HIP(h, launch_sample(probs, dim, sums, shots, seed, d_out, h->stream));
-    QSV_HIP(h, hipMemcpyAsync(out_states, d_out, size_t(shots) * 8, hipMemcpyDeviceToHost, h->stream));
-    QSV_HIP(h, hipStreamSynchronize(h->stream));
-    return QSV_OK;
+    return sample_batch_locked(h, circs, offsets, params ? params : &dummy, shots, seed, out_states, nullptr);
 }
 
 int qsv_set_profiling(qsv_t* h, int enabled) {

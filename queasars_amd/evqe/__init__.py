@@ -16,3 +16,11 @@ from queasars_amd.evqe.genome import (  # noqa: F401
     parameter_names,
     sorted_parameter_rank,
 )
+from queasars_amd.evqe.solver import (  # noqa: F401,E402
+    SPSA,
+    BestIndividualRelativeChangeTolerance,
+    EVQEMinimumEigensolver,
+    EVQEMinimumEigensolverConfiguration,
+    EVQEResult,
+    SPSATerminationChecker,
+)

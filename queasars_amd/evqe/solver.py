@@ -1,0 +1,406 @@
+"""EVQE driver over a circuit evaluator.
+
+Restates the control flow of the reference's solver so that the evaluator can be exercised end to end
+(BASELINE config 4), without Qiskit, Dask or a thread pool:
+
+* operator order and seeding chain: queasars/minimum_eigensolvers/evqe/evqe.py:188-229;
+* generation loop, callbacks, termination: queasars/minimum_eigensolvers/base/evolving_ansatz_minimum_eigensolver.py:331-433;
+* mutation: queasars/minimum_eigensolvers/evqe/evolutionary_algorithm/mutation.py:28-132 (layer optimisation),
+  :194-235 (who is mutated, with which seed), :328-334 / :347-353 / :383-395 (the four mutation operators);
+* speciation: .../speciation.py:34-90;  selection: .../selection.py:64-175;
+* termination criterion: queasars/minimum_eigensolvers/base/termination_criteria.py:90-144;
+* SPSA stopping rule: queasars/utility/spsa_termination.py:48-96.
+
+The optimiser itself lives in qiskit-algorithms (absent here); :class:`SPSA` restates its published first-order
+algorithm for the settings the reference's examples use (constant learning rate and perturbation, Bernoulli +-1
+directions from ``numpy.random.default_rng(seed)``, one resampling, optional trust region, ``last_avg=1``).
+
+MI355X-first difference: the reference farms one optimiser run per individual to a thread pool and lets a
+"batching mutex" glue their two-circuit requests together inside a 0.1 s window
+(queasars/circuit_evaluation/mutex_primitives.py:67-199).  Here all runs advance in lock-step and every SPSA
+iteration of the whole population is ONE ``evaluate_circuits`` call.  Each run still sees exactly the sequence of
+function values an independent run with its seed would see.
+"""
+
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from random import Random
+from statistics import mean, median
+from typing import Callable, Optional, Sequence
+
+import numpy as np
+
+from queasars_amd.evqe.genome import EVQEIndividual, EVQEPopulation, new_random_seed
+
+
+# ---- optimiser ------------------------------------------------------------------------------------------------
+
+
+class SPSATerminationChecker:
+    """Stop when |f_k - f_{k-1}| / f_{k-1} stayed below ``minimum_relative_change`` for
+    ``allowed_consecutive_violations + 1`` consecutive iterations (or ``maxfev`` is reached)."""
+
+    def __init__(self, minimum_relative_change: float, allowed_consecutive_violations: int, maxfev: Optional[int] = None):
+        self.minimum_relative_change = minimum_relative_change
+        self.allowed_consecutive_violations = allowed_consecutive_violations
+        self.maxfev = maxfev
+        self.function_value_history: list[float] = []
+        self._changes: list[float] = []
+
+    def fresh(self) -> "SPSATerminationChecker":
+        return SPSATerminationChecker(self.minimum_relative_change, self.allowed_consecutive_violations, self.maxfev)
+
+    def termination_check(self, n_function_evaluations: int, parameter_values, function_value: float, step_size: float, accepted: bool) -> bool:
+        if self.maxfev is not None and n_function_evaluations >= self.maxfev:
+            return True
+        if not accepted:
+            return False
+        self.function_value_history.append(function_value)
+        if len(self.function_value_history) < 2:
+            return False
+        previous = self.function_value_history[-2]
+        self._changes.append(abs(function_value - previous) / previous)
+        window = self.allowed_consecutive_violations + 1
+        if len(self._changes) < window:
+            return False
+        return max(self._changes[-window:]) < self.minimum_relative_change
+
+
+@dataclass
+class SPSA:
+    """First-order SPSA with constant gains (the configuration of examples/evqe_jssp_optimization.ipynb)."""
+
+    maxiter: int = 33
+    learning_rate: float = 0.43
+    perturbation: float = 0.35
+    trust_region: bool = True
+    termination_checker: Optional[SPSATerminationChecker] = None
+
+    @property
+    def n_circuit_evaluations(self) -> int:
+        return 2 * self.maxiter
+
+
+class _SPSARun:
+    """State of one SPSA minimisation; the driver advances many of them in lock-step."""
+
+    def __init__(self, config: SPSA, x0: Sequence[float], seed: Optional[int]):
+        self.config = config
+        self.x = np.asarray(x0, dtype=np.float64).copy()
+        self.rng = np.random.default_rng(seed)
+        self.checker = config.termination_checker.fresh() if config.termination_checker else None
+        self.nfev = 0
+        self.iteration = 0
+        self.done = self.x.size == 0 or config.maxiter <= 0
+        self._delta = None
+
+    def propose(self) -> list[np.ndarray]:
+        """The two points the next iteration evaluates."""
+        self._delta = 1 - 2 * self.rng.binomial(1, 0.5, size=self.x.size)
+        eps = self.config.perturbation
+        return [self.x + eps * self._delta, self.x - eps * self._delta]
+
+    def accept(self, f_plus: float, f_minus: float) -> None:
+        cfg = self.config
+        self.nfev += 2
+        self.iteration += 1
+        update = (f_plus - f_minus) / (2 * cfg.perturbation) * self._delta
+        if cfg.trust_region:
+            norm = float(np.linalg.norm(update))
+            if norm > 1:
+                update = update / norm
+        update = update * cfg.learning_rate
+        self.x = self.x - update
+        stop = self.iteration >= cfg.maxiter
+        if self.checker is not None and self.checker.termination_check(
+            self.nfev, self.x, 0.5 * (f_plus + f_minus), float(np.linalg.norm(update)), True
+        ):
+            stop = True
+        self.done = stop
+
+
+def _minimize_batched(evaluator, jobs: list[tuple[object, _SPSARun]]) -> None:
+    """Advance every (circuit, run) pair to completion; one evaluate_circuits call per SPSA iteration."""
+    active = [job for job in jobs if not job[1].done]
+    while active:
+        circuits, params = [], []
+        for circuit, run in active:
+            plus, minus = run.propose()
+            circuits += [circuit, circuit]
+            params += [plus.tolist(), minus.tolist()]
+        values = evaluator.evaluate_circuits(circuits, params)
+        for i, (_, run) in enumerate(active):
+            run.accept(values[2 * i], values[2 * i + 1])
+        active = [job for job in active if not job[1].done]
+
+
+# ---- configuration / result -----------------------------------------------------------------------------------
+
+
+class BestIndividualRelativeChangeTolerance:
+    def __init__(self, minimum_relative_change: float, allowed_consecutive_violations: int = 0):
+        if minimum_relative_change <= 0 or minimum_relative_change > 1:
+            raise ValueError("The minimum relative improvement parameter must not exceed the range )0,1)!")
+        if allowed_consecutive_violations < 0:
+            raise ValueError("allowed_consecutive_violations must be at least 0!")
+        self._threshold = minimum_relative_change
+        self._window = allowed_consecutive_violations + 1
+        self.reset_state()
+
+    def reset_state(self) -> None:
+        self._previous: Optional[float] = None
+        self._history: list[float] = []
+
+    def check_termination(self, best_expectation_value_of_generation: float) -> bool:
+        if self._previous is None:
+            self._previous = best_expectation_value_of_generation
+            return False
+        self._history.append(abs(self._previous - best_expectation_value_of_generation) / abs(self._previous))
+        self._previous = best_expectation_value_of_generation
+        if len(self._history) < self._window:
+            return False
+        return max(self._history[-self._window :]) < self._threshold
+
+
+@dataclass
+class EVQEMinimumEigensolverConfiguration:
+    """The solver knobs of queasars/minimum_eigensolvers/evqe/evqe.py:34-177 that do not concern primitives/executors."""
+
+    optimizer: SPSA
+    population_size: int
+    max_generations: Optional[int] = None
+    max_circuit_evaluations: Optional[int] = None
+    termination_criterion: Optional[BestIndividualRelativeChangeTolerance] = None
+    random_seed: Optional[int] = None
+    n_initial_layers: int = 1
+    randomize_initial_population_parameters: bool = False
+    speciation_genetic_distance_threshold: int = 2
+    use_tournament_selection: bool = False
+    tournament_size: Optional[int] = None
+    selection_alpha_penalty: float = 0.1
+    selection_beta_penalty: float = 0.1
+    parameter_search_probability: float = 0.24
+    topological_search_probability: float = 0.2
+    layer_removal_probability: float = 0.05
+
+    def __post_init__(self):
+        if self.population_size < 1:
+            raise ValueError("population_size must be at least 1!")
+        if self.max_generations is None and self.max_circuit_evaluations is None and self.termination_criterion is None:
+            raise ValueError("At least one of max_generations, max_circuit_evaluations or termination_criterion is needed!")
+        if self.use_tournament_selection and (self.tournament_size is None or self.tournament_size < 1):
+            raise ValueError("tournament_size cannot be None, if tournament selection should be used!")
+        for name in ("parameter_search_probability", "topological_search_probability", "layer_removal_probability"):
+            if not 0 <= getattr(self, name) <= 1:
+                raise ValueError(f"{name} must be in the range [0, 1]!")
+
+
+@dataclass
+class EVQEResult:
+    eigenvalue: float
+    best_individual: EVQEIndividual
+    generations: int
+    circuit_evaluations: list[int]
+    best_expectation_values: list[float] = field(default_factory=list)
+    median_expectation_values: list[float] = field(default_factory=list)
+    mean_expectation_values: list[float] = field(default_factory=list)
+
+
+# ---- the solver -----------------------------------------------------------------------------------------------
+
+
+class EVQEMinimumEigensolver:
+    def __init__(self, configuration: EVQEMinimumEigensolverConfiguration, log: Optional[Callable[[str], None]] = None):
+        self.configuration = configuration
+        self._log = log or (lambda message: None)
+        rng = Random(configuration.random_seed)
+        # one seed per consumer, drawn in the reference's order (evqe.py:188-229)
+        self._population_seed = new_random_seed(rng)
+        self._rng_last_layer = Random(new_random_seed(rng))
+        self._rng_speciation = Random(new_random_seed(rng))
+        self._rng_selection = Random(new_random_seed(rng))
+        self._rng_parameter_search = Random(new_random_seed(rng))
+        self._rng_topological = Random(new_random_seed(rng))
+        self._rng_layer_removal = Random(new_random_seed(rng))
+
+    # -- mutation helpers -----------------------------------------------------------------------------------
+    @staticmethod
+    def _chosen(population: EVQEPopulation, rng: Random, probability: float) -> dict[int, int]:
+        """index -> seed of the individuals an operator mutates (mutation.py:206-216)."""
+        chosen = {}
+        for i in range(len(population.individuals)):
+            if rng.random() <= probability:
+                chosen[i] = new_random_seed(rng)
+        return chosen
+
+    def _optimize_layers(self, evaluator, individuals: list[EVQEIndividual], layer_ids: list[int], seeds: list[int]):
+        """optimize_layer_of_individual (mutation.py:28-89) for many individuals at once."""
+        jobs = []
+        for individual, layer_id, seed in zip(individuals, layer_ids, seeds):
+            circuit = individual.get_partially_parameterized_quantum_circuit({layer_id})
+            run = _SPSARun(self.configuration.optimizer, individual.get_layer_parameter_values(layer_id), seed)
+            jobs.append((circuit, run))
+        _minimize_batched(evaluator, jobs)
+        out, nfev = [], 0
+        for individual, layer_id, (_, run) in zip(individuals, layer_ids, jobs):
+            out.append(EVQEIndividual.change_layer_parameter_values(individual, layer_id, tuple(run.x.tolist())))
+            nfev += run.nfev
+        return out, nfev
+
+    def _last_layer_search(self, evaluator, population: EVQEPopulation) -> tuple[EVQEPopulation, int]:
+        chosen = self._chosen(population, self._rng_last_layer, 1.0)
+        idx = sorted(chosen)
+        new, nfev = self._optimize_layers(evaluator, [population.individuals[i] for i in idx], [-1] * len(idx), [chosen[i] for i in idx])
+        individuals = list(population.individuals)
+        for i, ind in zip(idx, new):
+            individuals[i] = ind
+        return EVQEPopulation(tuple(individuals), population.species_representatives, None, None), nfev
+
+    def _parameter_search(self, evaluator, population: EVQEPopulation) -> tuple[EVQEPopulation, int]:
+        """optimize_all_parameters_of_individual (mutation.py:92-132): layers in a random order, one at a time; the
+        j-th layer of every chosen individual is optimised in the same batch."""
+        chosen = self._chosen(population, self._rng_parameter_search, self.configuration.parameter_search_probability)
+        state = {}
+        for i, seed in chosen.items():
+            randomizer = Random(seed)
+            state[i] = [population.individuals[i], list(range(len(population.individuals[i].layers))), randomizer]
+        total = 0
+        while any(todo for _, todo, _ in state.values()):
+            batch = [i for i, (_, todo, _) in state.items() if todo]
+            layers, seeds = [], []
+            for i in batch:
+                _, todo, randomizer = state[i]
+                layer = randomizer.choice(todo)
+                todo.remove(layer)
+                layers.append(layer)
+                seeds.append(new_random_seed(randomizer))
+            new, nfev = self._optimize_layers(evaluator, [state[i][0] for i in batch], layers, seeds)
+            total += nfev
+            for i, ind in zip(batch, new):
+                state[i][0] = ind
+        individuals = list(population.individuals)
+        for i, (ind, _, _) in state.items():
+            individuals[i] = ind
+        return EVQEPopulation(tuple(individuals), population.species_representatives, None, None), total
+
+    def _topological_search(self, population: EVQEPopulation) -> EVQEPopulation:
+        chosen = self._chosen(population, self._rng_topological, self.configuration.topological_search_probability)
+        individuals = list(population.individuals)
+        for i, seed in chosen.items():
+            individuals[i] = EVQEIndividual.add_random_layers(individuals[i], 1, False, random_seed=seed)
+        return EVQEPopulation(tuple(individuals), population.species_representatives, None, None)
+
+    def _layer_removal(self, population: EVQEPopulation) -> EVQEPopulation:
+        chosen = self._chosen(population, self._rng_layer_removal, self.configuration.layer_removal_probability)
+        individuals = list(population.individuals)
+        for i, seed in chosen.items():
+            ind = individuals[i]
+            if len(ind.layers) > 1:
+                individuals[i] = EVQEIndividual.remove_layers(ind, Random(seed).randrange(1, len(ind.layers)))
+        return EVQEPopulation(tuple(individuals), population.species_representatives, None, None)
+
+    # -- speciation / selection -----------------------------------------------------------------------------
+    def _speciation(self, population: EVQEPopulation) -> EVQEPopulation:
+        threshold = self.configuration.speciation_genetic_distance_threshold
+        representatives = list(population.species_representatives or [])
+        members: dict[EVQEIndividual, list[int]] = {rep: [] for rep in representatives}
+        for i, individual in enumerate(population.individuals):
+            for rep in representatives:
+                if EVQEIndividual.get_genetic_distance(individual, rep) < threshold or individual == rep:
+                    members[rep].append(i)
+                    break
+            else:
+                representatives.append(individual)
+                members[individual] = [i]
+        new_members: dict[EVQEIndividual, list[int]] = {}
+        for group in members.values():
+            if not group:
+                continue
+            representative = population.individuals[self._rng_speciation.choice(group)]
+            new_members.setdefault(representative, []).extend(group)
+        membership = {i: rep for rep, group in new_members.items() for i in group}
+        return EVQEPopulation(population.individuals, list(new_members), new_members, membership)
+
+    def _selection(self, population: EVQEPopulation, values: list[float]) -> EVQEPopulation:
+        cfg = self.configuration
+        rng = self._rng_selection
+        n = len(population.individuals)
+        species_size = [float(len(population.species_members[population.species_membership[i]])) for i in range(n)]
+        penalties = [
+            cfg.selection_alpha_penalty * len(ind.layers) + cfg.selection_beta_penalty * ind.get_n_controlled_gates()
+            for ind in population.individuals
+        ]
+        if not cfg.use_tournament_selection:
+            best = min(values)
+            offset = -best + 1 if best <= 0 else 0
+            fitness = [(values[i] + offset + penalties[i]) * species_size[i] for i in range(n)]
+            selected = rng.choices(population.individuals, weights=[1 / (f + offset) for f in fitness], k=n)
+        else:
+            fitness = [(values[i] + penalties[i]) * species_size[i] for i in range(n)]
+            selected = []
+            while len(selected) < n:
+                contenders = rng.choices(range(n), k=cfg.tournament_size)
+                winner = min(contenders, key=lambda j: (fitness[j], contenders.index(j)))
+                selected.append(population.individuals[winner])
+        return EVQEPopulation(tuple(selected), population.species_representatives, None, None)
+
+    # -- main loop ------------------------------------------------------------------------------------------
+    def compute_minimum_eigenvalue(self, evaluator) -> EVQEResult:
+        cfg = self.configuration
+        if cfg.termination_criterion is not None:
+            cfg.termination_criterion.reset_state()
+        population = EVQEPopulation.random_population(
+            evaluator.n_qubits, cfg.n_initial_layers, cfg.population_size, cfg.randomize_initial_population_parameters,
+            random_seed=self._population_seed,
+        )
+        evaluations: list[int] = [0]
+        result = EVQEResult(eigenvalue=math.inf, best_individual=population.individuals[0], generations=0, circuit_evaluations=evaluations)
+        n_opt = cfg.optimizer.n_circuit_evaluations
+
+        def budget_left(expected: int) -> bool:
+            if cfg.max_circuit_evaluations is None:
+                return True
+            used = sum(evaluations)
+            return used < cfg.max_circuit_evaluations and used + expected < cfg.max_circuit_evaluations
+
+        while True:
+            if cfg.max_generations is not None and result.generations >= cfg.max_generations:
+                break
+            # 1. last-layer parameter search on everyone
+            if not budget_left(len(population.individuals) * n_opt):
+                break
+            population, nfev = self._last_layer_search(evaluator, population)
+            evaluations[-1] += nfev
+            # 2. speciation, 3. selection (this is where a generation is scored)
+            population = self._speciation(population)
+            if not budget_left(len(population.individuals)):
+                break
+            circuits = [ind.get_parameterized_quantum_circuit() for ind in population.individuals]
+            values = evaluator.evaluate_circuits(circuits, [list(ind.parameter_values) for ind in population.individuals])
+            evaluations[-1] += len(values)
+            best = int(np.argmin(values))
+            if values[best] < result.eigenvalue:
+                result.eigenvalue, result.best_individual = values[best], population.individuals[best]
+            result.best_expectation_values.append(values[best])
+            result.median_expectation_values.append(median(values))
+            result.mean_expectation_values.append(mean(values))
+            self._log(f"generation {result.generations}: best {values[best]:.6f} median {median(values):.6f} mean {mean(values):.6f}")
+            result.generations += 1
+            evaluations.append(0)
+            terminate = cfg.termination_criterion is not None and cfg.termination_criterion.check_termination(values[best])
+            population = self._selection(population, values)
+            if terminate or (cfg.max_generations is not None and result.generations >= cfg.max_generations):
+                break
+            # 4. full parameter search, 5. growth, 6. pruning
+            expected = math.ceil(cfg.parameter_search_probability * sum(len(i.layers) for i in population.individuals) * n_opt)
+            if not budget_left(expected):
+                break
+            population, nfev = self._parameter_search(evaluator, population)
+            evaluations[-1] += nfev
+            population = self._topological_search(population)
+            population = self._layer_removal(population)
+        if evaluations and evaluations[-1] == 0 and len(evaluations) > 1:
+            evaluations.pop()
+        return result

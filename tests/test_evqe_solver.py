@@ -1,0 +1,138 @@
+"""EVQE driver on the CPU with an oracle-backed evaluator (the GPU run is in tests/test_gpu_parity.py).
+Modelled on the reference's end-to-end test: the solver must find x = 0, y = 3 for min x^2 - y^2
+(test/minimum_eigensolvers/evqe/test_evqe_algorithm.py:34-38)."""
+
+import numpy as np
+import pytest
+
+import helpers
+from queasars_amd.evqe import EVQEPopulation
+from queasars_amd.evqe.solver import (
+    SPSA,
+    BestIndividualRelativeChangeTolerance,
+    EVQEMinimumEigensolver,
+    EVQEMinimumEigensolverConfiguration,
+    SPSATerminationChecker,
+    _SPSARun,
+)
+from queasars_amd.ir import PauliOperator
+
+
+class OracleEvaluator:
+    def __init__(self, operator):
+        self.operator = operator
+        self.calls = 0
+        self.evaluations = 0
+
+    @property
+    def n_qubits(self):
+        return self.operator.num_qubits
+
+    def evaluate_circuits(self, circuits, parameter_values):
+        self.calls += 1
+        self.evaluations += len(circuits)
+        return [helpers.oracle_expectation(c, p, self.operator) for c, p in zip(circuits, parameter_values)]
+
+
+def xy_hamiltonian():
+    return PauliOperator.from_sparse_list(
+        [("Z", [0], -1.5), ("Z", [1], -3.0), ("ZZ", [0, 1], 1.0), ("Z", [2], 1.5), ("Z", [3], 3.0), ("ZZ", [2, 3], -1.0)], 4
+    )
+
+
+def make_config(**overrides):
+    args = dict(
+        optimizer=SPSA(maxiter=25, learning_rate=0.4, perturbation=0.3),
+        population_size=8,
+        max_generations=6,
+        random_seed=0,
+        n_initial_layers=2,
+        randomize_initial_population_parameters=True,
+        speciation_genetic_distance_threshold=2,
+        use_tournament_selection=True,
+        tournament_size=2,
+        selection_alpha_penalty=0.1,
+        selection_beta_penalty=0.1,
+        parameter_search_probability=0.3,
+        topological_search_probability=0.4,
+        layer_removal_probability=0.05,
+    )
+    args.update(overrides)
+    return EVQEMinimumEigensolverConfiguration(**args)
+
+
+def test_solver_finds_the_ground_state_and_is_seeded():
+    op = xy_hamiltonian()
+    ev = OracleEvaluator(op)
+    result = EVQEMinimumEigensolver(make_config()).compute_minimum_eigenvalue(ev)
+    assert result.generations == 6 and len(result.best_expectation_values) == 6
+    assert result.eigenvalue < -8.5  # the minimum is -9 at x = 0, y = 3
+    assert sum(result.circuit_evaluations) == ev.evaluations
+    # far fewer evaluator calls than evaluations: the optimiser runs are batched
+    assert ev.calls * 4 < ev.evaluations
+    state = helpers.oracle_state(
+        result.best_individual.get_parameterized_quantum_circuit(), list(result.best_individual.parameter_values)
+    )
+    assert int(np.argmax(np.abs(state))) == 0b1100
+    again = EVQEMinimumEigensolver(make_config()).compute_minimum_eigenvalue(OracleEvaluator(op))
+    assert again.eigenvalue == result.eigenvalue and again.best_individual == result.best_individual
+
+
+def test_termination_by_budget_and_by_criterion():
+    op = xy_hamiltonian()
+    ev = OracleEvaluator(op)
+    cfg = make_config(max_generations=None, max_circuit_evaluations=1500)
+    result = EVQEMinimumEigensolver(cfg).compute_minimum_eigenvalue(ev)
+    assert 0 < sum(result.circuit_evaluations) <= 1500 and result.generations >= 1
+    crit = BestIndividualRelativeChangeTolerance(minimum_relative_change=0.5)
+    result = EVQEMinimumEigensolver(make_config(max_generations=None, termination_criterion=crit)).compute_minimum_eigenvalue(OracleEvaluator(op))
+    assert 2 <= result.generations <= 10
+    with pytest.raises(ValueError):
+        make_config(max_generations=None)
+    with pytest.raises(ValueError):
+        make_config(use_tournament_selection=True, tournament_size=None)
+
+
+def test_growth_with_zero_angles_keeps_the_energy():
+    """Topological search appends a layer of zero angles: identity until optimised (mutation.py:348-353)."""
+    op = xy_hamiltonian()
+    pop = EVQEPopulation.random_population(4, 2, 4, True, 3)
+    solver = EVQEMinimumEigensolver(make_config(topological_search_probability=1.0))
+    grown = solver._topological_search(pop)
+    for before, after in zip(pop.individuals, grown.individuals):
+        assert len(after.layers) == len(before.layers) + 1
+        e0 = helpers.oracle_expectation(before.get_parameterized_quantum_circuit(), list(before.parameter_values), op)
+        e1 = helpers.oracle_expectation(after.get_parameterized_quantum_circuit(), list(after.parameter_values), op)
+        assert abs(e0 - e1) < 1e-13
+
+
+def test_spsa_run_matches_a_plain_sequential_spsa():
+    """The lock-step driver gives every run exactly the iterates of an independent SPSA with the same seed."""
+
+    def f(x):
+        return float(np.sum((x - 1.0) ** 2) + 3.0)
+
+    cfg = SPSA(maxiter=12, learning_rate=0.2, perturbation=0.1, trust_region=True,
+               termination_checker=SPSATerminationChecker(0.001, 1))
+    x0 = np.array([0.3, -0.2, 2.0])
+    run = _SPSARun(cfg, x0, seed=11)
+    while not run.done:
+        plus, minus = run.propose()
+        run.accept(f(plus), f(minus))
+    # plain restatement
+    rng = np.random.default_rng(11)
+    x, checker, nfev = x0.copy(), cfg.termination_checker.fresh(), 0
+    for _ in range(cfg.maxiter):
+        delta = 1 - 2 * rng.binomial(1, 0.5, size=3)
+        fp, fm = f(x + 0.1 * delta), f(x - 0.1 * delta)
+        nfev += 2
+        update = (fp - fm) / 0.2 * delta
+        norm = np.linalg.norm(update)
+        if norm > 1:
+            update = update / norm
+        update = update * 0.2
+        x = x - update
+        if checker.termination_check(nfev, x, 0.5 * (fp + fm), np.linalg.norm(update), True):
+            break
+    assert np.array_equal(run.x, x) and run.nfev == nfev
+    assert f(run.x) < f(x0)

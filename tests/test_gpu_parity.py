@@ -276,3 +276,33 @@ def test_jssp_notebook_energy_on_gpu():
     got = OperatorCircuitEvaluator(op).evaluate_circuits(circuits, params)
     ref = [helpers.oracle_expectation(c, p, op) for c, p in zip(circuits, params)]
     assert np.abs(np.asarray(got) - np.asarray(ref)).max() < 1e-9
+
+
+def test_config4_jssp_end_to_end_evqe():
+    """BASELINE config 4: EVQE (sampler + CVaR 0.5, 512 shots, SPSA 33 iterations, population 10) on the notebook's
+    12-qubit JSSP instance reaches the notebook's final energy 22.75 with a valid makespan-5 schedule
+    (examples/evqe_jssp_optimization.ipynb:384-392, :481)."""
+    import jssp_instances as inst
+    from queasars_amd.circuit_evaluation import OperatorSamplerCircuitEvaluator
+    from queasars_amd.evqe.solver import (
+        SPSA, BestIndividualRelativeChangeTolerance, EVQEMinimumEigensolver, EVQEMinimumEigensolverConfiguration, SPSATerminationChecker,
+    )
+    from queasars_amd.job_shop_scheduling import JSSPDomainWallHamiltonianEncoder
+
+    enc = JSSPDomainWallHamiltonianEncoder(inst.notebook_2x3(), makespan_limit=6, **inst.NOTEBOOK_PENALTIES)
+    evaluator = OperatorSamplerCircuitEvaluator(512, enc.get_problem_hamiltonian(), alpha=0.5, seed=0)
+    cfg = EVQEMinimumEigensolverConfiguration(
+        optimizer=SPSA(maxiter=33, perturbation=0.35, learning_rate=0.43, trust_region=True,
+                       termination_checker=SPSATerminationChecker(0.01, 2)),
+        population_size=10, max_generations=8, termination_criterion=BestIndividualRelativeChangeTolerance(0.01, 1),
+        random_seed=0, n_initial_layers=2, randomize_initial_population_parameters=True,
+        speciation_genetic_distance_threshold=1, use_tournament_selection=True, tournament_size=2,
+        selection_alpha_penalty=0.15, selection_beta_penalty=0.02, parameter_search_probability=0.39,
+        topological_search_probability=0.79, layer_removal_probability=0.02,
+    )
+    result = EVQEMinimumEigensolver(cfg).compute_minimum_eigenvalue(evaluator)
+    assert abs(result.eigenvalue - 22.75) < 1e-6
+    best = result.best_individual
+    probs = evaluator.statevector_device.probabilities(best.get_parameterized_quantum_circuit(), list(best.parameter_values))
+    schedule = enc.translate_result_bitstring(format(int(np.argmax(probs)), f"0{enc.n_qubits}b"))
+    assert schedule.is_valid and schedule.makespan == 5
