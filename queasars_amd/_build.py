@@ -33,14 +33,17 @@ def needs_build() -> bool:
     return any((CSRC / f).resolve().stat().st_mtime > built for f in SOURCES + HEADERS)
 
 
-def build(force: bool = False, verbose: bool = False) -> Path:
-    """Compile every HIP source for gfx950 into queasars_amd/libqsv.so and return its path."""
-    if not force and not needs_build():
+def build(force: bool = False, verbose: bool = False, defines: tuple = (), lib_path: Path = LIB_PATH) -> Path:
+    """Compile every HIP source for gfx950 into queasars_amd/libqsv.so and return its path.
+
+    ``defines`` / ``lib_path`` build a diagnostic variant next to it (scripts/stamps.py: -DQSV_STAMPS)."""
+    if not force and not defines and not needs_build():
         return LIB_PATH
-    obj_dir = PKG_DIR / "build"
+    obj_dir = PKG_DIR / ("build" if not defines else "build_" + "_".join(defines).lower())
     obj_dir.mkdir(exist_ok=True)
     hipcc = _hipcc()
     common = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+    common += [f"-D{d}" for d in defines]
     procs = []
     objs = []
     for src in SOURCES:
@@ -59,13 +62,13 @@ def build(force: bool = False, verbose: bool = False) -> Path:
             raise RuntimeError(f"hipcc failed on {src}:\n{out}")
         if verbose and out.strip():
             print(out)
-    tmp = LIB_PATH.with_suffix(".so.tmp")
+    tmp = lib_path.with_suffix(".so.tmp")
     link = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(tmp), *objs]
     res = subprocess.run(link, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if res.returncode != 0:
         raise RuntimeError(f"link failed:\n{res.stdout}")
-    os.replace(tmp, LIB_PATH)
-    return LIB_PATH
+    os.replace(tmp, lib_path)
+    return lib_path
 
 
 if __name__ == "__main__":

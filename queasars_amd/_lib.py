@@ -96,7 +96,9 @@ class QsvLibraryError(RuntimeError):
 
 
 def library_path() -> Path:
-    return _build.LIB_PATH
+    """queasars_amd/libqsv.so; QSV_LIBRARY points measurement scripts at a diagnostic build of the same sources."""
+    override = os.environ.get("QSV_LIBRARY")
+    return Path(override) if override else _build.LIB_PATH
 
 
 def load(build_if_missing: bool = True) -> C.CDLL:

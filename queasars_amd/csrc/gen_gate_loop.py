@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""Generates gate_loop_gen.inc: the fp64 gate loop of pass_kernel as one gfx950 assembly block per register width.
+
+Why assembly: the loop applies a run-time sequence of 2x2 butterflies to 2^R amplitudes that must stay in the SAME
+vector registers from one gate to the next.  Written in C++ (a switch over target bit / control bit inside the gate
+loop) hipcc merges the cases through PHI nodes it cannot coalesce and moves the whole register file of amplitudes
+around every gate: 40-60 v_mov_b64 per gate next to the 56 useful fp64 operations, and a 64-bit move costs a
+v_fma_f64's issue time on gfx950.  Here every butterfly writes its results in place and the only branches are scalar.
+
+Per gate (descriptor = 4 words w0, ct, cg, op; matrix = 8 doubles m00 m01 m10 m11 as (re, im), Im m00 = 0):
+    skip if the global control bit of this tile is 0              (base & cg) != cg              scalar
+    mask lanes whose thread-held control bit is 0                  (tid & ct) == ct               exec
+    J = w0 & 0xff picks the target register bit; for each of the 2^(R-1) amplitude pairs p, bit 16 + p of w0 says
+    whether the pair takes part (a register-held control switches half of them off)                 scalar
+    pair update, 14 fp64 operations, in place:
+        u = m01r a1r - m01i a1i      w = m01r a1i + m01i a1r
+        p = m11r a1r - m11i a1i + m10r a0r      q = m11r a1i + m11i a1r + m10r a0i
+        a1r' = p - m10i a0i    a1i' = q + m10i a0r    a0r' = m00 a0r + u    a0i' = m00 a0i + w
+
+Descriptor and matrix of gate g + 1 are fetched with scalar loads while gate g runs (two register sets, loop unrolled
+by two).  Scalar registers are hard-coded and declared as clobbers; amplitudes and temporaries are operands.
+
+    python gen_gate_loop.py            # rewrites gate_loop_gen.inc next to this file
+"""
+
+from __future__ import annotations
+
+import sys
+from pathlib import Path
+
+OUT = Path(__file__).resolve().parent / "gate_loop_gen.inc"
+
+# hard-coded scalar registers (all inside one clobbered window)
+MAT = {"A": 40, "B": 56}  # 16 SGPRs each: 8 doubles
+DESC = {"A": 72, "B": 76}  # w0, ct, cg, op
+SAVE = "s[80:81]"
+T0 = "s82"
+RP, MP, N = 84, 86, 88
+CLOBBER_RANGE = range(40, 89)
+
+
+def sreg2(base: int) -> str:
+    return f"s[{base}:{base + 1}]"
+
+
+def gate(lines: list[str], r: int, x: str, tag: str) -> None:
+    """Emit the code of one gate that reads register set x ('A' or 'B')."""
+    m, d = MAT[x], DESC[x]
+    w0, ct, cg = f"s{d}", f"s{d + 1}", f"s{d + 2}"
+    m00, m01r, m01i = sreg2(m), sreg2(m + 4), sreg2(m + 6)
+    m10r, m10i, m11r, m11i = sreg2(m + 8), sreg2(m + 10), sreg2(m + 12), sreg2(m + 14)
+    e = lines.append
+    e(f"s_and_b32 {T0}, %[base], {cg}")
+    e(f"s_cmp_eq_u32 {T0}, {cg}")
+    e(f"s_cbranch_scc0 Lskip{tag}_%=")
+    e(f"v_and_b32 %[vt], {ct}, %[tid]")
+    e(f"v_cmp_eq_u32 vcc, {ct}, %[vt]")
+    e(f"s_and_saveexec_b64 {SAVE}, vcc")
+    e(f"s_cbranch_execz Lrest{tag}_%=")
+    if r > 1:
+        e(f"s_and_b32 {T0}, {w0}, 0xff")
+        for j in range(r - 1):
+            e(f"s_cmp_eq_u32 {T0}, {j}")
+            e(f"s_cbranch_scc1 Lj{j}{tag}_%=")
+    order = [r - 1] + list(range(r - 1))  # fall-through case first, then the branch targets
+    for pos, j in enumerate(order):
+        if j != r - 1:
+            e(f"Lj{j}{tag}_%=:")
+        pair = 0
+        for e0 in range(1 << r):
+            if e0 & (1 << j):
+                continue
+            e1 = e0 | (1 << j)
+            a0r, a0i, a1r, a1i = f"%[a{e0}r]", f"%[a{e0}i]", f"%[a{e1}r]", f"%[a{e1}i]"
+            e(f"s_bitcmp1_b32 {w0}, {16 + pair}")
+            e(f"s_cbranch_scc0 Ln{j}_{pair}{tag}_%=")
+            e(f"v_mul_f64 %[u], {m01r}, {a1r}")
+            e(f"v_mul_f64 %[w], {m01r}, {a1i}")
+            e(f"v_mul_f64 %[p], {m11r}, {a1r}")
+            e(f"v_mul_f64 %[q], {m11r}, {a1i}")
+            e(f"v_fma_f64 %[u], -{m01i}, {a1i}, %[u]")
+            e(f"v_fma_f64 %[w], {m01i}, {a1r}, %[w]")
+            e(f"v_fma_f64 %[p], -{m11i}, {a1i}, %[p]")
+            e(f"v_fma_f64 %[q], {m11i}, {a1r}, %[q]")
+            e(f"v_fma_f64 %[p], {m10r}, {a0r}, %[p]")
+            e(f"v_fma_f64 %[q], {m10r}, {a0i}, %[q]")
+            e(f"v_fma_f64 {a1r}, -{m10i}, {a0i}, %[p]")
+            e(f"v_fma_f64 {a1i}, {m10i}, {a0r}, %[q]")
+            e(f"v_fma_f64 {a0r}, {m00}, {a0r}, %[u]")
+            e(f"v_fma_f64 {a0i}, {m00}, {a0i}, %[w]")
+            e(f"Ln{j}_{pair}{tag}_%=:")
+            pair += 1
+        if pos + 1 < len(order):
+            e(f"s_branch Lrest{tag}_%=")
+    e(f"Lrest{tag}_%=:")
+    e(f"s_mov_b64 exec, {SAVE}")
+    e(f"Lskip{tag}_%=:")
+
+
+def loop_body(r: int) -> list[str]:
+    a, b = MAT["A"], MAT["B"]
+    da, db = DESC["A"], DESC["B"]
+    rp, mp = sreg2(RP), sreg2(MP)
+    n = f"s{N}"
+    lines: list[str] = []
+    e = lines.append
+    e(f"s_mov_b64 {rp}, %[rp]")
+    e(f"s_mov_b64 {mp}, %[mp]")
+    e(f"s_mov_b32 {n}, %[n]")
+    e(f"s_load_dwordx4 s[{da}:{da + 3}], {rp}, 0x0")
+    e(f"s_load_dwordx16 s[{a}:{a + 15}], {mp}, 0x0")
+    e("Lloop_%=:")
+    e("s_waitcnt lgkmcnt(0)")
+    e(f"s_load_dwordx4 s[{db}:{db + 3}], {rp}, 0x10")
+    e(f"s_load_dwordx16 s[{b}:{b + 15}], {mp}, 0x40")
+    gate(lines, r, "A", "a")
+    e(f"s_sub_u32 {n}, {n}, 1")
+    e(f"s_cmp_eq_u32 {n}, 0")
+    e("s_cbranch_scc1 Ldone_%=")
+    e("s_waitcnt lgkmcnt(0)")
+    e(f"s_load_dwordx4 s[{da}:{da + 3}], {rp}, 0x20")
+    e(f"s_load_dwordx16 s[{a}:{a + 15}], {mp}, 0x80")
+    gate(lines, r, "B", "b")
+    e(f"s_add_u32 s{RP}, s{RP}, 32")
+    e(f"s_addc_u32 s{RP + 1}, s{RP + 1}, 0")
+    e(f"s_add_u32 s{MP}, s{MP}, 128")
+    e(f"s_addc_u32 s{MP + 1}, s{MP + 1}, 0")
+    e(f"s_sub_u32 {n}, {n}, 1")
+    e(f"s_cmp_lg_u32 {n}, 0")
+    e("s_cbranch_scc1 Lloop_%=")
+    e("Ldone_%=:")
+    e("s_waitcnt lgkmcnt(0)")  # the last prefetch must land before the compiler may reuse these registers
+    return lines
+
+
+def emit(r: int) -> str:
+    nr = 1 << r
+    out = []
+    out.append(f"// R = {r}: {nr} amplitudes per thread")
+    out.append("template <>")
+    out.append(f"struct GateLoopF64<{r}> {{")
+    out.append(
+        f"    static __device__ __forceinline__ void run(cx<double> (&amp)[{nr}], const uint32_t* rp, const double* mp,\n"
+        "                                               uint32_t n_gates, uint32_t base, uint32_t tid) {"
+    )
+    out.append("        // uniform by construction; say so to the compiler, which otherwise may hand a VGPR to an \"s\" operand")
+    out.append("        base = __builtin_amdgcn_readfirstlane(base);")
+    out.append("        n_gates = __builtin_amdgcn_readfirstlane(n_gates);")
+    out.append("        double u, w, p, q;")
+    out.append("        uint32_t vt;")
+    out.append("        asm volatile(")
+    for line in loop_body(r):
+        out.append(f'            "{line}\\n\\t"')
+    outs = []
+    for e in range(nr):
+        outs.append(f'[a{e}r] "+v"(amp[{e}].re)')
+        outs.append(f'[a{e}i] "+v"(amp[{e}].im)')
+    outs += ['[u] "=&v"(u)', '[w] "=&v"(w)', '[p] "=&v"(p)', '[q] "=&v"(q)', '[vt] "=&v"(vt)']
+    out.append("            : " + ",\n              ".join(outs))
+    out.append('            : [rp] "s"(rp), [mp] "s"(mp), [n] "s"(n_gates), [base] "s"(base), [tid] "v"(tid)')
+    clob = ['"vcc"', '"scc"'] + [f'"s{i}"' for i in CLOBBER_RANGE]
+    rows = [", ".join(clob[i : i + 12]) for i in range(0, len(clob), 12)]
+    out.append("            : " + ",\n              ".join(rows) + ");")
+    out.append("    }")
+    out.append("};")
+    return "\n".join(out)
+
+
+def render() -> str:
+    head = (
+        "// GENERATED by gen_gate_loop.py -- do not edit; regenerate with `python gen_gate_loop.py`.\n"
+        "// fp64 gate loop of pass_kernel in gfx950 assembly: see the generator's docstring for the design.\n"
+        "// Included inside namespace qsv by kernels.hip, after cx<> is defined.\n\n"
+        "template <int R>\nstruct GateLoopF64;  // specialised below for R = 1, 2, 3\n\n"
+    )
+    return head + "\n\n".join(emit(r) for r in (1, 2, 3)) + "\n"
+
+
+if __name__ == "__main__":
+    text = render()
+    if len(sys.argv) > 1 and sys.argv[1] == "--check":
+        sys.exit(0 if OUT.exists() and OUT.read_text() == text else 1)
+    OUT.write_text(text)
+    print(f"wrote {OUT} ({len(text.splitlines())} lines)")

@@ -15,6 +15,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 namespace qsv {
 
 template <typename real>
@@ -101,6 +103,26 @@ struct ButterflyDispatch<real, R, -1> {
     static __device__ __forceinline__ void run(int, cx<real> (&)[1 << R], const real (&)[7]) {}
 };
 
+#include "gate_loop_gen.inc"
+
+// Diagnostic build only (-DQSV_STAMPS, scripts/stamps.sh): per-phase shader-cycle counters of the pass kernel,
+// summed over waves.  The shipped library compiles every QSV_STAMP to nothing.
+#ifdef QSV_STAMPS
+__device__ unsigned long long qsv_stamp_table[kStampPasses * kStampPhases];
+#define QSV_STAMP_DECL unsigned long long st_acc[kStampPhases] = {}; unsigned long long st_last = qsv_stamp_now();
+#define QSV_STAMP(ph) do { const unsigned long long st_t = qsv_stamp_now(); st_acc[ph] += st_t - st_last; st_last = st_t; } while (0)
+static __device__ __forceinline__ unsigned long long qsv_stamp_now() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#else
+#define QSV_STAMP_DECL
+#define QSV_STAMP(ph)
+#endif
+
 // Read-only inputs are separate `const __restrict__` kernel parameters (not members of a by-value struct): that is
 // what lets hipcc prove they cannot alias the state stores and fetch plan words and matrices with SCALAR loads.
 struct PassScalars {
@@ -163,6 +185,7 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, PIPE>::waves_per_sim
     const bool do_diag = last && (a.mode & kModeFinalDiag);
     cxr* __restrict__ st0 = states + uint64_t(ev.state_slot) * a.state_stride;
 
+    QSV_STAMP_DECL
     const uint32_t tg = xor_columns(gl, t, tid), sg = xor_columns(gs, t, tid);
 
     const uint32_t n_tiles = a.tiles_per_block;
@@ -191,6 +214,7 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, PIPE>::waves_per_sim
         }
     }
 
+    QSV_STAMP(0);
     for (uint32_t j = 0; j < n_tiles; ++j) {
         const bool has_next = j + 1 < n_tiles;
         const uint64_t base_next = has_next ? tile_base(tile0 + j + 1, pos, k) : 0;
@@ -256,6 +280,7 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, PIPE>::waves_per_sim
             }
         }
 
+        QSV_STAMP(1);
         const uint32_t* __restrict__ rp = rounds0;
         const double* __restrict__ mp = mats0;
         for (int m = 0; m < n_rounds; ++m) {
@@ -314,6 +339,7 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, PIPE>::waves_per_sim
                         }
                     } else {
                         real* pl = reinterpret_cast<real*>(lds_raw);
+                        QSV_STAMP(2);
                         if (active) {
                             uint32_t off = wt;
 #pragma unroll
@@ -322,7 +348,9 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, PIPE>::waves_per_sim
                                 pl[off] = amp[gray_index(i)].re;
                             }
                         }
+                        QSV_STAMP(3);
                         __syncthreads();
+                        QSV_STAMP(4);
                         if (active) {
                             uint32_t off = rt;
 #pragma unroll
@@ -331,7 +359,9 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, PIPE>::waves_per_sim
                                 amp[gray_index(i)].re = pl[off];
                             }
                         }
+                        QSV_STAMP(5);
                         __syncthreads();
+                        QSV_STAMP(6);
                         if (active) {
                             uint32_t off = wt;
 #pragma unroll
@@ -340,7 +370,9 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, PIPE>::waves_per_sim
                                 pl[off] = amp[gray_index(i)].im;
                             }
                         }
+                        QSV_STAMP(7);
                         __syncthreads();
+                        QSV_STAMP(8);
                         if (active) {
                             uint32_t off = rt;
 #pragma unroll
@@ -349,34 +381,45 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, PIPE>::waves_per_sim
                                 amp[gray_index(i)].im = pl[off];
                             }
                         }
+                        QSV_STAMP(9);
                     }
                     lds_dirty = true;
                 }
             }
-            // gate stream: descriptor and matrix of gate g+1 are fetched (scalar loads) while gate g runs
-            uint32_t w0 = rp[0], ct = rp[1], cg = rp[2];
-            double m0 = mp[0], m1 = mp[2], m2 = mp[3], m3 = mp[4], m4 = mp[5], m5 = mp[6], m6 = mp[7];
-            for (int g = 0; g < n_gates; ++g) {
-                rp += kGateWords;
-                mp += 8;
-                const uint32_t nw0 = rp[0], nct = rp[1], ncg = rp[2];
-                const double n0 = mp[0], n1 = mp[2], n2 = mp[3], n3 = mp[4], n4 = mp[5], n5 = mp[6], n6 = mp[7];
-                if ((uint32_t(base) & cg) == cg) {  // else: the control is a fixed bit of this tile and it is 0
-                    const uint32_t creg = (w0 >> 8) & 0xffu;
-                    const int sel = int(w0 & 0xffu) * (R + 1) + (creg == 0xffu ? 0 : int(creg) + 1);
-                    const real mm[7] = {real(m0), real(m1), real(m2), real(m3), real(m4), real(m5), real(m6)};
-                    if (all_active && (ct & 63u) == 0) {
-                        // the control (if any) is a wave-index bit: whole waves either run the gate or skip it
-                        if ((wave_base & ct) == ct) ButterflyDispatch<real, R, R*(R + 1) - 1>::run(sel, amp, mm);
-                    } else if (active && ((tid & ct) == ct)) {
-                        // per-lane control: lanes whose control bit is 0 sit the gate out under the exec mask; the
-                        // butterfly updates registers in place, so the two paths merge without copies
-                        ButterflyDispatch<real, R, R*(R + 1) - 1>::run(sel, amp, mm);
-                    }
+            if constexpr (std::is_same<real, double>::value && R <= 3) {
+                // fp64: the gate loop is the generated assembly block (gate_loop_gen.inc); amplitudes never move
+                if (n_gates > 0) {
+                    if (active) GateLoopF64<R>::run(amp, rp, mp, uint32_t(n_gates), uint32_t(base), tid);
+                    rp += size_t(n_gates) * kGateWords;
+                    mp += size_t(n_gates) * 8;
                 }
-                w0 = nw0; ct = nct; cg = ncg;
-                m0 = n0; m1 = n1; m2 = n2; m3 = n3; m4 = n4; m5 = n5; m6 = n6;
+            } else {
+                // gate stream: descriptor and matrix of gate g+1 are fetched (scalar loads) while gate g runs
+                uint32_t w0 = rp[0], ct = rp[1], cg = rp[2];
+                double m0 = mp[0], m1 = mp[2], m2 = mp[3], m3 = mp[4], m4 = mp[5], m5 = mp[6], m6 = mp[7];
+                for (int g = 0; g < n_gates; ++g) {
+                    rp += kGateWords;
+                    mp += 8;
+                    const uint32_t nw0 = rp[0], nct = rp[1], ncg = rp[2];
+                    const double n0 = mp[0], n1 = mp[2], n2 = mp[3], n3 = mp[4], n4 = mp[5], n5 = mp[6], n6 = mp[7];
+                    if ((uint32_t(base) & cg) == cg) {  // else: the control is a fixed bit of this tile and it is 0
+                        const uint32_t creg = (w0 >> 8) & 0xffu;
+                        const int sel = int(w0 & 0xffu) * (R + 1) + (creg == 0xffu ? 0 : int(creg) + 1);
+                        const real mm[7] = {real(m0), real(m1), real(m2), real(m3), real(m4), real(m5), real(m6)};
+                        if (all_active && (ct & 63u) == 0) {
+                            // the control (if any) is a wave-index bit: whole waves either run the gate or skip it
+                            if ((wave_base & ct) == ct) ButterflyDispatch<real, R, R*(R + 1) - 1>::run(sel, amp, mm);
+                        } else if (active && ((tid & ct) == ct)) {
+                            // per-lane control: lanes whose control bit is 0 sit the gate out under the exec mask; the
+                            // butterfly updates registers in place, so the two paths merge without copies
+                            ButterflyDispatch<real, R, R*(R + 1) - 1>::run(sel, amp, mm);
+                        }
+                    }
+                    w0 = nw0; ct = nct; cg = ncg;
+                    m0 = n0; m1 = n1; m2 = n2; m3 = n3; m4 = n4; m5 = n5; m6 = n6;
+                }
             }
+            QSV_STAMP(10);
         }
 
         if (do_store && active) {
@@ -415,6 +458,7 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, PIPE>::waves_per_sim
             }
         }
         base = base_next;
+        QSV_STAMP(11);
     }
 
     if (do_diag) {
@@ -431,12 +475,29 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, PIPE>::waves_per_sim
             partials[size_t(ev.out_index) * gridDim.x + blockIdx.x] = total;
         }
     }
+#ifdef QSV_STAMPS
+    QSV_STAMP(12);
+    {
+        // sum the waves' counters in LDS first: one global atomic per phase per workgroup
+        unsigned long long* tab = reinterpret_cast<unsigned long long*>(lds_raw);
+        __syncthreads();
+        if (tid < kStampPhases) tab[tid] = 0;
+        __syncthreads();
+        if ((tid & 63u) == 0) {
+            for (int ph = 0; ph < kStampPhases - 1; ++ph) atomicAdd(&tab[ph], st_acc[ph]);
+            atomicAdd(&tab[kStampPhases - 1], 1ull);
+        }
+        __syncthreads();
+        if (tid < kStampPhases && a.pass_index < kStampPasses)
+            atomicAdd(&qsv_stamp_table[a.pass_index * kStampPhases + tid], tab[tid]);
+    }
+#endif
 }
 
 template <typename real, int R, int XMODE>
 static hipError_t launch_pass_t(dim3 grid, int threads, size_t lds_bytes, hipStream_t stream, const PassArgs& args) {
     // the block reduction at the end needs one double per wave
-    const size_t lds = lds_bytes < 64 ? 64 : lds_bytes;
+    const size_t lds = lds_bytes < 256 ? 256 : lds_bytes;
     const PassScalars sc{args.state_stride, args.pass_index, args.mode, args.tiles_per_block};
     cx<real>* st = reinterpret_cast<cx<real>*>(args.states);
     if (args.pipeline && args.tiles_per_block > 1)
@@ -450,7 +511,7 @@ static hipError_t launch_pass_t(dim3 grid, int threads, size_t lds_bytes, hipStr
 
 template <typename real, int R, int XMODE>
 static hipError_t configure_t(size_t lds_bytes) {
-    const int bytes = int(lds_bytes < 64 ? 64 : lds_bytes);
+    const int bytes = int(lds_bytes < 256 ? 256 : lds_bytes);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pass_kernel<real, R, XMODE, false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e != hipSuccess) return e;
@@ -474,6 +535,14 @@ static hipError_t pass_dispatch_r(int op, int r, dim3 grid, int threads, size_t 
 static hipError_t pass_dispatch(int op, int dtype, int r, int xmode, dim3 grid, int threads, size_t lds_bytes,
                                 hipStream_t stream, const PassArgs* args) {
     if (threads > 512) return hipErrorInvalidValue;
+#ifdef QSV_PROBE_ONLY  // scripts/isa_probe.sh: compile just the default instantiation to read its ISA quickly
+    if (op) return hipSuccess;
+    const PassScalars sc{args->state_stride, args->pass_index, args->mode, args->tiles_per_block};
+    hipLaunchKernelGGL((pass_kernel<double, 3, 2, false>), grid, dim3(threads), lds_bytes, stream, args->plan,
+                       args->mats, args->evals, reinterpret_cast<cx<double>*>(args->states), args->diag,
+                       args->partials, sc);
+    return hipGetLastError();
+#else
     if (dtype == 0) {
         switch (xmode) {
             case 0: return pass_dispatch_r<double, 0>(op, r, grid, threads, lds_bytes, stream, args);
@@ -487,6 +556,7 @@ static hipError_t pass_dispatch(int op, int dtype, int r, int xmode, dim3 grid, 
         case 2: return pass_dispatch_r<float, 2>(op, r, grid, threads, lds_bytes, stream, args);
         default: return hipErrorInvalidValue;
     }
+#endif
 }
 
 hipError_t launch_pass(int dtype, int r, int xmode, dim3 grid, int threads, size_t lds_bytes, hipStream_t stream,
@@ -849,6 +919,21 @@ hipError_t launch_state_to_f64(int dtype, const void* state, uint64_t dim, doubl
         hipLaunchKernelGGL(state_to_f64_kernel<float>, dim3(stream_blocks(dim)), dim3(256), 0, stream,
                            reinterpret_cast<const cx<float>*>(state), dim, out_re_im);
     return hipGetLastError();
+}
+
+hipError_t read_stamps(unsigned long long* out, int reset) {
+#ifdef QSV_STAMPS
+    hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) return e;
+    e = hipMemcpyFromSymbol(out, HIP_SYMBOL(qsv_stamp_table), sizeof(unsigned long long) * kStampPasses * kStampPhases);
+    if (e != hipSuccess || !reset) return e;
+    static const unsigned long long zeros[kStampPasses * kStampPhases] = {};
+    return hipMemcpyToSymbol(HIP_SYMBOL(qsv_stamp_table), zeros, sizeof(zeros));
+#else
+    (void)out;
+    (void)reset;
+    return hipErrorNotSupported;
+#endif
 }
 
 }  // namespace qsv

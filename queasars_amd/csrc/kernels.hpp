@@ -39,6 +39,13 @@ struct PassArgs {
     uint32_t pipeline;         // 1: prefetch the next tile into a second register set while computing (needs > 1 tile)
 };
 
+// Diagnostic stamps (only in a -DQSV_STAMPS build): [pass][phase] shader cycles summed over WAVES; the last phase
+// slot counts waves.  Phases: 0 setup, 1 load / synthesis, 2 xor-column setup + wait for the previous exchange's
+// readers, 3 write re, 4 barrier, 5 read re, 6 barrier, 7 write im, 8 barrier, 9 read im (exchange mode 2 only),
+// 10 gates, 11 store / reduce, 12 epilogue.
+constexpr int kStampPasses = 8, kStampPhases = 16;
+hipError_t read_stamps(unsigned long long* out, int reset);  // hipErrorNotSupported in the shipped build
+
 // doubles an evaluation's matrix region occupies for a circuit with n_real scheduled gates on n qubits
 inline uint32_t mat_region_doubles(uint32_t n_real, uint32_t n_qubits) { return 8 * n_real + 4 * n_qubits + 16; }
 

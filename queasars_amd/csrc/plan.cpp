@@ -465,7 +465,16 @@ CircuitPlan build_plan(int n, const std::vector<GateIn>& all_gates, const std::v
                     else
                         ct = 1u << thr_index_of[cb];
                 }
-                w.push_back(uint32_t(reg_index_of[tb]) | creg << 8);
+                // bit 16 + p: the p-th amplitude pair (register indices with the target bit clear, ascending) takes
+                // part; a register-held control switches off the pairs whose control bit is 0
+                const int jbit = reg_index_of[tb];
+                uint32_t pair_mask = 0;
+                for (int e0 = 0, pr = 0; e0 < (1 << r); ++e0) {
+                    if ((e0 >> jbit) & 1) continue;
+                    if (creg == 0xFF || ((e0 >> creg) & 1)) pair_mask |= 1u << pr;
+                    ++pr;
+                }
+                w.push_back(uint32_t(jbit) | creg << 8 | pair_mask << 16);
                 w.push_back(ct);
                 w.push_back(cg);
                 w.push_back(uint32_t(g.op));

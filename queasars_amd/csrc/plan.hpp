@@ -82,7 +82,9 @@ struct CircuitPlan {
 // round:   [0] n_gates | has_exchange<<16
 //          if has_exchange: (t+r) LDS write columns (previous layout), (t+r) LDS read columns (this layout),
 //                           both in ELEMENT units under the same swizzle
-//          then 4 words per gate: [0] target register bit | control register bit<<8 (0xFF: none)
+//          then 4 words per gate: [0] target register bit | control register bit<<8 (0xFF: none) | pair mask<<16
+//                                     (bit p: the p-th amplitude pair, register indices with the target bit
+//                                     clear in ascending order, takes part)
 //                                 [1] ctrl mask over the thread index   [2] ctrl mask over the global index
 //                                 [3] index of the originating op (informational; the kernel does not read it)
 //          Gates are numbered in the order they appear here (the SCHEDULE ORDER); the matrix of scheduled gate s

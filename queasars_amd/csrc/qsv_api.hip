@@ -528,6 +528,11 @@ extern "C" {
 
 const char* qsv_version(void) { return "libqsv 0.1.0 (gfx950)"; }
 
+// Not part of include/qsv.h: read-out of the per-phase cycle stamps of a diagnostic (-DQSV_STAMPS) build.
+int qsv_debug_stamps(unsigned long long* out, int reset) {
+    return qsv::read_stamps(out, reset) == hipSuccess ? QSV_OK : QSV_E_UNSUPPORTED;
+}
+
 int qsv_create(int n_qubits, int dtype, int device, const qsv_plan_config* cfg, qsv_t** out) {
     if (!out) return fail(nullptr, QSV_E_ARG, "out is null");
     *out = nullptr;

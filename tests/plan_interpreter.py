@@ -113,7 +113,8 @@ def decode(words: np.ndarray) -> dict:
                 w0, ct, cg, op = (int(x) for x in w[cur : cur + GATE_WORDS])
                 cur += GATE_WORDS
                 creg = (w0 >> 8) & 0xFF
-                gates.append({"tbit": w0 & 0xFF, "creg": None if creg == 0xFF else creg, "ct": ct, "cg": cg, "op": op, "sched": sched})
+                gates.append({"tbit": w0 & 0xFF, "creg": None if creg == 0xFF else creg, "pairs": w0 >> 16, "ct": ct, "cg": cg,
+                              "op": op, "sched": sched})
                 sched += 1
             rounds.append({"write_cols": wc, "read_cols": rc, "gates": gates})
         passes.append({"k": k, "r": r, "t": t, "pos": pos, "load_cols": gl, "store_cols": gs, "rounds": rounds, "first_gate": first_gate})
@@ -213,8 +214,13 @@ def run(words: np.ndarray, n_qubits: int, params, stats: dict | None = None, lds
                     bit = 1 << g["tbit"]
                     cbit = 0 if g["creg"] is None else 1 << g["creg"]
                     lane_on = (np.arange(n_thr) & g["ct"]) == g["ct"]
+                    pair = -1
                     for e0 in range(n_reg):
-                        if e0 & bit or (e0 & cbit) != cbit:
+                        if e0 & bit:
+                            continue
+                        pair += 1  # the kernel's assembly gate loop goes by the pair mask: it must say the same
+                        assert ((g["pairs"] >> pair) & 1) == int((e0 & cbit) == cbit), "pair mask disagrees with creg"
+                        if (e0 & cbit) != cbit:
                             continue
                         a0, a1 = amp[:, e0].copy(), amp[:, e0 | bit].copy()
                         amp[:, e0] = np.where(lane_on, m[0, 0] * a0 + m[0, 1] * a1, a0)
