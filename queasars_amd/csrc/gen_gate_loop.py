@@ -140,7 +140,7 @@ def emit(r: int) -> str:
     out.append("template <>")
     out.append(f"struct GateLoopF64<{r}> {{")
     out.append(
-        f"    static __device__ __forceinline__ void run(cx<double> (&amp)[{nr}], const uint32_t* rp, const double* mp,\n"
+        f"    static __device__ __forceinline__ void run(cx<double> (&amp)[{nr}], cu32p rp, cf64p mp,\n"
         "                                               uint32_t n_gates, uint32_t base, uint32_t tid) {"
     )
     out.append("        // uniform by construction; say so to the compiler, which otherwise may hand a VGPR to an \"s\" operand")

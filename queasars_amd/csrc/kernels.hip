@@ -24,14 +24,49 @@ struct alignas(2 * sizeof(real)) cx {
     real re, im;
 };
 
-__device__ __forceinline__ uint32_t xor_columns(const uint32_t* __restrict__ cols, int t, uint32_t tid) {
+// Plan words, gate matrices and evaluation descriptors are written by earlier launches and are constant while a pass
+// runs.  Reading them through constant-address-space pointers is what makes hipcc use SCALAR loads for them: through
+// ordinary global pointers every read that follows a barrier or a state store is a vector load with its own
+// s_waitcnt vmcnt(0), and the column loops below turn into chains of serialized L2 round trips.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define QSV_CONST_AS __attribute__((address_space(4)))
+#else
+#define QSV_CONST_AS  // the host pass only parses the kernels
+#endif
+using cu32p = const QSV_CONST_AS uint32_t*;
+using cf64p = const QSV_CONST_AS double*;
+template <typename T>
+__device__ __forceinline__ const QSV_CONST_AS T* as_constant(const T* p) {
+    return (const QSV_CONST_AS T*)(p);
+}
+
+// N consecutive plan words into scalar registers with wide loads (x4 chunks, 4-byte aligned is enough for s_load)
+// that are all issued before the first use.
+template <int N>
+__device__ __forceinline__ void load_words(cu32p p, uint32_t (&w)[N]) {
+    typedef uint32_t u32x4a __attribute__((ext_vector_type(4), aligned(4)));
+#pragma unroll
+    for (int i = 0; i + 4 <= N; i += 4) {
+        const u32x4a v = *(const QSV_CONST_AS u32x4a*)(p + i);
+        w[i] = v.x; w[i + 1] = v.y; w[i + 2] = v.z; w[i + 3] = v.w;
+    }
+#pragma unroll
+    for (int i = N & ~3; i < N; ++i) w[i] = p[i];
+}
+
+// Offset of a thread inside a layout: XOR of the columns selected by the bits of tid.  The block always holds
+// kMaxThreadBits columns (unused ones are 0), so there is nothing to predicate and the loop unrolls.
+__device__ __forceinline__ uint32_t xor_columns(cu32p cols, uint32_t tid) {
+    uint32_t c[kMaxThreadBits];
+    load_words<int(kMaxThreadBits)>(cols, c);
     uint32_t x = 0;
-    for (int u = 0; u < t; ++u) x ^= (0u - ((tid >> u) & 1u)) & cols[u];
+#pragma unroll
+    for (int u = 0; u < int(kMaxThreadBits); ++u) x ^= (0u - ((tid >> u) & 1u)) & c[u];
     return x;
 }
 
 template <int R>
-__device__ __forceinline__ void register_offsets(const uint32_t* __restrict__ rc, uint32_t (&ro)[1 << R]) {
+__device__ __forceinline__ void register_offsets(cu32p rc, uint32_t (&ro)[1 << R]) {
     ro[0] = 0;
 #pragma unroll
     for (int e = 1; e < (1 << R); ++e) ro[e] = ro[e & (e - 1)] ^ rc[__builtin_ctz(e)];
@@ -41,15 +76,19 @@ __device__ __forceinline__ void register_offsets(const uint32_t* __restrict__ rc
 // needs one XOR with one column (a scalar) per step and no 2^R-entry offset table has to stay live in SGPRs.
 //   for (int i = 0; i < NR; ++i) { off = gray_step<R>(i, off, cols); use(gray_index(i), off); }
 __device__ __forceinline__ constexpr int gray_index(int i) { return i ^ (i >> 1); }
-__device__ __forceinline__ uint32_t gray_step(int i, uint32_t off, const uint32_t* __restrict__ reg_cols) {
+__device__ __forceinline__ uint32_t gray_step(int i, uint32_t off, cu32p reg_cols) {
     return i == 0 ? off : off ^ reg_cols[__builtin_ctz(i)];
 }
 
 // Spread a tile number around the tile's bit positions: the fixed (non-tile) index bits of that tile.
-__device__ __forceinline__ uint64_t tile_base(uint32_t tile, const uint32_t* __restrict__ pos, int k) {
+// The block always holds kMaxTileBits positions; the unused ones are kPosPad (a no-op insert).
+__device__ __forceinline__ uint64_t tile_base(uint32_t tile, cu32p pos) {
+    uint32_t ps[kMaxTileBits];
+    load_words<int(kMaxTileBits)>(pos, ps);
     uint64_t base = tile;
-    for (int j = 0; j < k; ++j) {
-        const uint32_t p = pos[j];
+#pragma unroll
+    for (int j = 0; j < int(kMaxTileBits); ++j) {
+        const uint32_t p = ps[j];
         base = ((base >> p) << (p + 1)) | (base & ((uint64_t(1) << p) - 1));
     }
     return base;
@@ -159,12 +198,19 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, PIPE>::waves_per_sim
     constexpr int NR = 1 << R;
     extern __shared__ __align__(16) unsigned char lds_raw[];
 
-    const EvalDesc ev = evals[blockIdx.y];
-    const uint32_t* __restrict__ cp = plan_arena + ev.plan_base;
+    EvalDesc ev;
+    {
+        cu32p e = as_constant(reinterpret_cast<const uint32_t*>(evals + blockIdx.y));
+        ev.plan_base = e[0];
+        ev.mat_base = e[1];
+        ev.state_slot = e[2];
+        ev.out_index = e[3];
+    }
+    cu32p cp = as_constant(plan_arena) + ev.plan_base;
     const uint32_t n_passes = cp[0];
     if (a.pass_index >= n_passes) return;
     const uint32_t n_real = cp[1], n_qubits = cp[2];
-    const uint32_t* __restrict__ pp = cp + cp[kCircuitHeaderWords + a.pass_index];
+    cu32p pp = cp + cp[kCircuitHeaderWords + a.pass_index];
     const uint32_t hdr = pp[0];
     const int k = hdr & 0xff, t = (hdr >> 16) & 0xff, n_rounds = hdr >> 24;
     const uint32_t tid = threadIdx.x;
@@ -172,12 +218,12 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, PIPE>::waves_per_sim
     const bool active = tid < (1u << t);
     const uint32_t wave_base = __builtin_amdgcn_readfirstlane(tid & ~63u);
 
-    const uint32_t* __restrict__ pos = pp + kPassHeaderWords;
-    const uint32_t* __restrict__ gl = pos + k;
-    const uint32_t* __restrict__ gs = gl + (t + R);
-    const uint32_t* __restrict__ rounds0 = gs + (t + R);
-    const double* __restrict__ mats0 = mats_all + ev.mat_base + size_t(pp[1]) * 8;
-    const double* __restrict__ vecs = mats_all + ev.mat_base + size_t(n_real) * 8;
+    cu32p pos = pp + kPassHeaderWords;
+    cu32p glr = pp + kPassLoadColsOffset + kMaxThreadBits;   // register columns of the load layout
+    cu32p gsr = pp + kPassStoreColsOffset + kMaxThreadBits;  // ... of the store layout
+    cu32p rounds0 = pp + kPassRoundsOffset;
+    cf64p mats0 = as_constant(mats_all) + ev.mat_base + size_t(pp[1]) * 8;
+    cf64p vecs = as_constant(mats_all) + ev.mat_base + size_t(n_real) * 8;
 
     const bool synth = a.pass_index == 0 && (a.mode & kModeSynthFirst);
     const bool last = a.pass_index + 1 == n_passes;
@@ -186,21 +232,29 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, PIPE>::waves_per_sim
     cxr* __restrict__ st0 = states + uint64_t(ev.state_slot) * a.state_stride;
 
     QSV_STAMP_DECL
-    const uint32_t tg = xor_columns(gl, t, tid), sg = xor_columns(gs, t, tid);
+    const uint32_t tg = xor_columns(pp + kPassLoadColsOffset, tid), sg = xor_columns(pp + kPassStoreColsOffset, tid);
 
+    // synthesis tables of this evaluation (see prepare_kernel): thread factors, then tile factors
+    cf64p thread_factor = vecs + 4 * size_t(n_qubits) + kMatPadDoubles;
+    cf64p tile_factor = thread_factor + (size_t(2) << t);
+    double ttr = 1.0, tti = 0.0;
+    if (synth && active) {
+        ttr = thread_factor[2 * tid];
+        tti = thread_factor[2 * tid + 1];
+    }
     const uint32_t n_tiles = a.tiles_per_block;
     const uint32_t tile0 = blockIdx.x * n_tiles;
     cxr amp[NR], nxt[PIPE ? NR : 1];
     double dcur[PIPE ? NR : 1], dnxt[PIPE ? NR : 1];
     double acc = 0.0;
     bool lds_dirty = false;
-    uint64_t base = tile_base(tile0, pos, k);
+    uint64_t base = tile_base(tile0, pos);
     if constexpr (PIPE) {
         if (!synth && active) {
             uint32_t off = tg;
 #pragma unroll
             for (int i = 0; i < NR; ++i) {
-                off = gray_step(i, off, gl + t);
+                off = gray_step(i, off, glr);
                 amp[gray_index(i)] = st0[base + off];
             }
         }
@@ -208,7 +262,7 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, PIPE>::waves_per_sim
             uint32_t off = sg;
 #pragma unroll
             for (int i = 0; i < NR; ++i) {
-                off = gray_step(i, off, gs + t);
+                off = gray_step(i, off, gsr);
                 dcur[PIPE ? gray_index(i) : 0] = diag[base + off];
             }
         }
@@ -217,14 +271,14 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, PIPE>::waves_per_sim
     QSV_STAMP(0);
     for (uint32_t j = 0; j < n_tiles; ++j) {
         const bool has_next = j + 1 < n_tiles;
-        const uint64_t base_next = has_next ? tile_base(tile0 + j + 1, pos, k) : 0;
+        const uint64_t base_next = has_next ? tile_base(tile0 + j + 1, pos) : 0;
         if constexpr (PIPE) {
             if (has_next && active) {
                 if (!synth) {
                     uint32_t off = tg;
 #pragma unroll
                     for (int i = 0; i < NR; ++i) {
-                        off = gray_step(i, off, gl + t);
+                        off = gray_step(i, off, glr);
                         nxt[PIPE ? gray_index(i) : 0] = st0[base_next + off];
                     }
                 }
@@ -232,34 +286,22 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, PIPE>::waves_per_sim
                     uint32_t off = sg;
 #pragma unroll
                     for (int i = 0; i < NR; ++i) {
-                        off = gray_step(i, off, gs + t);
+                        off = gray_step(i, off, gsr);
                         dnxt[PIPE ? gray_index(i) : 0] = diag[base_next + off];
                     }
                 }
             }
         }
         if (synth) {
-            // initial product state: amplitude(i) = prod_q v_q[bit q of i]; v_q = vecs[4q .. 4q+3] = (v0, v1)
-            uint32_t reg_mask = 0;
-#pragma unroll
-            for (int v = 0; v < R; ++v) reg_mask |= gl[t + v];
-            const uint64_t g0 = base | tg;
-            double fr = 1.0, fi = 0.0;
-            for (uint32_t q = 0; q < n_qubits; ++q) {
-                if ((reg_mask >> q) & 1u) continue;
-                const bool one = (g0 >> q) & 1u;
-                // both factors are uniform (scalar loads); the lane picks one
-                const double v0r = vecs[4 * q], v0i = vecs[4 * q + 1], v1r = vecs[4 * q + 2], v1i = vecs[4 * q + 3];
-                const double vr = one ? v1r : v0r, vi = one ? v1i : v0i;
-                const double nr = fr * vr - fi * vi;
-                fi = fr * vi + fi * vr;
-                fr = nr;
-            }
-            amp[0].re = real(fr);
-            amp[0].im = real(fi);
+            // initial product state: amplitude(i) = prod_q v_q[bit q of i].  prepare_kernel has multiplied out the
+            // factors of the qubits outside the tile (one value per tile: tile_factor) and of the tile qubits held
+            // by thread bits (one value per thread: thread_factor); the register qubits are expanded here.
+            const double tfr = tile_factor[2 * size_t(tile0 + j)], tfi = tile_factor[2 * size_t(tile0 + j) + 1];
+            amp[0].re = real(tfr * ttr - tfi * tti);
+            amp[0].im = real(tfr * tti + tfi * ttr);
 #pragma unroll
             for (int v = 0; v < R; ++v) {
-                const uint32_t q = __builtin_ctz(gl[t + v]);
+                const uint32_t q = __builtin_ctz(glr[v]);
                 const real v0r = real(vecs[4 * q]), v0i = real(vecs[4 * q + 1]);
                 const real v1r = real(vecs[4 * q + 2]), v1i = real(vecs[4 * q + 3]);
 #pragma unroll
@@ -275,26 +317,26 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, PIPE>::waves_per_sim
             uint32_t off = tg;
 #pragma unroll
             for (int i = 0; i < NR; ++i) {
-                off = gray_step(i, off, gl + t);
+                off = gray_step(i, off, glr);
                 amp[gray_index(i)] = st0[base + off];
             }
         }
 
         QSV_STAMP(1);
-        const uint32_t* __restrict__ rp = rounds0;
-        const double* __restrict__ mp = mats0;
+        cu32p rp = rounds0;
+        cf64p mp = mats0;
         for (int m = 0; m < n_rounds; ++m) {
             const uint32_t rh = rp[0];
             const int n_gates = rh & 0xffff;
             rp += 1;
             if ((rh >> 16) & 1u) {
-                const uint32_t* __restrict__ wc = rp;
-                const uint32_t* __restrict__ rc = rp + (t + R);
-                rp += 2 * (t + R);
+                cu32p wc = rp;
+                cu32p rc = rp + kColumnWords;
+                rp += kExchangeWords;
                 {
-                    const uint32_t wt = xor_columns(wc, t, tid), rt = xor_columns(rc, t, tid);
-                    const uint32_t* __restrict__ wrc = wc + t;
-                    const uint32_t* __restrict__ rrc = rc + t;
+                    const uint32_t wt = xor_columns(wc, tid), rt = xor_columns(rc, tid);
+                    cu32p wrc = wc + kMaxThreadBits;
+                    cu32p rrc = rc + kMaxThreadBits;
                     if (lds_dirty) __syncthreads();  // everyone has finished reading the previous exchange
                     if constexpr (XMODE == 0) {
                         cxr* lds = reinterpret_cast<cxr*>(lds_raw);
@@ -426,7 +468,7 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, PIPE>::waves_per_sim
             uint32_t off = sg;
 #pragma unroll
             for (int i = 0; i < NR; ++i) {
-                off = gray_step(i, off, gs + t);
+                off = gray_step(i, off, gsr);
                 st0[base + off] = amp[gray_index(i)];
             }
         }
@@ -442,7 +484,7 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, PIPE>::waves_per_sim
                 uint32_t off = sg;
 #pragma unroll
                 for (int i = 0; i < NR; ++i) {
-                    off = gray_step(i, off, gs + t);
+                    off = gray_step(i, off, gsr);
                     const double re = double(amp[gray_index(i)].re), im = double(amp[gray_index(i)].im);
                     acc += (re * re + im * im) * d[off];
                 }
@@ -598,9 +640,10 @@ __device__ __forceinline__ void u_matrix(const Angles& a, double* m) {
 __global__ void __launch_bounds__(256) prepare_kernel(const uint32_t* __restrict__ plan,
                                                       const EvalDesc* __restrict__ evals,
                                                       const double* __restrict__ params, double* __restrict__ mats) {
+    __shared__ double sv[4 * 32];  // initial factors (v0, v1) of every qubit, n <= 32
     const EvalDesc ev = evals[blockIdx.x];
     const uint32_t* __restrict__ cp = plan + ev.plan_base;
-    const uint32_t n_real = cp[1], n_qubits = cp[2];
+    const uint32_t n_passes = cp[0], n_real = cp[1], n_qubits = cp[2];
     const uint32_t* __restrict__ table = cp + cp[3];
     const uint32_t* __restrict__ fold = cp + cp[4];
     const double* __restrict__ p = params + ev.param_base;
@@ -625,9 +668,58 @@ __global__ void __launch_bounds__(256) prepare_kernel(const uint32_t* __restrict
         }
         double* o = out + size_t(n_real) * 8 + size_t(q) * 4;
         o[0] = v0r; o[1] = v0i; o[2] = v1r; o[3] = v1i;
+        sv[4 * q] = v0r; sv[4 * q + 1] = v0i; sv[4 * q + 2] = v1r; sv[4 * q + 3] = v1i;
     }
+    double* pad = out + size_t(n_real) * 8 + size_t(n_qubits) * 4;
     // zero the padding the pass kernel's one-gate-ahead prefetch may read
-    for (uint32_t i = threadIdx.x; i < 16; i += blockDim.x) out[size_t(n_real) * 8 + size_t(n_qubits) * 4 + i] = 0.0;
+    for (uint32_t i = threadIdx.x; i < kMatPadDoubles; i += blockDim.x) pad[i] = 0.0;
+    if (n_passes == 0) return;
+    __syncthreads();
+
+    // Synthesis tables for pass 0 (the pass that writes the initial product state, amplitude(i) = prod_q v_q[i_q]):
+    //   thread_factor[tid] = product over the tile qubits that pass 0's load layout keeps on thread bits
+    //   tile_factor[tile]  = product over the qubits outside the tile
+    // The pass kernel multiplies the two and expands the register-held qubits itself.
+    const uint32_t* __restrict__ pp = cp + cp[kCircuitHeaderWords];
+    const uint32_t hdr = pp[0];
+    const int k = hdr & 0xff, t = (hdr >> 16) & 0xff;
+    const uint32_t* __restrict__ pos = pp + kPassHeaderWords;
+    const uint32_t* __restrict__ cols = pp + kPassLoadColsOffset;
+    uint32_t thread_mask = 0, tile_mask = 0;
+    for (int u = 0; u < t; ++u) thread_mask |= cols[u];
+    for (int j = 0; j < k; ++j) tile_mask |= 1u << pos[j];
+    double* thread_factor = pad + kMatPadDoubles;
+    double* tile_factor = thread_factor + (size_t(2) << t);
+    auto product = [&](uint64_t index, uint32_t qubits) {
+        double fr = 1.0, fi = 0.0;
+        for (uint32_t q = 0; q < n_qubits; ++q) {
+            if (!((qubits >> q) & 1u)) continue;
+            const double* v = sv + 4 * q + 2 * ((index >> q) & 1u);
+            const double nr = fr * v[0] - fi * v[1];
+            fi = fr * v[1] + fi * v[0];
+            fr = nr;
+        }
+        return make_double2(fr, fi);
+    };
+    for (uint32_t i = threadIdx.x; i < (1u << t); i += blockDim.x) {
+        uint32_t off = 0;
+        for (int u = 0; u < t; ++u) off ^= (0u - ((i >> u) & 1u)) & cols[u];
+        const double2 f = product(off, thread_mask);
+        thread_factor[2 * size_t(i)] = f.x;
+        thread_factor[2 * size_t(i) + 1] = f.y;
+    }
+    const uint32_t all_qubits = n_qubits >= 32 ? 0xffffffffu : ((1u << n_qubits) - 1u);
+    const uint32_t n_tiles = 1u << (n_qubits - uint32_t(k));
+    for (uint32_t tile = threadIdx.x; tile < n_tiles; tile += blockDim.x) {
+        uint64_t base = tile;
+        for (int j = 0; j < k; ++j) {
+            const uint32_t ps = pos[j];
+            base = ((base >> ps) << (ps + 1)) | (base & ((uint64_t(1) << ps) - 1));
+        }
+        const double2 f = product(base, all_qubits & ~tile_mask);
+        tile_factor[2 * size_t(tile)] = f.x;
+        tile_factor[2 * size_t(tile) + 1] = f.y;
+    }
 }
 
 hipError_t launch_prepare(const uint32_t* plan, const EvalDesc* evals, const double* params, double* mats, int n_evals,

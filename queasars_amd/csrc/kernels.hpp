@@ -10,8 +10,7 @@ namespace qsv {
 // One evaluation (circuit + parameter vector) inside a launch group.
 struct EvalDesc {
     uint32_t plan_base;   // word offset of the circuit plan in the plan arena
-    uint32_t mat_base;    // offset (in doubles) of this evaluation's matrix region: 8 doubles per scheduled gate,
-                          // then 4 doubles per qubit (the initial product-state factors), then padding
+    uint32_t mat_base;    // offset (in doubles) of this evaluation's matrix region (mat_region_doubles below)
     uint32_t state_slot;  // which resident state buffer the evaluation uses
     uint32_t out_index;   // row of `partials` / entry of the result vector
     uint32_t param_base;  // offset (in doubles) of this evaluation's parameter vector in the parameter buffer
@@ -47,7 +46,13 @@ constexpr int kStampPasses = 8, kStampPhases = 16;
 hipError_t read_stamps(unsigned long long* out, int reset);  // hipErrorNotSupported in the shipped build
 
 // doubles an evaluation's matrix region occupies for a circuit with n_real scheduled gates on n qubits
-inline uint32_t mat_region_doubles(uint32_t n_real, uint32_t n_qubits) { return 8 * n_real + 4 * n_qubits + 16; }
+// (gate matrices | 4 doubles per qubit: initial factors | kMatPadDoubles | thread factors: 2 * 2^t | tile factors:
+// 2 * 2^(n-k)); t = thread bits, n - k = bits outside a tile -- the synthesis tables prepare_kernel fills for pass 0
+constexpr uint32_t kMatPadDoubles = 16;
+inline size_t mat_region_doubles(uint32_t n_real, uint32_t n_qubits, int thread_bits, int outer_bits) {
+    return size_t(8) * n_real + size_t(4) * n_qubits + kMatPadDoubles + (size_t(2) << thread_bits) +
+           (size_t(2) << outer_bits);
+}
 
 // Angles -> gate matrices and initial product-state factors, one workgroup per evaluation.
 hipError_t launch_prepare(const uint32_t* plan, const EvalDesc* evals, const double* params, double* mats, int n_evals,

@@ -403,7 +403,7 @@ CircuitPlan build_plan(int n, const std::vector<GateIn>& all_gates, const std::v
         w[off_table + pi] = uint32_t(w.size());
         w.push_back(uint32_t(k) | uint32_t(r) << 8 | uint32_t(t) << 16 | uint32_t(pass.rounds.size()) << 24);
         w.push_back(uint32_t(schedule.size()));
-        for (int q : pass.pos) w.push_back(uint32_t(q));
+        for (uint32_t j = 0; j < kMaxTileBits; ++j) w.push_back(j < pass.pos.size() ? uint32_t(pass.pos[j]) : kPosPad);
         auto tile_bit = [&](int q) {
             auto it = std::lower_bound(pass.pos.begin(), pass.pos.end(), q);
             return (it != pass.pos.end() && *it == q) ? int(it - pass.pos.begin()) : -1;
@@ -428,10 +428,12 @@ CircuitPlan build_plan(int n, const std::vector<GateIn>& all_gates, const std::v
             }
             layouts.push_back(make_layout(k, rd.regbits, ctrl_bits));
         }
-        auto push_global_cols = [&](const Layout& l) {
-            for (int b : l.thr) w.push_back(1u << pass.pos[b]);
-            for (int b : l.reg) w.push_back(1u << pass.pos[b]);
+        // one layout's columns in the fixed shape: kMaxThreadBits thread columns, kMaxRegBits register columns
+        auto push_cols = [&](const Layout& l, auto&& col) {
+            for (uint32_t u = 0; u < kMaxThreadBits; ++u) w.push_back(u < l.thr.size() ? col(l.thr[u]) : 0u);
+            for (uint32_t v = 0; v < kMaxRegBits; ++v) w.push_back(v < l.reg.size() ? col(l.reg[v]) : 0u);
         };
+        auto push_global_cols = [&](const Layout& l) { push_cols(l, [&](int b) { return 1u << pass.pos[b]; }); };
         push_global_cols(layouts.front());
         push_global_cols(layouts.back());
 
@@ -444,10 +446,8 @@ CircuitPlan build_plan(int n, const std::vector<GateIn>& all_gates, const std::v
                 const SwizzleChoice sw = choose_swizzle(layouts[m - 1], lay, k, cfg.elem_bytes);
                 out.stats.lds_conflict_cycles += sw.cost;
                 out.stats.n_exchanges += 1;
-                for (int b : layouts[m - 1].thr) w.push_back(lds_col(b, sw.s));
-                for (int b : layouts[m - 1].reg) w.push_back(lds_col(b, sw.s));
-                for (int b : lay.thr) w.push_back(lds_col(b, sw.s));
-                for (int b : lay.reg) w.push_back(lds_col(b, sw.s));
+                push_cols(layouts[m - 1], [&](int b) { return lds_col(b, sw.s); });
+                push_cols(lay, [&](int b) { return lds_col(b, sw.s); });
             }
             std::vector<int> reg_index_of(k, -1), thr_index_of(k, -1);
             for (size_t v = 0; v < lay.reg.size(); ++v) reg_index_of[lay.reg[v]] = int(v);

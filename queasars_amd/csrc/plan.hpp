@@ -76,12 +76,17 @@ struct CircuitPlan {
 //          [4] offset of the FOLD INDEX  [5] n_fold_entries  [6..8) reserved
 //          [8 .. 8+n_passes) pass offsets
 // pass:    [0] k | r<<8 | t<<16 | n_rounds<<24      [1] index of the pass's first scheduled gate
-//          [2 .. 2+k) tile bit j -> qubit position (ascending)
-//          then (t+r) global columns for the load layout, (t+r) for the store layout (amplitude offsets)
-//          then the rounds
+//          [2 .. 15)  tile bit j -> qubit position (ascending), padded to kMaxTileBits entries with kPosPad
+//          [15 .. 28) load layout:  kMaxThreadBits thread columns then kMaxRegBits register columns (global
+//                     amplitude offsets), unused entries 0
+//          [28 .. 41) store layout, same shape
+//          [41 ..)    the rounds
+//          Every block has a FIXED size whatever k, r, t are: the kernel fetches each block with a few wide scalar
+//          loads issued together and indexes it with compile-time offsets; padded columns are 0 (XOR no-ops) and
+//          padded positions insert a zero bit above every index bit (a no-op too), so nothing is predicated.
 // round:   [0] n_gates | has_exchange<<16
-//          if has_exchange: (t+r) LDS write columns (previous layout), (t+r) LDS read columns (this layout),
-//                           both in ELEMENT units under the same swizzle
+//          if has_exchange: [1 .. 14) LDS write columns (previous layout), [14 .. 27) LDS read columns (this
+//                           layout), each kMaxThreadBits + kMaxRegBits entries, ELEMENT units, same swizzle
 //          then 4 words per gate: [0] target register bit | control register bit<<8 (0xFF: none) | pair mask<<16
 //                                     (bit p: the p-th amplitude pair, register indices with the target bit
 //                                     clear in ascending order, takes part)
@@ -95,9 +100,16 @@ struct CircuitPlan {
 //          into qubit q's initial factor, in program order.
 constexpr uint32_t kCircuitHeaderWords = 8;
 constexpr uint32_t kPassHeaderWords = 2;
+constexpr uint32_t kMaxTileBits = 13, kMaxThreadBits = 9, kMaxRegBits = 4;
+constexpr uint32_t kColumnWords = kMaxThreadBits + kMaxRegBits;                 // one layout's columns
+constexpr uint32_t kPassLoadColsOffset = kPassHeaderWords + kMaxTileBits;       // 15
+constexpr uint32_t kPassStoreColsOffset = kPassLoadColsOffset + kColumnWords;   // 28
+constexpr uint32_t kPassRoundsOffset = kPassStoreColsOffset + kColumnWords;     // 41
+constexpr uint32_t kExchangeWords = 2 * kColumnWords;                           // after the round's header word
+constexpr uint32_t kPosPad = 62;  // inserting a zero bit at position 62 leaves every index below 2^62 unchanged
 constexpr uint32_t kGateWords = 4;
 constexpr uint32_t kAngleEntryWords = 9;
-constexpr uint32_t kPlanPadWords = 16;  // readable padding after every plan (the kernel prefetches one gate ahead)
+constexpr uint32_t kPlanPadWords = 32;  // readable padding after every plan (the kernel prefetches one gate ahead)
 
 struct AngleSource {
     int32_t p_theta, p_phi, p_lambda;

@@ -276,7 +276,7 @@ int batch_layout(qsv_t* h, const std::vector<Circuit*>& circs, const std::vector
             return fail(h, QSV_E_ARG, "circuit needs " + std::to_string(circs[i]->n_params) + " parameter values, got " +
                                           std::to_string(n_params[i]));
         total_params += size_t(n_params[i]);
-        total_mats += mat_region_doubles(uint32_t(circs[i]->plan.stats.n_real_gates), uint32_t(h->n));
+        total_mats += mat_region_doubles(uint32_t(circs[i]->plan.stats.n_real_gates), uint32_t(h->n), h->geo.t, h->n - h->geo.k);
     }
     if (total_params >= (size_t(1) << 31) || total_mats >= (size_t(1) << 31))
         return fail(h, QSV_E_ARG, "batch too large");
@@ -297,7 +297,7 @@ int batch_layout(qsv_t* h, const std::vector<Circuit*>& circs, const std::vector
         b.param_base[i] = uint32_t(pcur);
         b.n_params[i] = uint32_t(n_params[i]);
         pcur += size_t(n_params[i]);
-        mcur += mat_region_doubles(uint32_t(c.plan.stats.n_real_gates), uint32_t(h->n));
+        mcur += mat_region_doubles(uint32_t(c.plan.stats.n_real_gates), uint32_t(h->n), h->geo.t, h->n - h->geo.k);
         h->prof.n_gates += uint64_t(c.n_gates);
     }
     QSV_HIP(h, hipMemcpyAsync(h->d_batch.ptr, h->h_batch, b.desc_bytes, hipMemcpyHostToDevice, h->stream));
