@@ -178,7 +178,8 @@ struct PassScalars {
 // Mode 2 halves the LDS footprint (32 KiB at k = 12, fp64) so three or four 512-thread workgroups fit a CU.
 // Occupancy is what sets the v_fma_f64 issue rate on gfx950 (measured with scripts/ubench/valu_rate.hip:
 // 13 / 7.2 / 5.8 / 4.7 cycles per instruction at 1 / 2 / 4 / 8 waves per SIMD), so the kernel is compiled for
-// 6 waves per SIMD (<= 80 VGPRs) in mode 2; at 8 (<= 64 VGPRs) hipcc spills the amplitudes.
+// 6 waves per SIMD (<= 80 VGPRs) in mode 2: three 512-thread workgroups per CU.  Four (8 waves per SIMD, 64 VGPRs)
+// fit too since the gate loop is assembly, but measured 4% slower: more LDS contention and scalar spills.
 // PIPE = true: software pipelining inside the workgroup.  Identical workgroups run in lock-step (all load, then
 // all compute, then all store), so memory time ADDS to compute time unless each wave keeps its own next tile's
 // loads in flight while it computes: the next tile's amplitudes (and diagonal values) are prefetched into a second

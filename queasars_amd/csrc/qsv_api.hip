@@ -565,19 +565,18 @@ int qsv_create(int n_qubits, int dtype, int device, const qsv_plan_config* cfg, 
     int group = cfg && cfg->group > 0 ? cfg->group : 0;
     if (const char* env = getenv("QSV_GROUP")) group = atoi(env);
     if (group <= 0) {
-        // keep a launch group's states inside half of the 256 MiB Infinity Cache so that consecutive passes
-        // over them are served on-die
-        const size_t budget = size_t(256) << 20;
-        group = int(std::max<size_t>(1, std::min<size_t>(1024, budget / state_bytes)));
+        // Evaluations that run side by side in one launch.  Measured on MI355X (scripts/sweep.sh): the passes are
+        // bound by fp64 issue and LDS traffic rather than by HBM, so keeping a group inside the 256 MiB Infinity
+        // Cache buys nothing, while larger groups amortise launch ramp-up and tail: 2 GiB of resident states, at
+        // most 256 evaluations (n = 16: 256, n = 20: 128, n = 24: 8, n >= 27: 1).
+        const size_t budget = size_t(2) << 30;
+        group = int(std::max<size_t>(1, std::min<size_t>(256, budget / state_bytes)));
     }
     h->group = group;
-    // workgroups sweep several consecutive tiles when a launch would otherwise have far more workgroups than the
-    // chip holds (less wave-dispatch and plan-parsing overhead): aim for about 1024 workgroups per launch
+    // a workgroup sweeps two consecutive tiles once a launch has plenty of workgroups anyway (>= 4096 tiles)
     {
         const uint64_t tiles_per_launch = uint64_t(geo.blocks_per_state) * uint64_t(group);
-        int tpb = 1;
-        while (tpb < 8 && tiles_per_launch / uint64_t(tpb * 2) >= 1024 && uint32_t(tpb * 2) <= geo.blocks_per_state) tpb *= 2;
-        h->tiles_per_block = tpb;
+        h->tiles_per_block = (tiles_per_launch >= 4096 && geo.blocks_per_state >= 2) ? 2 : 1;
     }
     if (const char* env = getenv("QSV_TILES_PER_BLOCK")) h->tiles_per_block = std::max(1, atoi(env));
     if (const char* env = getenv("QSV_PIPELINE")) h->pipeline = atoi(env) != 0;
