@@ -117,8 +117,8 @@ int qsv_eval_circuits(qsv_t* h, int n_evals, const int* circuit_ids, const int64
  * Streaming form of qsv_eval_circuits, for callers whose parameter vectors become available (or are converted)
  * piecemeal: qsv_eval_begin lays the batch out, each qsv_eval_push ships the packed parameter values of evaluations
  * [first, first+count) and launches them asynchronously, qsv_eval_end waits and returns all results.  Pushes must be
- * in order and cover whole launch groups (count a multiple of the group size, except for the last push).  The
- * handle is locked from begin to end; end must be called even after a failed push.
+ * in order and contiguous; a push of any size is accepted (at most qsv_group_size() of its evaluations run side by
+ * side in one launch).  The handle is locked from begin to end; end must be called even after a failed push.
  */
 int qsv_eval_begin(qsv_t* h, int n_evals, const int* circuit_ids, const int64_t* param_counts);
 int qsv_eval_push(qsv_t* h, int first, int count, const double* values);

@@ -401,8 +401,8 @@ int eval_push(qsv_t* h, size_t first, size_t count, const double* values) {
     if (first != b.pushed) return fail(h, QSV_E_STATE, "evaluations must be pushed in order");
     if (first + count > b.circs.size()) return fail(h, QSV_E_ARG, "push exceeds the batch");
     const size_t G = size_t(h->group);
-    if (first % G != 0 || (count % G != 0 && first + count != b.circs.size()))
-        return fail(h, QSV_E_ARG, "a push must cover whole launch groups (multiples of the group size)");
+    // state slot = evaluation index mod G (batch_layout): any run of <= G consecutive evaluations has distinct slots,
+    // and the stream orders a slot's reuse after its previous owner's last pass
     int rc = batch_ship(h, first, count, values);
     if (rc) return rc;
     const uint32_t mode = kModeSynthFirst | (h->diagonal ? kModeFinalDiag : kModeFinalStore) |
