@@ -55,13 +55,17 @@ __device__ __forceinline__ void load_words(cu32p p, uint32_t (&w)[N]) {
 }
 
 // Offset of a thread inside a layout: XOR of the columns selected by the bits of tid.  The block always holds
-// kMaxThreadBits columns (unused ones are 0), so there is nothing to predicate and the loop unrolls.
-__device__ __forceinline__ uint32_t xor_columns(cu32p cols, uint32_t tid) {
+// kMaxThreadBits columns (unused ones are 0), so there is nothing to predicate and the loop unrolls.  The six
+// lane bits of tid are passed as all-ones / all-zeros masks computed once per kernel (one VALU operation per
+// column); the wave-index bits are uniform, so their columns are folded on the scalar unit.
+__device__ __forceinline__ uint32_t xor_columns(cu32p cols, const uint32_t (&lane_mask)[6], uint32_t wave) {
     uint32_t c[kMaxThreadBits];
     load_words<int(kMaxThreadBits)>(cols, c);
     uint32_t x = 0;
 #pragma unroll
-    for (int u = 0; u < int(kMaxThreadBits); ++u) x ^= (0u - ((tid >> u) & 1u)) & c[u];
+    for (int u = 6; u < int(kMaxThreadBits); ++u) x ^= ((wave >> (u - 6)) & 1u) ? c[u] : 0u;
+#pragma unroll
+    for (int u = 0; u < 6; ++u) x ^= lane_mask[u] & c[u];
     return x;
 }
 
@@ -180,23 +184,26 @@ struct PassScalars {
 // 13 / 7.2 / 5.8 / 4.7 cycles per instruction at 1 / 2 / 4 / 8 waves per SIMD), so the kernel is compiled for
 // 6 waves per SIMD (<= 80 VGPRs) in mode 2: three 512-thread workgroups per CU.  Four (8 waves per SIMD, 64 VGPRs)
 // fit too since the gate loop is assembly, but measured 4% slower: more LDS contention and scalar spills.
-// PIPE = true: software pipelining inside the workgroup.  Identical workgroups run in lock-step (all load, then
-// all compute, then all store), so memory time ADDS to compute time unless each wave keeps its own next tile's
-// loads in flight while it computes: the next tile's amplitudes (and diagonal values) are prefetched into a second
-// register set before the current tile's gates run.
-template <int R, int XMODE, bool PIPE>
+template <int R, int XMODE>
 struct Occupancy {
     // 2^R amplitudes = 4 * 2^R VGPRs: R = 3 fits the 80-VGPR budget of 6 waves per SIMD, R = 4 needs the 128 of 4
-    static constexpr int waves_per_simd = (PIPE || R >= 4) ? 4 : (XMODE == 2 ? 6 : 4);
+    static constexpr int waves_per_simd = R >= 4 ? 4 : (XMODE == 2 ? 6 : 4);
 };
 
-template <typename real, int R, int XMODE, bool PIPE>
-__global__ void __launch_bounds__(512, (Occupancy<R, XMODE, PIPE>::waves_per_simd))
+template <typename T>
+struct Log2Size;
+template <> struct Log2Size<float> { static constexpr int value = 2; };
+template <> struct Log2Size<double> { static constexpr int value = 3; };
+
+template <typename real, int R, int XMODE>
+__global__ void __launch_bounds__(512, (Occupancy<R, XMODE>::waves_per_simd))
     pass_kernel(const uint32_t* __restrict__ plan_arena, const double* __restrict__ mats_all,
                 const EvalDesc* __restrict__ evals, cx<real>* __restrict__ states, const double* __restrict__ diag,
                 double* __restrict__ partials, const PassScalars a) {
     using cxr = cx<real>;
     constexpr int NR = 1 << R;
+    constexpr int ASH = Log2Size<real>::value + 1;         // log2 of an amplitude's bytes
+    constexpr int LSH = XMODE == 0 ? ASH : ASH - 1;        // log2 of an LDS element's bytes
     extern __shared__ __align__(16) unsigned char lds_raw[];
 
     EvalDesc ev;
@@ -213,11 +220,15 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, PIPE>::waves_per_sim
     const uint32_t n_real = cp[1], n_qubits = cp[2];
     cu32p pp = cp + cp[kCircuitHeaderWords + a.pass_index];
     const uint32_t hdr = pp[0];
-    const int k = hdr & 0xff, t = (hdr >> 16) & 0xff, n_rounds = hdr >> 24;
+    const int t = (hdr >> 16) & 0xff, n_rounds = hdr >> 24;
     const uint32_t tid = threadIdx.x;
     const bool all_active = blockDim.x == (1u << t);
     const bool active = tid < (1u << t);
-    const uint32_t wave_base = __builtin_amdgcn_readfirstlane(tid & ~63u);
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t wave_base = wave << 6;
+    uint32_t lane_mask[6];
+#pragma unroll
+    for (int u = 0; u < 6; ++u) lane_mask[u] = 0u - ((tid >> u) & 1u);
 
     cu32p pos = pp + kPassHeaderWords;
     cu32p glr = pp + kPassLoadColsOffset + kMaxThreadBits;   // register columns of the load layout
@@ -231,9 +242,14 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, PIPE>::waves_per_sim
     const bool do_store = !last || (a.mode & kModeFinalStore);
     const bool do_diag = last && (a.mode & kModeFinalDiag);
     cxr* __restrict__ st0 = states + uint64_t(ev.state_slot) * a.state_stride;
+    // Global offsets inside a state are XORs of plan columns.  While a state's byte size fits 32 bits (n <= 28 in
+    // fp64) they are kept as BYTE offsets in one 32-bit register per element next to a uniform tile pointer (one
+    // v_xor per access, scalar-base addressing); larger states take the 64-bit path.
+    const bool wide = n_qubits + uint32_t(ASH) > 32u;
 
     QSV_STAMP_DECL
-    const uint32_t tg = xor_columns(pp + kPassLoadColsOffset, tid), sg = xor_columns(pp + kPassStoreColsOffset, tid);
+    const uint32_t tg = xor_columns(pp + kPassLoadColsOffset, lane_mask, wave);
+    const uint32_t sg = xor_columns(pp + kPassStoreColsOffset, lane_mask, wave);
 
     // synthesis tables of this evaluation (see prepare_kernel): thread factors, then tile factors
     cf64p thread_factor = vecs + 4 * size_t(n_qubits) + kMatPadDoubles;
@@ -245,54 +261,14 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, PIPE>::waves_per_sim
     }
     const uint32_t n_tiles = a.tiles_per_block;
     const uint32_t tile0 = blockIdx.x * n_tiles;
-    cxr amp[NR], nxt[PIPE ? NR : 1];
-    double dcur[PIPE ? NR : 1], dnxt[PIPE ? NR : 1];
+    cxr amp[NR];
     double acc = 0.0;
-    bool lds_dirty = false;
-    uint64_t base = tile_base(tile0, pos);
-    if constexpr (PIPE) {
-        if (!synth && active) {
-            uint32_t off = tg;
-#pragma unroll
-            for (int i = 0; i < NR; ++i) {
-                off = gray_step(i, off, glr);
-                amp[gray_index(i)] = st0[base + off];
-            }
-        }
-        if (do_diag && active) {
-            uint32_t off = sg;
-#pragma unroll
-            for (int i = 0; i < NR; ++i) {
-                off = gray_step(i, off, gsr);
-                dcur[PIPE ? gray_index(i) : 0] = diag[base + off];
-            }
-        }
-    }
+    bool lds_dirty = false;      // LDS holds exchange data some wave may still be reading
+    bool cross_pending = false;  // ... and that wave may be another one (the last exchange crossed waves)
 
     QSV_STAMP(0);
     for (uint32_t j = 0; j < n_tiles; ++j) {
-        const bool has_next = j + 1 < n_tiles;
-        const uint64_t base_next = has_next ? tile_base(tile0 + j + 1, pos) : 0;
-        if constexpr (PIPE) {
-            if (has_next && active) {
-                if (!synth) {
-                    uint32_t off = tg;
-#pragma unroll
-                    for (int i = 0; i < NR; ++i) {
-                        off = gray_step(i, off, glr);
-                        nxt[PIPE ? gray_index(i) : 0] = st0[base_next + off];
-                    }
-                }
-                if (do_diag) {
-                    uint32_t off = sg;
-#pragma unroll
-                    for (int i = 0; i < NR; ++i) {
-                        off = gray_step(i, off, gsr);
-                        dnxt[PIPE ? gray_index(i) : 0] = diag[base_next + off];
-                    }
-                }
-            }
-        }
+        const uint64_t base = tile_base(tile0 + j, pos);
         if (synth) {
             // initial product state: amplitude(i) = prod_q v_q[bit q of i].  prepare_kernel has multiplied out the
             // factors of the qubits outside the tile (one value per tile: tile_factor) and of the tile qubits held
@@ -314,12 +290,22 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, PIPE>::waves_per_sim
                     amp[e].im = x.re * v0i + x.im * v0r;
                 }
             }
-        } else if (!PIPE && active) {
-            uint32_t off = tg;
+        } else if (active) {
+            if (!wide) {
+                const unsigned char* tile = reinterpret_cast<const unsigned char*>(st0 + base);
+                uint32_t ob = tg << ASH;
 #pragma unroll
-            for (int i = 0; i < NR; ++i) {
-                off = gray_step(i, off, glr);
-                amp[gray_index(i)] = st0[base + off];
+                for (int i = 0; i < NR; ++i) {
+                    if (i) ob ^= glr[__builtin_ctz(i)] << ASH;
+                    amp[gray_index(i)] = *reinterpret_cast<const cxr*>(tile + ob);
+                }
+            } else {
+                uint32_t off = tg;
+#pragma unroll
+                for (int i = 0; i < NR; ++i) {
+                    off = gray_step(i, off, glr);
+                    amp[gray_index(i)] = st0[base + off];
+                }
             }
         }
 
@@ -334,100 +320,89 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, PIPE>::waves_per_sim
                 cu32p wc = rp;
                 cu32p rc = rp + kColumnWords;
                 rp += kExchangeWords;
+                // LDS byte offsets: thread part once, then one v_xor per register element (columns scaled on the
+                // scalar unit); the same offsets serve the real and the imaginary plane
+                uint32_t wo[NR], ro[NR];
                 {
-                    const uint32_t wt = xor_columns(wc, tid), rt = xor_columns(rc, tid);
-                    cu32p wrc = wc + kMaxThreadBits;
-                    cu32p rrc = rc + kMaxThreadBits;
-                    if (lds_dirty) __syncthreads();  // everyone has finished reading the previous exchange
-                    if constexpr (XMODE == 0) {
-                        cxr* lds = reinterpret_cast<cxr*>(lds_raw);
-                        if (active) {
-                            uint32_t off = wt;
+                    uint32_t w = xor_columns(wc, lane_mask, wave) << LSH, r = xor_columns(rc, lane_mask, wave) << LSH;
 #pragma unroll
-                            for (int i = 0; i < NR; ++i) {
-                                off = gray_step(i, off, wrc);
-                                lds[off] = amp[gray_index(i)];
-                            }
+                    for (int i = 0; i < NR; ++i) {
+                        if (i) {
+                            w ^= wc[kMaxThreadBits + __builtin_ctz(i)] << LSH;
+                            r ^= rc[kMaxThreadBits + __builtin_ctz(i)] << LSH;
                         }
-                        __syncthreads();
-                        if (active) {
-                            uint32_t off = rt;
-#pragma unroll
-                            for (int i = 0; i < NR; ++i) {
-                                off = gray_step(i, off, rrc);
-                                amp[gray_index(i)] = lds[off];
-                            }
-                        }
-                    } else if constexpr (XMODE == 1) {
-                        real* pre = reinterpret_cast<real*>(lds_raw);
-                        real* pim = pre + (size_t(1) << k);
-                        if (active) {
-                            uint32_t off = wt;
-#pragma unroll
-                            for (int i = 0; i < NR; ++i) {
-                                off = gray_step(i, off, wrc);
-                                pre[off] = amp[gray_index(i)].re;
-                                pim[off] = amp[gray_index(i)].im;
-                            }
-                        }
-                        __syncthreads();
-                        if (active) {
-                            uint32_t off = rt;
-#pragma unroll
-                            for (int i = 0; i < NR; ++i) {
-                                off = gray_step(i, off, rrc);
-                                amp[gray_index(i)].re = pre[off];
-                                amp[gray_index(i)].im = pim[off];
-                            }
-                        }
-                    } else {
-                        real* pl = reinterpret_cast<real*>(lds_raw);
-                        QSV_STAMP(2);
-                        if (active) {
-                            uint32_t off = wt;
-#pragma unroll
-                            for (int i = 0; i < NR; ++i) {
-                                off = gray_step(i, off, wrc);
-                                pl[off] = amp[gray_index(i)].re;
-                            }
-                        }
-                        QSV_STAMP(3);
-                        __syncthreads();
-                        QSV_STAMP(4);
-                        if (active) {
-                            uint32_t off = rt;
-#pragma unroll
-                            for (int i = 0; i < NR; ++i) {
-                                off = gray_step(i, off, rrc);
-                                amp[gray_index(i)].re = pl[off];
-                            }
-                        }
-                        QSV_STAMP(5);
-                        __syncthreads();
-                        QSV_STAMP(6);
-                        if (active) {
-                            uint32_t off = wt;
-#pragma unroll
-                            for (int i = 0; i < NR; ++i) {
-                                off = gray_step(i, off, wrc);
-                                pl[off] = amp[gray_index(i)].im;
-                            }
-                        }
-                        QSV_STAMP(7);
-                        __syncthreads();
-                        QSV_STAMP(8);
-                        if (active) {
-                            uint32_t off = rt;
-#pragma unroll
-                            for (int i = 0; i < NR; ++i) {
-                                off = gray_step(i, off, rrc);
-                                amp[gray_index(i)].im = pl[off];
-                            }
-                        }
-                        QSV_STAMP(9);
+                        wo[gray_index(i)] = w;
+                        ro[gray_index(i)] = r;
                     }
-                    lds_dirty = true;
                 }
+                // An intra-wave exchange (plan.hpp) moves data only inside each wave, through the LDS region that
+                // wave owns: no barrier inside it, and none before it unless the previous exchange was a cross-wave
+                // one whose readers may still be busy in this wave's region.
+                const bool intra = (rh >> 17) & 1u;
+                if (intra ? cross_pending : lds_dirty) {
+                    __syncthreads();
+                    cross_pending = false;
+                }
+                if constexpr (XMODE == 0) {
+                    QSV_STAMP(2);
+                    if (active) {
+#pragma unroll
+                        for (int e = 0; e < NR; ++e) *reinterpret_cast<cxr*>(lds_raw + wo[e]) = amp[e];
+                    }
+                    if (!intra) __syncthreads();
+                    if (active) {
+#pragma unroll
+                        for (int e = 0; e < NR; ++e) amp[e] = *reinterpret_cast<const cxr*>(lds_raw + ro[e]);
+                    }
+                } else if constexpr (XMODE == 1) {
+                    QSV_STAMP(2);
+                    unsigned char* pim = lds_raw + (size_t(sizeof(real)) << (hdr & 0xff));
+                    if (active) {
+#pragma unroll
+                        for (int e = 0; e < NR; ++e) {
+                            *reinterpret_cast<real*>(lds_raw + wo[e]) = amp[e].re;
+                            *reinterpret_cast<real*>(pim + wo[e]) = amp[e].im;
+                        }
+                    }
+                    if (!intra) __syncthreads();
+                    if (active) {
+#pragma unroll
+                        for (int e = 0; e < NR; ++e) {
+                            amp[e].re = *reinterpret_cast<const real*>(lds_raw + ro[e]);
+                            amp[e].im = *reinterpret_cast<const real*>(pim + ro[e]);
+                        }
+                    }
+                } else {
+                    QSV_STAMP(2);
+                    if (active) {
+#pragma unroll
+                        for (int e = 0; e < NR; ++e) *reinterpret_cast<real*>(lds_raw + wo[e]) = amp[e].re;
+                    }
+                    QSV_STAMP(3);
+                    if (!intra) __syncthreads();
+                    QSV_STAMP(4);
+                    if (active) {
+#pragma unroll
+                        for (int e = 0; e < NR; ++e) amp[e].re = *reinterpret_cast<const real*>(lds_raw + ro[e]);
+                    }
+                    QSV_STAMP(5);
+                    if (!intra) __syncthreads();
+                    QSV_STAMP(6);
+                    if (active) {
+#pragma unroll
+                        for (int e = 0; e < NR; ++e) *reinterpret_cast<real*>(lds_raw + wo[e]) = amp[e].im;
+                    }
+                    QSV_STAMP(7);
+                    if (!intra) __syncthreads();
+                    QSV_STAMP(8);
+                    if (active) {
+#pragma unroll
+                        for (int e = 0; e < NR; ++e) amp[e].im = *reinterpret_cast<const real*>(lds_raw + ro[e]);
+                    }
+                    QSV_STAMP(9);
+                }
+                lds_dirty = true;
+                cross_pending = cross_pending || !intra;
             }
             if constexpr (std::is_same<real, double>::value && R <= 3) {
                 // fp64: the gate loop is the generated assembly block (gate_loop_gen.inc); amplitudes never move
@@ -453,8 +428,7 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, PIPE>::waves_per_sim
                             // the control (if any) is a wave-index bit: whole waves either run the gate or skip it
                             if ((wave_base & ct) == ct) ButterflyDispatch<real, R, R*(R + 1) - 1>::run(sel, amp, mm);
                         } else if (active && ((tid & ct) == ct)) {
-                            // per-lane control: lanes whose control bit is 0 sit the gate out under the exec mask; the
-                            // butterfly updates registers in place, so the two paths merge without copies
+                            // per-lane control: lanes whose control bit is 0 sit the gate out under the exec mask
                             ButterflyDispatch<real, R, R*(R + 1) - 1>::run(sel, amp, mm);
                         }
                     }
@@ -465,42 +439,37 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, PIPE>::waves_per_sim
             QSV_STAMP(10);
         }
 
-        if (do_store && active) {
-            uint32_t off = sg;
+        if (active && (do_store || do_diag)) {
+            if (!wide) {
+                unsigned char* tile = reinterpret_cast<unsigned char*>(st0 + base);
+                const unsigned char* dtile = reinterpret_cast<const unsigned char*>(diag + base);
+                uint32_t ob = sg << ASH;
 #pragma unroll
-            for (int i = 0; i < NR; ++i) {
-                off = gray_step(i, off, gsr);
-                st0[base + off] = amp[gray_index(i)];
-            }
-        }
-        if (do_diag && active) {
-            if constexpr (PIPE) {
-#pragma unroll
-                for (int e = 0; e < NR; ++e) {
-                    const double re = double(amp[e].re), im = double(amp[e].im);
-                    acc += (re * re + im * im) * dcur[PIPE ? e : 0];
+                for (int i = 0; i < NR; ++i) {
+                    if (i) ob ^= gsr[__builtin_ctz(i)] << ASH;
+                    const cxr x = amp[gray_index(i)];
+                    if (do_store) *reinterpret_cast<cxr*>(tile + ob) = x;
+                    if (do_diag) {
+                        // D[i] is a double: its byte offset is the amplitude's scaled by 8 / sizeof(amplitude)
+                        const double d = *reinterpret_cast<const double*>(dtile + (ob >> (ASH - 3)));
+                        const double re = double(x.re), im = double(x.im);
+                        acc += (re * re + im * im) * d;
+                    }
                 }
             } else {
-                const double* __restrict__ d = diag + base;
                 uint32_t off = sg;
 #pragma unroll
                 for (int i = 0; i < NR; ++i) {
                     off = gray_step(i, off, gsr);
-                    const double re = double(amp[gray_index(i)].re), im = double(amp[gray_index(i)].im);
-                    acc += (re * re + im * im) * d[off];
+                    const cxr x = amp[gray_index(i)];
+                    if (do_store) st0[base + off] = x;
+                    if (do_diag) {
+                        const double re = double(x.re), im = double(x.im);
+                        acc += (re * re + im * im) * diag[base + off];
+                    }
                 }
             }
         }
-        if constexpr (PIPE) {
-            if (has_next) {
-#pragma unroll
-                for (int e = 0; e < NR; ++e) {
-                    if (!synth) amp[e] = nxt[PIPE ? e : 0];
-                    if (do_diag) dcur[PIPE ? e : 0] = dnxt[PIPE ? e : 0];
-                }
-            }
-        }
-        base = base_next;
         QSV_STAMP(11);
     }
 
@@ -539,26 +508,19 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, PIPE>::waves_per_sim
 
 template <typename real, int R, int XMODE>
 static hipError_t launch_pass_t(dim3 grid, int threads, size_t lds_bytes, hipStream_t stream, const PassArgs& args) {
-    // the block reduction at the end needs one double per wave
+    // the block reduction at the end needs one double per wave (and the diagnostic build a table of counters)
     const size_t lds = lds_bytes < 256 ? 256 : lds_bytes;
     const PassScalars sc{args.state_stride, args.pass_index, args.mode, args.tiles_per_block};
     cx<real>* st = reinterpret_cast<cx<real>*>(args.states);
-    if (args.pipeline && args.tiles_per_block > 1)
-        hipLaunchKernelGGL((pass_kernel<real, R, XMODE, true>), grid, dim3(threads), lds, stream, args.plan, args.mats,
-                           args.evals, st, args.diag, args.partials, sc);
-    else
-        hipLaunchKernelGGL((pass_kernel<real, R, XMODE, false>), grid, dim3(threads), lds, stream, args.plan,
-                           args.mats, args.evals, st, args.diag, args.partials, sc);
+    hipLaunchKernelGGL((pass_kernel<real, R, XMODE>), grid, dim3(threads), lds, stream, args.plan, args.mats, args.evals,
+                       st, args.diag, args.partials, sc);
     return hipGetLastError();
 }
 
 template <typename real, int R, int XMODE>
 static hipError_t configure_t(size_t lds_bytes) {
     const int bytes = int(lds_bytes < 256 ? 256 : lds_bytes);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pass_kernel<real, R, XMODE, false>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&pass_kernel<real, R, XMODE, true>),
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&pass_kernel<real, R, XMODE>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
@@ -581,7 +543,7 @@ static hipError_t pass_dispatch(int op, int dtype, int r, int xmode, dim3 grid, 
 #ifdef QSV_PROBE_ONLY  // scripts/isa_probe.sh: compile just the default instantiation to read its ISA quickly
     if (op) return hipSuccess;
     const PassScalars sc{args->state_stride, args->pass_index, args->mode, args->tiles_per_block};
-    hipLaunchKernelGGL((pass_kernel<double, 3, 2, false>), grid, dim3(threads), lds_bytes, stream, args->plan,
+    hipLaunchKernelGGL((pass_kernel<double, 3, 2>), grid, dim3(threads), lds_bytes, stream, args->plan,
                        args->mats, args->evals, reinterpret_cast<cx<double>*>(args->states), args->diag,
                        args->partials, sc);
     return hipGetLastError();

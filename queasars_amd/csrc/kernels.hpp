@@ -35,7 +35,6 @@ struct PassArgs {
     uint32_t pass_index;
     uint32_t mode;
     uint32_t tiles_per_block;  // consecutive tiles each workgroup sweeps
-    uint32_t pipeline;         // 1: prefetch the next tile into a second register set while computing (needs > 1 tile)
 };
 
 // Diagnostic stamps (only in a -DQSV_STAMPS build): [pass][phase] shader cycles summed over WAVES; the last phase

@@ -59,15 +59,22 @@ Layout make_layout(int k, const std::vector<int>& regbits_sorted, const std::vec
 }
 
 // ---- LDS swizzle -------------------------------------------------------------------------------------
-// LDS element index of tile index x:  y = x ^ XOR_{bit p of x set} M[p],  M[p] < 2^min(p, sb).
-// Every M[p] only touches bits below p (and below sb), so the map is unit lower triangular over GF(2): a
-// bijection for any M.  sb = 4 for 16-byte elements (ds_read_b128 wants 16 distinct 16-B slots per lane
+// LDS element index of tile index x:  y = XOR_{bit p of x set} (2^pos[p] ^ M[p]),  M[p] < 2^min(pos[p], sb).
+// pos is a permutation of the address bits (the identity, except for exchanges that stay inside each wave, see
+// choose_swizzle); every M[p] only touches address bits below pos[p] (and below sb), so the map is unit lower
+// triangular over GF(2) in address order: a bijection for any M.  sb = 4 for 16-byte elements (ds_read_b128 wants 16 distinct 16-B slots per lane
 // group), 5 for 8-byte ones.
 struct Swizzle {
-    std::array<uint8_t, 16> m{};  // m[p] for tile bit p
+    std::array<uint8_t, 16> m{};    // m[p] for tile bit p
+    std::array<uint8_t, 16> pos{};  // address bit that carries tile bit p (a permutation of 0..k-1)
+    Swizzle() {
+        for (int p = 0; p < 16; ++p) pos[size_t(p)] = uint8_t(p);
+    }
 };
 
-inline uint32_t lds_col(int tile_bit, const Swizzle& s) { return (1u << tile_bit) ^ uint32_t(s.m[tile_bit]); }
+inline uint32_t lds_col(int tile_bit, const Swizzle& s) {
+    return (1u << s.pos[size_t(tile_bit)]) ^ uint32_t(s.m[size_t(tile_bit)]);
+}
 
 // Extra LDS cycles of one wave-instruction (beyond the conflict-free count) for a given layout's lane map.
 // Banking per MI355X_MICROARCH.md section LDS:
@@ -142,12 +149,19 @@ struct SwizzleChoice {
 // Pick M so that writing in layout `a` and reading in layout `b` are both bank-conflict free (or as close as a
 // short coordinate descent gets).  Results are memoised: layouts live in tile-bit space, so few distinct
 // pairs ever occur.
-SwizzleChoice choose_swizzle(const Layout& a, const Layout& b, int k, int elem_bytes) {
+// `wave_bits` (exchanges that stay inside each wave): the tile bits held by the wave-index thread bits, the same
+// before and after.  They are moved to the TOP address bits, so that a wave owns the contiguous LDS region numbered
+// by its own index under any swizzle (the terms M[p] stay below bit sb): consecutive exchanges of this kind cannot
+// touch each other's data, which is what lets the kernel drop their barriers.
+SwizzleChoice choose_swizzle(const Layout& a, const Layout& b, int k, int elem_bytes,
+                             const std::vector<int>& wave_bits = {}) {
     static std::mutex mu;
     static std::map<std::vector<int>, SwizzleChoice> memo;
     std::vector<int> key;
     key.push_back(k);
     key.push_back(elem_bytes);
+    key.insert(key.end(), wave_bits.begin(), wave_bits.end());
+    key.push_back(-2);
     key.insert(key.end(), a.thr.begin(), a.thr.end());
     key.push_back(-1);
     key.insert(key.end(), b.thr.begin(), b.thr.end());
@@ -155,6 +169,13 @@ SwizzleChoice choose_swizzle(const Layout& a, const Layout& b, int k, int elem_b
         std::lock_guard<std::mutex> lock(mu);
         auto it = memo.find(key);
         if (it != memo.end()) return it->second;
+    }
+    Swizzle base;
+    if (!wave_bits.empty()) {
+        int next = 0;
+        for (int p = 0; p < k; ++p)
+            if (std::find(wave_bits.begin(), wave_bits.end(), p) == wave_bits.end()) base.pos[size_t(p)] = uint8_t(next++);
+        for (int p : wave_bits) base.pos[size_t(p)] = uint8_t(next++);
     }
     const int sb = elem_bytes == 16 ? 4 : 5;
     auto cost_of = [&](const Swizzle& s) {
@@ -164,14 +185,15 @@ SwizzleChoice choose_swizzle(const Layout& a, const Layout& b, int k, int elem_b
     std::vector<int> relevant;
     for (const Layout* l : {&a, &b})
         for (size_t u = 0; u < l->thr.size() && u < 6; ++u)
-            if (l->thr[u] >= 1 && std::find(relevant.begin(), relevant.end(), l->thr[u]) == relevant.end())
+            if (base.pos[size_t(l->thr[u])] >= 1 && std::find(relevant.begin(), relevant.end(), l->thr[u]) == relevant.end())
                 relevant.push_back(l->thr[u]);
-    auto span_of = [&](int p) { return 1 << std::min(p, sb); };
+    auto span_of = [&](int p) { return 1 << std::min(int(base.pos[size_t(p)]), sb); };
     SwizzleChoice best;
+    best.s = base;
     best.cost = cost_of(best.s);
     uint32_t rng = 0x9E3779B9u;
     for (int restart = 0; restart < 24 && best.cost > 0; ++restart) {
-        Swizzle s;
+        Swizzle s = base;
         if (restart > 0)
             for (int p : relevant) {
                 rng = rng * 1664525u + 1013904223u;
@@ -399,7 +421,7 @@ CircuitPlan build_plan(int n, const std::vector<GateIn>& all_gates, const std::v
     std::vector<int> schedule;  // real-gate indices in schedule order
 
     for (size_t pi = 0; pi < passes.size(); ++pi) {
-        const PassPlan& pass = passes[pi];
+        PassPlan& pass = passes[pi];
         w[off_table + pi] = uint32_t(w.size());
         w.push_back(uint32_t(k) | uint32_t(r) << 8 | uint32_t(t) << 16 | uint32_t(pass.rounds.size()) << 24);
         w.push_back(uint32_t(schedule.size()));
@@ -409,24 +431,78 @@ CircuitPlan build_plan(int n, const std::vector<GateIn>& all_gates, const std::v
             return (it != pass.pos.end() && *it == q) ? int(it - pass.pos.begin()) : -1;
         };
 
-        // Layouts.  The first and the last one touch global memory, so their lanes stay on the lowest tile bits;
-        // layouts in between put the round's control bits on the highest thread bits (wave-uniform predicates).
-        std::vector<Layout> layouts;
-        for (size_t m = 0; m < pass.rounds.size(); ++m) {
-            const RoundPlan& rd = pass.rounds[m];
-            std::vector<int> ctrl_bits;
-            if (m > 0 && m + 1 < pass.rounds.size()) {
-                for (int gi : rd.gates) {
-                    if (gates[gi].control < 0) continue;
-                    const int cb = tile_bit(gates[gi].control);
-                    if (cb < 0 || std::find(rd.regbits.begin(), rd.regbits.end(), cb) != rd.regbits.end()) continue;
-                    if (std::find(ctrl_bits.begin(), ctrl_bits.end(), cb) == ctrl_bits.end()) ctrl_bits.push_back(cb);
-                }
-                std::sort(ctrl_bits.begin(), ctrl_bits.end());
-                const size_t wave_bits = t > 6 ? size_t(t - 6) : 0;
-                if (ctrl_bits.size() > wave_bits) ctrl_bits.resize(wave_bits);
+        // Layouts.  Every layout keeps `nw` tile bits on the wave-index thread bits (the wave set W).  As long as
+        // consecutive rounds can keep the same W (none of its bits is needed in registers) the exchange between
+        // them moves data only inside each wave and needs no barrier, so W is chosen like a cache victim: the bits
+        // whose next turn in registers is farthest away; ties go to controls of the round's gates (a wave whose
+        // control bit is 0 skips the gate), then to high bits.  The first and the last layout also face global
+        // memory: the lowest `cl` tile bits stay on the lowest lanes there, so they never enter W or the registers.
+        const size_t n_rounds_pass = pass.rounds.size();
+        const int nw = t > 6 ? t - 6 : 0;
+        std::vector<std::vector<int>> needed(n_rounds_pass);  // tile bits targeted by the round's gates
+        for (size_t m = 0; m < n_rounds_pass; ++m)
+            for (int gi : pass.rounds[m].gates) {
+                const int tb = tile_bit(gates[gi].target);
+                if (std::find(needed[m].begin(), needed[m].end(), tb) == needed[m].end()) needed[m].push_back(tb);
             }
-            layouts.push_back(make_layout(k, rd.regbits, ctrl_bits));
+        auto next_use = [&](int b, size_t m) {
+            for (size_t m2 = m + 1; m2 < n_rounds_pass; ++m2)
+                if (std::find(needed[m2].begin(), needed[m2].end(), b) != needed[m2].end()) return int(m2);
+            return int(n_rounds_pass) + 1;
+        };
+        auto contains = [](const std::vector<int>& v, int x) { return std::find(v.begin(), v.end(), x) != v.end(); };
+        std::vector<Layout> layouts;
+        std::vector<char> intra(n_rounds_pass, 0);
+        std::vector<std::vector<int>> wave_sets(n_rounds_pass);
+        std::vector<int> prev_w;
+        for (size_t m = 0; m < n_rounds_pass; ++m) {
+            RoundPlan& rd = pass.rounds[m];
+            const bool edge = m == 0 || m + 1 == n_rounds_pass;
+            std::vector<int> must = needed[m];
+            if (must.empty() && rd.gates.empty()) must = {};  // relayout-only round: registers are all filler
+            bool keep = m > 0 && int(prev_w.size()) == nw;
+            for (int b : prev_w) keep = keep && !contains(must, b);
+            std::vector<int> wset;
+            if (keep) {
+                wset = prev_w;
+            } else if (nw > 0) {
+                std::vector<int> ctrl;
+                for (int gi : rd.gates)
+                    if (gates[gi].control >= 0 && tile_bit(gates[gi].control) >= 0) ctrl.push_back(tile_bit(gates[gi].control));
+                std::vector<int> cand;
+                for (int b = cl; b < k; ++b)
+                    if (!contains(must, b)) cand.push_back(b);
+                std::stable_sort(cand.begin(), cand.end(), [&](int x, int y) {
+                    const int ux = next_use(x, m), uy = next_use(y, m);
+                    if (ux != uy) return ux > uy;
+                    const bool cx = contains(ctrl, x), cy = contains(ctrl, y);
+                    if (cx != cy) return cx;
+                    return x > y;
+                });
+                // leave enough bits outside W for the registers
+                const int spare = int(cand.size()) - (r - int(must.size()));
+                const int take = std::max(0, std::min(nw, spare));
+                wset.assign(cand.begin(), cand.begin() + take);
+                std::sort(wset.begin(), wset.end());
+            }
+            // registers: the needed bits, filled up from the top with bits that are neither in W nor pinned to lanes
+            std::vector<int> regs = must;
+            for (int b = k - 1; b >= 0 && int(regs.size()) < r; --b)
+                if (!contains(regs, b) && !contains(wset, b) && !(edge && b < cl)) regs.push_back(b);
+            for (int b = k - 1; b >= 0 && int(regs.size()) < r; --b)  // tiny tiles: give up wave bits, then low bits
+                if (!contains(regs, b) && !(edge && b < cl)) {
+                    regs.push_back(b);
+                    wset.erase(std::remove(wset.begin(), wset.end(), b), wset.end());
+                }
+            for (int b = k - 1; b >= 0 && int(regs.size()) < r; --b)
+                if (!contains(regs, b)) regs.push_back(b);
+            std::sort(regs.begin(), regs.end());
+            rd.regbits = regs;
+            layouts.push_back(make_layout(k, regs, wset));
+            // a workgroup of one wave (t <= 6) never needs a barrier
+            intra[m] = m > 0 && (nw == 0 || (int(wset.size()) == nw && wset == prev_w));
+            wave_sets[m] = wset;
+            prev_w = wset;
         }
         // one layout's columns in the fixed shape: kMaxThreadBits thread columns, kMaxRegBits register columns
         auto push_cols = [&](const Layout& l, auto&& col) {
@@ -441,9 +517,11 @@ CircuitPlan build_plan(int n, const std::vector<GateIn>& all_gates, const std::v
             const RoundPlan& rd = pass.rounds[m];
             const Layout& lay = layouts[m];
             const bool exch = m > 0;
-            w.push_back(uint32_t(rd.gates.size()) | (exch ? 1u << 16 : 0u));
+            w.push_back(uint32_t(rd.gates.size()) | (exch ? 1u << 16 : 0u) | (exch && intra[m] ? 1u << 17 : 0u));
             if (exch) {
-                const SwizzleChoice sw = choose_swizzle(layouts[m - 1], lay, k, cfg.elem_bytes);
+                const SwizzleChoice sw =
+                    choose_swizzle(layouts[m - 1], lay, k, cfg.elem_bytes, intra[m] ? wave_sets[m] : std::vector<int>{});
+                out.stats.n_intra_wave_exchanges += intra[m] ? 1 : 0;
                 out.stats.lds_conflict_cycles += sw.cost;
                 out.stats.n_exchanges += 1;
                 push_cols(layouts[m - 1], [&](int b) { return lds_col(b, sw.s); });

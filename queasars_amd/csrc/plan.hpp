@@ -60,6 +60,7 @@ struct PlanStats {
     int n_passes = 0;
     int n_rounds = 0;
     int n_exchanges = 0;
+    int n_intra_wave_exchanges = 0;  // exchanges that stay inside each wave (no barrier)
     int n_real_gates = 0;
     int n_folded_gates = 0;   // u gates absorbed into the initial product state
     int n_dropped_gates = 0;  // cu3 gates whose control is still |0>: identity
@@ -84,7 +85,8 @@ struct CircuitPlan {
 //          Every block has a FIXED size whatever k, r, t are: the kernel fetches each block with a few wide scalar
 //          loads issued together and indexes it with compile-time offsets; padded columns are 0 (XOR no-ops) and
 //          padded positions insert a zero bit above every index bit (a no-op too), so nothing is predicated.
-// round:   [0] n_gates | has_exchange<<16
+// round:   [0] n_gates | has_exchange<<16 | intra_wave<<17 (the exchange moves data only inside each wave: the wave-
+//              index thread bits hold the same tile bits before and after, so the kernel skips the barriers)
 //          if has_exchange: [1 .. 14) LDS write columns (previous layout), [14 .. 27) LDS read columns (this
 //                           layout), each kMaxThreadBits + kMaxRegBits entries, ELEMENT units, same swizzle
 //          then 4 words per gate: [0] target register bit | control register bit<<8 (0xFF: none) | pair mask<<16

@@ -66,7 +66,6 @@ struct qsv_handle {
     DeviceBuffer d_batch;     // [EvalDesc x B][parameter vectors]
     DeviceBuffer d_mats;      // per evaluation: gate matrices in schedule order + product-state factors
     int tiles_per_block = 1;
-    int pipeline = 0;
     DeviceBuffer d_partials;  // [B][blocks_per_state]
     DeviceBuffer d_out;       // [B]
     DeviceBuffer d_scratch;   // probabilities / converted state
@@ -345,7 +344,6 @@ int run_group(qsv_t* h, const std::vector<Circuit*>& circs, size_t first, size_t
     a.mode = mode;
     const unsigned chunks = chunks_per_state(h);
     a.tiles_per_block = h->geo.blocks_per_state / chunks;
-    a.pipeline = uint32_t(h->pipeline);
     dim3 grid(chunks, unsigned(count));
     for (int p = 0; p < max_passes; ++p) {
         a.pass_index = uint32_t(p);
@@ -579,7 +577,6 @@ int qsv_create(int n_qubits, int dtype, int device, const qsv_plan_config* cfg, 
         h->tiles_per_block = (tiles_per_launch >= 4096 && geo.blocks_per_state >= 2) ? 2 : 1;
     }
     if (const char* env = getenv("QSV_TILES_PER_BLOCK")) h->tiles_per_block = std::max(1, atoi(env));
-    if (const char* env = getenv("QSV_PIPELINE")) h->pipeline = atoi(env) != 0;
     auto bail = [&](hipError_t err, const char* what) {
         std::string msg = std::string(what) + ": " + hipGetErrorString(err);
         qsv_destroy(h);
@@ -983,7 +980,6 @@ static int bench_ops_locked(qsv_t* h, int n_ops, const qsv_op* ops, int reps, do
     a.mode = kModeFinalStore;  // read-modify-write of the resident state, no synthesis
     const unsigned chunks = chunks_per_state(h);
     a.tiles_per_block = h->geo.blocks_per_state / chunks;
-    a.pipeline = uint32_t(h->pipeline);
     dim3 grid(chunks, 1);
     const int n_passes = c.plan.stats.n_passes;
     auto sweep = [&]() -> hipError_t {

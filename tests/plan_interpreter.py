@@ -110,7 +110,8 @@ def decode(words: np.ndarray) -> dict:
         for _ in range(n_rounds):
             rh = int(w[cur])
             cur += 1
-            n_gates, exch = rh & 0xFFFF, (rh >> 16) & 1
+            n_gates, exch, intra = rh & 0xFFFF, (rh >> 16) & 1, (rh >> 17) & 1
+            assert not (intra and not exch)
             wc = rc = None
             if exch:
                 wc = block_cols(cur)
@@ -125,7 +126,7 @@ def decode(words: np.ndarray) -> dict:
                 gates.append({"tbit": w0 & 0xFF, "creg": None if creg == 0xFF else creg, "pairs": w0 >> 16, "ct": ct, "cg": cg,
                               "op": op, "sched": sched})
                 sched += 1
-            rounds.append({"write_cols": wc, "read_cols": rc, "gates": gates})
+            rounds.append({"write_cols": wc, "read_cols": rc, "gates": gates, "intra_wave": bool(intra)})
         passes.append({"k": k, "r": r, "t": t, "pos": pos, "load_cols": gl, "store_cols": gs, "rounds": rounds, "first_gate": first_gate})
     fold_index = [(int(w[fold_off + 2 * q]), int(w[fold_off + 2 * q + 1])) for q in range(n_qubits)]
     return {
@@ -188,8 +189,25 @@ def run(words: np.ndarray, n_qubits: int, params, stats: dict | None = None, lds
                 flat = m.reshape(-1)
                 assert flat.max() < (1 << k) and len(np.unique(flat)) == n_thr * n_reg, "LDS map is not a bijection"
             lds_maps.append((wmap, rmap))
+            if rd["intra_wave"]:
+                # the kernel runs this exchange without barriers: every wave must read back exactly the elements it
+                # wrote, and (so that consecutive barrier-free exchanges cannot collide either) its elements must be
+                # the ones whose address bits at the wave-held tile-bit positions spell the wave's own index
+                waves = max(1, n_thr // 64)
+                for wv in range(waves):
+                    rows = slice(wv * 64, min((wv + 1) * 64, n_thr))
+                    wrote, reads = set(wmap[rows].reshape(-1).tolist()), set(rmap[rows].reshape(-1).tolist())
+                    assert wrote == reads, "an intra-wave exchange reads another wave's elements"
+                if waves > 1:
+                    wave_cols_w, wave_cols_r = rd["write_cols"][6:t], rd["read_cols"][6:t]
+                    assert wave_cols_w == wave_cols_r, "wave-index bits moved in an intra-wave exchange"
+                    assert all(c & (c - 1) == 0 for c in wave_cols_w), "wave columns must be pure address bits"
+                    wave_mask = sum(wave_cols_w)
+                    lane_reg = rd["write_cols"][:6] + rd["write_cols"][t:] + rd["read_cols"][:6] + rd["read_cols"][t:]
+                    assert all((c & wave_mask) == 0 for c in lane_reg), "a swizzle term touches a wave address bit"
             if stats is not None:
                 stats["exchanges"] += 1
+                stats["intra_wave_exchanges"] = stats.get("intra_wave_exchanges", 0) + int(rd["intra_wave"])
                 model = bank_conflicts_b128 if lds_access_bytes == 16 else bank_conflicts_b64
                 stats["conflicts"] += model(rd["write_cols"][:t], True)
                 stats["conflicts"] += model(rd["read_cols"][:t], False)
