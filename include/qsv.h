@@ -73,9 +73,11 @@ typedef struct qsv_profile {
     uint64_t n_state_passes;   /* sum over launches of states swept (launch x circuits in its group) */
     uint64_t n_gates;          /* non-identity gates applied */
     uint64_t state_bytes;      /* bytes of state amplitudes the gate-pass launches read + wrote */
-    double pass_ms;            /* device time of all gate-pass launches (HIP events on the library's stream) */
+    double pass_ms;            /* device time of the gate-pass launches, summed over pushes (HIP events on the stream
+                                  each push runs on; pushes on the two streams overlap, so this can exceed wall time) */
     double expect_ms;          /* device time of expectation / reduction kernels */
     double total_ms;           /* device time of the whole call, first launch to last */
+    double pass_window_ms;     /* wall-clock window from the first gate-pass launch to the end of the last one */
 } qsv_profile;
 
 /* ---- lifetime ---------------------------------------------------------------------------------- */

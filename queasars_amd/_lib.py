@@ -50,6 +50,7 @@ class QsvProfile(C.Structure):
         ("pass_ms", C.c_double),
         ("expect_ms", C.c_double),
         ("total_ms", C.c_double),
+        ("pass_window_ms", C.c_double),
     ]
 
 

@@ -55,17 +55,17 @@ __device__ __forceinline__ void load_words(cu32p p, uint32_t (&w)[N]) {
 }
 
 // Offset of a thread inside a layout: XOR of the columns selected by the bits of tid.  The block always holds
-// kMaxThreadBits columns (unused ones are 0), so there is nothing to predicate and the loop unrolls.  The six
-// lane bits of tid are passed as all-ones / all-zeros masks computed once per kernel (one VALU operation per
-// column); the wave-index bits are uniform, so their columns are folded on the scalar unit.
-__device__ __forceinline__ uint32_t xor_columns(cu32p cols, const uint32_t (&lane_mask)[6], uint32_t wave) {
+// kMaxThreadBits columns (unused ones are 0), so there is nothing to predicate and the loop unrolls.  Lane bits cost
+// two VALU operations per column (bit -> mask, mask & column ^ x); the wave-index bits are uniform, so their columns
+// are folded on the scalar unit.
+__device__ __forceinline__ uint32_t xor_columns(cu32p cols, uint32_t tid, uint32_t wave) {
     uint32_t c[kMaxThreadBits];
     load_words<int(kMaxThreadBits)>(cols, c);
     uint32_t x = 0;
 #pragma unroll
     for (int u = 6; u < int(kMaxThreadBits); ++u) x ^= ((wave >> (u - 6)) & 1u) ? c[u] : 0u;
 #pragma unroll
-    for (int u = 0; u < 6; ++u) x ^= lane_mask[u] & c[u];
+    for (int u = 0; u < 6; ++u) x ^= uint32_t(int32_t(tid << (31 - u)) >> 31) & c[u];
     return x;
 }
 
@@ -166,6 +166,12 @@ static __device__ __forceinline__ unsigned long long qsv_stamp_now() {
 #define QSV_STAMP(ph)
 #endif
 
+// Workgroup barrier for the LDS exchanges.  __syncthreads() carries a release fence over GLOBAL memory as well: hipcc
+// puts s_waitcnt vmcnt(0) in front of s_barrier, so every wave would sit out the full latency of the previous
+// tile's state stores at the next barrier.  Nothing a workgroup writes to global memory is read by the same launch,
+// so only LDS traffic has to be ordered here.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // Read-only inputs are separate `const __restrict__` kernel parameters (not members of a by-value struct): that is
 // what lets hipcc prove they cannot alias the state stores and fetch plan words and matrices with SCALAR loads.
 struct PassScalars {
@@ -226,9 +232,6 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE>::waves_per_simd))
     const bool active = tid < (1u << t);
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t wave_base = wave << 6;
-    uint32_t lane_mask[6];
-#pragma unroll
-    for (int u = 0; u < 6; ++u) lane_mask[u] = 0u - ((tid >> u) & 1u);
 
     cu32p pos = pp + kPassHeaderWords;
     cu32p glr = pp + kPassLoadColsOffset + kMaxThreadBits;   // register columns of the load layout
@@ -248,12 +251,13 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE>::waves_per_simd))
     const bool wide = n_qubits + uint32_t(ASH) > 32u;
 
     QSV_STAMP_DECL
-    const uint32_t tg = xor_columns(pp + kPassLoadColsOffset, lane_mask, wave);
-    const uint32_t sg = xor_columns(pp + kPassStoreColsOffset, lane_mask, wave);
+    const uint32_t tg = xor_columns(pp + kPassLoadColsOffset, tid, wave);
+    const uint32_t sg = xor_columns(pp + kPassStoreColsOffset, tid, wave);
 
     // synthesis tables of this evaluation (see prepare_kernel): thread factors, then tile factors
     cf64p thread_factor = vecs + 4 * size_t(n_qubits) + kMatPadDoubles;
     cf64p tile_factor = thread_factor + (size_t(2) << t);
+    // loaded once: a load inside the tile loop would make pass 0 wait for the previous tile's stores (same counter)
     double ttr = 1.0, tti = 0.0;
     if (synth && active) {
         ttr = thread_factor[2 * tid];
@@ -269,6 +273,11 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE>::waves_per_simd))
     QSV_STAMP(0);
     for (uint32_t j = 0; j < n_tiles; ++j) {
         const uint64_t base = tile_base(tile0 + j, pos);
+        // Per-element offsets do not depend on the tile, so hipcc would compute all of them once, ahead of the tile
+        // loop, and keep (in fact spill) 3 * 2^R registers for them.  Recomputing them costs one v_xor per access:
+        // the opaque copies below stop the hoisting.
+        uint32_t tgv = tg, sgv = sg;
+        asm volatile("" : "+v"(tgv), "+v"(sgv));
         if (synth) {
             // initial product state: amplitude(i) = prod_q v_q[bit q of i].  prepare_kernel has multiplied out the
             // factors of the qubits outside the tile (one value per tile: tile_factor) and of the tile qubits held
@@ -293,20 +302,24 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE>::waves_per_simd))
         } else if (active) {
             if (!wide) {
                 const unsigned char* tile = reinterpret_cast<const unsigned char*>(st0 + base);
-                uint32_t ob = tg << ASH;
+                uint32_t ob = tgv << ASH;
 #pragma unroll
                 for (int i = 0; i < NR; ++i) {
                     if (i) ob ^= glr[__builtin_ctz(i)] << ASH;
                     amp[gray_index(i)] = *reinterpret_cast<const cxr*>(tile + ob);
                 }
             } else {
-                uint32_t off = tg;
+                uint32_t off = tgv;
 #pragma unroll
                 for (int i = 0; i < NR; ++i) {
                     off = gray_step(i, off, glr);
                     amp[gray_index(i)] = st0[base + off];
                 }
             }
+            // Wait for the loads HERE, inside the branch: at the join with the synthesis path hipcc would otherwise
+            // place this wait before the first use for both paths, and on the synthesis path (pass 0, which loads
+            // nothing) it would then wait for the previous tile's STORES, which share the counter.
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
         }
 
         QSV_STAMP(1);
@@ -320,84 +333,125 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE>::waves_per_simd))
                 cu32p wc = rp;
                 cu32p rc = rp + kColumnWords;
                 rp += kExchangeWords;
-                // LDS byte offsets: thread part once, then one v_xor per register element (columns scaled on the
-                // scalar unit); the same offsets serve the real and the imaginary plane
-                uint32_t wo[NR], ro[NR];
-                {
-                    uint32_t w = xor_columns(wc, lane_mask, wave) << LSH, r = xor_columns(rc, lane_mask, wave) << LSH;
-#pragma unroll
-                    for (int i = 0; i < NR; ++i) {
-                        if (i) {
-                            w ^= wc[kMaxThreadBits + __builtin_ctz(i)] << LSH;
-                            r ^= rc[kMaxThreadBits + __builtin_ctz(i)] << LSH;
-                        }
-                        wo[gray_index(i)] = w;
-                        ro[gray_index(i)] = r;
-                    }
-                }
+                // LDS byte offsets: the thread part once per exchange; the register part is walked in Gray-code
+                // order in every phase (one v_xor with a scalar per element) instead of being kept in 2 * 2^R
+                // registers, which the gate loop needs more
+                const uint32_t wt = xor_columns(wc, tid, wave) << LSH, rt = xor_columns(rc, tid, wave) << LSH;
+                cu32p wrc = wc + kMaxThreadBits;
+                cu32p rrc = rc + kMaxThreadBits;
                 // An intra-wave exchange (plan.hpp) moves data only inside each wave, through the LDS region that
                 // wave owns: no barrier inside it, and none before it unless the previous exchange was a cross-wave
                 // one whose readers may still be busy in this wave's region.
                 const bool intra = (rh >> 17) & 1u;
                 if (intra ? cross_pending : lds_dirty) {
-                    __syncthreads();
+                    lds_barrier();
                     cross_pending = false;
                 }
                 if constexpr (XMODE == 0) {
                     QSV_STAMP(2);
                     if (active) {
+{
+                            uint32_t o = wt;
 #pragma unroll
-                        for (int e = 0; e < NR; ++e) *reinterpret_cast<cxr*>(lds_raw + wo[e]) = amp[e];
+                            for (int i = 0; i < NR; ++i) {
+                                if (i) o ^= wrc[__builtin_ctz(i)] << LSH;
+                                const int e = gray_index(i);
+                                *reinterpret_cast<cxr*>(lds_raw + o) = amp[e];
+                            }
+                        }
                     }
-                    if (!intra) __syncthreads();
+                    if (!intra) lds_barrier();
                     if (active) {
+{
+                            uint32_t o = rt;
 #pragma unroll
-                        for (int e = 0; e < NR; ++e) amp[e] = *reinterpret_cast<const cxr*>(lds_raw + ro[e]);
+                            for (int i = 0; i < NR; ++i) {
+                                if (i) o ^= rrc[__builtin_ctz(i)] << LSH;
+                                const int e = gray_index(i);
+                                amp[e] = *reinterpret_cast<const cxr*>(lds_raw + o);
+                            }
+                        }
                     }
                 } else if constexpr (XMODE == 1) {
                     QSV_STAMP(2);
                     unsigned char* pim = lds_raw + (size_t(sizeof(real)) << (hdr & 0xff));
                     if (active) {
+{
+                            uint32_t o = wt;
 #pragma unroll
-                        for (int e = 0; e < NR; ++e) {
-                            *reinterpret_cast<real*>(lds_raw + wo[e]) = amp[e].re;
-                            *reinterpret_cast<real*>(pim + wo[e]) = amp[e].im;
+                            for (int i = 0; i < NR; ++i) {
+                                if (i) o ^= wrc[__builtin_ctz(i)] << LSH;
+                                const int e = gray_index(i);
+                                *reinterpret_cast<real*>(lds_raw + o) = amp[e].re; *reinterpret_cast<real*>(pim + o) = amp[e].im;
+                            }
                         }
                     }
-                    if (!intra) __syncthreads();
+                    if (!intra) lds_barrier();
                     if (active) {
+{
+                            uint32_t o = rt;
 #pragma unroll
-                        for (int e = 0; e < NR; ++e) {
-                            amp[e].re = *reinterpret_cast<const real*>(lds_raw + ro[e]);
-                            amp[e].im = *reinterpret_cast<const real*>(pim + ro[e]);
+                            for (int i = 0; i < NR; ++i) {
+                                if (i) o ^= rrc[__builtin_ctz(i)] << LSH;
+                                const int e = gray_index(i);
+                                amp[e].re = *reinterpret_cast<const real*>(lds_raw + o); amp[e].im = *reinterpret_cast<const real*>(pim + o);
+                            }
                         }
                     }
                 } else {
                     QSV_STAMP(2);
                     if (active) {
+{
+                            uint32_t o = wt;
 #pragma unroll
-                        for (int e = 0; e < NR; ++e) *reinterpret_cast<real*>(lds_raw + wo[e]) = amp[e].re;
+                            for (int i = 0; i < NR; ++i) {
+                                if (i) o ^= wrc[__builtin_ctz(i)] << LSH;
+                                const int e = gray_index(i);
+                                *reinterpret_cast<real*>(lds_raw + o) = amp[e].re;
+                            }
+                        }
                     }
                     QSV_STAMP(3);
-                    if (!intra) __syncthreads();
+                    if (!intra) lds_barrier();
                     QSV_STAMP(4);
                     if (active) {
+{
+                            uint32_t o = rt;
 #pragma unroll
-                        for (int e = 0; e < NR; ++e) amp[e].re = *reinterpret_cast<const real*>(lds_raw + ro[e]);
+                            for (int i = 0; i < NR; ++i) {
+                                if (i) o ^= rrc[__builtin_ctz(i)] << LSH;
+                                const int e = gray_index(i);
+                                amp[e].re = *reinterpret_cast<const real*>(lds_raw + o);
+                            }
+                        }
                     }
                     QSV_STAMP(5);
-                    if (!intra) __syncthreads();
+                    if (!intra) lds_barrier();
                     QSV_STAMP(6);
                     if (active) {
+{
+                            uint32_t o = wt;
 #pragma unroll
-                        for (int e = 0; e < NR; ++e) *reinterpret_cast<real*>(lds_raw + wo[e]) = amp[e].im;
+                            for (int i = 0; i < NR; ++i) {
+                                if (i) o ^= wrc[__builtin_ctz(i)] << LSH;
+                                const int e = gray_index(i);
+                                *reinterpret_cast<real*>(lds_raw + o) = amp[e].im;
+                            }
+                        }
                     }
                     QSV_STAMP(7);
-                    if (!intra) __syncthreads();
+                    if (!intra) lds_barrier();
                     QSV_STAMP(8);
                     if (active) {
+{
+                            uint32_t o = rt;
 #pragma unroll
-                        for (int e = 0; e < NR; ++e) amp[e].im = *reinterpret_cast<const real*>(lds_raw + ro[e]);
+                            for (int i = 0; i < NR; ++i) {
+                                if (i) o ^= rrc[__builtin_ctz(i)] << LSH;
+                                const int e = gray_index(i);
+                                amp[e].im = *reinterpret_cast<const real*>(lds_raw + o);
+                            }
+                        }
                     }
                     QSV_STAMP(9);
                 }
@@ -443,21 +497,31 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE>::waves_per_simd))
             if (!wide) {
                 unsigned char* tile = reinterpret_cast<unsigned char*>(st0 + base);
                 const unsigned char* dtile = reinterpret_cast<const unsigned char*>(diag + base);
-                uint32_t ob = sg << ASH;
+                if (do_store) {
+                    uint32_t ob = sgv << ASH;
 #pragma unroll
-                for (int i = 0; i < NR; ++i) {
-                    if (i) ob ^= gsr[__builtin_ctz(i)] << ASH;
-                    const cxr x = amp[gray_index(i)];
-                    if (do_store) *reinterpret_cast<cxr*>(tile + ob) = x;
-                    if (do_diag) {
-                        // D[i] is a double: its byte offset is the amplitude's scaled by 8 / sizeof(amplitude)
-                        const double d = *reinterpret_cast<const double*>(dtile + (ob >> (ASH - 3)));
-                        const double re = double(x.re), im = double(x.im);
-                        acc += (re * re + im * im) * d;
+                    for (int i = 0; i < NR; ++i) {
+                        if (i) ob ^= gsr[__builtin_ctz(i)] << ASH;
+                        *reinterpret_cast<cxr*>(tile + ob) = amp[gray_index(i)];
+                    }
+                }
+                if (do_diag) {
+                    // all D[i] loads first, so that they are in flight together (one latency, not 2^R in a row)
+                    double dv[NR];
+                    uint32_t ob = sgv << 3;
+#pragma unroll
+                    for (int i = 0; i < NR; ++i) {
+                        if (i) ob ^= gsr[__builtin_ctz(i)] << 3;
+                        dv[gray_index(i)] = *reinterpret_cast<const double*>(dtile + ob);
+                    }
+#pragma unroll
+                    for (int e = 0; e < NR; ++e) {
+                        const double re = double(amp[e].re), im = double(amp[e].im);
+                        acc += (re * re + im * im) * dv[e];
                     }
                 }
             } else {
-                uint32_t off = sg;
+                uint32_t off = sgv;
 #pragma unroll
                 for (int i = 0; i < NR; ++i) {
                     off = gray_step(i, off, gsr);
@@ -477,9 +541,9 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE>::waves_per_simd))
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
         double* red = reinterpret_cast<double*>(lds_raw);
-        if (lds_dirty) __syncthreads();
+        if (lds_dirty) lds_barrier();
         if ((tid & 63u) == 0) red[tid >> 6] = acc;
-        __syncthreads();
+        lds_barrier();
         if (tid == 0) {
             double total = 0.0;
             const int n_waves = (blockDim.x + 63) >> 6;

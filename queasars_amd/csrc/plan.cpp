@@ -460,33 +460,40 @@ CircuitPlan build_plan(int n, const std::vector<GateIn>& all_gates, const std::v
             const bool edge = m == 0 || m + 1 == n_rounds_pass;
             std::vector<int> must = needed[m];
             if (must.empty() && rd.gates.empty()) must = {};  // relayout-only round: registers are all filler
-            bool keep = m > 0 && int(prev_w.size()) == nw;
-            for (int b : prev_w) keep = keep && !contains(must, b);
+            // controls of the round's gates that are tile bits but not targets in this round
+            std::vector<int> ctrl;
+            for (int gi : rd.gates) {
+                const int cb = gates[gi].control >= 0 ? tile_bit(gates[gi].control) : -1;
+                if (cb >= 0 && !contains(must, cb) && !contains(ctrl, cb)) ctrl.push_back(cb);
+            }
+            // Spare registers go to controls first: a register-held control halves the gate's work, whereas a
+            // control on a lane bit only masks lanes (the full butterfly still issues).
+            std::vector<int> regs = must;
+            for (int cb : ctrl)
+                if (int(regs.size()) < r && !(edge && cb < cl)) regs.push_back(cb);
+            // Wave set: controls not in registers come first (whole waves skip the gate), then the previous wave
+            // bits (an unchanged set makes the exchange barrier-free), then the bits needed in registers latest.
             std::vector<int> wset;
-            if (keep) {
-                wset = prev_w;
-            } else if (nw > 0) {
-                std::vector<int> ctrl;
-                for (int gi : rd.gates)
-                    if (gates[gi].control >= 0 && tile_bit(gates[gi].control) >= 0) ctrl.push_back(tile_bit(gates[gi].control));
+            if (nw > 0) {
                 std::vector<int> cand;
                 for (int b = cl; b < k; ++b)
-                    if (!contains(must, b)) cand.push_back(b);
+                    if (!contains(regs, b)) cand.push_back(b);
                 std::stable_sort(cand.begin(), cand.end(), [&](int x, int y) {
-                    const int ux = next_use(x, m), uy = next_use(y, m);
-                    if (ux != uy) return ux > uy;
                     const bool cx = contains(ctrl, x), cy = contains(ctrl, y);
                     if (cx != cy) return cx;
+                    const bool px = contains(prev_w, x), py = contains(prev_w, y);
+                    if (px != py) return px;
+                    const int ux = next_use(x, m), uy = next_use(y, m);
+                    if (ux != uy) return ux > uy;
                     return x > y;
                 });
                 // leave enough bits outside W for the registers
-                const int spare = int(cand.size()) - (r - int(must.size()));
+                const int spare = int(cand.size()) - (r - int(regs.size()));
                 const int take = std::max(0, std::min(nw, spare));
                 wset.assign(cand.begin(), cand.begin() + take);
                 std::sort(wset.begin(), wset.end());
             }
-            // registers: the needed bits, filled up from the top with bits that are neither in W nor pinned to lanes
-            std::vector<int> regs = must;
+            // remaining registers: filled up from the top with bits that are neither in W nor pinned to lanes
             for (int b = k - 1; b >= 0 && int(regs.size()) < r; --b)
                 if (!contains(regs, b) && !contains(wset, b) && !(edge && b < cl)) regs.push_back(b);
             for (int b = k - 1; b >= 0 && int(regs.size()) < r; --b)  // tiny tiles: give up wave bits, then low bits

@@ -43,6 +43,12 @@ struct qsv_handle {
     size_t amp_bytes = 16;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    // Second stream for the streaming evaluation: consecutive pushes alternate between the two, so that the
+    // compute-bound first pass of one push runs beside the memory-bound later passes of the other.
+    hipStream_t stream2 = nullptr;
+    hipStream_t work = nullptr;  // stream of the push being issued (null: `stream`)
+    hipEvent_t ev_layout = nullptr, ev_join = nullptr;
+    bool dual_streams = true;
     mutable std::mutex mu;
     std::string err;
 
@@ -84,6 +90,9 @@ struct qsv_handle {
         size_t pushed = 0;                 // evaluations launched so far
         std::vector<std::pair<hipEvent_t, hipEvent_t>> pass_events, exp_events;
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        bool dual = false;   // this batch alternates pushes between the two streams
+        bool used2 = false;  // ... and the second one has work in flight
+        size_t n_pushes = 0;
     } batch;
     std::unique_lock<std::mutex> batch_lock;  // held from begin to end
 
@@ -100,6 +109,8 @@ int fail(qsv_t* h, int code, const std::string& msg) {
     else g_create_error = msg;
     return code;
 }
+
+inline hipStream_t ws(const qsv_t* h) { return h->work ? h->work : h->stream; }
 
 #define QSV_HIP(h, expr)                                                                          \
     do {                                                                                          \
@@ -317,10 +328,10 @@ int batch_ship(qsv_t* h, size_t first, size_t count, const double* values) {
     double* dp = reinterpret_cast<double*>(static_cast<char*>(h->d_batch.ptr) + b.desc_bytes);
     if (p1 > p0) {
         std::memcpy(hp + p0, values, (p1 - p0) * sizeof(double));
-        QSV_HIP(h, hipMemcpyAsync(dp + p0, hp + p0, (p1 - p0) * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        QSV_HIP(h, hipMemcpyAsync(dp + p0, hp + p0, (p1 - p0) * sizeof(double), hipMemcpyHostToDevice, ws(h)));
     }
     QSV_HIP(h, launch_prepare(static_cast<const uint32_t*>(h->d_arena.ptr), batch_evals(h) + first, dp,
-                              static_cast<double*>(h->d_mats.ptr), int(count), h->stream));
+                              static_cast<double*>(h->d_mats.ptr), int(count), ws(h)));
     return QSV_OK;
 }
 
@@ -347,7 +358,7 @@ int run_group(qsv_t* h, const std::vector<Circuit*>& circs, size_t first, size_t
     dim3 grid(chunks, unsigned(count));
     for (int p = 0; p < max_passes; ++p) {
         a.pass_index = uint32_t(p);
-        QSV_HIP(h, launch_pass(h->dtype, h->geo.r, h->cfg.xmode, grid, h->geo.threads_launch, h->geo.lds_bytes, h->stream, a));
+        QSV_HIP(h, launch_pass(h->dtype, h->geo.r, h->cfg.xmode, grid, h->geo.threads_launch, h->geo.lds_bytes, ws(h), a));
         h->prof.n_pass_launches += 1;
         h->prof.n_state_passes += count;
     }
@@ -372,9 +383,9 @@ hipError_t stamp(qsv_t* h, std::vector<std::pair<hipEvent_t, hipEvent_t>>& list,
         e = hipEventCreate(&p.second);
         if (e != hipSuccess) return e;
         list.push_back(p);
-        return hipEventRecord(p.first, h->stream);
+        return hipEventRecord(p.first, ws(h));
     }
-    return hipEventRecord(list.back().second, h->stream);
+    return hipEventRecord(list.back().second, ws(h));
 }
 
 int eval_begin(qsv_t* h, const std::vector<Circuit*>& circs, const std::vector<int64_t>& n_params) {
@@ -391,7 +402,15 @@ int eval_begin(qsv_t* h, const std::vector<Circuit*>& circs, const std::vector<i
         QSV_HIP(h, hipEventCreate(&h->batch.ev1));
         QSV_HIP(h, hipEventRecord(h->batch.ev0, h->stream));
     }
-    return batch_layout(h, circs, n_params);
+    if ((rc = batch_layout(h, circs, n_params))) return rc;
+    qsv_handle::Batch& b = h->batch;
+    // Two streams only when every evaluation of the batch has its own state slot (no reuse to order across streams)
+    // and the expectation is fused into the last pass (no scratch shared between pushes).
+    b.dual = h->dual_streams && h->diagonal && n_evals <= size_t(h->group) && n_evals >= 2;
+    b.used2 = false;
+    b.n_pushes = 0;
+    if (b.dual) QSV_HIP(h, hipEventRecord(h->ev_layout, h->stream));  // the descriptors are copied on `stream`
+    return QSV_OK;
 }
 
 int eval_push(qsv_t* h, size_t first, size_t count, const double* values) {
@@ -401,6 +420,16 @@ int eval_push(qsv_t* h, size_t first, size_t count, const double* values) {
     const size_t G = size_t(h->group);
     // state slot = evaluation index mod G (batch_layout): any run of <= G consecutive evaluations has distinct slots,
     // and the stream orders a slot's reuse after its previous owner's last pass
+    struct WorkGuard {
+        qsv_t* h;
+        ~WorkGuard() { h->work = nullptr; }
+    } guard{h};
+    if (b.dual && (b.n_pushes & 1)) {
+        h->work = h->stream2;
+        if (!b.used2) QSV_HIP(h, hipStreamWaitEvent(h->stream2, h->ev_layout, 0));
+        b.used2 = true;
+    }
+    b.n_pushes += 1;
     int rc = batch_ship(h, first, count, values);
     if (rc) return rc;
     const uint32_t mode = kModeSynthFirst | (h->diagonal ? kModeFinalDiag : kModeFinalStore) |
@@ -437,6 +466,11 @@ int eval_end(qsv_t* h, double* out) {
     const size_t n_evals = b.circs.size();
     if (b.pushed != n_evals) return fail(h, QSV_E_STATE, "not every evaluation of the batch was pushed");
     if (n_evals == 0) return QSV_OK;
+    if (b.used2) {
+        QSV_HIP(h, hipEventRecord(h->ev_join, h->stream2));
+        QSV_HIP(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
+        b.used2 = false;
+    }
     if (h->diagonal) {
         QSV_HIP(h, stamp(h, b.exp_events, true));
         QSV_HIP(h, launch_reduce_partials(static_cast<const double*>(h->d_partials.ptr), chunks_per_state(h),
@@ -454,6 +488,11 @@ int eval_end(qsv_t* h, double* out) {
         for (auto& p : b.pass_events) {
             QSV_HIP(h, hipEventElapsedTime(&ms, p.first, p.second));
             h->prof.pass_ms += ms;
+        }
+        // wall-clock window of the gate passes: with two streams the per-push intervals above overlap
+        if (!b.pass_events.empty() && !b.exp_events.empty()) {
+            QSV_HIP(h, hipEventElapsedTime(&ms, b.pass_events.front().first, b.exp_events.front().first));
+            h->prof.pass_window_ms = ms;
         }
         for (auto& p : b.exp_events) {
             QSV_HIP(h, hipEventElapsedTime(&ms, p.first, p.second));
@@ -478,6 +517,8 @@ void eval_close(qsv_t* h) {
     b.ev0 = b.ev1 = nullptr;
     b.circs.clear();
     b.open = false;
+    b.dual = b.used2 = false;
+    h->work = nullptr;
 }
 
 // One-shot evaluation: begin + one push + end.
@@ -584,6 +625,10 @@ int qsv_create(int n_qubits, int dtype, int device, const qsv_plan_config* cfg, 
     };
     if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
     h->own_stream = true;
+    if ((e = hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
+    if ((e = hipEventCreateWithFlags(&h->ev_layout, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
+    if ((e = hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
+    if (const char* env = getenv("QSV_STREAMS")) h->dual_streams = atoi(env) >= 2;
     if ((e = hipMalloc(&h->d_states.ptr, state_bytes * size_t(group))) != hipSuccess) return bail(e, "hipMalloc(states)");
     h->d_states.bytes = state_bytes * size_t(group);
     if ((e = configure_pass_kernels(dtype, geo.r, pc.xmode, geo.lds_bytes)) != hipSuccess) return bail(e, "hipFuncSetAttribute");
@@ -595,6 +640,12 @@ void qsv_destroy(qsv_t* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->stream2) {
+        (void)hipStreamSynchronize(h->stream2);
+        (void)hipStreamDestroy(h->stream2);
+    }
+    if (h->ev_layout) (void)hipEventDestroy(h->ev_layout);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     for (DeviceBuffer* b : {&h->d_z, &h->d_cre, &h->d_diag, &h->d_term_partials, &h->d_groups, &h->d_term_odd, &h->d_arena,
                             &h->d_states, &h->d_batch, &h->d_mats, &h->d_partials, &h->d_out, &h->d_scratch})
         if (b->ptr) (void)hipFree(b->ptr);
@@ -779,7 +830,10 @@ int qsv_eval_end(qsv_t* h, double* out_expectations) {
     if (!h->batch.open) return fail(h, QSV_E_STATE, "no open batch (call qsv_eval_begin first)");
     int rc = out_expectations || h->batch.circs.empty() ? eval_end(h, out_expectations)
                                                         : fail(h, QSV_E_ARG, "out is null");
-    if (rc) (void)hipStreamSynchronize(h->stream);  // nothing of the failed batch may still be running
+    if (rc) {  // nothing of the failed batch may still be running
+        (void)hipStreamSynchronize(h->stream);
+        (void)hipStreamSynchronize(h->stream2);
+    }
     eval_close(h);
     std::unique_lock<std::mutex> lock = std::move(h->batch_lock);
     return rc;  // `lock` releases the handle here
