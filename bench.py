@@ -195,10 +195,12 @@ def main() -> None:
                 "aggregate_achieved": prof["state_bytes"] / (prof["pass_window_ms"] * 1e-3) / 1e9
                 if prof["pass_window_ms"] > 0 else None,
                 "pass_window_ms_per_step": prof["pass_window_ms"] / args.steps,
-                "note": "state amplitudes read+written per launch (16 B each way per amplitude; pass 0 does not "
-                "read, the fused last pass does not write) / mean launch time from HIP events on the library's "
-                "stream; n=20 states (16 MiB) are cache-blocked into the 256 MiB Infinity Cache, so this can exceed "
-                "the HBM peak",
+                "note": "achieved = state amplitudes read + written per launch (16 B each way per amplitude; pass 0 "
+                "does not read, the fused last pass does not write) / mean launch time from HIP events on the stream "
+                "each launch runs on.  The two halves of a population run on two streams, so launches overlap and "
+                "each one sees part of the chip: aggregate_achieved (all bytes of a step / wall-clock window of its "
+                "gate passes) is the chip-level rate.  At n=20 a fused pass does ~9.5 flop per byte, the fp64 ridge of "
+                "the chip: the passes are bound by fp64 issue, LDS traffic and latency as much as by HBM (DESIGN.md)",
             },
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -22,6 +22,7 @@ There is no CPU fallback: if ``libqsv`` cannot be loaded or no GPU is present, c
 from __future__ import annotations
 
 import ctypes as C
+import os
 import threading
 import weakref
 from itertools import count
@@ -113,6 +114,7 @@ class StatevectorDevice:
         self._dtype = dtype
         self._group = max(1, int(self._lib.qsv_group_size(self._handle)))
         self._push_groups = 1  # launch groups per qsv_eval_push
+        self._push_evals = int(os.environ.get("QSV_PUSH_EVALS", "0"))  # measurement knob: evaluations per push
         self._operator: Optional[PauliOperator] = None
         self._reg_lock = threading.Lock()
         self._serial = next(_device_serial)  # key of this device in CircuitIR._registered (never reused)
@@ -221,6 +223,8 @@ class StatevectorDevice:
             # at least two pushes for a population, so that converting the second half overlaps the GPU work on the
             # first; never more than a launch group per push
             step = min(self._group * max(1, self._push_groups), max(8, (n + 1) // 2))
+            if self._push_evals:
+                step = self._push_evals
             for first in range(0, n, step):
                 chunk = parameter_values[first : first + step]
                 total = int(counts[first : first + step].sum())
