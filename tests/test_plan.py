@@ -106,3 +106,29 @@ def test_plan_build_rejects_bad_input():
         build_plan_words(c, tile_bits=3, reg_bits=4)
     with pytest.raises(ValueError):
         build_plan_words(c, reg_bits=7)
+
+
+def test_generated_gate_loop_is_current():
+    """gate_loop_gen.inc is committed next to its generator: the two must not drift apart."""
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    gen = Path(__file__).resolve().parent.parent / "queasars_amd" / "csrc" / "gen_gate_loop.py"
+    assert subprocess.run([sys.executable, str(gen), "--check"]).returncode == 0, "run gen_gate_loop.py"
+
+
+def test_plans_use_barrier_free_exchanges_and_keep_controls_off_the_lanes():
+    """Scheduler quality on the benchmark family: some exchanges stay inside a wave, few controls sit on lane bits."""
+    _, circuits, params = helpers.population_circuits(14, 4, 6, seed=0)
+    exchanges = intra = lane = gates = 0
+    for c, p in zip(circuits, params):
+        stats = {}
+        got = pi.run(build_plan_words(c), 14, p, stats)
+        assert np.abs(got - helpers.oracle_state(c, p)).max() < 1e-13
+        exchanges += stats["exchanges"]
+        intra += stats.get("intra_wave_exchanges", 0)
+        lane += stats["lane_ctrl"]
+        gates += stats["gates"]
+    assert intra > 0 and intra <= exchanges
+    assert lane <= 0.15 * gates
