@@ -115,6 +115,7 @@ class StatevectorDevice:
         self._group = max(1, int(self._lib.qsv_group_size(self._handle)))
         self._push_groups = 1  # launch groups per qsv_eval_push
         self._push_evals = int(os.environ.get("QSV_PUSH_EVALS", "0"))  # measurement knob: evaluations per push
+        self._push_plan = [int(x) for x in os.environ.get("QSV_PUSH_PLAN", "").split(",") if x]  # ... or explicit sizes
         self._operator: Optional[PauliOperator] = None
         self._reg_lock = threading.Lock()
         self._serial = next(_device_serial)  # key of this device in CircuitIR._registered (never reused)
@@ -220,14 +221,29 @@ class StatevectorDevice:
         self._check(lib.qsv_eval_begin(handle, n, _lib.as_ptr(ids), _lib.as_ptr(counts)))
         rc = _lib.QSV_OK
         try:
-            # at least two pushes for a population, so that converting the second half overlaps the GPU work on the
-            # first; never more than a launch group per push
+            # Several pushes per population: packing the later ones overlaps the GPU work on the earlier ones, and the
+            # library alternates pushes between two HIP streams.  A small first push (an eighth) gets the GPU going
+            # early, the rest goes in two equal pushes (measured: scripts/sweep.sh with QSV_PUSH_PLAN); never more
+            # than a launch group per push.
             step = min(self._group * max(1, self._push_groups), max(8, (n + 1) // 2))
             if self._push_evals:
                 step = self._push_evals
-            for first in range(0, n, step):
-                chunk = parameter_values[first : first + step]
-                total = int(counts[first : first + step].sum())
+            bounds = list(range(0, n, step)) + [n]
+            if not self._push_evals and not self._push_plan and 32 <= n <= self._group:
+                head = n // 8
+                bounds = [0, head, head + (n - head + 1) // 2, n]
+            if self._push_plan:
+                bounds, acc = [0], 0
+                for size in self._push_plan:
+                    acc = min(n, acc + size)
+                    bounds.append(acc)
+                while bounds[-1] < n:
+                    bounds.append(min(n, bounds[-1] + self._push_plan[-1]))
+            for first, last in zip(bounds[:-1], bounds[1:]):
+                if last <= first:
+                    continue
+                chunk = parameter_values[first:last]
+                total = int(counts[first:last].sum())
                 if total:
                     values = _pack_doubles(chunk, total)
                     rc = lib.qsv_eval_push(handle, first, len(chunk), _lib.as_ptr(values))

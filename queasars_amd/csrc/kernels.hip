@@ -664,11 +664,16 @@ __device__ __forceinline__ void u_matrix(const Angles& a, double* m) {
     m[6] = cpl * c;  m[7] = spl * c;
 }
 
+// `host_evals` and `params` point into PINNED HOST memory: the kernel fetches the few hundred bytes an evaluation
+// needs over PCIe itself and leaves a device copy of the descriptor for the pass kernels.  Separate H2D copies in
+// front of it cost two more dependent stream operations (~50 us before the first pass of a step could start).
 __global__ void __launch_bounds__(256) prepare_kernel(const uint32_t* __restrict__ plan,
-                                                      const EvalDesc* __restrict__ evals,
+                                                      const EvalDesc* __restrict__ host_evals,
+                                                      EvalDesc* __restrict__ evals,
                                                       const double* __restrict__ params, double* __restrict__ mats) {
     __shared__ double sv[4 * 32];  // initial factors (v0, v1) of every qubit, n <= 32
-    const EvalDesc ev = evals[blockIdx.x];
+    const EvalDesc ev = host_evals[blockIdx.x];
+    if (threadIdx.x == 0) evals[blockIdx.x] = ev;
     const uint32_t* __restrict__ cp = plan + ev.plan_base;
     const uint32_t n_passes = cp[0], n_real = cp[1], n_qubits = cp[2];
     const uint32_t* __restrict__ table = cp + cp[3];
@@ -749,9 +754,9 @@ __global__ void __launch_bounds__(256) prepare_kernel(const uint32_t* __restrict
     }
 }
 
-hipError_t launch_prepare(const uint32_t* plan, const EvalDesc* evals, const double* params, double* mats, int n_evals,
-                          hipStream_t stream) {
-    hipLaunchKernelGGL(prepare_kernel, dim3(n_evals), dim3(256), 0, stream, plan, evals, params, mats);
+hipError_t launch_prepare(const uint32_t* plan, const EvalDesc* host_evals, EvalDesc* evals, const double* params,
+                          double* mats, int n_evals, hipStream_t stream) {
+    hipLaunchKernelGGL(prepare_kernel, dim3(n_evals), dim3(256), 0, stream, plan, host_evals, evals, params, mats);
     return hipGetLastError();
 }
 

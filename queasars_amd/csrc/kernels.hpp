@@ -53,9 +53,10 @@ inline size_t mat_region_doubles(uint32_t n_real, uint32_t n_qubits, int thread_
            (size_t(2) << outer_bits);
 }
 
-// Angles -> gate matrices and initial product-state factors, one workgroup per evaluation.
-hipError_t launch_prepare(const uint32_t* plan, const EvalDesc* evals, const double* params, double* mats, int n_evals,
-                          hipStream_t stream);
+// Angles -> gate matrices, initial product-state factors and synthesis tables, one workgroup per evaluation.
+// host_evals / params are pinned host memory read by the kernel; evals receives the device copy of the descriptors.
+hipError_t launch_prepare(const uint32_t* plan, const EvalDesc* host_evals, EvalDesc* evals, const double* params,
+                          double* mats, int n_evals, hipStream_t stream);
 
 // dtype: 0 = fp64, 1 = fp32.  r = register bits (1..4).  xmode = LDS exchange mode (see kernels.hip).
 // Returns hipSuccess or the launch error.

@@ -47,7 +47,7 @@ struct qsv_handle {
     // compute-bound first pass of one push runs beside the memory-bound later passes of the other.
     hipStream_t stream2 = nullptr;
     hipStream_t work = nullptr;  // stream of the push being issued (null: `stream`)
-    hipEvent_t ev_layout = nullptr, ev_join = nullptr;
+    hipEvent_t ev_join = nullptr;
     bool dual_streams = true;
     mutable std::mutex mu;
     std::string err;
@@ -310,7 +310,8 @@ int batch_layout(qsv_t* h, const std::vector<Circuit*>& circs, const std::vector
         mcur += mat_region_doubles(uint32_t(c.plan.stats.n_real_gates), uint32_t(h->n), h->geo.t, h->n - h->geo.k);
         h->prof.n_gates += uint64_t(c.n_gates);
     }
-    QSV_HIP(h, hipMemcpyAsync(h->d_batch.ptr, h->h_batch, b.desc_bytes, hipMemcpyHostToDevice, h->stream));
+    // (no copy here: prepare_kernel reads descriptors and parameters from this pinned buffer and writes the device
+    // copy of the descriptors itself)
     b.pushed = 0;
     return QSV_OK;
 }
@@ -325,13 +326,11 @@ int batch_ship(qsv_t* h, size_t first, size_t count, const double* values) {
     const size_t p0 = b.param_base[first];
     const size_t p1 = size_t(b.param_base[first + count - 1]) + b.n_params[first + count - 1];
     double* hp = reinterpret_cast<double*>(static_cast<char*>(h->h_batch) + b.desc_bytes);
-    double* dp = reinterpret_cast<double*>(static_cast<char*>(h->d_batch.ptr) + b.desc_bytes);
-    if (p1 > p0) {
-        std::memcpy(hp + p0, values, (p1 - p0) * sizeof(double));
-        QSV_HIP(h, hipMemcpyAsync(dp + p0, hp + p0, (p1 - p0) * sizeof(double), hipMemcpyHostToDevice, ws(h)));
-    }
-    QSV_HIP(h, launch_prepare(static_cast<const uint32_t*>(h->d_arena.ptr), batch_evals(h) + first, dp,
-                              static_cast<double*>(h->d_mats.ptr), int(count), ws(h)));
+    if (p1 > p0) std::memcpy(hp + p0, values, (p1 - p0) * sizeof(double));
+    const EvalDesc* host_evals = static_cast<const EvalDesc*>(h->h_batch);
+    QSV_HIP(h, launch_prepare(static_cast<const uint32_t*>(h->d_arena.ptr), host_evals + first,
+                              static_cast<EvalDesc*>(h->d_batch.ptr) + first, hp, static_cast<double*>(h->d_mats.ptr),
+                              int(count), ws(h)));
     return QSV_OK;
 }
 
@@ -404,12 +403,15 @@ int eval_begin(qsv_t* h, const std::vector<Circuit*>& circs, const std::vector<i
     }
     if ((rc = batch_layout(h, circs, n_params))) return rc;
     qsv_handle::Batch& b = h->batch;
-    // Two streams only when every evaluation of the batch has its own state slot (no reuse to order across streams)
-    // and the expectation is fused into the last pass (no scratch shared between pushes).
+    // Two streams (consecutive pushes alternate between them, so that kernels of different pushes share the chip:
+    // +15 % on the benchmark population) only when every evaluation of the batch has its own state slot (no reuse to
+    // order across streams) and the expectation is fused into the last pass (no scratch shared between pushes).
+    // Measured alternative: pass 0 of every push on one stream and the later passes on the other (compute-bound
+    // beside memory-bound by construction) is 10 % slower: two resident kernels mostly take workgroup slots from
+    // each other.
     b.dual = h->dual_streams && h->diagonal && n_evals <= size_t(h->group) && n_evals >= 2;
     b.used2 = false;
     b.n_pushes = 0;
-    if (b.dual) QSV_HIP(h, hipEventRecord(h->ev_layout, h->stream));  // the descriptors are copied on `stream`
     return QSV_OK;
 }
 
@@ -426,7 +428,6 @@ int eval_push(qsv_t* h, size_t first, size_t count, const double* values) {
     } guard{h};
     if (b.dual && (b.n_pushes & 1)) {
         h->work = h->stream2;
-        if (!b.used2) QSV_HIP(h, hipStreamWaitEvent(h->stream2, h->ev_layout, 0));
         b.used2 = true;
     }
     b.n_pushes += 1;
@@ -434,13 +435,13 @@ int eval_push(qsv_t* h, size_t first, size_t count, const double* values) {
     if (rc) return rc;
     const uint32_t mode = kModeSynthFirst | (h->diagonal ? kModeFinalDiag : kModeFinalStore) |
                           (h->has_diag_part ? kModeFinalDiag : 0u);
-    if (h->diagonal) QSV_HIP(h, stamp(h, b.pass_events, true));
     for (size_t g0 = first; g0 < first + count; g0 += G) {
         const size_t gc = std::min(G, first + count - g0);
-        if (!h->diagonal) QSV_HIP(h, stamp(h, b.pass_events, true));
-        if ((rc = run_group(h, b.circs, g0, gc, mode))) return rc;
+        QSV_HIP(h, stamp(h, b.pass_events, true));
+        rc = run_group(h, b.circs, g0, gc, mode);
+        if (!rc) QSV_HIP(h, stamp(h, b.pass_events, false));
+        if (rc) return rc;
         if (!h->diagonal) {
-            QSV_HIP(h, stamp(h, b.pass_events, false));
             QSV_HIP(h, stamp(h, b.exp_events, true));
             QSV_HIP(h, launch_pauli_groups(h->dtype, h->d_states.ptr, uint64_t(1) << h->n, h->n, int(gc), h->n_groups,
                                            static_cast<const PauliGroup*>(h->d_groups.ptr),
@@ -456,7 +457,6 @@ int eval_push(qsv_t* h, size_t first, size_t count, const double* values) {
             QSV_HIP(h, stamp(h, b.exp_events, false));
         }
     }
-    if (h->diagonal) QSV_HIP(h, stamp(h, b.pass_events, false));
     b.pushed = first + count;
     return QSV_OK;
 }
@@ -473,12 +473,14 @@ int eval_end(qsv_t* h, double* out) {
     }
     if (h->diagonal) {
         QSV_HIP(h, stamp(h, b.exp_events, true));
+        // the reduction writes its n_evals doubles straight into the pinned result buffer: no D2H copy to wait for
         QSV_HIP(h, launch_reduce_partials(static_cast<const double*>(h->d_partials.ptr), chunks_per_state(h),
-                                          int(n_evals), static_cast<double*>(h->d_out.ptr), h->stream));
+                                          int(n_evals), h->h_out, h->stream));
         QSV_HIP(h, stamp(h, b.exp_events, false));
     }
     if (h->profiling) QSV_HIP(h, hipEventRecord(b.ev1, h->stream));
-    QSV_HIP(h, hipMemcpyAsync(h->h_out, h->d_out.ptr, n_evals * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (!h->diagonal)
+        QSV_HIP(h, hipMemcpyAsync(h->h_out, h->d_out.ptr, n_evals * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     QSV_HIP(h, hipStreamSynchronize(h->stream));
     std::memcpy(out, h->h_out, n_evals * sizeof(double));
     if (h->profiling) {
@@ -626,7 +628,6 @@ int qsv_create(int n_qubits, int dtype, int device, const qsv_plan_config* cfg, 
     if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
     h->own_stream = true;
     if ((e = hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
-    if ((e = hipEventCreateWithFlags(&h->ev_layout, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
     if ((e = hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
     if (const char* env = getenv("QSV_STREAMS")) h->dual_streams = atoi(env) >= 2;
     if ((e = hipMalloc(&h->d_states.ptr, state_bytes * size_t(group))) != hipSuccess) return bail(e, "hipMalloc(states)");
@@ -644,7 +645,6 @@ void qsv_destroy(qsv_t* h) {
         (void)hipStreamSynchronize(h->stream2);
         (void)hipStreamDestroy(h->stream2);
     }
-    if (h->ev_layout) (void)hipEventDestroy(h->ev_layout);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     for (DeviceBuffer* b : {&h->d_z, &h->d_cre, &h->d_diag, &h->d_term_partials, &h->d_groups, &h->d_term_odd, &h->d_arena,
                             &h->d_states, &h->d_batch, &h->d_mats, &h->d_partials, &h->d_out, &h->d_scratch})
