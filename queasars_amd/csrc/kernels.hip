@@ -189,7 +189,7 @@ struct PassScalars {
 // Occupancy is what sets the v_fma_f64 issue rate on gfx950 (measured with scripts/ubench/valu_rate.hip:
 // 13 / 7.2 / 5.8 / 4.7 cycles per instruction at 1 / 2 / 4 / 8 waves per SIMD), so the kernel is compiled for
 // 6 waves per SIMD (<= 80 VGPRs) in mode 2: three 512-thread workgroups per CU.  Four (8 waves per SIMD, 64 VGPRs)
-// fit too since the gate loop is assembly, but measured 4% slower: more LDS contention and scalar spills.
+// fit too since the gate loop is assembly, but measured 3-4% slower (twice): fewer scalar registers, more spills.
 template <int R, int XMODE>
 struct Occupancy {
     // 2^R amplitudes = 4 * 2^R VGPRs: R = 3 fits the 80-VGPR budget of 6 waves per SIMD, R = 4 needs the 128 of 4
