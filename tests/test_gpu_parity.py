@@ -138,6 +138,23 @@ def test_results_ordered_by_input_index_and_batch_invariance():
     assert rev[::-1] == together
 
 
+def test_two_streams_and_push_plans_do_not_change_results(monkeypatch):
+    """A population goes to the device in several pushes on two HIP streams; one push on one stream must give the
+    same bits (every evaluation has its own state slot and its own partial sums)."""
+    n = 14
+    _, circuits, params = helpers.population_circuits(n, 3, 40, seed=21)
+    op = helpers.random_ising_operator(n, seed=5)
+    default = OperatorCircuitEvaluator(op).evaluate_circuits(circuits, params)
+    ref = [helpers.oracle_expectation(c, p, op) for c, p in zip(circuits[:4], params[:4])]
+    assert np.abs(np.asarray(default[:4]) - np.asarray(ref)).max() < EXP_TOL
+    monkeypatch.setenv("QSV_STREAMS", "1")
+    monkeypatch.setenv("QSV_PUSH_EVALS", "40")
+    assert OperatorCircuitEvaluator(op).evaluate_circuits(circuits, params) == default
+    monkeypatch.setenv("QSV_STREAMS", "2")
+    monkeypatch.setenv("QSV_PUSH_EVALS", "7")
+    assert OperatorCircuitEvaluator(op).evaluate_circuits(circuits, params) == default
+
+
 def test_initial_state_circuit():
     n = 5
     _, circuits, params = helpers.population_circuits(n, 2, 2, seed=13)
