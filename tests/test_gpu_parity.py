@@ -206,6 +206,29 @@ def test_round_trip_and_norm_at_full_size(n_qubits, c_oracle):
         assert np.abs(np.asarray(e1) - np.asarray(ref)).max() < EXP_TOL
 
 
+def test_states_beyond_32_bit_byte_offsets():
+    """n = 29: a state is 8 GiB, byte offsets inside it no longer fit 32 bits and the pass kernel takes its 64-bit
+    addressing path.  Checked through properties: <I> = 1, <Z_q> of a circuit followed by its inverse is 1 for
+    every q (diagonal operator, fused reduction), and a general operator on the highest qubits (pair kernels)."""
+    n = 29
+    _, circuits, params = helpers.population_circuits(n, 2, 1, seed=3)
+    c, p = circuits[0], params[0]
+    dev = StatevectorDevice(n)
+    round_trip = helpers.bound_copy(c, p).compose(helpers.inverse_circuit(c, p))
+    weights = np.linspace(0.5, 1.5, n)
+    z_sum = PauliOperator.from_sparse_list([("Z", [q], float(w)) for q, w in enumerate(weights)], n)
+    ev = OperatorCircuitEvaluator(z_sum, statevector_device=dev)
+    assert abs(ev.evaluate_circuits([round_trip], [[]])[0] - weights.sum()) < 1e-9
+    ident = PauliOperator(["I" * n], [1.0])
+    assert abs(OperatorCircuitEvaluator(ident, statevector_device=dev).evaluate_circuits([c], [p])[0] - 1.0) < 1e-11
+    # one u gate on the top qubit: <X> = sin(theta) cos(phi), <Y> = sin(theta) sin(phi), <Z> = cos(theta)
+    theta, phi = 0.7, 0.4
+    single = CircuitIR(n).u(theta, phi, 0.3, n - 1).u(0.2, 0.1, 0.0, 0)
+    xyz = PauliOperator.from_sparse_list([("X", [n - 1], 1.0), ("Y", [n - 1], 10.0), ("Z", [n - 1], 100.0)], n)
+    want = np.sin(theta) * np.cos(phi) + 10.0 * np.sin(theta) * np.sin(phi) + 100.0 * np.cos(theta)
+    assert abs(OperatorCircuitEvaluator(xyz, statevector_device=dev).evaluate_circuits([single], [[]])[0] - want) < 1e-9
+
+
 # ---- sampler branch --------------------------------------------------------------------------------------
 
 
