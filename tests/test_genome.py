@@ -168,3 +168,42 @@ class TestParameterOrder:
         ops = ind.get_parameterized_quantum_circuit().bound_ops(list(ind.parameter_values))
         # sorted names: q0_lambda, q0_phi, q0_theta, q1_lambda, ... -> (theta, phi, lam) = (12, 11, 10)
         assert ops[0][3:] == (12.0, 11.0, 10.0) and ops[1][3:] == (22.0, 21.0, 20.0)
+
+
+def test_population_wire_format_round_trip_and_key_names():
+    """Same JSON keys as the reference's encoders (evqe/serialization.py:33-66, quantum_circuit/serialization.py:29-59)."""
+    import json
+
+    from queasars_amd.evqe import serialization as ser
+
+    pop = EVQEPopulation.random_population(6, 3, 5, True, random_seed=7)
+    pop.species_representatives = [pop.individuals[0], pop.individuals[3]]
+    pop.species_members = {pop.individuals[0]: [0, 1, 2], pop.individuals[3]: [3, 4]}
+    pop.species_membership = {0: pop.individuals[0], 1: pop.individuals[0], 2: pop.individuals[0], 3: pop.individuals[3], 4: pop.individuals[3]}
+    text = ser.dumps(pop)
+    data = json.loads(text)
+    assert set(data) == {
+        "evqe_population_individuals", "evqe_population_species_representatives", "evqe_population_species_members",
+        "evqe_population_species_membership",
+    }
+    ind = data["evqe_population_individuals"][0]
+    assert set(ind) == {"evqe_individual_n_qubits", "evqe_individual_layers", "evqe_individual_parameter_values"}
+    layer = ind["evqe_individual_layers"][0]
+    assert set(layer) == {"evqe_circuit_layer_n_qubits", "evqe_circuit_layer_gates"}
+    kinds = {g["evqe_gate_type"] for i in data["evqe_population_individuals"] for l in i["evqe_individual_layers"] for g in l["evqe_circuit_layer_gates"]}
+    assert kinds <= {"identity", "rotation", "control", "controlled_rotation"} and "rotation" in kinds
+    for i in data["evqe_population_individuals"]:
+        for l in i["evqe_individual_layers"]:
+            for g in l["evqe_circuit_layer_gates"]:
+                if g["evqe_gate_type"] == "control":
+                    assert "evqe_controlled_qubit_index" in g
+                if g["evqe_gate_type"] == "controlled_rotation":
+                    assert "evqe_control_qubit_index" in g
+    back = ser.loads(text)
+    assert back.individuals == pop.individuals
+    assert back.species_representatives == pop.species_representatives
+    assert back.species_members == pop.species_members and back.species_membership == pop.species_membership
+    # a population without species bookkeeping keeps its nulls
+    plain = EVQEPopulation.random_population(4, 1, 2, False, random_seed=1)
+    assert json.loads(ser.dumps(plain))["evqe_population_species_members"] is None
+    assert ser.loads(ser.dumps(plain)).individuals == plain.individuals
