@@ -155,6 +155,20 @@ def test_two_streams_and_push_plans_do_not_change_results(monkeypatch):
     assert OperatorCircuitEvaluator(op).evaluate_circuits(circuits, params) == default
 
 
+def test_evaluator_survives_pickling():
+    """Process-based executors (the reference supports Dask workers, evqe.py:39-44) rebuild the evaluator from plain
+    data on the other side: the clone owns a new device handle and gives the same bits."""
+    import pickle
+
+    n = 9
+    _, circuits, params = helpers.population_circuits(n, 2, 3, seed=6)
+    ev = OperatorCircuitEvaluator(helpers.random_ising_operator(n, seed=2))
+    want = ev.evaluate_circuits(circuits, params)
+    clone = pickle.loads(pickle.dumps(ev))
+    moved = pickle.loads(pickle.dumps(circuits))
+    assert clone.n_qubits == n and clone.evaluate_circuits(moved, params) == want
+
+
 def test_initial_state_circuit():
     n = 5
     _, circuits, params = helpers.population_circuits(n, 2, 2, seed=13)
