@@ -403,13 +403,14 @@ int eval_begin(qsv_t* h, const std::vector<Circuit*>& circs, const std::vector<i
     }
     if ((rc = batch_layout(h, circs, n_params))) return rc;
     qsv_handle::Batch& b = h->batch;
-    // Two streams (consecutive pushes alternate between them, so that kernels of different pushes share the chip:
-    // +15 % on the benchmark population) only when every evaluation of the batch has its own state slot (no reuse to
-    // order across streams) and the expectation is fused into the last pass (no scratch shared between pushes).
+    // Two streams: consecutive pushes alternate between them, so that kernels of different pushes share the chip
+    // (+15 % on the benchmark population).  Each stream owns one half of the state slots (eval_push assigns them),
+    // so a slot is only ever reused on the stream that used it before and needs no cross-stream ordering.  Only when
+    // the expectation is fused into the last pass (no scratch shared between pushes).
     // Measured alternative: pass 0 of every push on one stream and the later passes on the other (compute-bound
     // beside memory-bound by construction) is 10 % slower: two resident kernels mostly take workgroup slots from
     // each other.
-    b.dual = h->dual_streams && h->diagonal && n_evals <= size_t(h->group) && n_evals >= 2;
+    b.dual = h->dual_streams && h->diagonal && h->group >= 2 && n_evals >= 2;
     b.used2 = false;
     b.n_pushes = 0;
     return QSV_OK;
@@ -419,16 +420,23 @@ int eval_push(qsv_t* h, size_t first, size_t count, const double* values) {
     qsv_handle::Batch& b = h->batch;
     if (first != b.pushed) return fail(h, QSV_E_STATE, "evaluations must be pushed in order");
     if (first + count > b.circs.size()) return fail(h, QSV_E_ARG, "push exceeds the batch");
-    const size_t G = size_t(h->group);
-    // state slot = evaluation index mod G (batch_layout): any run of <= G consecutive evaluations has distinct slots,
-    // and the stream orders a slot's reuse after its previous owner's last pass
+    // Launch groups: G evaluations whose states are resident together.  On one stream the slot of an evaluation is its
+    // index mod G (batch_layout) and the stream orders every reuse.  With two streams each push takes its stream's
+    // half of the slots and is cut into launch groups of G / 2.
+    size_t G = size_t(h->group);
     struct WorkGuard {
         qsv_t* h;
         ~WorkGuard() { h->work = nullptr; }
     } guard{h};
-    if (b.dual && (b.n_pushes & 1)) {
-        h->work = h->stream2;
-        b.used2 = true;
+    if (b.dual) {
+        const size_t half = G / 2, side = b.n_pushes & 1;
+        EvalDesc* hd = static_cast<EvalDesc*>(h->h_batch);  // pinned; prepare_kernel reads it after this point
+        for (size_t j = 0; j < count; ++j) hd[first + j].state_slot = uint32_t(side * half + j % half);
+        G = half;
+        if (side) {
+            h->work = h->stream2;
+            b.used2 = true;
+        }
     }
     b.n_pushes += 1;
     int rc = batch_ship(h, first, count, values);
