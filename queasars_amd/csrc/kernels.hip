@@ -176,6 +176,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // what lets hipcc prove they cannot alias the state stores and fetch plan words and matrices with SCALAR loads.
 struct PassScalars {
     uint64_t state_stride;
+    uint64_t wtab_stride;  // amplitudes per state slot in the compact-table buffer
     uint32_t pass_index;
     uint32_t mode;
     uint32_t tiles_per_block;
@@ -201,11 +202,13 @@ struct Log2Size;
 template <> struct Log2Size<float> { static constexpr int value = 2; };
 template <> struct Log2Size<double> { static constexpr int value = 3; };
 
-template <typename real, int R, int XMODE>
+// FIRST = the pass synthesises its input (pass 0 of an evaluation from |0..0>): two instantiations, so that neither
+// carries the other's load path through register allocation.
+template <typename real, int R, int XMODE, bool FIRST>
 __global__ void __launch_bounds__(512, (Occupancy<R, XMODE>::waves_per_simd))
     pass_kernel(const uint32_t* __restrict__ plan_arena, const double* __restrict__ mats_all,
-                const EvalDesc* __restrict__ evals, cx<real>* __restrict__ states, const double* __restrict__ diag,
-                double* __restrict__ partials, const PassScalars a) {
+                const EvalDesc* __restrict__ evals, cx<real>* __restrict__ states, cx<real>* __restrict__ wtabs,
+                const double* __restrict__ diag, double* __restrict__ partials, const PassScalars a) {
     using cxr = cx<real>;
     constexpr int NR = 1 << R;
     constexpr int ASH = Log2Size<real>::value + 1;         // log2 of an amplitude's bytes
@@ -226,7 +229,8 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE>::waves_per_simd))
     const uint32_t n_real = cp[1], n_qubits = cp[2];
     cu32p pp = cp + cp[kCircuitHeaderWords + a.pass_index];
     const uint32_t hdr = pp[0];
-    const int t = (hdr >> 16) & 0xff, n_rounds = hdr >> 24;
+    const int k = hdr & 0xff, t = (hdr >> 16) & 0xff, n_rounds = hdr >> 24;
+    const uint32_t pass_flags = pp[2];
     const uint32_t tid = threadIdx.x;
     const bool all_active = blockDim.x == (1u << t);
     const bool active = tid < (1u << t);
@@ -240,15 +244,23 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE>::waves_per_simd))
     cf64p mats0 = as_constant(mats_all) + ev.mat_base + size_t(pp[1]) * 8;
     cf64p vecs = as_constant(mats_all) + ev.mat_base + size_t(n_real) * 8;
 
-    const bool synth = a.pass_index == 0 && (a.mode & kModeSynthFirst);
+    constexpr bool synth = FIRST;  // the launcher picks FIRST = (pass_index == 0 && mode & kModeSynthFirst)
     const bool last = a.pass_index + 1 == n_passes;
     const bool do_store = !last || (a.mode & kModeFinalStore);
     const bool do_diag = last && (a.mode & kModeFinalDiag);
     cxr* __restrict__ st0 = states + uint64_t(ev.state_slot) * a.state_stride;
+    // the compact table of this state slot lives in its own buffer: pass 1 may already be storing the state while
+    // other workgroups of the same launch still read the table
+    cxr* __restrict__ wt0 = wtabs + uint64_t(ev.state_slot) * a.wtab_stride;
     // Global offsets inside a state are XORs of plan columns.  While a state's byte size fits 32 bits (n <= 28 in
     // fp64) they are kept as BYTE offsets in one 32-bit register per element next to a uniform tile pointer (one
     // v_xor per access, scalar-base addressing); larger states take the 64-bit path.
     const bool wide = n_qubits + uint32_t(ASH) > 32u;
+    // COMPACT (plan.hpp): pass 0 computes one tile per pattern of its outer control qubits and stores them back to
+    // back at the start of the state slot (the table W); pass 1 builds its input as W[..] * tile_factor[..].
+    const bool cstore = synth && (pass_flags & kPassCompactStore);
+    const bool cload = !FIRST && a.pass_index == 1 && (a.mode & kModeSynthFirst) && (pass_flags & kPassCompactLoad);
+    const uint32_t total_tiles = cstore ? 1u << ((pass_flags >> 8) & 0xffu) : 1u << (n_qubits - uint32_t(k));
 
     QSV_STAMP_DECL
     const uint32_t tg = xor_columns(pp + kPassLoadColsOffset, tid, wave);
@@ -263,8 +275,9 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE>::waves_per_simd))
         ttr = thread_factor[2 * tid];
         tti = thread_factor[2 * tid + 1];
     }
-    const uint32_t n_tiles = a.tiles_per_block;
-    const uint32_t tile0 = blockIdx.x * n_tiles;
+    const uint32_t tile0 = blockIdx.x * a.tiles_per_block;
+    if (tile0 >= total_tiles) return;  // a compact pass 0 has fewer tiles than the grid (uniform: before any barrier)
+    const uint32_t n_tiles = a.tiles_per_block < total_tiles - tile0 ? a.tiles_per_block : total_tiles - tile0;
     cxr amp[NR];
     double acc = 0.0;
     bool lds_dirty = false;      // LDS holds exchange data some wave may still be reading
@@ -272,17 +285,29 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE>::waves_per_simd))
 
     QSV_STAMP(0);
     for (uint32_t j = 0; j < n_tiles; ++j) {
-        const uint64_t base = tile_base(tile0 + j, pos);
+        uint64_t base;
+        if (cstore) {
+            // the tile of control pattern x: its "outer bits" are the pattern's bits at the control qubits' positions
+            uint32_t cp8[kMaxCompactBits];
+            load_words<int(kMaxCompactBits)>(pp + kPassCompactOffset, cp8);
+            base = 0;
+#pragma unroll
+            for (int b = 0; b < int(kMaxCompactBits); ++b) base |= uint64_t(((tile0 + j) >> b) & 1u) << cp8[b];
+        } else {
+            base = tile_base(tile0 + j, pos);
+        }
         // Per-element offsets do not depend on the tile, so hipcc would compute all of them once, ahead of the tile
         // loop, and keep (in fact spill) 3 * 2^R registers for them.  Recomputing them costs one v_xor per access:
         // the opaque copies below stop the hoisting.
         uint32_t tgv = tg, sgv = sg;
         asm volatile("" : "+v"(tgv), "+v"(sgv));
-        if (synth) {
+        if constexpr (synth) {
             // initial product state: amplitude(i) = prod_q v_q[bit q of i].  prepare_kernel has multiplied out the
             // factors of the qubits outside the tile (one value per tile: tile_factor) and of the tile qubits held
             // by thread bits (one value per thread: thread_factor); the register qubits are expanded here.
-            const double tfr = tile_factor[2 * size_t(tile0 + j)], tfi = tile_factor[2 * size_t(tile0 + j) + 1];
+            // (a compact pass 0 leaves the tile factor to pass 1)
+            const double tfr = cstore ? 1.0 : tile_factor[2 * size_t(tile0 + j)];
+            const double tfi = cstore ? 0.0 : tile_factor[2 * size_t(tile0 + j) + 1];
             amp[0].re = real(tfr * ttr - tfi * tti);
             amp[0].im = real(tfr * tti + tfi * ttr);
 #pragma unroll
@@ -299,27 +324,71 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE>::waves_per_simd))
                     amp[e].im = x.re * v0i + x.im * v0r;
                 }
             }
-        } else if (active) {
-            if (!wide) {
-                const unsigned char* tile = reinterpret_cast<const unsigned char*>(st0 + base);
-                uint32_t ob = tgv << ASH;
+        } else {
+            // Input of a later pass: the tile's amplitudes from the state -- or, behind a compact pass 0, the table
+            // entry W[..] (same load code, other base / thread offset / register columns) times the tile factor F[..].
+            uint32_t wbase = 0, fbase = 0;
+            if (cload) {
+                // index parts of this tile: XOR of the columns of the set bits of its tile number (scalar)
+                uint32_t wb[kMaxOuterBits], fb[kMaxOuterBits];
+                load_words<int(kMaxOuterBits)>(pp + kPassCompactWBase, wb);
+                load_words<int(kMaxOuterBits)>(pp + kPassCompactFBase, fb);
+                const uint32_t tile_number = __builtin_amdgcn_readfirstlane(tile0 + j);  // uniform: keep this scalar
 #pragma unroll
-                for (int i = 0; i < NR; ++i) {
-                    if (i) ob ^= glr[__builtin_ctz(i)] << ASH;
-                    amp[gray_index(i)] = *reinterpret_cast<const cxr*>(tile + ob);
-                }
-            } else {
-                uint32_t off = tgv;
-#pragma unroll
-                for (int i = 0; i < NR; ++i) {
-                    off = gray_step(i, off, glr);
-                    amp[gray_index(i)] = st0[base + off];
+                for (int b = 0; b < int(kMaxOuterBits); ++b) {
+                    const bool on = (tile_number >> b) & 1u;
+                    wbase ^= on ? wb[b] : 0u;
+                    fbase ^= on ? fb[b] : 0u;
                 }
             }
-            // Wait for the loads HERE, inside the branch: at the join with the synthesis path hipcc would otherwise
-            // place this wait before the first use for both paths, and on the synthesis path (pass 0, which loads
-            // nothing) it would then wait for the previous tile's STORES, which share the counter.
-            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+            if (active) {
+                if (!wide || cload) {
+                    const unsigned char* tile = reinterpret_cast<const unsigned char*>(cload ? wt0 : st0 + base);
+                    cu32p rcols = cload ? pp + kPassCompactWCols + kMaxThreadBits : glr;
+                    uint32_t ob = (cload ? wbase ^ xor_columns(pp + kPassCompactWCols, tid, wave) : tgv) << ASH;
+#pragma unroll
+                    for (int i = 0; i < NR; ++i) {
+                        if (i) ob ^= rcols[__builtin_ctz(i)] << ASH;
+                        amp[gray_index(i)] = *reinterpret_cast<const cxr*>(tile + ob);
+                    }
+                } else {
+                    uint32_t off = tgv;
+#pragma unroll
+                    for (int i = 0; i < NR; ++i) {
+                        off = gray_step(i, off, glr);
+                        amp[gray_index(i)] = st0[base + off];
+                    }
+                }
+                if (cload) {
+                    // times F: two halves (register budget), each walking its 2^(R-1) elements in Gray-code order
+                    const unsigned char* ftab = reinterpret_cast<const unsigned char*>(
+                        mats_all + ev.mat_base + size_t(n_real) * 8 + 4 * size_t(n_qubits) + kMatPadDoubles + (size_t(2) << t));
+                    cu32p frc = pp + kPassCompactFCols + kMaxThreadBits;
+                    const uint32_t fo = (fbase ^ xor_columns(pp + kPassCompactFCols, tid, wave)) << 4;
+                    constexpr int HB = NR > 1 ? NR / 2 : 1;
+#pragma unroll
+                    for (int h = 0; h < NR / HB; ++h) {
+                        uint32_t fh = h ? fo ^ (frc[R - 1] << 4) : fo;
+                        double fr[HB], fi[HB];
+#pragma unroll
+                        for (int i = 0; i < HB; ++i) {
+                            if (i) fh ^= frc[__builtin_ctz(i)] << 4;
+                            fr[gray_index(i)] = *reinterpret_cast<const double*>(ftab + fh);
+                            fi[gray_index(i)] = *reinterpret_cast<const double*>(ftab + fh + 8);
+                        }
+#pragma unroll
+                        for (int e = 0; e < HB; ++e) {
+                            const double wr = double(amp[h * HB + e].re), wi = double(amp[h * HB + e].im);
+                            amp[h * HB + e].re = real(wr * fr[e] - wi * fi[e]);
+                            amp[h * HB + e].im = real(wr * fi[e] + wi * fr[e]);
+                        }
+                    }
+                }
+                // Wait for the loads HERE, inside the branch: at the join with the synthesis path hipcc would otherwise
+                // place this wait before the first use for both paths, and on the synthesis path (pass 0, which loads
+                // nothing) it would then wait for the previous tile's STORES, which share the counter.
+                __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+            }
         }
 
         QSV_STAMP(1);
@@ -494,8 +563,8 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE>::waves_per_simd))
         }
 
         if (active && (do_store || do_diag)) {
-            if (!wide) {
-                unsigned char* tile = reinterpret_cast<unsigned char*>(st0 + base);
+            if (!wide || cstore) {
+                unsigned char* tile = reinterpret_cast<unsigned char*>(cstore ? wt0 + (uint64_t(tile0 + j) << k) : st0 + base);
                 const unsigned char* dtile = reinterpret_cast<const unsigned char*>(diag + base);
                 if (do_store) {
                     uint32_t ob = sgv << ASH;
@@ -574,17 +643,25 @@ template <typename real, int R, int XMODE>
 static hipError_t launch_pass_t(dim3 grid, int threads, size_t lds_bytes, hipStream_t stream, const PassArgs& args) {
     // the block reduction at the end needs one double per wave (and the diagnostic build a table of counters)
     const size_t lds = lds_bytes < 256 ? 256 : lds_bytes;
-    const PassScalars sc{args.state_stride, args.pass_index, args.mode, args.tiles_per_block};
+    const PassScalars sc{args.state_stride, args.wtab_stride, args.pass_index, args.mode, args.tiles_per_block};
     cx<real>* st = reinterpret_cast<cx<real>*>(args.states);
-    hipLaunchKernelGGL((pass_kernel<real, R, XMODE>), grid, dim3(threads), lds, stream, args.plan, args.mats, args.evals,
-                       st, args.diag, args.partials, sc);
+    const bool first = args.pass_index == 0 && (args.mode & kModeSynthFirst);
+    if (first)
+        hipLaunchKernelGGL((pass_kernel<real, R, XMODE, true>), grid, dim3(threads), lds, stream, args.plan, args.mats,
+                           args.evals, st, reinterpret_cast<cx<real>*>(args.wtab), args.diag, args.partials, sc);
+    else
+        hipLaunchKernelGGL((pass_kernel<real, R, XMODE, false>), grid, dim3(threads), lds, stream, args.plan, args.mats,
+                           args.evals, st, reinterpret_cast<cx<real>*>(args.wtab), args.diag, args.partials, sc);
     return hipGetLastError();
 }
 
 template <typename real, int R, int XMODE>
 static hipError_t configure_t(size_t lds_bytes) {
     const int bytes = int(lds_bytes < 256 ? 256 : lds_bytes);
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&pass_kernel<real, R, XMODE>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pass_kernel<real, R, XMODE, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&pass_kernel<real, R, XMODE, false>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
@@ -606,10 +683,15 @@ static hipError_t pass_dispatch(int op, int dtype, int r, int xmode, dim3 grid, 
     if (threads > 512) return hipErrorInvalidValue;
 #ifdef QSV_PROBE_ONLY  // scripts/isa_probe.sh: compile just the default instantiation to read its ISA quickly
     if (op) return hipSuccess;
-    const PassScalars sc{args->state_stride, args->pass_index, args->mode, args->tiles_per_block};
-    hipLaunchKernelGGL((pass_kernel<double, 3, 2>), grid, dim3(threads), lds_bytes, stream, args->plan,
-                       args->mats, args->evals, reinterpret_cast<cx<double>*>(args->states), args->diag,
-                       args->partials, sc);
+    const PassScalars sc{args->state_stride, args->wtab_stride, args->pass_index, args->mode, args->tiles_per_block};
+    if (args->pass_index == 0 && (args->mode & kModeSynthFirst))
+        hipLaunchKernelGGL((pass_kernel<double, 3, 2, true>), grid, dim3(threads), lds_bytes, stream, args->plan,
+                           args->mats, args->evals, reinterpret_cast<cx<double>*>(args->states),
+                           reinterpret_cast<cx<double>*>(args->wtab), args->diag, args->partials, sc);
+    else
+    hipLaunchKernelGGL((pass_kernel<double, 3, 2, false>), grid, dim3(threads), lds_bytes, stream, args->plan,
+                       args->mats, args->evals, reinterpret_cast<cx<double>*>(args->states),
+                       reinterpret_cast<cx<double>*>(args->wtab), args->diag, args->partials, sc);
     return hipGetLastError();
 #else
     if (dtype == 0) {

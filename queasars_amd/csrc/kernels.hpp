@@ -29,9 +29,11 @@ struct PassArgs {
     const double* mats;    // matrix regions (see EvalDesc::mat_base); 8 doubles per gate: m00 m01 m10 m11 as (re, im)
     const EvalDesc* evals; // blockIdx.y indexes this array
     void* states;          // slot s starts at s * state_stride amplitudes
+    void* wtab;            // compact tables (plan.hpp COMPACT): slot s starts at s * wtab_stride amplitudes
     const double* diag;    // D[i] for the diagonal fast path (may be null)
     double* partials;      // [out_index][gridDim.x]
     uint64_t state_stride;
+    uint64_t wtab_stride;
     uint32_t pass_index;
     uint32_t mode;
     uint32_t tiles_per_block;  // consecutive tiles each workgroup sweeps

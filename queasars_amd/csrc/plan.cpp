@@ -420,11 +420,37 @@ CircuitPlan build_plan(int n, const std::vector<GateIn>& all_gates, const std::v
     w.resize(w.size() + passes.size(), 0);
     std::vector<int> schedule;  // real-gate indices in schedule order
 
+    // ---- COMPACT first pass (plan.hpp): worthwhile when there is a second pass to read the table and the outer
+    // control patterns are far fewer than the tiles
+    int compact_bits = -1;
+    std::vector<int> compact_ctrl;  // outer qubits pass 0 uses as controls, ascending
+    if (cfg.fold && cfg.compact && passes.size() >= 2 && n > k) {
+        const PassPlan& p0 = passes[0];
+        for (const RoundPlan& rd : p0.rounds)
+            for (int gi : rd.gates) {
+                const int c = gates[size_t(gi)].control;
+                if (c >= 0 && !std::binary_search(p0.pos.begin(), p0.pos.end(), c) &&
+                    std::find(compact_ctrl.begin(), compact_ctrl.end(), c) == compact_ctrl.end())
+                    compact_ctrl.push_back(c);
+            }
+        std::sort(compact_ctrl.begin(), compact_ctrl.end());
+        if (int(compact_ctrl.size()) <= int(kMaxCompactBits) && int(compact_ctrl.size()) + 2 <= n - k &&
+            n - k <= int(kMaxOuterBits))
+            compact_bits = int(compact_ctrl.size());
+    }
+    out.stats.compact_bits = compact_bits;
+
     for (size_t pi = 0; pi < passes.size(); ++pi) {
         PassPlan& pass = passes[pi];
         w[off_table + pi] = uint32_t(w.size());
         w.push_back(uint32_t(k) | uint32_t(r) << 8 | uint32_t(t) << 16 | uint32_t(pass.rounds.size()) << 24);
         w.push_back(uint32_t(schedule.size()));
+        // COMPACT (plan.hpp): pass 0 over the patterns of its outer control qubits, pass 1 reading W x F
+        uint32_t pass_flags = 0;
+        if (compact_bits >= 0 && pi == 0) pass_flags = kPassCompactStore | uint32_t(compact_bits) << 8;
+        if (compact_bits >= 0 && pi == 1) pass_flags = kPassCompactLoad | uint32_t(compact_bits) << 8;
+        w.push_back(pass_flags);
+        w.push_back(0);
         for (uint32_t j = 0; j < kMaxTileBits; ++j) w.push_back(j < pass.pos.size() ? uint32_t(pass.pos[j]) : kPosPad);
         auto tile_bit = [&](int q) {
             auto it = std::lower_bound(pass.pos.begin(), pass.pos.end(), q);
@@ -518,7 +544,42 @@ CircuitPlan build_plan(int n, const std::vector<GateIn>& all_gates, const std::v
         };
         auto push_global_cols = [&](const Layout& l) { push_cols(l, [&](int b) { return 1u << pass.pos[b]; }); };
         push_global_cols(layouts.front());
-        push_global_cols(layouts.back());
+        const bool cstore = compact_bits >= 0 && pi == 0, cload = compact_bits >= 0 && pi == 1;
+        if (cstore)
+            push_cols(layouts.back(), [&](int b) { return 1u << b; });  // offsets inside the pattern's own tile
+        else
+            push_global_cols(layouts.back());
+        {
+            // compact block (fixed size, zero unless used)
+            const PassPlan& p0 = passes[0];
+            auto rank_in = [](const std::vector<int>& v, int q) {
+                auto it = std::lower_bound(v.begin(), v.end(), q);
+                return (it != v.end() && *it == q) ? int(it - v.begin()) : -1;
+            };
+            std::vector<int> outer0;  // pass 0's outer qubits, ascending: bit j of a pass-0 tile number
+            for (int q = 0; q < n; ++q)
+                if (rank_in(p0.pos, q) < 0) outer0.push_back(q);
+            auto wcol = [&](int q) {  // W index = control pattern * 2^k + index inside pass 0's tile
+                uint32_t c = 0;
+                if (rank_in(p0.pos, q) >= 0) c |= 1u << rank_in(p0.pos, q);
+                if (rank_in(compact_ctrl, q) >= 0) c |= 1u << (k + rank_in(compact_ctrl, q));
+                return c;
+            };
+            auto fcol = [&](int q) { return rank_in(outer0, q) >= 0 ? 1u << rank_in(outer0, q) : 0u; };
+            for (uint32_t j = 0; j < kMaxCompactBits; ++j)
+                w.push_back(cstore && j < compact_ctrl.size() ? uint32_t(compact_ctrl[j]) : 63u);
+            if (cload) {
+                push_cols(layouts.front(), [&](int b) { return wcol(pass.pos[b]); });
+                push_cols(layouts.front(), [&](int b) { return fcol(pass.pos[b]); });
+                std::vector<int> outer_here;  // this pass's outer qubits: bit j of ITS tile number
+                for (int q = 0; q < n; ++q)
+                    if (rank_in(pass.pos, q) < 0) outer_here.push_back(q);
+                for (uint32_t j = 0; j < kMaxOuterBits; ++j) w.push_back(j < outer_here.size() ? wcol(outer_here[j]) : 0u);
+                for (uint32_t j = 0; j < kMaxOuterBits; ++j) w.push_back(j < outer_here.size() ? fcol(outer_here[j]) : 0u);
+            } else {
+                for (uint32_t j = 0; j < 2 * kColumnWords + 2 * kMaxOuterBits; ++j) w.push_back(0u);
+            }
+        }
 
         for (size_t m = 0; m < pass.rounds.size(); ++m) {
             const RoundPlan& rd = pass.rounds[m];

@@ -38,6 +38,7 @@ struct PlanConfig {
     int amp_bytes = 16;  // bytes of one complex amplitude (16 = fp64, 8 = fp32)
     int xmode = 2;       // LDS exchange mode (kernels.hip): 0 whole element, 1 two resident planes, 2 one plane buffer
     bool fold = true;    // absorb leading gates into the synthesised initial product state
+    bool compact = true; // (needs fold) pass 0 computes one tile per pattern of its outer control qubits, see below
 };
 
 struct GateIn {
@@ -61,6 +62,7 @@ struct PlanStats {
     int n_rounds = 0;
     int n_exchanges = 0;
     int n_intra_wave_exchanges = 0;  // exchanges that stay inside each wave (no barrier)
+    int compact_bits = -1;           // >= 0: pass 0 is compact over this many outer control qubits
     int n_real_gates = 0;
     int n_folded_gates = 0;   // u gates absorbed into the initial product state
     int n_dropped_gates = 0;  // cu3 gates whose control is still |0>: identity
@@ -77,14 +79,29 @@ struct CircuitPlan {
 //          [4] offset of the FOLD INDEX  [5] n_fold_entries  [6..8) reserved
 //          [8 .. 8+n_passes) pass offsets
 // pass:    [0] k | r<<8 | t<<16 | n_rounds<<24      [1] index of the pass's first scheduled gate
-//          [2 .. 15)  tile bit j -> qubit position (ascending), padded to kMaxTileBits entries with kPosPad
-//          [15 .. 28) load layout:  kMaxThreadBits thread columns then kMaxRegBits register columns (global
+//          [2] flags: bit 0 COMPACT_STORE, bit 1 COMPACT_LOAD, bits 8..15 m (see COMPACT below)   [3] reserved
+//          [4 .. 17)  tile bit j -> qubit position (ascending), padded to kMaxTileBits entries with kPosPad
+//          [17 .. 30) load layout:  kMaxThreadBits thread columns then kMaxRegBits register columns (global
 //                     amplitude offsets), unused entries 0
-//          [28 .. 41) store layout, same shape
-//          [41 ..)    the rounds
+//          [30 .. 43) store layout, same shape (COMPACT_STORE: offsets inside the pattern's tile, 1 << tile bit)
+//          [43 .. 117) compact block, zero unless a flag is set:
+//                     [43 .. 51)  COMPACT_STORE: positions of the m outer control qubits (pad 63)
+//                     [51 .. 64)  COMPACT_LOAD: the load layout's columns in W-index space
+//                     [64 .. 77)  ... and in tile-factor-index space
+//                     [77 .. 97)  W-index column of tile-number bit j (the pass's outer qubits, ascending; pad 0)
+//                     [97 .. 117) tile-factor-index column of tile-number bit j
+//          [117 ..)   the rounds
 //          Every block has a FIXED size whatever k, r, t are: the kernel fetches each block with a few wide scalar
 //          loads issued together and indexes it with compile-time offsets; padded columns are 0 (XOR no-ops) and
 //          padded positions insert a zero bit above every index bit (a no-op too), so nothing is predicated.
+// COMPACT: pass 0 starts from a product state and only targets its tile qubits T; the other (outer) qubits O stay
+//          in product form and matter only as controls.  With C = the m outer qubits pass 0 uses as controls, the
+//          state after pass 0 is  psi[i] = F[o(i)] * W[x(i)][t(i)]  (o, x, t = bits of i on O, C, T): F = the product
+//          of the outer qubits' initial factors (prepare_kernel's tile-factor table), W[x] = the tile vector for
+//          control pattern x WITHOUT that factor.  A COMPACT_STORE pass 0 therefore computes 2^m tiles instead of
+//          2^(n-k) and writes them back to back at the start of the state slot (W[x][t] at x * 2^k + t); the
+//          COMPACT_LOAD pass 1 builds its input from W and F (both cache resident) instead of reading the state:
+//          no full-state write and read between the first two passes.
 // round:   [0] n_gates | has_exchange<<16 | intra_wave<<17 (the exchange moves data only inside each wave: the wave-
 //              index thread bits hold the same tile bits before and after, so the kernel skips the barriers)
 //          if has_exchange: [1 .. 14) LDS write columns (previous layout), [14 .. 27) LDS read columns (this
@@ -101,12 +118,19 @@ struct CircuitPlan {
 // FOLD INDEX: per qubit q two words {first fold entry (index into the angle table), count}: the u gates folded
 //          into qubit q's initial factor, in program order.
 constexpr uint32_t kCircuitHeaderWords = 8;
-constexpr uint32_t kPassHeaderWords = 2;
+constexpr uint32_t kPassHeaderWords = 4;
 constexpr uint32_t kMaxTileBits = 13, kMaxThreadBits = 9, kMaxRegBits = 4;
 constexpr uint32_t kColumnWords = kMaxThreadBits + kMaxRegBits;                 // one layout's columns
-constexpr uint32_t kPassLoadColsOffset = kPassHeaderWords + kMaxTileBits;       // 15
-constexpr uint32_t kPassStoreColsOffset = kPassLoadColsOffset + kColumnWords;   // 28
-constexpr uint32_t kPassRoundsOffset = kPassStoreColsOffset + kColumnWords;     // 41
+constexpr uint32_t kPassLoadColsOffset = kPassHeaderWords + kMaxTileBits;       // 17
+constexpr uint32_t kPassStoreColsOffset = kPassLoadColsOffset + kColumnWords;   // 30
+constexpr uint32_t kMaxCompactBits = 8, kMaxOuterBits = 20;
+constexpr uint32_t kPassCompactOffset = kPassStoreColsOffset + kColumnWords;    // 43: positions of the control qubits
+constexpr uint32_t kPassCompactWCols = kPassCompactOffset + kMaxCompactBits;    // 51
+constexpr uint32_t kPassCompactFCols = kPassCompactWCols + kColumnWords;        // 64
+constexpr uint32_t kPassCompactWBase = kPassCompactFCols + kColumnWords;        // 77
+constexpr uint32_t kPassCompactFBase = kPassCompactWBase + kMaxOuterBits;       // 97
+constexpr uint32_t kPassRoundsOffset = kPassCompactFBase + kMaxOuterBits;       // 117
+constexpr uint32_t kPassCompactStore = 1u, kPassCompactLoad = 2u;               // flags word
 constexpr uint32_t kExchangeWords = 2 * kColumnWords;                           // after the round's header word
 constexpr uint32_t kPosPad = 62;  // inserting a zero bit at position 62 leaves every index below 2^62 unchanged
 constexpr uint32_t kGateWords = 4;

@@ -69,6 +69,8 @@ struct qsv_handle {
     DeviceBuffer d_arena;  // plans (uint32 words)
     size_t arena_used_words = 0;
     DeviceBuffer d_states;
+    DeviceBuffer d_wtab;      // compact tables of pass 0 (plan.hpp COMPACT), one per state slot
+    uint64_t wtab_stride = 0; // amplitudes per slot
     DeviceBuffer d_batch;     // [EvalDesc x B][parameter vectors]
     DeviceBuffer d_mats;      // per evaluation: gate matrices in schedule order + product-state factors
     int tiles_per_block = 1;
@@ -174,6 +176,7 @@ PlanConfig resolve_config(const qsv_plan_config* cfg, int dtype) {
     if (const char* e = getenv("QSV_LOW_BITS")) pc.low_bits = atoi(e);
     if (const char* e = getenv("QSV_LANE_BITS")) pc.lane_bits = atoi(e);
     if (const char* e = getenv("QSV_FOLD")) pc.fold = atoi(e) != 0;
+    if (const char* e = getenv("QSV_COMPACT")) pc.compact = atoi(e) != 0;
     if (cfg) {
         if (cfg->tile_bits > 0) pc.tile_bits = cfg->tile_bits;
         if (cfg->reg_bits > 0) pc.reg_bits = cfg->reg_bits;
@@ -348,6 +351,8 @@ int run_group(qsv_t* h, const std::vector<Circuit*>& circs, size_t first, size_t
     a.mats = static_cast<const double*>(h->d_mats.ptr);
     a.evals = batch_evals(h) + first;
     a.states = h->d_states.ptr;
+    a.wtab = h->d_wtab.ptr;
+    a.wtab_stride = h->wtab_stride;
     a.diag = static_cast<const double*>(h->d_diag.ptr);
     a.partials = static_cast<double*>(h->d_partials.ptr);
     a.state_stride = uint64_t(1) << h->n;
@@ -368,6 +373,12 @@ int run_group(qsv_t* h, const std::vector<Circuit*>& circs, size_t first, size_t
         uint64_t halves = 2 * uint64_t(np);          // every pass: one read + one write ...
         if (mode & kModeSynthFirst) halves -= 1;     // ... except that a synthesising pass 0 does not read
         if (!(mode & kModeFinalStore)) halves -= 1;  // ... and the fused last pass does not write
+        const int cb = circs[first + i]->plan.stats.compact_bits;
+        if ((mode & kModeSynthFirst) && cb >= 0) {
+            // compact first pass: it writes, and pass 1 reads, the table of 2^cb tiles instead of the state
+            halves -= 2;
+            h->prof.state_bytes += 2 * ((uint64_t(1) << (cb + h->geo.k)) * h->amp_bytes);
+        }
         h->prof.state_bytes += halves * sweep;
     }
     return QSV_OK;
@@ -640,6 +651,11 @@ int qsv_create(int n_qubits, int dtype, int device, const qsv_plan_config* cfg, 
     if (const char* env = getenv("QSV_STREAMS")) h->dual_streams = atoi(env) >= 2;
     if ((e = hipMalloc(&h->d_states.ptr, state_bytes * size_t(group))) != hipSuccess) return bail(e, "hipMalloc(states)");
     h->d_states.bytes = state_bytes * size_t(group);
+    // compact tables: at most 2^kMaxCompactBits tiles per slot, never more than a state
+    h->wtab_stride = std::min<uint64_t>(uint64_t(1) << n_qubits, uint64_t(1) << (geo.k + int(kMaxCompactBits)));
+    if ((e = hipMalloc(&h->d_wtab.ptr, size_t(h->wtab_stride) * h->amp_bytes * size_t(group))) != hipSuccess)
+        return bail(e, "hipMalloc(compact tables)");
+    h->d_wtab.bytes = size_t(h->wtab_stride) * h->amp_bytes * size_t(group);
     if ((e = configure_pass_kernels(dtype, geo.r, pc.xmode, geo.lds_bytes)) != hipSuccess) return bail(e, "hipFuncSetAttribute");
     *out = h;
     return QSV_OK;
@@ -655,7 +671,7 @@ void qsv_destroy(qsv_t* h) {
     }
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     for (DeviceBuffer* b : {&h->d_z, &h->d_cre, &h->d_diag, &h->d_term_partials, &h->d_groups, &h->d_term_odd, &h->d_arena,
-                            &h->d_states, &h->d_batch, &h->d_mats, &h->d_partials, &h->d_out, &h->d_scratch})
+                            &h->d_states, &h->d_wtab, &h->d_batch, &h->d_mats, &h->d_partials, &h->d_out, &h->d_scratch})
         if (b->ptr) (void)hipFree(b->ptr);
     if (h->h_batch) (void)hipHostFree(h->h_batch);
     if (h->h_out) (void)hipHostFree(h->h_out);
@@ -1038,6 +1054,8 @@ static int bench_ops_locked(qsv_t* h, int n_ops, const qsv_op* ops, int reps, do
     a.mats = static_cast<const double*>(h->d_mats.ptr);
     a.evals = batch_evals(h);
     a.states = h->d_states.ptr;
+    a.wtab = h->d_wtab.ptr;
+    a.wtab_stride = h->wtab_stride;
     a.state_stride = uint64_t(1) << h->n;
     a.mode = kModeFinalStore;  // read-modify-write of the resident state, no synthesis
     const unsigned chunks = chunks_per_state(h);

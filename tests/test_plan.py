@@ -132,3 +132,19 @@ def test_plans_use_barrier_free_exchanges_and_keep_controls_off_the_lanes():
         gates += stats["gates"]
     assert intra > 0 and intra <= exchanges
     assert lane <= 0.15 * gates
+
+
+@pytest.mark.parametrize("n_qubits,cfg", [(14, dict(tile_bits=8, reg_bits=2, low_bits=2)), (13, dict(tile_bits=7, reg_bits=2, low_bits=2)),
+                                           (16, dict())])
+def test_compact_first_pass_reproduces_the_circuit(n_qubits, cfg):
+    """COMPACT (plan.hpp): pass 0 over the patterns of its outer control qubits, pass 1 reading W x F.  The interpreter
+    executes the encoded plan literally and cross-checks the W / F index columns against their definition."""
+    _, circuits, params = helpers.population_circuits(n_qubits, 3, 6, seed=3)
+    seen = 0
+    for c, p in zip(circuits, params):
+        words = build_plan_words(c, **cfg)
+        first = pi.decode(words)["passes"][0]["compact"]
+        seen += int(first["store"])
+        assert np.abs(pi.run(words, n_qubits, p) - helpers.oracle_state(c, p)).max() < 1e-13
+    if cfg:
+        assert seen >= 3, "small tiles leave several outer qubits: most plans should take the compact first pass"
