@@ -275,9 +275,14 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE>::waves_per_simd))
         ttr = thread_factor[2 * tid];
         tti = thread_factor[2 * tid + 1];
     }
-    const uint32_t tile0 = blockIdx.x * a.tiles_per_block;
-    if (tile0 >= total_tiles) return;  // a compact pass 0 has fewer tiles than the grid (uniform: before any barrier)
-    const uint32_t n_tiles = a.tiles_per_block < total_tiles - tile0 ? a.tiles_per_block : total_tiles - tile0;
+    // Workgroup b sweeps tiles b, b + gridDim.x, b + 2 gridDim.x, ..: neighbouring workgroups (which run at the same
+    // time) work on neighbouring tiles, and a compact pass 0 -- fewer tiles than the grid -- gives each working
+    // workgroup a single tile instead of leaving half of them idle.
+    const uint32_t tile0 = blockIdx.x, tile_step = gridDim.x;
+    if (tile0 >= total_tiles) return;  // (uniform, before any barrier)
+    const uint32_t n_tiles = (total_tiles - tile0 + tile_step - 1) / tile_step < a.tiles_per_block
+                                 ? (total_tiles - tile0 + tile_step - 1) / tile_step
+                                 : a.tiles_per_block;
     cxr amp[NR];
     double acc = 0.0;
     bool lds_dirty = false;      // LDS holds exchange data some wave may still be reading
@@ -292,9 +297,9 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE>::waves_per_simd))
             load_words<int(kMaxCompactBits)>(pp + kPassCompactOffset, cp8);
             base = 0;
 #pragma unroll
-            for (int b = 0; b < int(kMaxCompactBits); ++b) base |= uint64_t(((tile0 + j) >> b) & 1u) << cp8[b];
+            for (int b = 0; b < int(kMaxCompactBits); ++b) base |= uint64_t(((tile0 + j * tile_step) >> b) & 1u) << cp8[b];
         } else {
-            base = tile_base(tile0 + j, pos);
+            base = tile_base(tile0 + j * tile_step, pos);
         }
         // Per-element offsets do not depend on the tile, so hipcc would compute all of them once, ahead of the tile
         // loop, and keep (in fact spill) 3 * 2^R registers for them.  Recomputing them costs one v_xor per access:
@@ -306,8 +311,8 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE>::waves_per_simd))
             // factors of the qubits outside the tile (one value per tile: tile_factor) and of the tile qubits held
             // by thread bits (one value per thread: thread_factor); the register qubits are expanded here.
             // (a compact pass 0 leaves the tile factor to pass 1)
-            const double tfr = cstore ? 1.0 : tile_factor[2 * size_t(tile0 + j)];
-            const double tfi = cstore ? 0.0 : tile_factor[2 * size_t(tile0 + j) + 1];
+            const double tfr = cstore ? 1.0 : tile_factor[2 * size_t(tile0 + j * tile_step)];
+            const double tfi = cstore ? 0.0 : tile_factor[2 * size_t(tile0 + j * tile_step) + 1];
             amp[0].re = real(tfr * ttr - tfi * tti);
             amp[0].im = real(tfr * tti + tfi * ttr);
 #pragma unroll
@@ -333,7 +338,7 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE>::waves_per_simd))
                 uint32_t wb[kMaxOuterBits], fb[kMaxOuterBits];
                 load_words<int(kMaxOuterBits)>(pp + kPassCompactWBase, wb);
                 load_words<int(kMaxOuterBits)>(pp + kPassCompactFBase, fb);
-                const uint32_t tile_number = __builtin_amdgcn_readfirstlane(tile0 + j);  // uniform: keep this scalar
+                const uint32_t tile_number = __builtin_amdgcn_readfirstlane(tile0 + j * tile_step);  // uniform: keep this scalar
 #pragma unroll
                 for (int b = 0; b < int(kMaxOuterBits); ++b) {
                     const bool on = (tile_number >> b) & 1u;
@@ -564,7 +569,7 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE>::waves_per_simd))
 
         if (active && (do_store || do_diag)) {
             if (!wide || cstore) {
-                unsigned char* tile = reinterpret_cast<unsigned char*>(cstore ? wt0 + (uint64_t(tile0 + j) << k) : st0 + base);
+                unsigned char* tile = reinterpret_cast<unsigned char*>(cstore ? wt0 + (uint64_t(tile0 + j * tile_step) << k) : st0 + base);
                 const unsigned char* dtile = reinterpret_cast<const unsigned char*>(diag + base);
                 if (do_store) {
                     uint32_t ob = sgv << ASH;

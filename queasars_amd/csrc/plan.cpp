@@ -434,7 +434,7 @@ CircuitPlan build_plan(int n, const std::vector<GateIn>& all_gates, const std::v
                     compact_ctrl.push_back(c);
             }
         std::sort(compact_ctrl.begin(), compact_ctrl.end());
-        if (int(compact_ctrl.size()) <= int(kMaxCompactBits) && int(compact_ctrl.size()) + 2 <= n - k &&
+        if (int(compact_ctrl.size()) <= int(kMaxCompactBits) && int(compact_ctrl.size()) + 1 <= n - k &&
             n - k <= int(kMaxOuterBits))
             compact_bits = int(compact_ctrl.size());
     }
