@@ -114,6 +114,7 @@ class StatevectorDevice:
         self._dtype = dtype
         self._group = max(1, int(self._lib.qsv_group_size(self._handle)))
         self._push_groups = 1  # launch groups per qsv_eval_push
+        self._last_batch = None  # (identities, circuits, ids, parameter counts) of the previous expectation_values call
         self._push_evals = int(os.environ.get("QSV_PUSH_EVALS", "0"))  # measurement knob: evaluations per push
         self._push_plan = [int(x) for x in os.environ.get("QSV_PUSH_PLAN", "").split(",") if x]  # ... or explicit sizes
         self._operator: Optional[PauliOperator] = None
@@ -211,11 +212,21 @@ class StatevectorDevice:
             raise ValueError("circuits and parameter_values must have the same length")
         if n == 0:
             return np.zeros(0, dtype=np.float64)
-        ids = np.fromiter((self.circuit_id(c) for c in circuits), dtype=np.int32, count=n)
-        counts = np.fromiter((len(p) for p in parameter_values), dtype=np.int64, count=n)
-        for i, c in enumerate(circuits):
-            if counts[i] < c.num_parameters:
-                raise ValueError(f"circuit {i} needs {c.num_parameters} parameter values, got {counts[i]}")
+        # An optimiser calls with the same circuit objects over and over: their ids and parameter counts are kept from
+        # the previous call (keyed by the objects' identities; the circuits themselves are kept alive by the key's
+        # owner list, so an identity cannot be recycled while the entry exists).
+        key = tuple(map(id, circuits))
+        cached = self._last_batch
+        if cached is not None and cached[0] == key:
+            ids, need = cached[2], cached[3]
+        else:
+            ids = np.fromiter((self.circuit_id(c) for c in circuits), dtype=np.int32, count=n)
+            need = np.fromiter((c.num_parameters for c in circuits), dtype=np.int64, count=n)
+            self._last_batch = (key, list(circuits), ids, need)
+        counts = np.fromiter(map(len, parameter_values), dtype=np.int64, count=n)
+        if (counts < need).any():
+            i = int(np.argmax(counts < need))
+            raise ValueError(f"circuit {i} needs {int(need[i])} parameter values, got {int(counts[i])}")
         out = np.empty(n, dtype=np.float64)
         lib, handle = self._lib, self._handle
         self._check(lib.qsv_eval_begin(handle, n, _lib.as_ptr(ids), _lib.as_ptr(counts)))
@@ -289,11 +300,21 @@ class StatevectorDevice:
         values = np.empty((n, int(shots)), dtype=np.float64) if with_values else None
         if n == 0 or shots == 0:
             return states, values
-        ids = np.fromiter((self.circuit_id(c) for c in circuits), dtype=np.int32, count=n)
-        counts = np.fromiter((len(p) for p in parameter_values), dtype=np.int64, count=n)
-        for i, c in enumerate(circuits):
-            if counts[i] < c.num_parameters:
-                raise ValueError(f"circuit {i} needs {c.num_parameters} parameter values, got {counts[i]}")
+        # An optimiser calls with the same circuit objects over and over: their ids and parameter counts are kept from
+        # the previous call (keyed by the objects' identities; the circuits themselves are kept alive by the key's
+        # owner list, so an identity cannot be recycled while the entry exists).
+        key = tuple(map(id, circuits))
+        cached = self._last_batch
+        if cached is not None and cached[0] == key:
+            ids, need = cached[2], cached[3]
+        else:
+            ids = np.fromiter((self.circuit_id(c) for c in circuits), dtype=np.int32, count=n)
+            need = np.fromiter((c.num_parameters for c in circuits), dtype=np.int64, count=n)
+            self._last_batch = (key, list(circuits), ids, need)
+        counts = np.fromiter(map(len, parameter_values), dtype=np.int64, count=n)
+        if (counts < need).any():
+            i = int(np.argmax(counts < need))
+            raise ValueError(f"circuit {i} needs {int(need[i])} parameter values, got {int(counts[i])}")
         offsets = np.zeros(n + 1, dtype=np.int64)
         np.cumsum(counts, out=offsets[1:])
         flat = _pack_doubles(parameter_values, int(offsets[-1])) if offsets[-1] else np.zeros(1)
