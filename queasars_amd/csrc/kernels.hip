@@ -283,6 +283,12 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE>::waves_per_simd))
     const uint32_t n_tiles = (total_tiles - tile0 + tile_step - 1) / tile_step < a.tiles_per_block
                                  ? (total_tiles - tile0 + tile_step - 1) / tile_step
                                  : a.tiles_per_block;
+    // compact load: this thread's part of the W index and of the tile-factor index, the same for every tile
+    uint32_t wthr = 0, fthr = 0;
+    if (cload) {
+        wthr = xor_columns(pp + kPassCompactWCols, tid, wave);
+        fthr = xor_columns(pp + kPassCompactFCols, tid, wave);
+    }
     cxr amp[NR];
     double acc = 0.0;
     bool lds_dirty = false;      // LDS holds exchange data some wave may still be reading
@@ -350,7 +356,7 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE>::waves_per_simd))
                 if (!wide || cload) {
                     const unsigned char* tile = reinterpret_cast<const unsigned char*>(cload ? wt0 : st0 + base);
                     cu32p rcols = cload ? pp + kPassCompactWCols + kMaxThreadBits : glr;
-                    uint32_t ob = (cload ? wbase ^ xor_columns(pp + kPassCompactWCols, tid, wave) : tgv) << ASH;
+                    uint32_t ob = (cload ? wbase ^ wthr : tgv) << ASH;
 #pragma unroll
                     for (int i = 0; i < NR; ++i) {
                         if (i) ob ^= rcols[__builtin_ctz(i)] << ASH;
@@ -369,7 +375,7 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE>::waves_per_simd))
                     const unsigned char* ftab = reinterpret_cast<const unsigned char*>(
                         mats_all + ev.mat_base + size_t(n_real) * 8 + 4 * size_t(n_qubits) + kMatPadDoubles + (size_t(2) << t));
                     cu32p frc = pp + kPassCompactFCols + kMaxThreadBits;
-                    const uint32_t fo = (fbase ^ xor_columns(pp + kPassCompactFCols, tid, wave)) << 4;
+                    const uint32_t fo = (fbase ^ fthr) << 4;
                     constexpr int HB = NR > 1 ? NR / 2 : 1;
 #pragma unroll
                     for (int h = 0; h < NR / HB; ++h) {
