@@ -180,7 +180,7 @@ def main() -> None:
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "qsv::pass_kernel<double, 3, 2>",
+                "kernel": "qsv::pass_kernel<double, 3, 2, *> (both instantiations: the synthesising pass 0 and later passes)",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
@@ -195,12 +195,13 @@ def main() -> None:
                 "aggregate_achieved": prof["state_bytes"] / (prof["pass_window_ms"] * 1e-3) / 1e9
                 if prof["pass_window_ms"] > 0 else None,
                 "pass_window_ms_per_step": prof["pass_window_ms"] / args.steps,
-                "note": "achieved = state amplitudes read + written per launch (16 B each way per amplitude; pass 0 "
-                "does not read, the fused last pass does not write) / mean launch time from HIP events on the stream "
-                "each launch runs on.  The two halves of a population run on two streams, so launches overlap and "
-                "each one sees part of the chip: aggregate_achieved (all bytes of a step / wall-clock window of its "
-                "gate passes) is the chip-level rate.  At n=20 a fused pass does ~9.5 flop per byte, the fp64 ridge of "
-                "the chip: the passes are bound by fp64 issue, LDS traffic and latency as much as by HBM (DESIGN.md)",
+                "note": "achieved = state bytes read + written per pass launch / mean launch time (HIP events on the "
+                "stream each launch runs on; launches of different pushes run side by side on two streams, so "
+                "aggregate_achieved = all bytes of a step / wall-clock window of its passes is the chip-level rate).  "
+                "Bytes are what the design has to move: a compact first pass (DESIGN.md 4.1 item 1b) writes a table of "
+                "2^m tiles instead of the state and pass 1 builds its input from it, so two-pass circuits move almost no "
+                "state through HBM and the passes are bound by fp64 issue, LDS traffic and latency: the HBM fraction is "
+                "low by construction, the figure to read is circuit-evals/s",
             },
         }
         if world == 1 and not args.no_cpu_baseline:
