@@ -195,6 +195,10 @@ def main() -> None:
                 "aggregate_achieved": prof["state_bytes"] / (prof["pass_window_ms"] * 1e-3) / 1e9
                 if prof["pass_window_ms"] > 0 else None,
                 "pass_window_ms_per_step": prof["pass_window_ms"] / args.steps,
+                # SURVEY.md 8(d) prices a pass at 32 * 2^n bytes per state (read once, write once) whatever a design
+                # manages not to move: the same launches at that price, for comparison with sweep-per-gate simulators
+                "sweep_equivalent_achieved": prof["n_state_passes"] * 32.0 * (1 << N_QUBITS) / (prof["pass_ms"] * 1e-3) / 1e9
+                if prof["pass_ms"] > 0 else None,
                 "note": "achieved = state bytes read + written per pass launch / mean launch time (HIP events on the "
                 "stream each launch runs on; launches of different pushes run side by side on two streams, so "
                 "aggregate_achieved = all bytes of a step / wall-clock window of its passes is the chip-level rate).  "
