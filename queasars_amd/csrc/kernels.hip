@@ -1,15 +1,18 @@
-// HIP kernels for gfx950 (MI355X).  See plan.hpp for the pass/round/exchange model and the plan encoding.
+// HIP kernels for gfx950 (MI355X).  See plan.hpp for the pass/round/exchange model and the plan encoding,
+// DESIGN.md section 4 for measurements.
 //
-// pass_kernel: one workgroup owns one tile of 2^k amplitudes for a whole pass.
-//   HBM  -> registers : each thread loads 2^R amplitudes, 16 B (one complex double) per lane per instruction,
-//                       lanes on the lowest tile bits (>= 256 B contiguous per 16 lanes)
-//   rounds            : 2x2 butterflies between registers of one thread (v_fma_f64), gate matrices are uniform
-//                       and arrive through scalar loads
-//   exchanges         : tile transposed through LDS (ds_write_b128 / ds_read_b128) under a host-chosen XOR swizzle
-//                       that makes both sides bank-conflict free
-//   registers -> HBM  : same layout as the load; or, on the last pass of an evaluation with a diagonal operator,
+// pass_kernel: one workgroup owns one tile of 2^k amplitudes at a time for a whole pass.
+//   input             : pass 0 SYNTHESISES the initial product state from per-thread and per-tile factor tables
+//                       (prepare_kernel); a compact pass 0 does so only for one tile per pattern of its outer control
+//                       qubits.  Later passes load 2^R amplitudes per thread (16 B per lane per instruction, >= 256 B
+//                       contiguous runs) -- or, behind a compact pass 0, build them from two cache-resident tables.
+//   rounds            : 2x2 butterflies between registers of one thread; for fp64 the whole gate loop is a generated
+//                       assembly block (gate_loop_gen.inc): in-place v_fma_f64, matrices in scalar registers
+//   exchanges         : tile transposed through LDS, real plane then imaginary plane, under a host-chosen XOR swizzle
+//                       that makes both sides bank-conflict free; exchanges that stay inside a wave run barrier-free
+//   output            : same layout as the load; or, on the last pass of an evaluation with a diagonal operator,
 //                       no store at all: sum_i |a_i|^2 D[i] is reduced on chip and one double per workgroup leaves
-// No MFMA: a 2x2 gate over 32 B of traffic is 0.4 flop/B, the kernel is HBM bound by construction.
+// No MFMA: 2x2 gates; fp64 MFMA has the vector rate on this part anyway.
 #include "kernels.hpp"
 #include "plan.hpp"
 
@@ -67,13 +70,6 @@ __device__ __forceinline__ uint32_t xor_columns(cu32p cols, uint32_t tid, uint32
 #pragma unroll
     for (int u = 0; u < 6; ++u) x ^= uint32_t(int32_t(tid << (31 - u)) >> 31) & c[u];
     return x;
-}
-
-template <int R>
-__device__ __forceinline__ void register_offsets(cu32p rc, uint32_t (&ro)[1 << R]) {
-    ro[0] = 0;
-#pragma unroll
-    for (int e = 1; e < (1 << R); ++e) ro[e] = ro[e & (e - 1)] ^ rc[__builtin_ctz(e)];
 }
 
 // Visit the 2^R register indices in Gray-code order: consecutive indices differ in one bit, so the running offset
