@@ -4,7 +4,7 @@
 // pass_kernel: one workgroup owns one tile of 2^k amplitudes at a time for a whole pass.
 //   input             : pass 0 SYNTHESISES the initial product state from per-thread and per-tile factor tables
 //                       (prepare_kernel); a compact pass 0 does so only for one tile per pattern of its outer control
-//                       qubits.  Later passes load 2^R amplitudes per thread (16 B per lane per instruction, >= 256 B
+//                       qubits.  Later passes load 2^R amplitudes per thread (16 B per lane per instruction, >= 64 B
 //                       contiguous runs) -- or, behind a compact pass 0, build them from two cache-resident tables.
 //   rounds            : 2x2 butterflies between registers of one thread; for fp64 the whole gate loop is a generated
 //                       assembly block (gate_loop_gen.inc): in-place v_fma_f64, matrices in scalar registers

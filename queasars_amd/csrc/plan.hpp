@@ -31,7 +31,10 @@ namespace qsv {
 struct PlanConfig {
     int tile_bits = 12;  // k for n >= k
     int reg_bits = 3;    // r
-    int low_bits = 4;    // c: tile always contains qubits 0..c-1 (coalescing)
+    int low_bits = 2;    // c: tile always contains qubits 0..c-1, so contiguous runs in HBM are >= 16 * 2^c bytes (64 B).
+                         // Measured: single-gate sweeps stream at the same rate for c = 2, 3, 4 (5.25 TB/s at n = 26),
+                         // and every qubit not spent on c is one more NEW qubit per later pass (+9 % evals/s at n = 20,
+                         // +15 % at n = 24 for c = 2 against 4)
     int lane_bits = 2;   // of those, the lowest `lane_bits` must sit on lanes in the layouts that touch global memory
                          // (64-byte runs per 4 lanes keep full bandwidth; measured)
     int elem_bytes = 16; // bytes of one LDS access of the exchange (16: complex fp64; 8: complex fp32 or one fp64 plane)
