@@ -48,6 +48,34 @@ def test_statevector_other_geometries(cfg):
         assert np.abs(dev.statevector(c, p) - helpers.oracle_state(c, p)).max() < AMP_TOL
 
 
+@pytest.mark.parametrize(
+    "n_qubits,cfg",
+    [
+        (13, dict(tile_bits=7, reg_bits=2, low_bits=2)),
+        (14, dict(tile_bits=8, reg_bits=2, low_bits=1)),
+        (15, dict(tile_bits=9, reg_bits=3, low_bits=3)),
+        (16, dict(tile_bits=10, reg_bits=3, low_bits=2)),
+        (17, dict(tile_bits=11, reg_bits=3, low_bits=2)),
+        (18, dict(tile_bits=12, reg_bits=3, low_bits=1)),
+        (16, dict(tile_bits=8, reg_bits=2, low_bits=2, dtype="fp32")),
+    ],
+)
+def test_compact_first_pass_on_device(n_qubits, cfg):
+    """Small tiles leave many outer qubits: most of these circuits take the compact first pass (plan.hpp COMPACT) and
+    several passes; amplitudes and fused expectation values against the oracle."""
+    cfg = dict(cfg)
+    dtype = cfg.pop("dtype", "fp64")
+    _, circuits, params = helpers.population_circuits(n_qubits, 3, 5, seed=17)
+    dev = StatevectorDevice(n_qubits, dtype=dtype, **cfg)
+    tol = AMP_TOL if dtype == "fp64" else 2e-5
+    for c, p in zip(circuits, params):
+        assert np.abs(dev.statevector(c, p) - helpers.oracle_state(c, p)).max() < tol
+    op = helpers.random_ising_operator(n_qubits, seed=4)
+    got = OperatorCircuitEvaluator(op, statevector_device=dev).evaluate_circuits(circuits, params)
+    ref = [helpers.oracle_expectation(c, p, op) for c, p in zip(circuits, params)]
+    assert np.abs(np.asarray(got) - np.asarray(ref)).max() < (EXP_TOL if dtype == "fp64" else 1e-3)
+
+
 def test_config1_plumbing_general_paulis():
     """BASELINE config 1: n=8, P=4, L=2, 20 random Pauli strings."""
     n = 8
