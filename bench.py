@@ -126,7 +126,7 @@ def main() -> None:
         step()
     # ---- timed region: exactly K steps -------------------------------------------------------------------
     device.set_profiling(True)  # HIP events on the library's stream around every group of pass launches
-    prof = {"pass_ms": 0.0, "pass_window_ms": 0.0, "n_pass_launches": 0, "state_bytes": 0, "n_state_passes": 0,
+    prof = {"pass_ms": 0.0, "pass_window_ms": 0.0, "n_pass_launches": 0, "state_bytes": 0, "moved_bytes": 0, "n_state_passes": 0,
             "expect_ms": 0.0, "n_gates": 0}
     fence()
     t0 = time.perf_counter()
@@ -190,22 +190,23 @@ def main() -> None:
                 "avg_launch_ms": avg_launch_ms,
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "gates_per_s": prof["n_gates"] / (prof["pass_window_ms"] * 1e-3) if prof["pass_window_ms"] > 0 else None,
-                # the two halves of a population run on two HIP streams, so launches overlap: the aggregate rate over
-                # the wall-clock window of all gate passes of a step is the figure that is comparable across designs
+                # launches of different pushes overlap on two HIP streams: the same bytes over the wall-clock window
+                # of a step's passes is the chip-level rate
                 "aggregate_achieved": prof["state_bytes"] / (prof["pass_window_ms"] * 1e-3) / 1e9
                 if prof["pass_window_ms"] > 0 else None,
                 "pass_window_ms_per_step": prof["pass_window_ms"] / args.steps,
-                # SURVEY.md 8(d) prices a pass at 32 * 2^n bytes per state (read once, write once) whatever a design
-                # manages not to move: the same launches at that price, for comparison with sweep-per-gate simulators
+                # state bytes the launches really moved (a compact first pass replaces the state round trip between
+                # the first two passes by a small table) and, for comparison with sweep-per-gate simulators, the same
+                # launches at SURVEY.md 8(d)'s flat price of 32 * 2^n bytes per state and pass
+                "moved_bytes_per_launch": prof["moved_bytes"] / launches,
                 "sweep_equivalent_achieved": prof["n_state_passes"] * 32.0 * (1 << N_QUBITS) / (prof["pass_ms"] * 1e-3) / 1e9
                 if prof["pass_ms"] > 0 else None,
-                "note": "achieved = state bytes read + written per pass launch / mean launch time (HIP events on the "
-                "stream each launch runs on; launches of different pushes run side by side on two streams, so "
-                "aggregate_achieved = all bytes of a step / wall-clock window of its passes is the chip-level rate).  "
-                "Bytes are what the design has to move: a compact first pass (DESIGN.md 4.1 item 1b) writes a table of "
-                "2^m tiles instead of the state and pass 1 builds its input from it, so two-pass circuits move almost no "
-                "state through HBM and the passes are bound by fp64 issue, LDS traffic and latency: the HBM fraction is "
-                "low by construction, the figure to read is circuit-evals/s",
+                "note": "achieved = algorithmic state bytes per pass launch / mean launch time (HIP events on the stream "
+                "each launch runs on).  Algorithmic bytes: 16 * 2^n per state and direction a fused-pass design has to "
+                "move (SURVEY 8(d): 32 * 2^n per full pass; pass 0 synthesises and only writes, the last pass fuses the "
+                "expectation and only reads).  The compact first pass (DESIGN.md 4.1 item 1b) then avoids most of that "
+                "traffic (moved_bytes_per_launch, and `traffic` from the PMC counters), so the passes are bound by fp64 "
+                "issue, LDS traffic and latency rather than by HBM",
             },
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -72,12 +72,15 @@ typedef struct qsv_profile {
     uint64_t n_pass_launches;  /* launches of the gate-pass kernel */
     uint64_t n_state_passes;   /* sum over launches of states swept (launch x circuits in its group) */
     uint64_t n_gates;          /* non-identity gates applied */
-    uint64_t state_bytes;      /* bytes of state amplitudes the gate-pass launches read + wrote */
+    uint64_t state_bytes;      /* algorithmic state bytes of the gate-pass launches: 16 * 2^n per state and direction a
+                                  fused pass design has to move (pass 0 only writes, a fused last pass only reads) */
     double pass_ms;            /* device time of the gate-pass launches, summed over pushes (HIP events on the stream
                                   each push runs on; pushes on the two streams overlap, so this can exceed wall time) */
     double expect_ms;          /* device time of expectation / reduction kernels */
     double total_ms;           /* device time of the whole call, first launch to last */
     double pass_window_ms;     /* wall-clock window from the first gate-pass launch to the end of the last one */
+    uint64_t moved_bytes;      /* state bytes the launches really moved: less than state_bytes when a compact first pass
+                                  replaced the state round trip between the first two passes by a small table */
 } qsv_profile;
 
 /* ---- lifetime ---------------------------------------------------------------------------------- */

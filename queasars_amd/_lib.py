@@ -51,6 +51,7 @@ class QsvProfile(C.Structure):
         ("expect_ms", C.c_double),
         ("total_ms", C.c_double),
         ("pass_window_ms", C.c_double),
+        ("moved_bytes", C.c_uint64),
     ]
 
 

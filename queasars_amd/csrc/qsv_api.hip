@@ -373,13 +373,13 @@ int run_group(qsv_t* h, const std::vector<Circuit*>& circs, size_t first, size_t
         uint64_t halves = 2 * uint64_t(np);          // every pass: one read + one write ...
         if (mode & kModeSynthFirst) halves -= 1;     // ... except that a synthesising pass 0 does not read
         if (!(mode & kModeFinalStore)) halves -= 1;  // ... and the fused last pass does not write
-        const int cb = circs[first + i]->plan.stats.compact_bits;
-        if ((mode & kModeSynthFirst) && cb >= 0) {
-            // compact first pass: it writes, and pass 1 reads, the table of 2^cb tiles instead of the state
-            halves -= 2;
-            h->prof.state_bytes += 2 * ((uint64_t(1) << (cb + h->geo.k)) * h->amp_bytes);
-        }
         h->prof.state_bytes += halves * sweep;
+        // what the launches really move: a compact first pass writes, and pass 1 reads, a table of 2^cb tiles
+        const int cb = circs[first + i]->plan.stats.compact_bits;
+        if ((mode & kModeSynthFirst) && cb >= 0)
+            h->prof.moved_bytes += (halves - 2) * sweep + 2 * ((uint64_t(1) << (cb + h->geo.k)) * h->amp_bytes);
+        else
+            h->prof.moved_bytes += halves * sweep;
     }
     return QSV_OK;
 }
