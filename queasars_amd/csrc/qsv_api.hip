@@ -439,15 +439,19 @@ int eval_push(qsv_t* h, size_t first, size_t count, const double* values) {
         qsv_t* h;
         ~WorkGuard() { h->work = nullptr; }
     } guard{h};
+    EvalDesc* hd = static_cast<EvalDesc*>(h->h_batch);  // pinned; prepare_kernel reads it after this point
     if (b.dual) {
         const size_t half = G / 2, side = b.n_pushes & 1;
-        EvalDesc* hd = static_cast<EvalDesc*>(h->h_batch);  // pinned; prepare_kernel reads it after this point
         for (size_t j = 0; j < count; ++j) hd[first + j].state_slot = uint32_t(side * half + j % half);
         G = half;
         if (side) {
             h->work = h->stream2;
             b.used2 = true;
         }
+    } else {
+        // every launch group of this push occupies slots 0 .. count-1 in order (the expectation kernels of the
+        // general-operator path index states by position in the group), wherever the push starts in the batch
+        for (size_t j = 0; j < count; ++j) hd[first + j].state_slot = uint32_t(j % G);
     }
     b.n_pushes += 1;
     int rc = batch_ship(h, first, count, values);

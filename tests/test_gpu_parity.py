@@ -107,6 +107,17 @@ def test_general_expectation_matches_oracle(n_qubits):
     assert np.abs(np.asarray(got) - np.asarray(ref)).max() < EXP_TOL
 
 
+def test_general_operator_population_in_several_pushes():
+    """A population of 40 goes to the device in three pushes; with X / Y terms the expectation kernels run per launch
+    group and must find each group's states where the passes left them."""
+    n = 10
+    _, circuits, params = helpers.population_circuits(n, 2, 40, seed=9)
+    op = helpers.random_pauli_operator(n, 12, seed=31)
+    got = OperatorCircuitEvaluator(op).evaluate_circuits(circuits, params)
+    ref = [helpers.oracle_expectation(c, p, op) for c, p in zip(circuits, params)]
+    assert np.abs(np.asarray(got) - np.asarray(ref)).max() < EXP_TOL
+
+
 def test_zero_angles_known_answer():
     """u(0,0,0) = cu3(0,0,0) = I: the state stays |0..0>, <H> = sum of the I/Z-only coefficients."""
     n = 6
