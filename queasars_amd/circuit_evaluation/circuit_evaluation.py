@@ -215,14 +215,14 @@ class StatevectorDevice:
         # An optimiser calls with the same circuit objects over and over: their ids and parameter counts are kept from
         # the previous call (keyed by the objects' identities; the circuits themselves are kept alive by the key's
         # owner list, so an identity cannot be recycled while the entry exists).
-        key = tuple(map(id, circuits))
+        key = (CircuitIR.edits_of_registered, *map(id, circuits))
         cached = self._last_batch
         if cached is not None and cached[0] == key:
             ids, need = cached[2], cached[3]
         else:
             ids = np.fromiter((self.circuit_id(c) for c in circuits), dtype=np.int32, count=n)
             need = np.fromiter((c.num_parameters for c in circuits), dtype=np.int64, count=n)
-            self._last_batch = (key, list(circuits), ids, need)
+            self._last_batch = ((CircuitIR.edits_of_registered, *map(id, circuits)), list(circuits), ids, need)
         counts = np.fromiter(map(len, parameter_values), dtype=np.int64, count=n)
         if (counts < need).any():
             i = int(np.argmax(counts < need))
@@ -303,14 +303,14 @@ class StatevectorDevice:
         # An optimiser calls with the same circuit objects over and over: their ids and parameter counts are kept from
         # the previous call (keyed by the objects' identities; the circuits themselves are kept alive by the key's
         # owner list, so an identity cannot be recycled while the entry exists).
-        key = tuple(map(id, circuits))
+        key = (CircuitIR.edits_of_registered, *map(id, circuits))
         cached = self._last_batch
         if cached is not None and cached[0] == key:
             ids, need = cached[2], cached[3]
         else:
             ids = np.fromiter((self.circuit_id(c) for c in circuits), dtype=np.int32, count=n)
             need = np.fromiter((c.num_parameters for c in circuits), dtype=np.int64, count=n)
-            self._last_batch = (key, list(circuits), ids, need)
+            self._last_batch = ((CircuitIR.edits_of_registered, *map(id, circuits)), list(circuits), ids, need)
         counts = np.fromiter(map(len, parameter_values), dtype=np.int64, count=n)
         if (counts < need).any():
             i = int(np.argmax(counts < need))

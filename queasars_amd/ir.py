@@ -63,6 +63,8 @@ class CircuitIR:
     ``QuantumCircuit.u(theta, phi, lam, qubit)`` and ``CU3Gate(theta, phi, lam)`` on ``(control, target)``).
     """
 
+    edits_of_registered = 0  # counts edits of circuits some device had registered (see _append)
+
     def __init__(self, n_qubits: int):
         if not 1 <= int(n_qubits) <= 34:
             raise ValueError("n_qubits must be in [1, 34]")
@@ -92,7 +94,11 @@ class CircuitIR:
         (it, vt), (ip, vp), (il, vl) = self._angle(theta), self._angle(phi), self._angle(lam)
         self._rows.append((kind, target, control, 0, it, ip, il, vt, vp, vl))
         self._packed = None
-        self._registered = {}
+        if self._registered:
+            # a circuit that a device already knows is being edited: devices must register it again, and any batch
+            # metadata they cached by object identity is void
+            CircuitIR.edits_of_registered += 1
+            self._registered = {}
         return self
 
     def id(self, qubit: int) -> "CircuitIR":

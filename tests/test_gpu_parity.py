@@ -118,6 +118,21 @@ def test_general_operator_population_in_several_pushes():
     assert np.abs(np.asarray(got) - np.asarray(ref)).max() < EXP_TOL
 
 
+def test_editing_a_circuit_after_evaluation_is_noticed():
+    """Batch metadata is cached by object identity between calls; editing a circuit in place must void it."""
+    n = 6
+    op = helpers.random_ising_operator(n, seed=1)
+    ev = OperatorCircuitEvaluator(op)
+    c = CircuitIR(n).u(0.3, 0.1, 0.2, 0).cu3(0.5, 0.2, 0.1, 0, 3)
+    circuits = [c, CircuitIR(n).u(1.1, 0.0, 0.0, 2)]
+    first = ev.evaluate_circuits(circuits, [[], []])
+    assert abs(first[0] - helpers.oracle_expectation(c, [], op)) < EXP_TOL
+    c.u(0.9, 0.4, 0.0, 5)  # same object, one more gate
+    second = ev.evaluate_circuits(circuits, [[], []])
+    assert abs(second[0] - helpers.oracle_expectation(c, [], op)) < EXP_TOL and second[0] != first[0]
+    assert second[1] == first[1]
+
+
 def test_zero_angles_known_answer():
     """u(0,0,0) = cu3(0,0,0) = I: the state stays |0..0>, <H> = sum of the I/Z-only coefficients."""
     n = 6
