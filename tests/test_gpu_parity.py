@@ -133,6 +133,21 @@ def test_editing_a_circuit_after_evaluation_is_noticed():
     assert second[1] == first[1]
 
 
+def test_concurrent_callers_share_one_evaluator():
+    """The reference calls evaluate_circuits from up to population_size threads at once (evqe.py:232-236,
+    selection.py:75-85, one circuit per call): calls on one handle are serialised and every caller gets its own result."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    n = 11
+    _, circuits, params = helpers.population_circuits(n, 2, 16, seed=12)
+    ev = OperatorCircuitEvaluator(helpers.random_ising_operator(n, seed=6))
+    serial = [ev.evaluate_circuits([c], [p])[0] for c, p in zip(circuits, params)]
+    with ThreadPoolExecutor(max_workers=16) as pool:
+        for _ in range(3):
+            futures = [pool.submit(ev.evaluate_circuits, [c], [p]) for c, p in zip(circuits, params)]
+            assert [f.result()[0] for f in futures] == serial
+
+
 def test_zero_angles_known_answer():
     """u(0,0,0) = cu3(0,0,0) = I: the state stays |0..0>, <H> = sum of the I/Z-only coefficients."""
     n = 6
