@@ -104,3 +104,57 @@ class TestSamplerPostProcessing:
         dist = {0b001: 0.5, 0b110: 0.5}
         assert get_expectation_with_bitstring_evaluator(dist, ev, 1.0) == 0.5 * 1 + 0.5 * 6
         assert get_expectation_with_bitstring_evaluator(dist, ev, 0.5) == 1.0
+
+
+class TestCoalescing:
+    """queasars_amd.circuit_evaluation.coalescing: concurrent one-circuit calls are answered from merged batches."""
+
+    class _Fake:
+        n_qubits = 3
+
+        def __init__(self, fail_on=None):
+            self.calls = []
+            self.fail_on = fail_on
+
+        def evaluate_circuits(self, circuits, parameter_values):
+            import time as _t
+
+            self.calls.append(len(circuits))
+            _t.sleep(0.002)  # callers pile up meanwhile
+            if self.fail_on is not None and self.fail_on in circuits:
+                raise RuntimeError("boom")
+            return [float(c) + sum(p) for c, p in zip(circuits, parameter_values)]
+
+    def test_merges_concurrent_calls_and_keeps_every_callers_order(self):
+        from concurrent.futures import ThreadPoolExecutor
+
+        from queasars_amd.circuit_evaluation import CoalescingCircuitEvaluator
+
+        fake = self._Fake()
+        ev = CoalescingCircuitEvaluator(fake, window_s=1e-3)
+        assert ev.n_qubits == 3
+        jobs = [([10 * i, 10 * i + 1], [[0.5], [0.25, 0.25]]) for i in range(24)]
+        with ThreadPoolExecutor(max_workers=24) as pool:
+            got = list(pool.map(lambda j: ev.evaluate_circuits(*j), jobs))
+        assert got == [[10 * i + 0.5, 10 * i + 1 + 0.5] for i in range(24)]
+        assert sum(fake.calls) == 48 and len(fake.calls) < 24 and ev.n_batches == len(fake.calls)
+        assert ev.evaluate_circuits([], []) == []
+        assert ev.evaluate_circuits([7], [[1.0]]) == [8.0]  # a lone caller is its own leader
+
+    def test_failure_reaches_every_caller_of_the_batch_and_the_evaluator_recovers(self):
+        from concurrent.futures import ThreadPoolExecutor
+
+        import pytest as _pytest
+
+        from queasars_amd.circuit_evaluation import CoalescingCircuitEvaluator
+
+        fake = self._Fake(fail_on=13)
+        ev = CoalescingCircuitEvaluator(fake, window_s=2e-3)
+        with ThreadPoolExecutor(max_workers=4) as pool:
+            futures = [pool.submit(ev.evaluate_circuits, [c], [[0.0]]) for c in (11, 12, 13, 14)]
+            errors = [f.exception() for f in futures]
+        assert any(isinstance(e, RuntimeError) for e in errors)
+        fake.fail_on = None
+        assert ev.evaluate_circuits([5], [[0.5]]) == [5.5]
+        with _pytest.raises(ValueError):
+            ev.evaluate_circuits([1], [])
