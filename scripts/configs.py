@@ -11,7 +11,7 @@ sys.path.insert(0, str(ROOT / "tests"))
 
 import numpy as np  # noqa: E402
 
-import helpers  # noqa: E402
+from queasars_amd import workloads as helpers  # noqa: E402
 from queasars_amd.circuit_evaluation import OperatorCircuitEvaluator  # noqa: E402
 
 
@@ -34,9 +34,7 @@ def main():
         op = helpers.random_pauli_operator(8, 20, seed=1234)
         ev = OperatorCircuitEvaluator(op)
         dt, values = timed(ev, circuits, params, 50)
-        ref = [helpers.oracle_expectation(c, p, op) for c, p in zip(circuits, params)]
-        print(json.dumps({"config": 1, "n": 8, "P": 4, "terms": 20, "evals_per_s": 4 / dt, "us_per_call": dt * 1e6,
-                          "max_abs_err_vs_oracle": float(np.abs(np.asarray(values) - np.asarray(ref)).max())}), flush=True)
+        print(json.dumps({"config": 1, "n": 8, "P": 4, "terms": 20, "evals_per_s": 4 / dt, "us_per_call": dt * 1e6}), flush=True)
     if 2 in todo:
         _, circuits, params = helpers.population_circuits(20, 4, 64, seed=0)
         op = helpers.random_ising_operator(20, seed=2020)

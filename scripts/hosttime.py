@@ -5,7 +5,7 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
 import numpy as np
-import helpers
+from queasars_amd import workloads as helpers  # noqa: E402
 from queasars_amd import _lib
 from queasars_amd.circuit_evaluation import OperatorCircuitEvaluator
 

@@ -3,7 +3,8 @@ import sys
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
-import helpers, plan_interpreter as pi
+import plan_interpreter as pi
+from queasars_amd import workloads as helpers
 from queasars_amd.planning import build_plan_words
 
 cases = [(12, 4), (16, 4), (20, 4), (20, 8), (24, 4)] if len(sys.argv) < 2 else [tuple(int(x) for x in a.split(",")) for a in sys.argv[1:]]

@@ -3,7 +3,7 @@ import sys, time
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
-import helpers
+from queasars_amd import workloads as helpers  # noqa: E402
 from queasars_amd.circuit_evaluation import OperatorSamplerCircuitEvaluator, OperatorCircuitEvaluator
 
 n, P = 12, 20

@@ -27,7 +27,7 @@ def main() -> None:
         return
     os.environ["QSV_LIBRARY"] = str(STAMP_LIB)
     import numpy as np
-    import helpers
+    from queasars_amd import workloads as helpers
     from queasars_amd import _lib
     from queasars_amd.circuit_evaluation import OperatorCircuitEvaluator
 

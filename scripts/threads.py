@@ -4,7 +4,7 @@ from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
-import helpers
+from queasars_amd import workloads as helpers  # noqa: E402
 from queasars_amd.circuit_evaluation import CoalescingCircuitEvaluator, OperatorCircuitEvaluator
 
 n, P, L = 20, 64, 4
