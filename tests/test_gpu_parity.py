@@ -260,6 +260,22 @@ def test_fp32_state_close_to_fp64():
         assert np.abs(dev.statevector(c, p) - helpers.oracle_state(c, p)).max() < 2e-5
 
 
+def test_random_populations_against_the_c_oracle(c_oracle):
+    """A sweep over sizes, depths and seeds (default geometry: compact first pass whenever n > 13), expectation values
+    against the plain-C oracle."""
+    rng = np.random.default_rng(77)
+    worst = 0.0
+    for trial in range(24):
+        n = int(rng.integers(8, 20))
+        layers = int(rng.integers(1, 7))
+        _, circuits, params = helpers.population_circuits(n, layers, 3, seed=int(rng.integers(0, 10**6)))
+        op = helpers.random_ising_operator(n, seed=trial)
+        got = OperatorCircuitEvaluator(op).evaluate_circuits(circuits, params)
+        ref = [c_oracle.evaluate(c, p, op) for c, p in zip(circuits, params)]
+        worst = max(worst, float(np.abs(np.asarray(got) - np.asarray(ref)).max()))
+    assert worst < EXP_TOL
+
+
 # ---- size-independent properties at the benchmark sizes --------------------------------------------------
 
 
