@@ -614,18 +614,12 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE>::waves_per_simd))
     }
 
     if (do_diag) {
+        // one partial sum per WAVE leaves the kernel (fixed shuffle tree, no LDS, no barrier); reduce_partials_kernel
+        // adds them in a fixed order
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
-        double* red = reinterpret_cast<double*>(lds_raw);
-        if (lds_dirty) lds_barrier();
-        if ((tid & 63u) == 0) red[tid >> 6] = acc;
-        lds_barrier();
-        if (tid == 0) {
-            double total = 0.0;
-            const int n_waves = (blockDim.x + 63) >> 6;
-            for (int w = 0; w < n_waves; ++w) total += red[w];
-            partials[size_t(ev.out_index) * gridDim.x + blockIdx.x] = total;
-        }
+        const uint32_t n_waves = blockDim.x >> 6;
+        if ((tid & 63u) == 0) partials[(size_t(ev.out_index) * gridDim.x + blockIdx.x) * n_waves + wave] = acc;
     }
 #ifdef QSV_STAMPS
     QSV_STAMP(12);

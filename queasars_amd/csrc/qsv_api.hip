@@ -342,6 +342,9 @@ unsigned chunks_per_state(const qsv_t* h) {
     return h->geo.blocks_per_state / tpb;
 }
 
+// partial sums the fused last pass leaves per state: one per wave of every workgroup
+unsigned partials_per_state(const qsv_t* h) { return chunks_per_state(h) * unsigned(h->geo.threads_launch / 64); }
+
 // Run the gate passes of evaluations [first, first+count) of the current batch (one launch group).
 int run_group(qsv_t* h, const std::vector<Circuit*>& circs, size_t first, size_t count, uint32_t mode) {
     int max_passes = 0;
@@ -404,7 +407,7 @@ int eval_begin(qsv_t* h, const std::vector<Circuit*>& circs, const std::vector<i
     h->prof.n_evals = uint64_t(circs.size());
     int rc;
     const size_t n_evals = circs.size();
-    if ((rc = ensure(h, h->d_partials, std::max<size_t>(1, n_evals) * chunks_per_state(h) * sizeof(double)))) return rc;
+    if ((rc = ensure(h, h->d_partials, std::max<size_t>(1, n_evals) * partials_per_state(h) * sizeof(double)))) return rc;
     if ((rc = ensure(h, h->d_out, std::max<size_t>(1, n_evals) * sizeof(double)))) return rc;
     if ((rc = ensure_host_out(h, std::max<size_t>(1, n_evals)))) return rc;
     if (h->profiling) {
@@ -475,7 +478,7 @@ int eval_push(qsv_t* h, size_t first, size_t count, const double* values) {
             QSV_HIP(h, launch_pauli_combine(static_cast<const double*>(h->d_term_partials.ptr),
                                             uint32_t(h->n_groups) * uint32_t(h->pauli_nb),
                                             h->has_diag_part ? static_cast<const double*>(h->d_partials.ptr) : nullptr,
-                                            chunks_per_state(h), int(gc), batch_evals(h) + g0,
+                                            partials_per_state(h), int(gc), batch_evals(h) + g0,
                                             static_cast<double*>(h->d_out.ptr), h->stream));
             QSV_HIP(h, stamp(h, b.exp_events, false));
         }
@@ -497,7 +500,7 @@ int eval_end(qsv_t* h, double* out) {
     if (h->diagonal) {
         QSV_HIP(h, stamp(h, b.exp_events, true));
         // the reduction writes its n_evals doubles straight into the pinned result buffer: no D2H copy to wait for
-        QSV_HIP(h, launch_reduce_partials(static_cast<const double*>(h->d_partials.ptr), chunks_per_state(h),
+        QSV_HIP(h, launch_reduce_partials(static_cast<const double*>(h->d_partials.ptr), partials_per_state(h),
                                           int(n_evals), h->h_out, h->stream));
         QSV_HIP(h, stamp(h, b.exp_events, false));
     }
@@ -579,7 +582,7 @@ int run_single_to_state(qsv_t* h, int circuit_id, const double* params, int n_pa
     h->prof = qsv_profile{};
     int rc = batch_layout(h, cc, std::vector<int64_t>{int64_t(n_params)});
     if (!rc) rc = batch_ship(h, 0, 1, params);
-    if (!rc) rc = ensure(h, h->d_partials, size_t(chunks_per_state(h)) * sizeof(double));
+    if (!rc) rc = ensure(h, h->d_partials, size_t(partials_per_state(h)) * sizeof(double));
     if (!rc) rc = run_group(h, cc, 0, 1, kModeSynthFirst | kModeFinalStore);
     h->batch.circs.clear();
     return rc;
@@ -968,7 +971,7 @@ static int sample_batch_locked(qsv_t* h, const std::vector<Circuit*>& circs, con
     const size_t states_off = ((probs_bytes + sums_bytes + 63) / 64) * 64;
     const size_t values_off = states_off + n_evals * size_t(shots) * 8;
     if ((rc = ensure(h, h->d_scratch, values_off + (out_values ? n_evals * size_t(shots) * 8 : 0)))) return rc;
-    if ((rc = ensure(h, h->d_partials, std::max<size_t>(1, n_evals) * chunks_per_state(h) * sizeof(double)))) return rc;
+    if ((rc = ensure(h, h->d_partials, std::max<size_t>(1, n_evals) * partials_per_state(h) * sizeof(double)))) return rc;
     double* probs = static_cast<double*>(h->d_scratch.ptr);
     double* sums = probs + G * dim;
     uint64_t* d_states = reinterpret_cast<uint64_t*>(static_cast<char*>(h->d_scratch.ptr) + states_off);
