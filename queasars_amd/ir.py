@@ -113,6 +113,17 @@ class CircuitIR:
             raise ValueError("control and target must differ")
         return self._append(OP_CU3, t, c, theta, phi, lam)
 
+    def declare_parameters(self, n_parameters: int) -> "CircuitIR":
+        """State that an evaluation is called with at least ``n_parameters`` values even if the highest-indexed ones are
+        not used by any gate (a Qiskit circuit's ``parameters`` may hold such entries)."""
+        if n_parameters > self._n_parameters:
+            self._n_parameters = int(n_parameters)
+            if self._registered:
+                CircuitIR.edits_of_registered += 1
+                self._registered = {}
+            self._packed = None
+        return self
+
     def compose(self, other: "CircuitIR") -> "CircuitIR":
         """New circuit: ``self`` followed by ``other`` (parameter indices of both are kept as they are)."""
         if other.n_qubits != self.n_qubits:

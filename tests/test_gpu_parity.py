@@ -148,6 +148,32 @@ def test_concurrent_callers_share_one_evaluator():
             assert [f.result()[0] for f in futures] == serial
 
 
+def test_primitive_shaped_front_ends():
+    """queasars_amd.primitives: the two call shapes the reference's evaluators use on Qiskit primitives
+    (circuit_evaluation.py:204-215, :50-59), here with CircuitIR pubs."""
+    from queasars_amd.primitives import GpuEstimator, GpuSampler
+
+    n = 9
+    _, circuits, params = helpers.population_circuits(n, 2, 5, seed=3)
+    op_a, op_b = helpers.random_ising_operator(n, seed=1), helpers.random_pauli_operator(n, 6, seed=2)
+    pubs = [(c, op_a if i % 2 == 0 else op_b, p) for i, (c, p) in enumerate(zip(circuits, params))]
+    results = GpuEstimator().run(pubs=pubs, precision=0.0).result()
+    got = [float(np.real(r.data.evs)) for r in results]
+    ref = [helpers.oracle_expectation(c, p, op) for c, op, p in pubs]
+    assert np.abs(np.asarray(got) - np.asarray(ref)).max() < EXP_TOL
+    noisy = [float(r.data.evs) for r in GpuEstimator(seed=5).run(pubs=pubs, precision=0.05).result()]
+    assert 0 < np.abs(np.asarray(noisy) - np.asarray(ref)).max() < 0.5
+    # sampler: a basis state is measured with certainty; bitstrings have the highest qubit leftmost
+    flip = CircuitIR(n).u(np.pi, 0.0, np.pi, 2).u(np.pi, 0.0, np.pi, 7)
+    counts = GpuSampler(n, seed=3).run(pubs=[(flip, [])], shots=200).result()[0].data["meas"].get_counts()
+    assert counts == {format((1 << 2) | (1 << 7), f"0{n}b"): 200}
+    shots = 4000
+    res = GpuSampler(n, seed=9).run(pubs=[(circuits[0], params[0])], shots=shots).result()[0].data["meas"].get_int_counts()
+    probs = np.abs(helpers.oracle_state(circuits[0], params[0])) ** 2
+    top = int(np.argmax(probs))
+    assert abs(res.get(top, 0) / shots - probs[top]) < 6 * np.sqrt(probs[top] * (1 - probs[top]) / shots) + 2 / shots
+
+
 def test_zero_angles_known_answer():
     """u(0,0,0) = cu3(0,0,0) = I: the state stays |0..0>, <H> = sum of the I/Z-only coefficients."""
     n = 6

@@ -158,3 +158,79 @@ class TestCoalescing:
         assert ev.evaluate_circuits([5], [[0.5]]) == [5.5]
         with _pytest.raises(ValueError):
             ev.evaluate_circuits([1], [])
+
+
+class TestQiskitAdapter:
+    """queasars_amd.qiskit_adapter is duck-typed: stand-ins with the attributes of QuantumCircuit / SparsePauliOp that it
+    documents are enough to exercise it without Qiskit."""
+
+    class _Param:
+        def __init__(self, name):
+            self.name = name
+            self.parameters = {self}
+
+        def __str__(self):
+            return self.name
+
+        def __hash__(self):
+            return hash(self.name)
+
+        def __eq__(self, other):
+            return isinstance(other, type(self)) and other.name == self.name
+
+    class _Circuit:
+        def __init__(self, n, data, parameters):
+            from types import SimpleNamespace
+
+            self.num_qubits = n
+            self.parameters = parameters
+            self.data = [SimpleNamespace(operation=SimpleNamespace(name=name, params=params), qubits=qubits) for name, params, qubits in data]
+
+        def find_bit(self, q):
+            from types import SimpleNamespace
+
+            return SimpleNamespace(index=q)
+
+    def test_lowering_follows_name_sorted_parameters_and_control_target_order(self):
+        from queasars_amd import qiskit_adapter
+        from queasars_amd.ir import CircuitIR, ParamRef
+
+        P = self._Param
+        # Qiskit keeps circuit.parameters sorted by name: layer0_q1_* before layer0_q2_*
+        a, b, c = P("layer0_q1_lambda"), P("layer0_q1_phi"), P("layer0_q1_theta")
+        d = P("layer0_q2_theta")
+        qc = self._Circuit(
+            3,
+            [("id", [], [0]), ("u", [c, b, a], [1]), ("cu3", [d, 0.25, 0.5], [1, 2]), ("barrier", [], [0, 1, 2]), ("measure", [], [0])],
+            [a, b, c, d],
+        )
+        got = qiskit_adapter.circuit_from_qiskit(qc)
+        want = CircuitIR(3).id(0).u(ParamRef(2), ParamRef(1), ParamRef(0), 1).cu3(ParamRef(3), 0.25, 0.5, 1, 2)
+        assert got.num_parameters == 4 and got.packed().tobytes() == want.packed().tobytes()
+
+    def test_rejects_what_it_cannot_represent(self):
+        import pytest as _pytest
+
+        from queasars_amd import qiskit_adapter
+
+        with _pytest.raises(ValueError, match="unsupported instruction"):
+            qiskit_adapter.circuit_from_qiskit(self._Circuit(2, [("cx", [], [0, 1])], []))
+
+        class _Expr:
+            def __init__(self, p):
+                self.parameters = {p}
+
+            def __str__(self):
+                return "2*x"
+
+        with _pytest.raises(ValueError, match="expression"):
+            qiskit_adapter.circuit_from_qiskit(self._Circuit(1, [("u", [_Expr(self._Param("x")), 0.0, 0.0], [0])], [self._Param("x")]))
+
+    def test_operator_labels_keep_qiskits_order(self):
+        from types import SimpleNamespace
+
+        from queasars_amd import qiskit_adapter
+
+        op = SimpleNamespace(paulis=SimpleNamespace(to_labels=lambda: ["IZ", "XI"]), coeffs=[0.5, -1.0])
+        got = qiskit_adapter.operator_from_qiskit(op)
+        assert got.labels == ["IZ", "XI"] and got.z_mask.tolist() == [1, 0] and got.x_mask.tolist() == [0, 2]
