@@ -26,6 +26,14 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found; libqsv cannot be built")
 
 
+def have_hipcc() -> bool:
+    try:
+        _hipcc()
+        return True
+    except RuntimeError:
+        return False
+
+
 def needs_build() -> bool:
     if not LIB_PATH.exists():
         return True

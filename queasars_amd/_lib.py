@@ -114,6 +114,8 @@ def load(build_if_missing: bool = True) -> C.CDLL:
             if not build_if_missing:
                 raise QsvLibraryError(f"{path} is missing; run `python -c 'import __graft_entry__ as g; g.build()'`")
             _build.build()
+        elif build_if_missing and path == _build.LIB_PATH and _build.needs_build() and _build.have_hipcc():
+            _build.build()  # a source is newer than the library: never run a stale build silently
         if os.environ.get("QSV_NO_TORCH") != "1":
             # torch ships its own HIP runtime (same soname as /opt/rocm's).  Importing it first makes libqsv and
             # torch share ONE runtime instance, so streams and events are interchangeable between them.

@@ -24,6 +24,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 import threading
+import uuid
 import weakref
 from itertools import count
 from abc import ABC, abstractmethod
@@ -60,6 +61,7 @@ class BaseCircuitEvaluator(ABC):
 
 
 _device_serial = count(1)
+_PROCESS_TOKEN = uuid.uuid4().hex  # registrations are process-local: a pickled circuit must not match here by accident
 
 
 def _pack_doubles(vectors: Sequence[Sequence[float]], total: int) -> np.ndarray:
@@ -119,7 +121,14 @@ class StatevectorDevice:
         self._push_plan = [int(x) for x in os.environ.get("QSV_PUSH_PLAN", "").split(",") if x]  # ... or explicit sizes
         self._operator: Optional[PauliOperator] = None
         self._reg_lock = threading.Lock()
-        self._serial = next(_device_serial)  # key of this device in CircuitIR._registered (never reused)
+        # key of this device in CircuitIR._registered: never reused, and unique across processes
+        self._serial = (_PROCESS_TOKEN, next(_device_serial))
+        # ids of circuits whose Python objects are gone.  Their finalizers only append here (they may run inside ANY
+        # allocation, also between qsv_eval_begin and qsv_eval_end, where a call into the library would wait for the
+        # handle this very thread holds); the ids are destroyed at the start of the next call that registers circuits.
+        self._dead: list[int] = []
+        # held across "set the operator, then evaluate" by evaluators that share this device
+        self.operator_lock = threading.RLock()
 
     # -- plumbing -------------------------------------------------------------------------------
     def __reduce__(self):
@@ -182,6 +191,7 @@ class StatevectorDevice:
         if circuit.n_qubits != self._n_qubits:
             raise ValueError(f"circuit has {circuit.n_qubits} qubits, the evaluator {self._n_qubits}")
         with self._reg_lock:
+            self._reap()
             cid = circuit._registered.get(self._serial)
             if cid is None:
                 ops = circuit.packed()
@@ -198,8 +208,32 @@ class StatevectorDevice:
     @staticmethod
     def _release(device_ref, cid: int) -> None:
         device = device_ref()
-        if device is not None and getattr(device, "_handle", None):
-            device._lib.qsv_circuit_destroy(device._handle, cid)
+        if device is not None:
+            device._dead.append(cid)  # no library call here: see __init__
+
+    def _reap(self) -> None:
+        """Destroy the device-side plans of circuits that were garbage collected (caller holds ``_reg_lock``)."""
+        while self._dead:
+            cid = self._dead.pop()
+            if self._handle:
+                self._lib.qsv_circuit_destroy(self._handle, cid)
+
+    def _batch_metadata(self, circuits: Sequence[CircuitIR]) -> tuple[np.ndarray, np.ndarray]:
+        """(circuit ids, parameter counts) of a batch.  An optimiser calls with the same circuit objects over and
+        over: both arrays are kept from the previous call, keyed by the objects' identities (the entry holds the
+        circuits, so an identity cannot be recycled while it exists) and by the global edit counter."""
+        n = len(circuits)
+        key = (CircuitIR.edits_of_registered, *map(id, circuits))
+        cached = self._last_batch
+        if cached is not None and cached[0] == key:
+            return cached[2], cached[3]
+        if self._dead:
+            with self._reg_lock:
+                self._reap()
+        ids = np.fromiter((self.circuit_id(c) for c in circuits), dtype=np.int32, count=n)
+        need = np.fromiter((c.num_parameters for c in circuits), dtype=np.int64, count=n)
+        self._last_batch = ((CircuitIR.edits_of_registered, *map(id, circuits)), list(circuits), ids, need)
+        return ids, need
 
     def expectation_values(self, circuits: Sequence[CircuitIR], parameter_values: Sequence[Sequence[float]]) -> np.ndarray:
         """Exact ``real(<psi_i|H|psi_i>)`` for every (circuit, parameter vector) pair, in input order.
@@ -212,17 +246,7 @@ class StatevectorDevice:
             raise ValueError("circuits and parameter_values must have the same length")
         if n == 0:
             return np.zeros(0, dtype=np.float64)
-        # An optimiser calls with the same circuit objects over and over: their ids and parameter counts are kept from
-        # the previous call (keyed by the objects' identities; the circuits themselves are kept alive by the key's
-        # owner list, so an identity cannot be recycled while the entry exists).
-        key = (CircuitIR.edits_of_registered, *map(id, circuits))
-        cached = self._last_batch
-        if cached is not None and cached[0] == key:
-            ids, need = cached[2], cached[3]
-        else:
-            ids = np.fromiter((self.circuit_id(c) for c in circuits), dtype=np.int32, count=n)
-            need = np.fromiter((c.num_parameters for c in circuits), dtype=np.int64, count=n)
-            self._last_batch = ((CircuitIR.edits_of_registered, *map(id, circuits)), list(circuits), ids, need)
+        ids, need = self._batch_metadata(circuits)
         counts = np.fromiter(map(len, parameter_values), dtype=np.int64, count=n)
         if (counts < need).any():
             i = int(np.argmax(counts < need))
@@ -300,17 +324,7 @@ class StatevectorDevice:
         values = np.empty((n, int(shots)), dtype=np.float64) if with_values else None
         if n == 0 or shots == 0:
             return states, values
-        # An optimiser calls with the same circuit objects over and over: their ids and parameter counts are kept from
-        # the previous call (keyed by the objects' identities; the circuits themselves are kept alive by the key's
-        # owner list, so an identity cannot be recycled while the entry exists).
-        key = (CircuitIR.edits_of_registered, *map(id, circuits))
-        cached = self._last_batch
-        if cached is not None and cached[0] == key:
-            ids, need = cached[2], cached[3]
-        else:
-            ids = np.fromiter((self.circuit_id(c) for c in circuits), dtype=np.int32, count=n)
-            need = np.fromiter((c.num_parameters for c in circuits), dtype=np.int64, count=n)
-            self._last_batch = ((CircuitIR.edits_of_registered, *map(id, circuits)), list(circuits), ids, need)
+        ids, need = self._batch_metadata(circuits)
         counts = np.fromiter(map(len, parameter_values), dtype=np.int64, count=n)
         if (counts < need).any():
             i = int(np.argmax(counts < need))
@@ -357,6 +371,38 @@ def _rebuild_device(args, operator):
     return dev
 
 
+class _ComposedCircuits:
+    """``initial_state_circuit + circuit`` for the circuits an evaluator is called with, without pinning them: entries
+    are keyed by identity, hold the user's circuit only weakly (the entry goes when the circuit goes, and with it the
+    composed circuit and its device-side plan), notice in-place edits through the circuit's version counter, and are
+    bounded in number (the reference creates fresh circuits on every call: such entries are dead weight)."""
+
+    def __init__(self, initial_state_circuit: Optional[CircuitIR], limit: int = 1024):
+        self._initial = initial_state_circuit
+        self._limit = int(limit)
+        self._entries: dict[int, tuple[weakref.ref, int, CircuitIR]] = {}
+        self._lock = threading.Lock()
+
+    def __len__(self) -> int:
+        return len(self._entries)
+
+    def get(self, circuit: CircuitIR) -> CircuitIR:
+        if self._initial is None:
+            return circuit
+        key = id(circuit)
+        hit = self._entries.get(key)
+        if hit is not None and hit[0]() is circuit and hit[1] == circuit._version:
+            return hit[2]
+        composed = self._initial.compose(circuit)
+        with self._lock:
+            if len(self._entries) >= self._limit:
+                for old in list(self._entries)[: self._limit // 2]:  # dicts keep insertion order: drop the oldest half
+                    self._entries.pop(old, None)
+            entries = self._entries
+            self._entries[key] = (weakref.ref(circuit, lambda _r, k=key: entries.pop(k, None)), circuit._version, composed)
+        return composed
+
+
 def _check_initial_state(initial_state_circuit: Optional[CircuitIR], n_qubits: int, what: str) -> None:
     if initial_state_circuit is not None and initial_state_circuit.num_qubits != n_qubits:
         raise ValueError(
@@ -399,23 +445,20 @@ class OperatorCircuitEvaluator(BaseCircuitEvaluator):
         self._device = statevector_device or StatevectorDevice(operator.num_qubits, dtype=dtype, device=device)
         if self._device.n_qubits != operator.num_qubits:
             raise ValueError("statevector_device was created for a different number of qubits")
-        self._device.set_operator(operator)
-        self._composed: dict[int, CircuitIR] = {}
+        with self._device.operator_lock:
+            self._device.set_operator(operator)
+        self._composed = _ComposedCircuits(initial_state_circuit)
 
     def _with_initial_state(self, circuit: CircuitIR) -> CircuitIR:
-        if self._initial_state_circuit is None:
-            return circuit
-        cached = self._composed.get(id(circuit))
-        if cached is None or cached[0] is not circuit:
-            cached = (circuit, self._initial_state_circuit.compose(circuit))
-            self._composed[id(circuit)] = cached
-        return cached[1]
+        return self._composed.get(circuit)
 
     def evaluate_circuits(self, circuits: list[CircuitIR], parameter_values: list[list[float]]) -> list[float]:
         pairs = [(c, p) for c, p in zip(circuits, parameter_values) if c is not None and p is not None]
-        if self._device._operator is not self._operator:  # the device is shared with another evaluator
-            self._device.set_operator(self._operator)
-        values = self._device.expectation_values([self._with_initial_state(c) for c, _ in pairs], [p for _, p in pairs])
+        # evaluators may share one device: "is it my operator? else set it" and the evaluation are one critical section
+        with self._device.operator_lock:
+            if self._device._operator is not self._operator:
+                self._device.set_operator(self._operator)
+            values = self._device.expectation_values([self._with_initial_state(c) for c, _ in pairs], [p for _, p in pairs])
         if self._precision > 0:
             values = values + self._rng.normal(0.0, self._precision, size=values.shape)
         return [float(v) for v in values]
@@ -492,7 +535,9 @@ class OperatorSamplerCircuitEvaluator(BaseCircuitEvaluator):
         self._initial_state_circuit = initial_state_circuit
         self._rng = np.random.default_rng(seed)
         self._device = statevector_device or StatevectorDevice(operator.num_qubits, dtype=dtype, device=device)
-        self._device.set_operator(operator)
+        with self._device.operator_lock:
+            self._device.set_operator(operator)
+        self._composed = _ComposedCircuits(initial_state_circuit)
 
     @property
     def statevector_device(self) -> StatevectorDevice:
@@ -501,14 +546,13 @@ class OperatorSamplerCircuitEvaluator(BaseCircuitEvaluator):
     def evaluate_circuits(self, circuits: list[CircuitIR], parameter_values: list[list[float]]) -> list[float]:
         """Samples every circuit on the device and gathers each sample's operator value from the device-resident
         diagonal table, so the host only sorts ``shots`` numbers per circuit for the CVaR."""
-        if self._initial_state_circuit is not None:
-            circuits = [self._initial_state_circuit.compose(c) for c in circuits]
-        pairs = [(c, p) for c, p in zip(circuits, parameter_values) if c is not None and p is not None]
-        if self._device._operator is not self._operator:
-            self._device.set_operator(self._operator)
-        _, values = self._device.sample_batch(
-            [c for c, _ in pairs], [p for _, p in pairs], self._shots, int(self._rng.integers(0, 2**63 - 1)), with_values=True
-        )
+        pairs = [(self._composed.get(c), p) for c, p in zip(circuits, parameter_values) if c is not None and p is not None]
+        with self._device.operator_lock:
+            if self._device._operator is not self._operator:
+                self._device.set_operator(self._operator)
+            _, values = self._device.sample_batch(
+                [c for c, _ in pairs], [p for _, p in pairs], self._shots, int(self._rng.integers(0, 2**63 - 1)), with_values=True
+            )
         return [_cvar_of_samples(row, self._alpha) for row in values]
 
     @property
@@ -542,10 +586,10 @@ class BitstringCircuitEvaluator(BaseCircuitEvaluator):
         self._initial_state_circuit = initial_state_circuit
         self._rng = np.random.default_rng(seed)
         self._device = statevector_device or StatevectorDevice(bitstring_evaluator.input_length, dtype=dtype, device=device)
+        self._composed = _ComposedCircuits(initial_state_circuit)
 
     def evaluate_circuits(self, circuits: list[CircuitIR], parameter_values: list[list[float]]) -> list[float]:
-        if self._initial_state_circuit is not None:
-            circuits = [self._initial_state_circuit.compose(c) for c in circuits]
+        circuits = [None if c is None else self._composed.get(c) for c in circuits]
         dists = measure_quasi_distributions(
             circuits, parameter_values, self._device, self._shots, seed=int(self._rng.integers(0, 2**63 - 1))
         )

@@ -26,18 +26,17 @@ def _check_alpha(alpha: float) -> None:
 
 
 def _get_expectation(state_list: list[tuple[Any, float, float]], alpha: float) -> float:
-    """Gather probability mass in order (ascending value when alpha != 1) until alpha is reached."""
+    """Expectation (alpha == 1) or CVaR_alpha of ``(state, probability, value)`` entries: the mean of ``value`` over
+    the probability mass ``alpha`` with the lowest values (reference [14-32]).  Vectorised: sort by value, take the
+    cumulative mass, clip it at ``alpha``; the increments of the clipped curve are the weights."""
+    probabilities = np.fromiter((entry[1] for entry in state_list), dtype=np.float64, count=len(state_list))
+    values = np.fromiter((entry[2] for entry in state_list), dtype=np.float64, count=len(state_list))
     if not np.isclose(alpha, 1):
-        state_list = sorted(state_list, key=lambda entry: entry[2])
-    gathered = 0.0
-    expectation = 0.0
-    for _, probability, value in state_list:
-        probability = min(alpha - gathered, probability)
-        expectation += probability * value
-        gathered += probability
-        if np.isclose(gathered, alpha):
-            break
-    return expectation / alpha
+        order = np.argsort(values, kind="stable")
+        probabilities, values = probabilities[order], values[order]
+    clipped = np.minimum(np.cumsum(probabilities), alpha)
+    weights = np.diff(clipped, prepend=0.0)
+    return float(np.dot(weights, values) / alpha)
 
 
 def basis_state_values(states: np.ndarray, operator: PauliOperator) -> np.ndarray:

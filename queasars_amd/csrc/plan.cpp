@@ -84,59 +84,42 @@ inline uint32_t lds_col(int tile_bit, const Swizzle& s) {
 //   ds_read_b64  : 2 groups of 32 lanes, bank = (addr/4) % 64 -> 8-B slot mod 32
 // Lanes with identical addresses broadcast (cannot happen here: the map is injective).
 int conflict_cycles(const Layout& l, const Swizzle& s, int elem_bytes, bool is_write) {
+    // lane -> LDS element offset: XOR of the columns of the lane's set bits, filled in lowest-set-bit order
     uint32_t lane_off[64];
     const int nlane_bits = std::min<int>(6, int(l.thr.size()));
-    for (int lane = 0; lane < 64; ++lane) {
-        uint32_t off = 0;
-        for (int u = 0; u < nlane_bits; ++u)
-            if ((lane >> u) & 1) off ^= lds_col(l.thr[u], s);
-        lane_off[lane] = off;
-    }
     const int active = 1 << nlane_bits;
-    auto group_cost = [&](const std::vector<int>& lanes, int slot_mod) {
-        int count[32] = {0};
-        int worst = 0;
-        for (int lane : lanes) {
-            if (lane >= active) continue;
-            int slot = int(lane_off[lane] % uint32_t(slot_mod));
-            worst = std::max(worst, ++count[slot]);
-        }
-        return worst > 0 ? worst - 1 : 0;
-    };
-    int extra = 0;
+    lane_off[0] = 0;
+    for (int u = 0; u < nlane_bits; ++u) {
+        const uint32_t col = lds_col(l.thr[size_t(u)], s);
+        for (int lane = 0; lane < (1 << u); ++lane) lane_off[lane | (1 << u)] = lane_off[lane] ^ col;
+    }
+    // lane groups of the four access kinds (see the comment above), as flat tables
+    static const uint8_t kReadB128[4][16] = {
+        {0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27},
+        {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31},
+        {32, 33, 34, 35, 44, 45, 46, 47, 52, 53, 54, 55, 56, 57, 58, 59},
+        {36, 37, 38, 39, 40, 41, 42, 43, 48, 49, 50, 51, 60, 61, 62, 63}};
+    int group_size, slot_mod;
+    bool contiguous = true;
     if (elem_bytes == 16) {
-        if (is_write) {
-            for (int g = 0; g < 8; ++g) {
-                std::vector<int> lanes;
-                for (int i = 0; i < 8; ++i) lanes.push_back(g * 8 + i);
-                extra += group_cost(lanes, 8);
-            }
-        } else {
-            static const int g0[16] = {0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27};
-            static const int g1[16] = {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31};
-            for (int half = 0; half < 2; ++half) {
-                std::vector<int> a, b;
-                for (int i = 0; i < 16; ++i) {
-                    a.push_back(g0[i] + 32 * half);
-                    b.push_back(g1[i] + 32 * half);
-                }
-                extra += group_cost(a, 16) + group_cost(b, 16);
-            }
-        }
+        group_size = is_write ? 8 : 16;
+        slot_mod = is_write ? 8 : 16;
+        contiguous = is_write;
     } else {
-        if (is_write) {
-            for (int g = 0; g < 4; ++g) {
-                std::vector<int> lanes;
-                for (int i = 0; i < 16; ++i) lanes.push_back(g * 16 + i);
-                extra += group_cost(lanes, 16);
-            }
-        } else {
-            for (int g = 0; g < 2; ++g) {
-                std::vector<int> lanes;
-                for (int i = 0; i < 32; ++i) lanes.push_back(g * 32 + i);
-                extra += group_cost(lanes, 32);
-            }
+        group_size = is_write ? 16 : 32;
+        slot_mod = is_write ? 16 : 32;
+    }
+    int extra = 0;
+    for (int g = 0; g < 64 / group_size; ++g) {
+        uint8_t count[32] = {0};
+        int worst = 0;
+        for (int i = 0; i < group_size; ++i) {
+            const int lane = contiguous ? g * group_size + i : int(kReadB128[g][i]);
+            if (lane >= active) continue;
+            const int c = ++count[lane_off[lane] & uint32_t(slot_mod - 1)];
+            worst = c > worst ? c : worst;
         }
+        extra += worst > 0 ? worst - 1 : 0;
     }
     return extra;
 }
@@ -192,6 +175,21 @@ SwizzleChoice choose_swizzle(const Layout& a, const Layout& b, int k, int elem_b
     best.s = base;
     best.cost = cost_of(best.s);
     uint32_t rng = 0x9E3779B9u;
+    // Cheap first: random draws.  A conflict-free swizzle only asks that the images of the tile bits on the lowest
+    // lane bits be linearly independent modulo the bank count, which a random assignment satisfies about one time
+    // in ten; a draw costs two conflict counts, a descent sweep several hundred.
+    for (int trial = 0; trial < 96 && best.cost > 0; ++trial) {
+        Swizzle s = base;
+        for (int p : relevant) {
+            rng = rng * 1664525u + 1013904223u;
+            s.m[size_t(p)] = uint8_t((rng >> 24) & uint32_t(span_of(p) - 1));
+        }
+        const int cst = cost_of(s);
+        if (cst < best.cost) {
+            best.s = s;
+            best.cost = cst;
+        }
+    }
     for (int restart = 0; restart < 24 && best.cost > 0; ++restart) {
         Swizzle s = base;
         if (restart > 0)

@@ -2,11 +2,13 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -18,13 +20,20 @@ using namespace qsv;
 
 namespace {
 
+// Error text is kept per calling thread (and per handle it belongs to): the thread that received a failing return code
+// is the one that asks for the text, and it must not race with another thread's failure on the same handle.
+constexpr size_t kInlineCacheLimit = 4096;  // structures qsv_eval_batch keeps registered between calls
+
 thread_local std::string g_create_error;
+thread_local std::string g_handle_error;
+thread_local const void* g_handle_error_owner = nullptr;
 
 struct Circuit {
     int n_params = 0;
     int n_gates = 0;                // non-identity ops
     CircuitPlan plan;
     bool uploaded = false;
+    bool staged = false;            // scratch flag of upload_plans (a circuit may appear several times in a batch)
     uint32_t plan_base = 0;         // word offset in the device arena
 };
 
@@ -50,7 +59,7 @@ struct qsv_handle {
     hipEvent_t ev_join = nullptr;
     bool dual_streams = true;
     mutable std::mutex mu;
-    std::string err;
+    std::atomic<std::thread::id> batch_owner{};  // thread that holds `mu` between qsv_eval_begin and qsv_eval_end
 
     // operator
     int n_terms = 0;
@@ -79,6 +88,8 @@ struct qsv_handle {
     DeviceBuffer d_scratch;   // probabilities / converted state
     void* h_batch = nullptr;  // pinned
     size_t h_batch_bytes = 0;
+    uint32_t* h_stage = nullptr;  // pinned staging buffer for plan uploads
+    size_t h_stage_words = 0;
     double* h_out = nullptr;  // pinned
     size_t h_out_count = 0;
 
@@ -107,8 +118,12 @@ struct qsv_handle {
 namespace {
 
 int fail(qsv_t* h, int code, const std::string& msg) {
-    if (h) h->err = msg;
-    else g_create_error = msg;
+    if (h) {
+        g_handle_error = msg;
+        g_handle_error_owner = h;
+    } else {
+        g_create_error = msg;
+    }
     return code;
 }
 
@@ -121,10 +136,17 @@ inline hipStream_t ws(const qsv_t* h) { return h->work ? h->work : h->stream; }
             return fail((h), QSV_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e));    \
     } while (0)
 
+// Nothing on either stream may still be using a buffer that is about to be replaced.
+hipError_t sync_streams(qsv_t* h) {
+    hipError_t e = h->stream ? hipStreamSynchronize(h->stream) : hipSuccess;
+    if (e == hipSuccess && h->stream2) e = hipStreamSynchronize(h->stream2);
+    return e;
+}
+
 int ensure(qsv_t* h, DeviceBuffer& b, size_t bytes) {
     if (b.bytes >= bytes && b.ptr) return QSV_OK;
     if (b.ptr) {
-        QSV_HIP(h, hipStreamSynchronize(h->stream));
+        QSV_HIP(h, sync_streams(h));
         QSV_HIP(h, hipFree(b.ptr));
         b.ptr = nullptr;
         b.bytes = 0;
@@ -188,57 +210,124 @@ PlanConfig resolve_config(const qsv_plan_config* cfg, int dtype) {
     return pc;
 }
 
-int register_circuit(qsv_t* h, int n_ops, const qsv_op* ops, int n_params, int* out_id, bool fold = true) {
-    int rc = validate_ops(h, h->n, n_ops, ops, n_params);
-    if (rc) return rc;
-    Circuit c;
-    c.n_params = n_params;
+// Validate an op list and schedule it.  Touches only immutable parts of the handle (n, cfg), so it needs no lock and
+// several threads may build plans at the same time.
+int build_circuit(qsv_t* h, int n_ops, const qsv_op* ops, int n_params, bool fold, Circuit* out, std::string* err) {
+    std::string local;
+    {
+        // validate_ops reports through fail(): keep its text
+        int rc = validate_ops(h, h->n, n_ops, ops, n_params);
+        if (rc) {
+            if (err) *err = g_handle_error;
+            return rc;
+        }
+    }
+    out->n_params = n_params;
     std::vector<AngleSource> angles;
     std::vector<GateIn> gates = gates_of(ops, n_ops, &angles);
-    c.n_gates = int(gates.size());
+    out->n_gates = int(gates.size());
     try {
         PlanConfig pc = h->cfg;
         pc.fold = pc.fold && fold;
-        c.plan = build_plan(h->n, gates, angles, pc);
+        out->plan = build_plan(h->n, gates, angles, pc);
     } catch (const std::exception& e) {
-        return fail(h, QSV_E_ARG, std::string("plan: ") + e.what());
+        if (err) *err = std::string("plan: ") + e.what();
+        return QSV_E_ARG;
     }
-    const int id = h->next_circuit_id++;
-    h->circuits.emplace(id, std::move(c));
-    *out_id = id;
     return QSV_OK;
 }
 
-int upload_plan(qsv_t* h, Circuit& c) {
-    if (c.uploaded) return QSV_OK;
-    const size_t need = c.plan.words.size();
+// (caller holds h->mu)
+int insert_circuit(qsv_t* h, Circuit&& c) {
+    const int id = h->next_circuit_id++;
+    h->circuits.emplace(id, std::move(c));
+    return id;
+}
+
+int register_circuit(qsv_t* h, int n_ops, const qsv_op* ops, int n_params, int* out_id, bool fold = true) {
+    Circuit c;
+    std::string err;
+    int rc = build_circuit(h, n_ops, ops, n_params, fold, &c, &err);
+    if (rc) return fail(h, rc, err);
+    *out_id = insert_circuit(h, std::move(c));
+    return QSV_OK;
+}
+
+// Make the plans of `circs` resident in the device arena.  New plans are staged back to back in one pinned host buffer
+// and shipped with ONE copy per batch (a population of fresh structures used to cost one copy + one stream
+// synchronisation per circuit).  When the arena is full it is rebuilt from the circuits that are still registered: the
+// space of destroyed circuits is reclaimed, and the arena only grows when the live plans really need more room.
+int upload_plans(qsv_t* h, const std::vector<Circuit*>& circs) {
+    std::vector<Circuit*> fresh;
+    size_t need = 0;
+    for (Circuit* c : circs)
+        if (!c->uploaded && !c->staged) {
+            c->staged = true;
+            fresh.push_back(c);
+            need += c->plan.words.size();
+        }
+    for (Circuit* c : fresh) c->staged = false;
+    if (fresh.empty()) return QSV_OK;
     const size_t cap = h->d_arena.bytes / 4;
     if (h->arena_used_words + need > cap) {
-        // grow: new arena, every circuit re-uploads lazily
-        size_t new_cap = std::max(cap * 2, std::max(need * 2, size_t(1) << 20));
-        QSV_HIP(h, hipStreamSynchronize(h->stream));
-        if (h->d_arena.ptr) QSV_HIP(h, hipFree(h->d_arena.ptr));
-        h->d_arena = DeviceBuffer{};
-        QSV_HIP(h, hipMalloc(&h->d_arena.ptr, new_cap * 4));
-        h->d_arena.bytes = new_cap * 4;
-        h->arena_used_words = 0;
+        // rebuild: everything still registered that is part of this batch goes in again; plans of other live circuits
+        // are re-uploaded when they are next used
+        QSV_HIP(h, sync_streams(h));
         for (auto& kv : h->circuits) kv.second.uploaded = false;
+        fresh.clear();
+        need = 0;
+        for (Circuit* c : circs)
+            if (!c->staged) {
+                c->staged = true;
+                fresh.push_back(c);
+                need += c->plan.words.size();
+            }
+        for (Circuit* c : fresh) c->staged = false;
+        h->arena_used_words = 0;
+        if (need > cap) {
+            const size_t new_cap = std::max(need * 2, size_t(1) << 20);
+            if (h->d_arena.ptr) QSV_HIP(h, hipFree(h->d_arena.ptr));
+            h->d_arena = DeviceBuffer{};
+            QSV_HIP(h, hipMalloc(&h->d_arena.ptr, new_cap * 4));
+            h->d_arena.bytes = new_cap * 4;
+        }
     }
-    c.plan_base = uint32_t(h->arena_used_words);
-    QSV_HIP(h, hipMemcpyAsync(static_cast<uint32_t*>(h->d_arena.ptr) + c.plan_base, c.plan.words.data(), need * 4,
+    if (h->h_stage_words < need) {
+        if (h->h_stage) {
+            QSV_HIP(h, sync_streams(h));
+            QSV_HIP(h, hipHostFree(h->h_stage));
+            h->h_stage = nullptr;
+            h->h_stage_words = 0;
+        }
+        const size_t want = std::max(need * 2, size_t(1) << 16);
+        QSV_HIP(h, hipHostMalloc(reinterpret_cast<void**>(&h->h_stage), want * 4, hipHostMallocDefault));
+        h->h_stage_words = want;
+    } else {
+        // the previous batch's copy out of the staging buffer must be complete before it is overwritten
+        QSV_HIP(h, hipStreamSynchronize(h->stream));
+    }
+    size_t cur = 0;
+    for (Circuit* c : fresh) {
+        std::memcpy(h->h_stage + cur, c->plan.words.data(), c->plan.words.size() * 4);
+        c->plan_base = uint32_t(h->arena_used_words + cur);
+        cur += c->plan.words.size();
+        c->uploaded = true;
+    }
+    QSV_HIP(h, hipMemcpyAsync(static_cast<uint32_t*>(h->d_arena.ptr) + h->arena_used_words, h->h_stage, need * 4,
                               hipMemcpyHostToDevice, h->stream));
-    // the host vector may be freed or moved before the copy runs if the caller destroys the circuit: make the
-    // copy complete now (plans are uploaded once per structure, not per evaluation)
-    QSV_HIP(h, hipStreamSynchronize(h->stream));
     h->arena_used_words += need;
-    c.uploaded = true;
+    // launches on the second stream read the arena too: they wait for this copy
+    if (h->stream2) {
+        QSV_HIP(h, hipEventRecord(h->ev_join, h->stream));
+        QSV_HIP(h, hipStreamWaitEvent(h->stream2, h->ev_join, 0));
+    }
     return QSV_OK;
 }
 
 int ensure_host_batch(qsv_t* h, size_t bytes) {
     if (h->h_batch_bytes >= bytes) return QSV_OK;
     if (h->h_batch) {
-        QSV_HIP(h, hipStreamSynchronize(h->stream));
+        QSV_HIP(h, sync_streams(h));
         QSV_HIP(h, hipHostFree(h->h_batch));
         h->h_batch = nullptr;
     }
@@ -251,7 +340,7 @@ int ensure_host_batch(qsv_t* h, size_t bytes) {
 int ensure_host_out(qsv_t* h, size_t count) {
     if (h->h_out_count >= count) return QSV_OK;
     if (h->h_out) {
-        QSV_HIP(h, hipStreamSynchronize(h->stream));
+        QSV_HIP(h, sync_streams(h));
         QSV_HIP(h, hipHostFree(h->h_out));
         h->h_out = nullptr;
     }
@@ -274,15 +363,7 @@ int batch_layout(qsv_t* h, const std::vector<Circuit*>& circs, const std::vector
     qsv_handle::Batch& b = h->batch;
     const size_t n_evals = circs.size();
     int rc;
-    // a growing arena invalidates earlier uploads: repeat until every plan of the batch is resident
-    for (int attempt = 0; attempt < 16; ++attempt) {
-        bool all = true;
-        for (Circuit* c : circs)
-            if ((rc = upload_plan(h, *c))) return rc;
-        for (Circuit* c : circs) all = all && c->uploaded;
-        if (all) break;
-        if (attempt == 15) return fail(h, QSV_E_DEVICE, "plan arena could not hold the batch");
-    }
+    if ((rc = upload_plans(h, circs))) return rc;
     size_t total_params = 0, total_mats = 0;
     for (size_t i = 0; i < n_evals; ++i) {
         if (n_params[i] < circs[i]->n_params)
@@ -681,12 +762,16 @@ void qsv_destroy(qsv_t* h) {
                             &h->d_states, &h->d_wtab, &h->d_batch, &h->d_mats, &h->d_partials, &h->d_out, &h->d_scratch})
         if (b->ptr) (void)hipFree(b->ptr);
     if (h->h_batch) (void)hipHostFree(h->h_batch);
+    if (h->h_stage) (void)hipHostFree(h->h_stage);
     if (h->h_out) (void)hipHostFree(h->h_out);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
 
-const char* qsv_last_error(const qsv_t* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+const char* qsv_last_error(const qsv_t* h) {
+    if (!h) return g_create_error.c_str();
+    return g_handle_error_owner == h ? g_handle_error.c_str() : "";
+}
 
 int qsv_set_stream(qsv_t* h, void* hip_stream) {
     if (!h) return QSV_E_ARG;
@@ -792,9 +877,15 @@ int qsv_set_operator(qsv_t* h, int n_terms, const uint64_t* x_mask, const uint64
 
 int qsv_circuit_create(qsv_t* h, int n_ops, const qsv_op* ops, int n_params, int* out_circuit_id) {
     if (!h) return QSV_E_ARG;
-    std::lock_guard<std::mutex> lock(h->mu);
     if (!out_circuit_id || n_params < 0) return fail(h, QSV_E_ARG, "bad arguments");
-    return register_circuit(h, n_ops, ops, n_params, out_circuit_id);
+    // the scheduler runs outside the handle lock: callers on several threads register structures side by side
+    Circuit c;
+    std::string err;
+    int rc = build_circuit(h, n_ops, ops, n_params, true, &c, &err);
+    if (rc) return fail(h, rc, err);
+    std::lock_guard<std::mutex> lock(h->mu);
+    *out_circuit_id = insert_circuit(h, std::move(c));
+    return QSV_OK;
 }
 
 int qsv_circuit_destroy(qsv_t* h, int circuit_id) {
@@ -825,6 +916,9 @@ int qsv_eval_circuits(qsv_t* h, int n_evals, const int* circuit_ids, const int64
 
 int qsv_eval_begin(qsv_t* h, int n_evals, const int* circuit_ids, const int64_t* param_counts) {
     if (!h) return QSV_E_ARG;
+    // a second begin from the thread that already holds the handle (between begin and end) would wait for itself
+    if (h->batch_owner.load() == std::this_thread::get_id())
+        return fail(h, QSV_E_STATE, "a batch is already open on this handle");
     std::unique_lock<std::mutex> lock(h->mu);
     if (h->batch.open) return fail(h, QSV_E_STATE, "a batch is already open on this handle");
     if (n_evals < 0 || (n_evals > 0 && (!circuit_ids || !param_counts))) return fail(h, QSV_E_ARG, "bad arguments");
@@ -844,6 +938,7 @@ int qsv_eval_begin(qsv_t* h, int n_evals, const int* circuit_ids, const int64_t*
         return rc;
     }
     h->batch.open = true;
+    h->batch_owner.store(std::this_thread::get_id());
     h->batch_lock = std::move(lock);  // other threads wait until qsv_eval_end
     return QSV_OK;
 }
@@ -866,6 +961,7 @@ int qsv_eval_end(qsv_t* h, double* out_expectations) {
         (void)hipStreamSynchronize(h->stream2);
     }
     eval_close(h);
+    h->batch_owner.store(std::thread::id());
     std::unique_lock<std::mutex> lock = std::move(h->batch_lock);
     return rc;  // `lock` releases the handle here
 }
@@ -877,31 +973,83 @@ int qsv_eval_batch(qsv_t* h, int n_evals, const int64_t* op_offsets, const qsv_o
     if (n_evals < 0 || (n_evals > 0 && (!op_offsets || !param_offsets || !out)))
         return fail(h, QSV_E_ARG, "bad arguments");
     QSV_HIP(h, hipSetDevice(h->device));
-    std::vector<Circuit*> circs(size_t(n_evals), nullptr);
+    // The cache of inline structures is bounded.  It is emptied only HERE, before any circuit of this call has been
+    // looked up: evicting inside the loop below would free plans that earlier evaluations of the same call point at.
+    if (h->inline_cache.size() > kInlineCacheLimit) {
+        QSV_HIP(h, sync_streams(h));
+        for (auto& kv : h->inline_cache) h->circuits.erase(kv.second);
+        h->inline_cache.clear();
+    }
+    // pass 1: ids of known structures, list of the new ones (each distinct structure once)
+    std::vector<int> ids(size_t(n_evals), 0);
+    std::vector<std::string> keys;
+    keys.resize(size_t(n_evals));
+    struct Fresh {
+        int first_eval;
+        Circuit circuit;
+        std::string err;
+        int rc = QSV_OK;
+    };
+    std::vector<Fresh> fresh;
+    std::unordered_map<std::string, int> fresh_index;  // key -> index in `fresh`
+    std::vector<int> pending(size_t(n_evals), -1);
     for (int i = 0; i < n_evals; ++i) {
         const int64_t b = op_offsets[i], e = op_offsets[i + 1];
         if (e < b) return fail(h, QSV_E_ARG, "op_offsets must be non-decreasing");
         const int64_t np = param_offsets[i + 1] - param_offsets[i];
         if (np < 0) return fail(h, QSV_E_ARG, "param_offsets must be non-decreasing");
-        // structure key: everything but the literal angles' use is part of the identity of a registered circuit,
-        // and literals are part of it too (they are baked into the registered ops)
-        std::string key(reinterpret_cast<const char*>(ops + b), size_t(e - b) * sizeof(qsv_op));
+        // structure key: the ops (literal angles are baked into a registered circuit, so they are part of its
+        // identity) and the length of the parameter vector
+        std::string& key = keys[size_t(i)];
+        key.assign(reinterpret_cast<const char*>(ops + b), size_t(e - b) * sizeof(qsv_op));
         key.append(reinterpret_cast<const char*>(&np), sizeof(np));
         auto it = h->inline_cache.find(key);
-        int id;
-        if (it == h->inline_cache.end()) {
-            if (h->inline_cache.size() > 4096) {
-                for (auto& kv : h->inline_cache) h->circuits.erase(kv.second);
-                h->inline_cache.clear();
-            }
-            int rc = register_circuit(h, int(e - b), ops + b, int(np), &id);
-            if (rc) return rc;
-            h->inline_cache.emplace(std::move(key), id);
-        } else {
-            id = it->second;
+        if (it != h->inline_cache.end()) {
+            ids[size_t(i)] = it->second;
+            continue;
         }
-        circs[size_t(i)] = &h->circuits.find(id)->second;
+        auto fi = fresh_index.find(key);
+        if (fi == fresh_index.end()) {
+            fi = fresh_index.emplace(key, int(fresh.size())).first;
+            fresh.emplace_back();
+            fresh.back().first_eval = i;
+        }
+        pending[size_t(i)] = fi->second;
     }
+    // pass 2: schedule the new structures, on several host threads when there are many (a generation of EVQE brings
+    // up to a population of new structures at once)
+    if (!fresh.empty()) {
+        auto build_one = [&](Fresh& f) {
+            const int i = f.first_eval;
+            const int64_t b = op_offsets[i], e = op_offsets[i + 1];
+            f.rc = build_circuit(h, int(e - b), ops + b, int(param_offsets[i + 1] - param_offsets[i]), true, &f.circuit, &f.err);
+        };
+        const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+        const size_t n_threads = std::min<size_t>(hw, fresh.size() / 2);
+        if (n_threads >= 2) {
+            std::atomic<size_t> next{0};
+            std::vector<std::thread> pool;
+            for (size_t t = 0; t < n_threads; ++t)
+                pool.emplace_back([&]() {
+                    for (size_t j = next.fetch_add(1); j < fresh.size(); j = next.fetch_add(1)) build_one(fresh[j]);
+                });
+            for (std::thread& t : pool) t.join();
+        } else {
+            for (Fresh& f : fresh) build_one(f);
+        }
+        for (Fresh& f : fresh)
+            if (f.rc) return fail(h, f.rc, f.err + " (evaluation " + std::to_string(f.first_eval) + ")");
+        std::vector<int> fresh_id(fresh.size());
+        for (size_t j = 0; j < fresh.size(); ++j) {
+            fresh_id[j] = insert_circuit(h, std::move(fresh[j].circuit));
+            h->inline_cache.emplace(keys[size_t(fresh[j].first_eval)], fresh_id[j]);
+        }
+        for (int i = 0; i < n_evals; ++i)
+            if (pending[size_t(i)] >= 0) ids[size_t(i)] = fresh_id[size_t(pending[size_t(i)])];
+    }
+    // pass 3: only now, with every registration done, take pointers into the circuit table
+    std::vector<Circuit*> circs(size_t(n_evals), nullptr);
+    for (int i = 0; i < n_evals; ++i) circs[size_t(i)] = &h->circuits.find(ids[size_t(i)])->second;
     static const double dummy = 0.0;
     return eval_all(h, circs, param_offsets, params ? params : &dummy, out);
 }

@@ -72,8 +72,26 @@ class CircuitIR:
         self._rows: list[tuple] = []
         self._n_parameters = 0
         self._packed: Optional[np.ndarray] = None
-        # (id(handle) -> circuit id) cache used by the evaluator; cleared on mutation
-        self._registered: dict[int, int] = {}
+        self._version = 0  # bumped by every edit (caches of derived circuits compare it)
+        # (device key -> circuit id) cache used by the evaluator; cleared on mutation.  Process-local: a device key
+        # is only meaningful in the process that created the device, so copies and pickles start without it.
+        self._registered: dict[object, int] = {}
+
+    # -- copying ----------------------------------------------------------------------------------
+    def __getstate__(self) -> dict:
+        state = self.__dict__.copy()
+        state["_registered"] = {}
+        state["_packed"] = None
+        return state
+
+    def __deepcopy__(self, memo) -> "CircuitIR":
+        out = CircuitIR(self._n_qubits)
+        out._rows = list(self._rows)  # rows are immutable tuples
+        out._n_parameters = self._n_parameters
+        memo[id(self)] = out
+        return out
+
+    __copy__ = lambda self: self.__deepcopy__({})  # noqa: E731
 
     # -- construction ---------------------------------------------------------------------------
     def _angle(self, a: Angle) -> tuple[int, float]:
@@ -94,6 +112,7 @@ class CircuitIR:
         (it, vt), (ip, vp), (il, vl) = self._angle(theta), self._angle(phi), self._angle(lam)
         self._rows.append((kind, target, control, 0, it, ip, il, vt, vp, vl))
         self._packed = None
+        self._version += 1
         if self._registered:
             # a circuit that a device already knows is being edited: devices must register it again, and any batch
             # metadata they cached by object identity is void
@@ -118,6 +137,7 @@ class CircuitIR:
         not used by any gate (a Qiskit circuit's ``parameters`` may hold such entries)."""
         if n_parameters > self._n_parameters:
             self._n_parameters = int(n_parameters)
+            self._version += 1
             if self._registered:
                 CircuitIR.edits_of_registered += 1
                 self._registered = {}
@@ -152,10 +172,7 @@ class CircuitIR:
     def packed(self) -> np.ndarray:
         """The ops as a contiguous ``qsv_op`` array (cached)."""
         if self._packed is None:
-            arr = np.zeros(len(self._rows), dtype=QSV_OP_DTYPE)
-            for i, row in enumerate(self._rows):
-                arr[i] = row
-            self._packed = arr
+            self._packed = np.array(self._rows, dtype=QSV_OP_DTYPE) if self._rows else np.zeros(0, dtype=QSV_OP_DTYPE)
         return self._packed
 
     def bound_ops(self, parameter_values: Sequence[float]) -> list[tuple]:

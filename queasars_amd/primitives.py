@@ -16,6 +16,8 @@ per object).
 
 from __future__ import annotations
 
+import weakref
+from collections import OrderedDict
 from types import SimpleNamespace
 from typing import Any, Iterable, Optional, Sequence
 
@@ -34,57 +36,98 @@ class _Job:
         return self._results
 
 
+class _IdentityCache:
+    """Conversion results keyed by object identity WITHOUT pinning the objects: an entry holds its key object weakly
+    and disappears with it (so does the converted circuit, and with it the device-side plan); objects that cannot be
+    weakly referenced are held in a small bounded table instead.  The reference creates fresh circuits on almost every
+    call (``measure_all(inplace=False)``, one circuit per individual and generation), so an unbounded identity cache
+    would only ever grow."""
+
+    def __init__(self, convert, limit: int = 512):
+        self._convert, self._limit = convert, int(limit)
+        self._weak: dict[int, tuple[weakref.ref, Any]] = {}
+        self._strong: dict[int, tuple[Any, Any]] = {}
+
+    def __len__(self) -> int:
+        return len(self._weak) + len(self._strong)
+
+    def get(self, obj: Any) -> Any:
+        key = id(obj)
+        hit = self._weak.get(key)
+        if hit is not None and hit[0]() is obj:
+            return hit[1]
+        hit = self._strong.get(key)
+        if hit is not None and hit[0] is obj:
+            return hit[1]
+        value = self._convert(obj)
+        try:
+            table = self._weak
+            table[key] = (weakref.ref(obj, lambda _r, k=key, t=table: t.pop(k, None)), value)
+        except TypeError:
+            if len(self._strong) >= self._limit:
+                for old in list(self._strong)[: self._limit // 2]:
+                    self._strong.pop(old, None)
+            self._strong[key] = (obj, value)
+        return value
+
+
 class _Converter:
-    """Caches the plain-data form of foreign circuit / operator objects by identity (the objects are kept alive)."""
+    """Plain-data form of foreign circuit / operator objects (see :class:`_IdentityCache`)."""
 
     def __init__(self) -> None:
-        self._circuits: dict[int, tuple[Any, CircuitIR]] = {}
-        self._operators: dict[int, tuple[Any, PauliOperator]] = {}
+        self._circuits = _IdentityCache(qiskit_adapter.circuit_from_qiskit)
+        self._operators = _IdentityCache(qiskit_adapter.operator_from_qiskit)
 
     def circuit(self, c: Any) -> CircuitIR:
-        if isinstance(c, CircuitIR):
-            return c
-        hit = self._circuits.get(id(c))
-        if hit is None:
-            hit = (c, qiskit_adapter.circuit_from_qiskit(c))
-            self._circuits[id(c)] = hit
-        return hit[1]
+        return c if isinstance(c, CircuitIR) else self._circuits.get(c)
 
     def operator(self, op: Any) -> PauliOperator:
-        if isinstance(op, PauliOperator):
-            return op
-        hit = self._operators.get(id(op))
-        if hit is None:
-            hit = (op, qiskit_adapter.operator_from_qiskit(op))
-            self._operators[id(op)] = hit
-        return hit[1]
+        return op if isinstance(op, PauliOperator) else self._operators.get(op)
+
+
+def _operator_key(op: PauliOperator) -> tuple:
+    return (op.num_qubits, op.x_mask.tobytes(), op.z_mask.tobytes(), op.coeffs.tobytes())
 
 
 class GpuEstimator:
     """``run(pubs, precision=...)`` over exact statevector expectation values; ``precision`` other than 0 / None adds
-    Gaussian noise of that standard deviation (what an estimator's target precision means to the reference)."""
+    Gaussian noise of that standard deviation (what an estimator's target precision means to the reference).
 
-    def __init__(self, dtype: str = "fp64", device: int = 0, seed: Optional[int] = None):
+    One :class:`StatevectorDevice` per qubit count serves every operator (its tables are rebuilt when the operator
+    changes); operators are recognised by content, not identity, and at most ``max_operators`` evaluators are kept."""
+
+    def __init__(self, dtype: str = "fp64", device: int = 0, seed: Optional[int] = None, max_operators: int = 8):
         self._dtype, self._device_index = dtype, device
         self._rng = np.random.default_rng(seed)
         self._convert = _Converter()
-        self._evaluators: dict[int, tuple[PauliOperator, OperatorCircuitEvaluator]] = {}
+        self._devices: dict[int, StatevectorDevice] = {}
+        self._evaluators: "OrderedDict[tuple, OperatorCircuitEvaluator]" = OrderedDict()
+        self._max_operators = max(1, int(max_operators))
 
     def _evaluator(self, operator: PauliOperator) -> OperatorCircuitEvaluator:
-        hit = self._evaluators.get(id(operator))
+        key = _operator_key(operator)
+        hit = self._evaluators.get(key)
         if hit is None:
-            hit = (operator, OperatorCircuitEvaluator(operator, dtype=self._dtype, device=self._device_index))
-            self._evaluators[id(operator)] = hit
-        return hit[1]
+            dev = self._devices.get(operator.num_qubits)
+            if dev is None:
+                dev = StatevectorDevice(operator.num_qubits, dtype=self._dtype, device=self._device_index)
+                self._devices[operator.num_qubits] = dev
+            hit = OperatorCircuitEvaluator(operator, statevector_device=dev)
+            self._evaluators[key] = hit
+            while len(self._evaluators) > self._max_operators:
+                self._evaluators.popitem(last=False)
+        else:
+            self._evaluators.move_to_end(key)
+        return hit
 
     def run(self, pubs: Iterable[Sequence[Any]], *, precision: Optional[float] = None) -> _Job:
         pubs = [tuple(pub) for pub in pubs]
         out: list[Optional[float]] = [None] * len(pubs)
-        by_operator: dict[int, list[int]] = {}
+        by_operator: dict[tuple, list[int]] = {}
         operators = []
         for i, pub in enumerate(pubs):
             operators.append(self._convert.operator(pub[1]))
-            by_operator.setdefault(id(operators[-1]), []).append(i)
+            by_operator.setdefault(_operator_key(operators[-1]), []).append(i)
         for indices in by_operator.values():  # one batched call per distinct operator
             evaluator = self._evaluator(operators[indices[0]])
             circuits = [self._convert.circuit(pubs[i][0]) for i in indices]
