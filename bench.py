@@ -1,16 +1,23 @@
 #!/usr/bin/env python3
 """Headline benchmark: circuit-evals/sec of an EVQE population on MI355X.
 
-Workload (BASELINE.json configs[1], SURVEY.md 8(d) "Config 2"): n = 20 qubits, P = 64 individuals per GPU,
-L = 4 layers, genomes from the restated ``EVQEPopulation.random_population(..., random_seed=0)``, random Ising
-Hamiltonian (190 ZZ + 20 Z terms, J, h ~ N(0,1), default_rng(2020)), fp64.  One "step" = one fitness evaluation
-of the rank's 64 individuals (``evaluate_circuits`` on all of them) followed by the fitness all-gather.
+Workload of the headline number (BASELINE.json configs[1], SURVEY.md 8(d) "Config 2"): n = 20 qubits, P = 64
+individuals per GPU, L = 4 layers, genomes from the restated ``EVQEPopulation.random_population(..., random_seed=0)``,
+random Ising Hamiltonian (190 ZZ + 20 Z terms, J, h ~ N(0,1), default_rng(2020)), fp64.  One "step" = one fitness
+evaluation of the whole population through the product's ``evaluate_population_sharded`` (each rank evaluates its
+block, then one RCCL all-gather of the fitness values).
 
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-Weak scaling: every rank evaluates its own 64 individuals (rank r takes individuals [64r, 64r+64) of one
-64*N population), so value = 64 * N * K / T.  Rank 0 prints ONE JSON line.
+Weak scaling: the population has 64 * N individuals, rank r owns [64r, 64r+64); value = 64 * N * K / T.
+Rank 0 prints ONE JSON line.  Beside the contract's fields it carries
+
+  roofline          per instantiation of the gate-pass kernel (HIP events around every launch, measured in extra
+                    profiled steps AFTER the timed region), and ``microbench``: single-gate sweeps at n = 24 and 26
+  config3           BASELINE.json configs[2] at this N: n = 24, P = 256 in total (strong scaling), per-rank times
+  cold_structure_evals_per_s / threaded_b1_evals_per_s   the reference's real calling patterns (N = 1 only)
+  cpu_baseline      the plain-C oracle on the host cores, the NumPy oracle, and Qiskit Aer when importable (N = 1 only)
 """
 
 from __future__ import annotations
@@ -33,24 +40,24 @@ import torch.distributed as dist  # noqa: E402
 N_QUBITS = int(os.environ.get("QSV_BENCH_QUBITS", 20))
 POP_PER_GPU = int(os.environ.get("QSV_BENCH_POP", 64))
 N_LAYERS = int(os.environ.get("QSV_BENCH_LAYERS", 4))
-HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measured copy rate)
+FP64_PEAK_TFLOPS = 78.6     # vector fp64, half the 157.3 TFLOP/s fp32 vector rate of MI355X_MICROARCH.md (spec)
+KERNEL_NAMES = ("qsv::pass_kernel<double, 3, 2, true> (pass 0: synthesises the product state, writes only)",
+                "qsv::pass_kernel<double, 3, 2, false> (later passes; the last one fuses the diagonal expectation and only reads)")
 
 
 def ising_operator(n_qubits: int, seed: int):
-    from queasars_amd.ir import PauliOperator
+    from queasars_amd.workloads import random_ising_operator
 
-    rng = np.random.default_rng(seed)
-    terms = []
-    for i in range(n_qubits):
-        for j in range(i + 1, n_qubits):
-            terms.append(("ZZ", [i, j], float(rng.normal())))
-    for i in range(n_qubits):
-        terms.append(("Z", [i], float(rng.normal())))
-    return PauliOperator.from_sparse_list(terms, n_qubits)
+    return random_ising_operator(n_qubits, seed)
+
+
+# ---- CPU baselines (rank 0, N = 1 only; the oracle is the checker and the baseline, never the product) ---------------
 
 
 def cpu_baseline(circuits, params, operator, budget_s: float = 12.0):
-    """Time the plain-C oracle (OpenMP, all host cores) on a bounded sample of the same workload."""
+    """Time the plain-C oracle (OpenMP, the host cores of this job) on a bounded sample of the same workload; also the
+    NumPy oracle on two individuals, and Qiskit Aer's statevector estimator when it can be imported."""
     import helpers  # tests/helpers.py: the only place outside tests/ that touches oracle/, as the timed baseline
 
     orc = helpers.load_c_oracle()
@@ -67,14 +74,227 @@ def cpu_baseline(circuits, params, operator, budget_s: float = 12.0):
         values.append(orc.evaluate(circuits[done], params[done], operator, table, scratch))
         done += 1
     elapsed = time.perf_counter() - t0
-    return {
+    out = {
         "value": done / elapsed,
         "unit": "circuit-evals/s",
         "cores": cores,
         "kind": "port",
         "sample": f"first {done} of the {len(circuits)} individuals of the same workload, plain-C oracle with OpenMP "
         f"({cores} threads), one sweep per gate, diagonal table prebuilt",
-    }, values
+    }
+    # NumPy oracle (single process): SURVEY.md 8(d) "CPU baseline" item 2
+    t0 = time.perf_counter()
+    numpy_values = [helpers.oracle_expectation(c, p, operator) for c, p in zip(circuits[:2], params[:2])]
+    out["numpy_oracle"] = {"value": 2 / (time.perf_counter() - t0), "unit": "circuit-evals/s", "cores": 1,
+                           "sample": "first 2 individuals, oracle/statevector_oracle.py (tensor-reshape formulation)",
+                           "max_abs_diff_vs_c_oracle": float(np.abs(np.asarray(numpy_values) - np.asarray(values[:2])).max())}
+    out["aer"] = aer_baseline(circuits, params, operator)
+    return out, values
+
+
+def aer_baseline(circuits, params, operator):
+    """SURVEY.md 8(d) "CPU baseline" item 1: Qiskit Aer's statevector estimator on the same pubs, if the host has it."""
+    try:
+        import qiskit_aer  # noqa: F401
+        from qiskit import QuantumCircuit
+        from qiskit.circuit.library import CU3Gate
+        from qiskit.quantum_info import SparsePauliOp
+        from qiskit_aer.primitives import EstimatorV2
+    except Exception as exc:  # not installable offline (SURVEY.md 8(c))
+        return {"status": "unavailable", "reason": f"{type(exc).__name__}: {exc}"}
+    pubs = []
+    for c, p in list(zip(circuits, params))[:4]:
+        qc = QuantumCircuit(c.n_qubits)
+        for kind, target, control, theta, phi, lam in c.bound_ops(p):
+            if kind == 1:
+                qc.u(theta, phi, lam, target)
+            elif kind == 2:
+                qc.append(CU3Gate(theta, phi, lam), [control, target])
+        pubs.append((qc, SparsePauliOp(operator.labels, operator.coeffs)))
+    est = EstimatorV2(options={"backend_options": {"method": "statevector"}})
+    est.run(pubs[:1], precision=0).result()
+    t0 = time.perf_counter()
+    result = est.run(pubs, precision=0).result()
+    dt = time.perf_counter() - t0
+    return {"status": "measured", "value": len(pubs) / dt, "unit": "circuit-evals/s", "cores": os.cpu_count(),
+            "omp_num_threads": os.environ.get("OMP_NUM_THREADS"), "values": [float(np.real(r.data.evs)) for r in result]}
+
+
+# ---- extra measurements around the headline ---------------------------------------------------------------------------
+
+
+def kernel_rooflines(device, step, profiled_steps: int, traffic: dict):
+    """Per instantiation of the gate-pass kernel: launches, mean launch time (HIP events on the stream each launch runs
+    on), algorithmic bytes and flops per launch, and the fractions of the two roofs.  Measured in steps of their own,
+    after the timed region: the per-launch events cost a few microseconds each."""
+    device.set_profiling(True)
+    acc = None
+    for _ in range(profiled_steps):
+        step()
+        p = device.profile()
+        if acc is None:
+            acc = {k: (list(v) if isinstance(v, list) else v) for k, v in p.items()}
+        else:
+            for k, v in p.items():
+                acc[k] = [a + b for a, b in zip(acc[k], v)] if isinstance(v, list) else acc[k] + v
+    device.set_profiling(False)
+    kernels = []
+    for kind in (0, 1):
+        launches = acc["kernel_launches"][kind]
+        if not launches or acc["kernel_ms"][kind] <= 0:
+            continue
+        avg_ms = acc["kernel_ms"][kind] / launches
+        alg = acc["kernel_bytes"][kind] / launches
+        moved = acc["kernel_moved_bytes"][kind] / launches
+        flops = acc["kernel_flops"][kind] / launches
+        measured = traffic.get("kernels", {}).get(str(kind), {}).get("hbm_bytes_per_launch")
+        entry = {
+            "kernel": KERNEL_NAMES[kind],
+            "launches": launches,
+            "states_per_launch": acc["kernel_states"][kind] / launches,
+            "avg_launch_us": avg_ms * 1e3,
+            "algorithmic_bytes_per_launch": alg,
+            "achieved_GBps": alg / (avg_ms * 1e-3) / 1e9,
+            "frac_hbm_algorithmic": alg / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+            "moved_state_bytes_per_launch": moved,
+            "traffic_bytes_per_launch": measured,
+            "frac_hbm_measured_traffic": (measured / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if measured else None,
+            "flops_per_launch": flops,
+            "achieved_fp64_TFLOPs": flops / (avg_ms * 1e-3) / 1e12,
+            "frac_fp64": flops / (avg_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+        }
+        # what the counters say limits the kernel: neither roof is near -> a chain of dependent latencies
+        entry["bound"] = "hbm" if entry["frac_hbm_algorithmic"] > 0.5 and (measured or 0) > 0.5 * alg else (
+            "fp64" if entry["frac_fp64"] > 0.5 else "latency/issue")
+        kernels.append(entry)
+    return kernels, acc
+
+
+def microbench_block():
+    """SURVEY.md 8(d) config 3's microbenchmark, timed inside this run: one u and one cu3 per sweep of a 2^n fp64
+    state (32 * 2^n algorithmic bytes per sweep), a few targets each, at n = 24 (256 MiB: the size of the Infinity
+    Cache, so back-to-back sweeps are served on-die) and n = 26 (1 GiB: HBM)."""
+    from queasars_amd.circuit_evaluation import StatevectorDevice
+
+    out = {}
+    for n in (24, 26):
+        dev = StatevectorDevice(n, group=1)
+        sweep_bytes = 32.0 * (1 << n)
+        rows = []
+        for target in sorted({0, 3, 7, 11, 12, 17, n - 3, n - 1}):
+            control = (target + n // 2) % n
+            ms_u = dev.bench_gate(target, -1, reps=20)
+            ms_c = dev.bench_gate(target, control, reps=20)
+            rows.append((target, sweep_bytes / ms_u / 1e6, sweep_bytes / ms_c / 1e6))
+        rates = [r for _, u, c in rows for r in (u, c)]
+        out[f"n{n}"] = {
+            "state_MiB": (16 << n) >> 20,
+            "targets": [t for t, _, _ in rows],
+            "u_GBps": [round(u, 1) for _, u, _ in rows],
+            "cu3_GBps": [round(c, 1) for _, _, c in rows],
+            "min_GBps": min(rates), "mean_GBps": sum(rates) / len(rates), "max_GBps": max(rates),
+            "frac_of_8TBps_mean": sum(rates) / len(rates) / HBM_PEAK_GBPS,
+            "bound": "hbm" if n >= 26 else "infinity cache (state = 256 MiB)",
+        }
+        dev.close()
+    out["note"] = ("achieved = 32 * 2^n bytes per sweep / mean sweep time (HIP events, 20 sweeps back to back); "
+                   "the HBM-honest row is n = 26; north_star's 60 % target is quoted on n = 24")
+    return out
+
+
+def cold_and_threaded(operator, n_steps: int = 4):
+    """The reference's calling patterns (N = 1): (a) every step brings a population of structures the device has never
+    seen (selection after topological search / layer removal: plan building and upload are inside the timed region);
+    (b) population_size threads, one circuit per call (selection.py:75-82), through CoalescingCircuitEvaluator."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from queasars_amd.circuit_evaluation import CoalescingCircuitEvaluator, OperatorCircuitEvaluator
+    from queasars_amd.evqe import EVQEPopulation
+
+    evaluator = OperatorCircuitEvaluator(operator)
+    pops = []
+    for s in range(n_steps + 1):
+        pop = EVQEPopulation.random_population(N_QUBITS, N_LAYERS, POP_PER_GPU, True, 1000 + s)
+        pops.append(([ind.get_parameterized_quantum_circuit() for ind in pop.individuals],
+                     [list(ind.parameter_values) for ind in pop.individuals]))
+    evaluator.evaluate_circuits(*pops[0])  # code objects, buffers
+    t0 = time.perf_counter()
+    for circuits, params in pops[1:]:
+        evaluator.evaluate_circuits(circuits, params)
+    cold = POP_PER_GPU * n_steps / (time.perf_counter() - t0)
+    circuits, params = pops[0]
+    merged = CoalescingCircuitEvaluator(evaluator)
+    with ThreadPoolExecutor(max_workers=POP_PER_GPU) as pool:
+        def one(j):
+            return merged.evaluate_circuits([circuits[j]], [params[j]])[0]
+
+        for _ in range(3):
+            list(pool.map(one, range(POP_PER_GPU)))
+        reps = 20
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            got = list(pool.map(one, range(POP_PER_GPU)))
+        threaded = POP_PER_GPU * reps / (time.perf_counter() - t0)
+    assert got == evaluator.evaluate_circuits(circuits, params)
+    evaluator.statevector_device.close()
+    return cold, threaded
+
+
+def config3_block(world: int, rank: int, local_rank: int, steps: int = 2):
+    """BASELINE.json configs[2] as north_star states it: n = 24, L = 4, P = 256 IN TOTAL (strong scaling: at N = 8 rank r
+    takes [32r, 32r+32), at N = 1 the one GPU evaluates all 256), 300-term Ising operator of default_rng(2024), through
+    the product's ``evaluate_population_sharded``."""
+    from queasars_amd.circuit_evaluation import OperatorCircuitEvaluator
+    from queasars_amd.distributed import evaluate_population_sharded, shard_bounds
+    from queasars_amd.evqe import EVQEPopulation
+
+    n, total = 24, 256
+    population = EVQEPopulation.random_population(n, 4, total, True, 0)
+    circuits = [ind.get_parameterized_quantum_circuit() for ind in population.individuals]
+    params = [list(ind.parameter_values) for ind in population.individuals]
+    operator = ising_operator(n, 2024)
+    evaluator = OperatorCircuitEvaluator(operator, device=local_rank)
+    lo, hi = shard_bounds(total, world, rank)
+
+    class Timed:  # this rank's own block, timed inside the sharded call: what the imbalance is computed from
+        own_s = 0.0
+
+        def evaluate_circuits(self, cs, ps):
+            t1 = time.perf_counter()
+            out = evaluator.evaluate_circuits(cs, ps)
+            Timed.own_s += time.perf_counter() - t1
+            return out
+
+    timed = Timed()
+    evaluate_population_sharded(timed, circuits, params)  # warm-up: plans, buffers
+    Timed.own_s = 0.0
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        values = evaluate_population_sharded(timed, circuits, params)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    assert len(values) == total and all(np.isfinite(values))
+    per_rank = [Timed.own_s / steps]
+    if world > 1:
+        t = torch.tensor([elapsed, Timed.own_s / steps], dtype=torch.float64, device="cuda")
+        gathered = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(gathered, t)
+        elapsed = max(float(g[0]) for g in gathered)
+        per_rank = [float(g[1]) for g in gathered]
+    evaluator.statevector_device.close()
+    return {
+        "workload": "24-qubit EVQE population = 256 in total, 4 layers, Ising 300 terms (default_rng(2024)), fp64 "
+        "(BASELINE.json configs[2]); strong scaling: rank r evaluates its contiguous block, one RCCL all-gather",
+        "value": total * steps / elapsed, "unit": "circuit-evals/s", "n_gpus": world, "steps": steps,
+        "ms_per_step": elapsed / steps * 1e3, "scaling": "strong", "individuals_per_rank": hi - lo,
+        "per_rank_ms_own_block": [round(x * 1e3, 3) for x in per_rank],
+        "imbalance_max_over_mean": max(per_rank) / (sum(per_rank) / len(per_rank)),
+    }
 
 
 def main() -> None:
@@ -83,6 +303,7 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="only the headline measurement (profiling runs)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -97,24 +318,21 @@ def main() -> None:
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     from queasars_amd.circuit_evaluation import OperatorCircuitEvaluator
+    from queasars_amd.distributed import evaluate_population_sharded, shard_bounds
     from queasars_amd.evqe import EVQEPopulation
 
     # ---- synthetic workload: one population of 64 * N individuals, rank r owns block r -------------------
     population = EVQEPopulation.random_population(N_QUBITS, N_LAYERS, POP_PER_GPU * world, True, 0)
-    mine = population.individuals[rank * POP_PER_GPU : (rank + 1) * POP_PER_GPU]
-    circuits = [ind.get_parameterized_quantum_circuit() for ind in mine]
-    params = [list(ind.parameter_values) for ind in mine]
+    circuits = [ind.get_parameterized_quantum_circuit() for ind in population.individuals]
+    params = [list(ind.parameter_values) for ind in population.individuals]
+    lo, hi = shard_bounds(len(circuits), world, rank)
     operator = ising_operator(N_QUBITS, 2020)
     evaluator = OperatorCircuitEvaluator(operator, device=local_rank)
     device = evaluator.statevector_device
-    fitness_all = torch.empty(world * POP_PER_GPU, dtype=torch.float64, device="cuda")
 
     def step():
-        local = evaluator.evaluate_circuits(circuits, params)
-        if world > 1:
-            send = torch.as_tensor(np.asarray(local), device="cuda")
-            dist.all_gather_into_tensor(fitness_all, send)  # RCCL: 64 doubles per rank
-        return local
+        # the product's sharding function: this rank's block on its GPU, then one all-gather of the fitness values
+        return evaluate_population_sharded(evaluator, circuits, params)
 
     def fence():
         torch.cuda.synchronize()
@@ -124,38 +342,64 @@ def main() -> None:
 
     for _ in range(args.warmup):
         step()
-    # ---- timed region: exactly K steps -------------------------------------------------------------------
-    device.set_profiling(True)  # HIP events on the library's stream around every group of pass launches
-    prof = {"pass_ms": 0.0, "pass_window_ms": 0.0, "n_pass_launches": 0, "state_bytes": 0, "moved_bytes": 0, "n_state_passes": 0,
-            "expect_ms": 0.0, "n_gates": 0}
+    # ---- timed region: exactly K steps (no profiling events inside) ---------------------------------------
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         values = step()
-        p = device.profile()
-        for key in prof:
-            prof[key] += p[key]
     fence()
     elapsed = time.perf_counter() - t0
-    device.set_profiling(False)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # ---- after the timed region: per-kernel roofline of the same step -------------------------------------
+    traffic = {}
+    tfile = ROOT / "profiles" / "traffic.json"
+    if tfile.exists():
+        try:
+            traffic = json.loads(tfile.read_text())
+        except Exception:
+            traffic = {}
+    kernels, prof = kernel_rooflines(device, step, min(args.steps, 10), traffic)
+    config3 = None
+    if not args.no_extras:
+        config3 = config3_block(world, rank, local_rank)
+
     if rank == 0:
         total_evals = POP_PER_GPU * world * args.steps
-        launches = max(prof["n_pass_launches"], 1)
-        avg_launch_ms = prof["pass_ms"] / launches
-        bytes_per_launch = prof["state_bytes"] / launches
-        achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
-        traffic = None
-        tfile = ROOT / "profiles" / "traffic.json"
-        if tfile.exists():
-            try:
-                traffic = json.loads(tfile.read_text()).get("pass_kernel_hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        dominant = max(kernels, key=lambda k: k["launches"] * k["avg_launch_us"]) if kernels else None
+        roofline = None
+        if dominant is not None:
+            roofline = {
+                "bound": "hbm",
+                "kernel": dominant["kernel"],
+                "achieved": dominant["achieved_GBps"],
+                "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s",
+                "frac": dominant["frac_hbm_algorithmic"],
+                "traffic": dominant["traffic_bytes_per_launch"],
+                "traffic_source": traffic.get("source"),
+                "avg_launch_us": dominant["avg_launch_us"],
+                "algorithmic_bytes_per_launch": dominant["algorithmic_bytes_per_launch"],
+                "observed_limiter": dominant["bound"],
+                "frac_hbm_on_measured_traffic": dominant["frac_hbm_measured_traffic"],
+                "frac_fp64": dominant["frac_fp64"],
+                "kernels": kernels,
+                "gates_per_s": prof["n_gates"] / (prof["pass_window_ms"] * 1e-3) if prof["pass_window_ms"] > 0 else None,
+                "pass_window_ms_per_step": prof["pass_window_ms"] / min(args.steps, 10),
+                "note": "top-level fields describe the instantiation with the most GPU time.  achieved = algorithmic state "
+                "bytes per launch (16 * 2^n per state and direction the pass has to move: pass 0 synthesises and only "
+                "writes, a last pass with the fused diagonal expectation only reads, passes in between do both; SURVEY "
+                "8(d)) / mean launch time from HIP events around every launch on its own stream, measured in "
+                "profiled steps after the timed region.  HBM is the roof SURVEY 8(d) names for the path; at n = 20 the "
+                "counters say the launches are bound by dependent latencies and instruction issue instead "
+                "(observed_limiter; the compact first pass keeps most state traffic on chip: traffic << algorithmic "
+                "bytes), so frac_fp64 and frac_hbm_on_measured_traffic are given too.  traffic = 2 x FETCH_SIZE + "
+                "WRITE_SIZE per launch from separate rocprofv3 --pmc passes of this command (profiles/, see "
+                "traffic_source), gfx950 correction of MI355X_MICROARCH.md",
+            }
         result = {
             "metric": "circuit-evals/sec (EVQE population) at n qubits; achieved HBM GB/s vs roofline",
             "value": total_evals / elapsed,
@@ -178,37 +422,19 @@ def main() -> None:
                 "pauli_terms": len(operator),
                 "parallelism": f"population sharded over {world} GPU(s), RCCL all-gather of fitness" if world > 1 else "1 GPU",
             },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": "qsv::pass_kernel<double, 3, 2, *> (both instantiations: the synthesising pass 0 and later passes)",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": traffic,
-                "launches": launches,
-                "avg_launch_ms": avg_launch_ms,
-                "algorithmic_bytes_per_launch": bytes_per_launch,
-                "gates_per_s": prof["n_gates"] / (prof["pass_window_ms"] * 1e-3) if prof["pass_window_ms"] > 0 else None,
-                # launches of different pushes overlap on two HIP streams: the same bytes over the wall-clock window
-                # of a step's passes is the chip-level rate
-                "aggregate_achieved": prof["state_bytes"] / (prof["pass_window_ms"] * 1e-3) / 1e9
-                if prof["pass_window_ms"] > 0 else None,
-                "pass_window_ms_per_step": prof["pass_window_ms"] / args.steps,
-                # state bytes the launches really moved (a compact first pass replaces the state round trip between
-                # the first two passes by a small table) and, for comparison with sweep-per-gate simulators, the same
-                # launches at SURVEY.md 8(d)'s flat price of 32 * 2^n bytes per state and pass
-                "moved_bytes_per_launch": prof["moved_bytes"] / launches,
-                "sweep_equivalent_achieved": prof["n_state_passes"] * 32.0 * (1 << N_QUBITS) / (prof["pass_ms"] * 1e-3) / 1e9
-                if prof["pass_ms"] > 0 else None,
-                "note": "achieved = algorithmic state bytes per pass launch / mean launch time (HIP events on the stream "
-                "each launch runs on).  Algorithmic bytes: 16 * 2^n per state and direction a fused-pass design has to "
-                "move (SURVEY 8(d): 32 * 2^n per full pass; pass 0 synthesises and only writes, the last pass fuses the "
-                "expectation and only reads).  The compact first pass (DESIGN.md 4.1 item 1b) then avoids most of that "
-                "traffic (moved_bytes_per_launch, and `traffic` from the PMC counters), so the passes are bound by fp64 "
-                "issue, LDS traffic and latency rather than by HBM",
-            },
+            "roofline": roofline,
         }
+        if config3 is not None:
+            result["config3"] = config3
+        if world == 1 and not args.no_extras:
+            result["roofline"]["microbench"] = microbench_block()
+            cold, threaded = cold_and_threaded(operator)
+            result["cold_structure_evals_per_s"] = cold
+            result["threaded_b1_evals_per_s"] = threaded
+            result["calling_pattern_note"] = (
+                "cold: every step evaluates 64 circuit structures the device has never seen (plan building + upload "
+                "inside the timed region); threaded: 64 host threads, one circuit per call (the reference's selection "
+                "operator, selection.py:75-82) through CoalescingCircuitEvaluator")
         if world == 1 and not args.no_cpu_baseline:
             base, ref_values = cpu_baseline(circuits, params, operator)
             result["cpu_baseline"] = base

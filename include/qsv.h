@@ -81,6 +81,17 @@ typedef struct qsv_profile {
     double pass_window_ms;     /* wall-clock window from the first gate-pass launch to the end of the last one */
     uint64_t moved_bytes;      /* state bytes the launches really moved: less than state_bytes when a compact first pass
                                   replaced the state round trip between the first two passes by a small table */
+    /* The gate-pass kernel has two instantiations; with profiling on, every launch is bracketed by HIP events on the
+       stream it runs on.  [0] = the synthesising first pass (writes only), [1] = every later pass (the last one fuses
+       the diagonal expectation and then only reads).  bytes = algorithmic state bytes at the pass's own price
+       (16 * 2^n per state and direction it has to move), moved = what it really moves (compact tables), flops =
+       24 per amplitude pair the pass updates (4 multiplications + 10 fused multiply-adds). */
+    uint64_t kernel_launches[2];
+    double kernel_ms[2];
+    uint64_t kernel_bytes[2];
+    uint64_t kernel_moved_bytes[2];
+    double kernel_flops[2];
+    uint64_t kernel_states[2]; /* states swept, summed over launches */
 } qsv_profile;
 
 /* ---- lifetime ---------------------------------------------------------------------------------- */

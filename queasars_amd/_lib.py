@@ -52,6 +52,12 @@ class QsvProfile(C.Structure):
         ("total_ms", C.c_double),
         ("pass_window_ms", C.c_double),
         ("moved_bytes", C.c_uint64),
+        ("kernel_launches", C.c_uint64 * 2),
+        ("kernel_ms", C.c_double * 2),
+        ("kernel_bytes", C.c_uint64 * 2),
+        ("kernel_moved_bytes", C.c_uint64 * 2),
+        ("kernel_flops", C.c_double * 2),
+        ("kernel_states", C.c_uint64 * 2),
     ]
 
 

@@ -347,7 +347,11 @@ class StatevectorDevice:
     def profile(self) -> dict:
         prof = _lib.QsvProfile()
         self._check(self._lib.qsv_get_profile(self._handle, C.byref(prof)))
-        return {name: getattr(prof, name) for name, _ in prof._fields_}
+        out = {}
+        for name, ctype in prof._fields_:
+            value = getattr(prof, name)
+            out[name] = list(value) if hasattr(value, "__len__") else value
+        return out
 
     def bench_gate(self, target: int, control: int = -1, theta=1.0, phi=0.5, lam=0.25, reps: int = 100) -> float:
         """Average device milliseconds of one read-modify-write sweep applying a single u / cu3 gate."""

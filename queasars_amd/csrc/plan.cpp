@@ -579,6 +579,8 @@ CircuitPlan build_plan(int n, const std::vector<GateIn>& all_gates, const std::v
             }
         }
 
+        const double pass_tiles = cstore ? double(uint64_t(1) << compact_bits) : double(uint64_t(1) << (n - k));
+        double pairs_this_pass = 0.0;
         for (size_t m = 0; m < pass.rounds.size(); ++m) {
             const RoundPlan& rd = pass.rounds[m];
             const Layout& lay = layouts[m];
@@ -623,9 +625,11 @@ CircuitPlan build_plan(int n, const std::vector<GateIn>& all_gates, const std::v
                 w.push_back(cg);
                 w.push_back(uint32_t(g.op));
                 schedule.push_back(gi);
+                pairs_this_pass += pass_tiles * double(uint64_t(1) << (k - 1)) * (g.control >= 0 ? 0.5 : 1.0);
             }
             out.stats.n_rounds += 1;
         }
+        out.stats.pass_pairs.push_back(pairs_this_pass);
     }
     // angle table: scheduled gates first, then the fold entries; fold index per qubit
     w[3] = uint32_t(w.size());

@@ -70,6 +70,10 @@ struct PlanStats {
     int n_folded_gates = 0;   // u gates absorbed into the initial product state
     int n_dropped_gates = 0;  // cu3 gates whose control is still |0>: identity
     int lds_conflict_cycles = 0;  // extra LDS cycles per wave-instruction summed over exchanges (0 = conflict free)
+    // amplitude pairs each pass really updates per state (controls and a compact first pass taken into account: a
+    // control held by a register, a thread or the tile index halves a gate's pairs); one pair = 4 multiplications +
+    // 10 fused multiply-adds
+    std::vector<double> pass_pairs;
 };
 
 struct CircuitPlan {

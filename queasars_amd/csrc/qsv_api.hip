@@ -102,6 +102,7 @@ struct qsv_handle {
         size_t desc_bytes = 0;
         size_t pushed = 0;                 // evaluations launched so far
         std::vector<std::pair<hipEvent_t, hipEvent_t>> pass_events, exp_events;
+        std::vector<std::pair<hipEvent_t, hipEvent_t>> launch_events[2];  // per launch: [0] first pass, [1] later passes
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
         bool dual = false;   // this batch alternates pushes between the two streams
         bool used2 = false;  // ... and the second one has work in flight
@@ -111,6 +112,7 @@ struct qsv_handle {
 
     // profiling
     bool profiling = false;
+    bool stamping = false;  // per-launch events are recorded (inside qsv_eval_push of a profiled batch only)
     qsv_profile prof{};
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
 };
@@ -426,6 +428,20 @@ unsigned chunks_per_state(const qsv_t* h) {
 // partial sums the fused last pass leaves per state: one per wave of every workgroup
 unsigned partials_per_state(const qsv_t* h) { return chunks_per_state(h) * unsigned(h->geo.threads_launch / 64); }
 
+hipError_t stamp(qsv_t* h, std::vector<std::pair<hipEvent_t, hipEvent_t>>& list, bool begin) {
+    if (!h->profiling) return hipSuccess;
+    if (begin) {
+        std::pair<hipEvent_t, hipEvent_t> p{nullptr, nullptr};
+        hipError_t e = hipEventCreate(&p.first);
+        if (e != hipSuccess) return e;
+        e = hipEventCreate(&p.second);
+        if (e != hipSuccess) return e;
+        list.push_back(p);
+        return hipEventRecord(p.first, ws(h));
+    }
+    return hipEventRecord(list.back().second, ws(h));
+}
+
 // Run the gate passes of evaluations [first, first+count) of the current batch (one launch group).
 int run_group(qsv_t* h, const std::vector<Circuit*>& circs, size_t first, size_t count, uint32_t mode) {
     int max_passes = 0;
@@ -444,42 +460,38 @@ int run_group(qsv_t* h, const std::vector<Circuit*>& circs, size_t first, size_t
     const unsigned chunks = chunks_per_state(h);
     a.tiles_per_block = h->geo.blocks_per_state / chunks;
     dim3 grid(chunks, unsigned(count));
+    const uint64_t sweep = (uint64_t(1) << h->n) * h->amp_bytes;
     for (int p = 0; p < max_passes; ++p) {
         a.pass_index = uint32_t(p);
+        const int kind = (p == 0 && (mode & kModeSynthFirst)) ? 0 : 1;  // which instantiation of the kernel runs
+        if (h->stamping) QSV_HIP(h, stamp(h, h->batch.launch_events[kind], true));
         QSV_HIP(h, launch_pass(h->dtype, h->geo.r, h->cfg.xmode, grid, h->geo.threads_launch, h->geo.lds_bytes, ws(h), a));
+        if (h->stamping) QSV_HIP(h, stamp(h, h->batch.launch_events[kind], false));
         h->prof.n_pass_launches += 1;
         h->prof.n_state_passes += count;
-    }
-    // state bytes moved: pass 0 synthesises (write only), the last pass only reads when the expectation is fused
-    const uint64_t sweep = (uint64_t(1) << h->n) * h->amp_bytes;
-    for (size_t i = 0; i < count; ++i) {
-        const int np = circs[first + i]->plan.stats.n_passes;
-        uint64_t halves = 2 * uint64_t(np);          // every pass: one read + one write ...
-        if (mode & kModeSynthFirst) halves -= 1;     // ... except that a synthesising pass 0 does not read
-        if (!(mode & kModeFinalStore)) halves -= 1;  // ... and the fused last pass does not write
-        h->prof.state_bytes += halves * sweep;
-        // what the launches really move: a compact first pass writes, and pass 1 reads, a table of 2^cb tiles
-        const int cb = circs[first + i]->plan.stats.compact_bits;
-        if ((mode & kModeSynthFirst) && cb >= 0)
-            h->prof.moved_bytes += (halves - 2) * sweep + 2 * ((uint64_t(1) << (cb + h->geo.k)) * h->amp_bytes);
-        else
-            h->prof.moved_bytes += halves * sweep;
+        h->prof.kernel_launches[kind] += 1;
+        // Algorithmic state bytes at this pass's own price: every pass reads and writes the state once, except that a
+        // synthesising pass 0 does not read and a fused last pass does not write.  What it really moves is less when
+        // a compact pass 0 writes, and pass 1 reads, a table of 2^cb tiles instead of the state.
+        for (size_t i = 0; i < count; ++i) {
+            const PlanStats& st = circs[first + i]->plan.stats;
+            if (p >= st.n_passes) continue;
+            const bool reads = !(p == 0 && (mode & kModeSynthFirst));
+            const bool writes = !(p + 1 == st.n_passes && !(mode & kModeFinalStore));
+            const uint64_t table = (mode & kModeSynthFirst) && st.compact_bits >= 0
+                                       ? (uint64_t(1) << (st.compact_bits + h->geo.k)) * h->amp_bytes
+                                       : sweep;
+            const uint64_t alg = (reads ? sweep : 0) + (writes ? sweep : 0);
+            const uint64_t moved = (reads ? (p == 1 ? table : sweep) : 0) + (writes ? (p == 0 ? table : sweep) : 0);
+            h->prof.state_bytes += alg;
+            h->prof.moved_bytes += moved;
+            h->prof.kernel_bytes[kind] += alg;
+            h->prof.kernel_moved_bytes[kind] += moved;
+            h->prof.kernel_states[kind] += 1;
+            if (size_t(p) < st.pass_pairs.size()) h->prof.kernel_flops[kind] += 24.0 * st.pass_pairs[size_t(p)];
+        }
     }
     return QSV_OK;
-}
-
-hipError_t stamp(qsv_t* h, std::vector<std::pair<hipEvent_t, hipEvent_t>>& list, bool begin) {
-    if (!h->profiling) return hipSuccess;
-    if (begin) {
-        std::pair<hipEvent_t, hipEvent_t> p{nullptr, nullptr};
-        hipError_t e = hipEventCreate(&p.first);
-        if (e != hipSuccess) return e;
-        e = hipEventCreate(&p.second);
-        if (e != hipSuccess) return e;
-        list.push_back(p);
-        return hipEventRecord(p.first, ws(h));
-    }
-    return hipEventRecord(list.back().second, ws(h));
 }
 
 int eval_begin(qsv_t* h, const std::vector<Circuit*>& circs, const std::vector<int64_t>& n_params) {
@@ -521,8 +533,12 @@ int eval_push(qsv_t* h, size_t first, size_t count, const double* values) {
     size_t G = size_t(h->group);
     struct WorkGuard {
         qsv_t* h;
-        ~WorkGuard() { h->work = nullptr; }
+        ~WorkGuard() {
+            h->work = nullptr;
+            h->stamping = false;
+        }
     } guard{h};
+    h->stamping = h->profiling;
     EvalDesc* hd = static_cast<EvalDesc*>(h->h_batch);  // pinned; prepare_kernel reads it after this point
     if (b.dual) {
         const size_t half = G / 2, side = b.n_pushes & 1;
@@ -598,6 +614,11 @@ int eval_end(qsv_t* h, double* out) {
             QSV_HIP(h, hipEventElapsedTime(&ms, p.first, p.second));
             h->prof.pass_ms += ms;
         }
+        for (int kind = 0; kind < 2; ++kind)
+            for (auto& p : b.launch_events[kind]) {
+                QSV_HIP(h, hipEventElapsedTime(&ms, p.first, p.second));
+                h->prof.kernel_ms[kind] += ms;
+            }
         // wall-clock window of the gate passes: with two streams the per-push intervals above overlap
         if (!b.pass_events.empty() && !b.exp_events.empty()) {
             QSV_HIP(h, hipEventElapsedTime(&ms, b.pass_events.front().first, b.exp_events.front().first));
@@ -614,7 +635,7 @@ int eval_end(qsv_t* h, double* out) {
 // Releases whatever a batch holds (events) and marks it closed; safe to call on error paths.
 void eval_close(qsv_t* h) {
     qsv_handle::Batch& b = h->batch;
-    for (auto* list : {&b.pass_events, &b.exp_events}) {
+    for (auto* list : {&b.pass_events, &b.exp_events, &b.launch_events[0], &b.launch_events[1]}) {
         for (auto& p : *list) {
             if (p.first) (void)hipEventDestroy(p.first);
             if (p.second) (void)hipEventDestroy(p.second);

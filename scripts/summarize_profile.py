@@ -47,21 +47,29 @@ if stats:
     print("\n== pass_kernel, both instantiations ==")
     print(f"calls={calls} total_ns={total:.0f} avg_ns={total / calls:.0f}")
 
-# HBM traffic per pass launch, corrected as MI355X_MICROARCH.md (HBM section) prescribes: FETCH_SIZE under-reports
-# wide coalesced reads by exactly 2x on gfx950; WRITE_SIZE is exact; both are in KiB.
-fetch, write = [], []
+# HBM traffic per launch and per instantiation of the gate-pass kernel, corrected as MI355X_MICROARCH.md (HBM section)
+# prescribes: FETCH_SIZE under-reports wide coalesced reads by exactly 2x on gfx950; WRITE_SIZE is exact; both in KiB.
+# bench.py reads this file (profiles/traffic.json) for roofline.traffic.
+kernels = {}
 for kern, counters in acc.items():
-    if "pass_kernel" in kern:
-        fetch += counters.get("FETCH_SIZE", [])
-        write += counters.get("WRITE_SIZE", [])
-if fetch and write:
-    f_mean, w_mean = sum(fetch) / len(fetch), sum(write) / len(write)
+    if "pass_kernel" not in kern:
+        continue
+    kind = "0" if ", true>" in kern else "1"
+    fetch, write = counters.get("FETCH_SIZE", []), counters.get("WRITE_SIZE", [])
+    if fetch and write:
+        f_mean, w_mean = sum(fetch) / len(fetch), sum(write) / len(write)
+        kernels[kind] = {
+            "kernel": kern,
+            "FETCH_SIZE_KiB_mean": f_mean,
+            "WRITE_SIZE_KiB_mean": w_mean,
+            "hbm_bytes_per_launch": (2.0 * f_mean + w_mean) * 1024.0,
+            "dispatches_sampled": len(fetch),
+        }
+if kernels:
     out = {
-        "kernel": "qsv::pass_kernel<double, 3, 2, *> (both instantiations)",
-        "FETCH_SIZE_KiB_mean": f_mean,
-        "WRITE_SIZE_KiB_mean": w_mean,
-        "pass_kernel_hbm_bytes_per_launch": (2.0 * f_mean + w_mean) * 1024.0,
-        "note": "mean over the pass launches of the profiled run; reads = 2 x FETCH_SIZE (gfx950 correction), writes = WRITE_SIZE",
+        "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `python3 bench.py --steps 3 --warmup 1 --no-extras "
+        f"--no-cpu-baseline` ({root}); reads = 2 x FETCH_SIZE (gfx950 correction), writes = WRITE_SIZE, KiB -> bytes",
+        "kernels": kernels,
     }
     print("\n== traffic ==")
     print(json.dumps(out))

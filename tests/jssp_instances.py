@@ -47,3 +47,14 @@ def three_by_three():
         Job(f"j{j}", tuple(Operation(f"op{k}", f"j{j}", m[route[k]], 1) for k in range(3))) for j, route in enumerate(routes)
     )
     return JobShopSchedulingProblemInstance("3_jobs_3_machines", m, jobs)
+
+
+def three_by_three_contended():
+    """3 jobs x 3 machines, unit durations, makespan limit 5 -> 18 qubits, with two jobs starting on the same machine:
+    unlike :func:`three_by_three` the all-zero state (every operation as early as possible) is NOT a valid schedule."""
+    m = (Machine("m0"), Machine("m1"), Machine("m2"))
+    routes = ((0, 1, 2), (0, 2, 1), (1, 0, 2))
+    jobs = tuple(
+        Job(f"j{j}", tuple(Operation(f"op{k}", f"j{j}", m[route[k]], 1) for k in range(3))) for j, route in enumerate(routes)
+    )
+    return JobShopSchedulingProblemInstance("3_jobs_3_machines_contended", m, jobs)

@@ -1,0 +1,343 @@
+"""GPU tests of the BASELINE.json configurations at (or near) their full sizes, of the committed golden fixtures
+through the two batch entry points of the C ABI, and of the remaining ABI surface.  Run on the MI355X box with -m gpu.
+
+Tolerances (stated where used): fp64 expectation values within 1e-10 of the oracle (north_star); fp32 expectation
+values within FP32_REL * sum_k |c_k| of the fp64 value (fp32 carries 2^-24 = 6e-8 per rounding; a four-layer circuit
+applies a few dozen butterflies to every amplitude and the reductions accumulate in fp64).
+"""
+
+import ctypes as C
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import helpers
+from queasars_amd import _lib
+from queasars_amd.circuit_evaluation import OperatorCircuitEvaluator, StatevectorDevice
+from queasars_amd.ir import QSV_OP_DTYPE, CircuitIR, PauliOperator
+
+pytestmark = pytest.mark.gpu
+
+EXP_TOL = 1e-10
+FP32_REL = 2e-6
+GOLDEN = Path(__file__).resolve().parent / "golden" / "evqe_small.json"
+
+
+# ---- raw C ABI helpers (no StatevectorDevice: these tests call libqsv the way INTEGRATION.md's stub does) -----------
+
+
+class RawHandle:
+    def __init__(self, n_qubits, dtype=_lib.QSV_F64):
+        self.lib = _lib.load()
+        self.h = C.c_void_p()
+        rc = self.lib.qsv_create(n_qubits, dtype, 0, None, C.byref(self.h))
+        assert rc == _lib.QSV_OK, _lib.last_error(self.lib, None)
+
+    def check(self, rc):
+        assert rc == _lib.QSV_OK, _lib.last_error(self.lib, self.h)
+
+    def set_operator(self, op: PauliOperator):
+        x, z = np.ascontiguousarray(op.x_mask), np.ascontiguousarray(op.z_mask)
+        cre, cim = np.ascontiguousarray(op.coeffs.real), np.ascontiguousarray(op.coeffs.imag)
+        self.check(self.lib.qsv_set_operator(self.h, len(op), _lib.as_ptr(x), _lib.as_ptr(z), _lib.as_ptr(cre), _lib.as_ptr(cim)))
+
+    def close(self):
+        if self.h:
+            self.lib.qsv_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+def ops_array(rows, parameterised: bool):
+    """qsv_op records of bound ``(kind, target, control, theta, phi, lam)`` rows: with literal angles, or with every
+    angle of gate g taken from params[3g .. 3g+3) (and a literal that must then be ignored)."""
+    arr = np.zeros(len(rows), dtype=QSV_OP_DTYPE)
+    params = []
+    for i, (kind, target, control, theta, phi, lam) in enumerate(rows):
+        ctrl = 0xFF if control is None or control < 0 else control
+        if parameterised and kind != 0:
+            base = len(params)
+            params += [theta, phi, lam]
+            arr[i] = (kind, target, ctrl, 0, base, base + 1, base + 2, 99.0, 99.0, 99.0)
+        else:
+            arr[i] = (kind, target, ctrl, 0, -1, -1, -1, theta, phi, lam)
+    return arr, np.asarray(params, dtype=np.float64)
+
+
+def golden_cases():
+    return json.loads(GOLDEN.read_text())["cases"]
+
+
+# ---- (iii) committed golden fixtures through qsv_eval_batch and qsv_eval_circuits --------------------------------
+
+
+@pytest.mark.parametrize("parameterised", [False, True])
+def test_golden_fixtures_through_qsv_eval_batch(parameterised):
+    """Every case of tests/golden/evqe_small.json through ``qsv_eval_batch`` (op lists inline; replaces
+    ``estimator.run(pubs)``, circuit_evaluation.py:204-215).  Cases of one qubit count share a handle and operator
+    changes in between; the batch holds each case three times to exercise the inline-structure cache."""
+    by_n = {}
+    for case in golden_cases():
+        by_n.setdefault(case["n_qubits"], []).append(case)
+    worst = 0.0
+    for n, cases in sorted(by_n.items()):
+        with RawHandle(n) as raw:
+            for case in cases:
+                raw.set_operator(PauliOperator(case["labels"], case["coeffs"]))
+                ops, params = ops_array([tuple(o) for o in case["ops"]], parameterised)
+                reps = 3
+                all_ops = np.concatenate([ops] * reps)
+                op_offsets = np.arange(reps + 1, dtype=np.int64) * len(ops)
+                all_params = np.concatenate([params] * reps) if params.size else np.zeros(1)
+                param_offsets = np.arange(reps + 1, dtype=np.int64) * len(params)
+                out = np.full(reps, np.nan)
+                raw.check(raw.lib.qsv_eval_batch(raw.h, reps, _lib.as_ptr(op_offsets), _lib.as_ptr(all_ops),
+                                                 _lib.as_ptr(param_offsets), _lib.as_ptr(all_params), _lib.as_ptr(out)))
+                assert out[0] == out[1] == out[2]
+                worst = max(worst, abs(out[0] - case["expectation"]))
+    assert worst < EXP_TOL
+
+
+def test_golden_fixtures_through_qsv_eval_circuits_and_statevector():
+    """The same fixtures through ``qsv_circuit_create`` + ``qsv_eval_circuits`` (the call INTEGRATION.md's ctypes stub
+    makes), all cases of one qubit count in ONE call where they share an operator... they do not, so one call per
+    case plus one mixed call with gaps between the parameter vectors; stored amplitudes through ``qsv_statevector``."""
+    worst_e = worst_a = 0.0
+    for case in golden_cases():
+        n = case["n_qubits"]
+        with RawHandle(n) as raw:
+            raw.set_operator(PauliOperator(case["labels"], case["coeffs"]))
+            rows = [tuple(o) for o in case["ops"]]
+            lit, _ = ops_array(rows, False)
+            par, params = ops_array(rows, True)
+            cid_lit, cid_par = C.c_int(0), C.c_int(0)
+            raw.check(raw.lib.qsv_circuit_create(raw.h, len(lit), _lib.as_ptr(lit), 0, C.byref(cid_lit)))
+            raw.check(raw.lib.qsv_circuit_create(raw.h, len(par), _lib.as_ptr(par), len(params), C.byref(cid_par)))
+            # three evaluations; the parameter vectors sit in a buffer with unused gaps between them
+            ids = np.asarray([cid_par.value, cid_lit.value, cid_par.value], dtype=np.int32)
+            buf = np.full(2 * len(params) + 7, 1234.5)
+            buf[: len(params)] = params
+            buf[len(params) + 5 : 2 * len(params) + 5] = params
+            offsets = np.asarray([0, len(params), len(params) + 5, 2 * len(params) + 5], dtype=np.int64)
+            # evaluation 1 (literal circuit) declares the gap as its vector: extra values are ignored
+            out = np.full(3, np.nan)
+            raw.check(raw.lib.qsv_eval_circuits(raw.h, 3, _lib.as_ptr(ids), _lib.as_ptr(offsets), _lib.as_ptr(buf), _lib.as_ptr(out)))
+            worst_e = max(worst_e, float(np.abs(out - case["expectation"]).max()))
+            if "state_re" in case:
+                state = np.empty(2 << n)
+                raw.check(raw.lib.qsv_statevector(raw.h, cid_par.value, _lib.as_ptr(params) if params.size else None,
+                                                  len(params), _lib.as_ptr(state)))
+                want = np.asarray(case["state_re"]) + 1j * np.asarray(case["state_im"])
+                worst_a = max(worst_a, float(np.abs(state.view(np.complex128) - want).max()))
+            raw.check(raw.lib.qsv_circuit_destroy(raw.h, cid_lit.value))
+            assert raw.lib.qsv_circuit_destroy(raw.h, cid_lit.value) == _lib.QSV_E_ARG  # already gone
+    assert worst_e < EXP_TOL and worst_a < 1e-12
+
+
+def test_eval_batch_survives_more_structures_than_its_cache_holds():
+    """``qsv_eval_batch`` keeps at most 4096 inline structures registered.  Push more distinct structures than that,
+    within one call and across calls: every result must still be right (the round-1 library freed plans that earlier
+    evaluations of the same call pointed at)."""
+    n = 5
+    op = helpers.random_pauli_operator(n, 6, seed=3)
+    rng = np.random.default_rng(0)
+
+    def batch(count):
+        angles = rng.uniform(0, 2 * np.pi, size=(count, 6))
+        ops = np.zeros(3 * count, dtype=QSV_OP_DTYPE)
+        for i, a in enumerate(angles):
+            ops[3 * i] = (1, 0, 0xFF, 0, -1, -1, -1, a[0], a[1], a[2])
+            ops[3 * i + 1] = (1, 3, 0xFF, 0, -1, -1, -1, a[3], 0.1, 0.2)
+            ops[3 * i + 2] = (2, 2, 0, 0, -1, -1, -1, a[4], a[5], 0.3)  # cu3 control 0 -> target 2
+        return angles, ops
+
+    def reference(a):
+        c = CircuitIR(n).u(a[0], a[1], a[2], 0).u(a[3], 0.1, 0.2, 3).cu3(a[4], a[5], 0.3, 0, 2)
+        return helpers.oracle_expectation(c, [], op)
+
+    with RawHandle(n) as raw:
+        raw.set_operator(op)
+        for count in (3000, 3000, 5000, 10):  # the cache overflows between calls 2 and 3, and inside call 3
+            angles, ops = batch(count)
+            op_offsets = np.arange(count + 1, dtype=np.int64) * 3
+            param_offsets = np.zeros(count + 1, dtype=np.int64)
+            out = np.full(count, np.nan)
+            raw.check(raw.lib.qsv_eval_batch(raw.h, count, _lib.as_ptr(op_offsets), _lib.as_ptr(ops), _lib.as_ptr(param_offsets),
+                                             None, _lib.as_ptr(out)))
+            for i in list(range(0, count, max(1, count // 40))) + [count - 1]:
+                assert abs(out[i] - reference(angles[i])) < EXP_TOL
+
+
+def test_sample_single_and_foreign_stream():
+    """``qsv_sample`` (one circuit) and ``qsv_set_stream`` (launch on a caller-owned HIP stream, here one of torch's)."""
+    import torch
+
+    n = 9
+    _, circuits, params = helpers.population_circuits(n, 2, 2, seed=5)
+    op = helpers.random_ising_operator(n, seed=7)
+    with RawHandle(n) as raw:
+        raw.set_operator(op)
+        ops = circuits[0].packed()
+        cid = C.c_int(0)
+        raw.check(raw.lib.qsv_circuit_create(raw.h, len(ops), _lib.as_ptr(ops), circuits[0].num_parameters, C.byref(cid)))
+        p = np.asarray(params[0], dtype=np.float64)
+        offsets = np.asarray([0, len(p)], dtype=np.int64)
+        ids = np.asarray([cid.value], dtype=np.int32)
+        before = np.zeros(1)
+        raw.check(raw.lib.qsv_eval_circuits(raw.h, 1, _lib.as_ptr(ids), _lib.as_ptr(offsets), _lib.as_ptr(p), _lib.as_ptr(before)))
+        stream = torch.cuda.Stream()
+        raw.check(raw.lib.qsv_set_stream(raw.h, C.c_void_p(stream.cuda_stream)))
+        after = np.zeros(1)
+        raw.check(raw.lib.qsv_eval_circuits(raw.h, 1, _lib.as_ptr(ids), _lib.as_ptr(offsets), _lib.as_ptr(p), _lib.as_ptr(after)))
+        assert after[0] == before[0] and abs(after[0] - helpers.oracle_expectation(circuits[0], params[0], op)) < EXP_TOL
+        shots = 50_000
+        states = np.zeros(shots, dtype=np.uint64)
+        raw.check(raw.lib.qsv_sample(raw.h, cid.value, _lib.as_ptr(p), len(p), shots, C.c_uint64(77), _lib.as_ptr(states)))
+        again = np.zeros(shots, dtype=np.uint64)
+        raw.check(raw.lib.qsv_sample(raw.h, cid.value, _lib.as_ptr(p), len(p), shots, C.c_uint64(77), _lib.as_ptr(again)))
+        assert np.array_equal(states, again)
+        probs = np.abs(helpers.oracle_state(circuits[0], params[0])) ** 2
+        freq = np.bincount(states.astype(np.int64), minlength=1 << n) / shots
+        assert np.all(np.abs(freq - probs) < 6 * np.sqrt(probs * (1 - probs) / shots) + 2.0 / shots)
+        raw.check(raw.lib.qsv_set_stream(raw.h, None))  # back to a stream of the library's own
+        raw.check(raw.lib.qsv_eval_circuits(raw.h, 1, _lib.as_ptr(ids), _lib.as_ptr(offsets), _lib.as_ptr(p), _lib.as_ptr(after)))
+        assert after[0] == before[0]
+        # a second begin on the thread that holds an open batch is refused instead of waiting for itself
+        counts = np.asarray([len(p)], dtype=np.int64)
+        raw.check(raw.lib.qsv_eval_begin(raw.h, 1, _lib.as_ptr(ids), _lib.as_ptr(counts)))
+        assert raw.lib.qsv_eval_begin(raw.h, 1, _lib.as_ptr(ids), _lib.as_ptr(counts)) == _lib.QSV_E_STATE
+        raw.check(raw.lib.qsv_eval_push(raw.h, 0, 1, _lib.as_ptr(p)))
+        raw.check(raw.lib.qsv_eval_end(raw.h, _lib.as_ptr(after)))
+        assert after[0] == before[0]
+
+
+# ---- (ii) BASELINE config 3's workload on one GPU, against the C oracle -------------------------------------------
+
+
+def test_config3_n24_population_against_the_c_oracle(c_oracle):
+    """n = 24, L = 4, the 300-term Ising operator of default_rng(2024): individuals 0, 1, 100 and 255 of the
+    256-individual population (seed 0) directly against the plain-C oracle, |dE| <= 1e-10."""
+    n = 24
+    _, circuits, params = helpers.population_circuits(n, 4, 256, seed=0)
+    pick = [0, 1, 100, 255]
+    cs, ps = [circuits[i] for i in pick], [params[i] for i in pick]
+    op = helpers.random_ising_operator(n, seed=2024)
+    assert len(op) == 300
+    got = np.asarray(OperatorCircuitEvaluator(op).evaluate_circuits(cs, ps))
+    table = c_oracle.diagonal_table(op)
+    scratch = np.zeros(2 << n)
+    ref = np.asarray([c_oracle.evaluate(c, p, op, table, scratch) for c, p in zip(cs, ps)])
+    assert np.abs(got - ref).max() < EXP_TOL
+
+
+# ---- (i) BASELINE config 5: general 500-term operator, fp64 and fp32 ----------------------------------------------
+
+
+@pytest.mark.parametrize("n_qubits", [20, 23])
+def test_config5_general_operator_against_the_c_oracle(n_qubits, c_oracle):
+    """The general-operator path (x-mask groups, pair kernels) with config 5's operator family -- 500 random Pauli
+    strings over {I,X,Y,Z}, coefficients uniform(-1,1), default_rng(2028) -- at sizes the C oracle finishes in
+    seconds: fp64 within 1e-10, fp32 within FP32_REL * sum |c_k| of the oracle."""
+    _, circuits, params = helpers.population_circuits(n_qubits, 4, 2, seed=0)
+    op = helpers.random_pauli_operator(n_qubits, 500, seed=2028)
+    ref = np.asarray([c_oracle.evaluate(c, p, op) for c, p in zip(circuits, params)])
+    got64 = np.asarray(OperatorCircuitEvaluator(op).evaluate_circuits(circuits, params))
+    assert np.abs(got64 - ref).max() < EXP_TOL
+    got32 = np.asarray(OperatorCircuitEvaluator(op, dtype="fp32").evaluate_circuits(circuits, params))
+    assert np.abs(got32 - ref).max() < FP32_REL * float(np.abs(op.coeffs).sum())
+
+
+def test_config5_n28_fp32_against_fp64():
+    """BASELINE config 5 at full size: n = 28, one genome (L = 4, seed 0), 500 Pauli strings (default_rng(2028)), fp64
+    (4 GiB state) and fp32 (2 GiB).  No CPU oracle at this size: fp32 against fp64 within
+    FP32_REL * sum |c_k|, and on the fp64 path size-independent properties -- the two halves of the operator add up to
+    the whole (1e-10), <I> = 1, and a basis-state circuit gives the diagonal terms' exact value."""
+    n = 28
+    _, circuits, params = helpers.population_circuits(n, 4, 1, seed=0)
+    op = helpers.random_pauli_operator(n, 500, seed=2028)
+    dev = StatevectorDevice(n)
+    whole = OperatorCircuitEvaluator(op, statevector_device=dev).evaluate_circuits(circuits, params)[0]
+    labels, coeffs = op.labels, op.coeffs
+    first = OperatorCircuitEvaluator(PauliOperator(labels[:250], coeffs[:250]), statevector_device=dev).evaluate_circuits(circuits, params)[0]
+    second = OperatorCircuitEvaluator(PauliOperator(labels[250:], coeffs[250:]), statevector_device=dev).evaluate_circuits(circuits, params)[0]
+    assert abs(whole - (first + second)) < EXP_TOL
+    ident = PauliOperator(["I" * n], [1.0])
+    assert abs(OperatorCircuitEvaluator(ident, statevector_device=dev).evaluate_circuits(circuits, params)[0] - 1.0) < 1e-11
+    # basis state |b>: <P> = 0 for every string with an X or Y, +-1 for I/Z strings
+    bits = 0b1011_0000_1111_0101_0011_1100_1010
+    flip = CircuitIR(n)
+    for q in range(n):
+        if (bits >> q) & 1:
+            flip.u(np.pi, 0.0, np.pi, q)
+    mixed = PauliOperator(["Z" * n, "I" * (n - 3) + "ZIZ", "X" + "I" * (n - 1), "I" * (n - 1) + "Y"], [0.5, -2.0, 7.0, 11.0])
+    want = 0.5 * (-1) ** bin(bits).count("1") - 2.0 * (-1) ** bin(bits & 0b101).count("1")
+    assert abs(OperatorCircuitEvaluator(mixed, statevector_device=dev).evaluate_circuits([flip], [[]])[0] - want) < 1e-12
+    dev.close()
+    single = OperatorCircuitEvaluator(op, dtype="fp32").evaluate_circuits(circuits, params)[0]
+    assert abs(single - whole) < FP32_REL * float(np.abs(coeffs).sum())
+
+
+# ---- (v) fp32 expectation values against fp64 ---------------------------------------------------------------------
+
+
+@pytest.mark.parametrize("n_qubits", [12, 16, 20])
+def test_fp32_expectation_error_is_bounded(n_qubits):
+    """fp32 states, fp64 accumulation: |<H>_fp32 - <H>_fp64| <= FP32_REL * sum |c_k| for the diagonal (fused) path and
+    for the general path, on four individuals each."""
+    _, circuits, params = helpers.population_circuits(n_qubits, 4, 4, seed=n_qubits)
+    for op in (helpers.random_ising_operator(n_qubits, seed=5), helpers.random_pauli_operator(n_qubits, 40, seed=6)):
+        e64 = np.asarray(OperatorCircuitEvaluator(op).evaluate_circuits(circuits, params))
+        e32 = np.asarray(OperatorCircuitEvaluator(op, dtype="fp32").evaluate_circuits(circuits, params))
+        assert np.abs(e32 - e64).max() < FP32_REL * float(np.abs(op.coeffs).sum())
+        assert np.abs(e32 - e64).max() > 0  # fp32 really ran
+
+
+# ---- (iv) the 3 x 3 JSSP instance (18 qubits) ----------------------------------------------------------------------
+
+
+def test_config4_three_by_three_jssp_end_to_end():
+    """BASELINE.json words config 4 as a 3-jobs x 3-machines instance: unit durations, makespan limit 5, 18 qubits.
+    EVQE (sampler + CVaR 0.5, 512 shots) must end on a valid schedule of optimal makespan 3, and the energy it
+    reports must be the exact energy of that schedule's basis state."""
+    import jssp_instances as inst
+    from queasars_amd.circuit_evaluation import OperatorSamplerCircuitEvaluator
+    from queasars_amd.evqe.solver import (
+        SPSA, BestIndividualRelativeChangeTolerance, EVQEMinimumEigensolver, EVQEMinimumEigensolverConfiguration, SPSATerminationChecker,
+    )
+    from queasars_amd.job_shop_scheduling import JSSPDomainWallHamiltonianEncoder
+
+    enc = JSSPDomainWallHamiltonianEncoder(inst.three_by_three(), makespan_limit=5, **inst.NOTEBOOK_PENALTIES)
+    assert enc.n_qubits == 18
+    op = enc.get_problem_hamiltonian()
+    evaluator = OperatorSamplerCircuitEvaluator(512, op, alpha=0.5, seed=0)
+    cfg = EVQEMinimumEigensolverConfiguration(
+        optimizer=SPSA(maxiter=33, perturbation=0.35, learning_rate=0.43, trust_region=True,
+                       termination_checker=SPSATerminationChecker(0.01, 2)),
+        population_size=10, max_generations=8, termination_criterion=BestIndividualRelativeChangeTolerance(0.01, 1),
+        random_seed=0, n_initial_layers=2, randomize_initial_population_parameters=True,
+        speciation_genetic_distance_threshold=1, use_tournament_selection=True, tournament_size=2,
+        selection_alpha_penalty=0.15, selection_beta_penalty=0.02, parameter_search_probability=0.39,
+        topological_search_probability=0.79, layer_removal_probability=0.02,
+    )
+    result = EVQEMinimumEigensolver(cfg).compute_minimum_eigenvalue(evaluator)
+    best = result.best_individual
+    dev = evaluator.statevector_device
+    probs = dev.probabilities(best.get_parameterized_quantum_circuit(), list(best.parameter_values))
+    top = int(np.argmax(probs))
+    schedule = enc.translate_result_bitstring(format(top, f"0{enc.n_qubits}b"))
+    assert schedule.is_valid and schedule.makespan == 3
+    # the energy of that basis state, exactly, through the estimator branch on the same device
+    prep = CircuitIR(enc.n_qubits)
+    for q in range(enc.n_qubits):
+        if (top >> q) & 1:
+            prep.u(np.pi, 0.0, np.pi, q)
+    exact = OperatorCircuitEvaluator(op, statevector_device=dev).evaluate_circuits([prep], [[]])[0]
+    assert abs(exact - 5.0625) < 1e-9
+    assert result.eigenvalue >= exact - 1e-9 and result.eigenvalue < exact + 1.0

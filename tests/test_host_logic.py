@@ -234,3 +234,119 @@ class TestQiskitAdapter:
         op = SimpleNamespace(paulis=SimpleNamespace(to_labels=lambda: ["IZ", "XI"]), coeffs=[0.5, -1.0])
         got = qiskit_adapter.operator_from_qiskit(op)
         assert got.labels == ["IZ", "XI"] and got.z_mask.tolist() == [1, 0] and got.x_mask.tolist() == [0, 2]
+
+
+class TestProcessLocalRegistrations:
+    """A circuit's device registrations are meaningful only in the process (and for the device) that made them
+    (advisor finding, round 1): copies and pickles start without them."""
+
+    def test_pickle_and_copies_drop_the_registration(self):
+        import copy
+
+        c = CircuitIR(4).u(0.1, ParamRef(0), 0.3, 1).cu3(0.2, 0.3, ParamRef(1), 0, 2)
+        c.packed()
+        c._registered[("token", 1)] = 5
+        for clone in (pickle.loads(pickle.dumps(c)), copy.deepcopy(c), copy.copy(c)):
+            assert clone._registered == {} and clone.bound_ops([1.0, 2.0]) == c.bound_ops([1.0, 2.0])
+            assert clone.num_parameters == 2 and np.array_equal(clone.packed(), c.packed())
+        assert c._registered == {("token", 1): 5}
+        clone = copy.deepcopy(c)
+        clone.u(0.5, 0.5, 0.5, 3)  # editing a copy leaves the original (and its registration) alone
+        assert len(c) == 2 and c._registered
+
+    def test_device_keys_differ_between_processes(self):
+        """The key a device files its registrations under carries a per-process random token: a circuit registered in
+        one process and shipped to another (where device serials restart at 1) cannot be taken for registered there."""
+        import subprocess
+        import sys
+
+        code = "from queasars_amd.circuit_evaluation import circuit_evaluation as ce; print(ce._PROCESS_TOKEN)"
+        tokens = {subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True).stdout.strip() for _ in range(2)}
+        from queasars_amd.circuit_evaluation import circuit_evaluation as ce
+
+        assert len(tokens) == 2 and ce._PROCESS_TOKEN not in tokens
+
+    def test_finalizers_only_queue_ids(self):
+        """weakref finalizers may run inside any allocation, also while this thread holds the handle between
+        qsv_eval_begin and qsv_eval_end: they must not call into the library."""
+        import gc
+        import weakref
+
+        from queasars_amd.circuit_evaluation.circuit_evaluation import StatevectorDevice
+
+        class FakeLib:
+            destroyed = []
+
+            def qsv_circuit_destroy(self, handle, cid):
+                self.destroyed.append(cid)
+                return 0
+
+        dev = object.__new__(StatevectorDevice)  # no GPU here: only the bookkeeping is exercised
+        dev._dead, dev._handle, dev._lib = [], 1, FakeLib()
+        c = CircuitIR(2).u(0.1, 0.2, 0.3, 0)
+        weakref.finalize(c, StatevectorDevice._release, weakref.ref(dev), 17)
+        del c
+        gc.collect()
+        assert dev._dead == [17] and FakeLib.destroyed == []
+        dev._reap()
+        assert dev._dead == [] and FakeLib.destroyed == [17]
+        dev._handle = None  # keep __del__ from calling qsv_destroy on the fake
+
+
+class TestUnpinnedCaches:
+    def test_composed_circuits_follow_edits_and_do_not_pin(self):
+        import gc
+
+        from queasars_amd.circuit_evaluation.circuit_evaluation import _ComposedCircuits
+
+        init = CircuitIR(3).u(0.3, 0.0, 0.0, 0)
+        cache = _ComposedCircuits(init, limit=8)
+        c = CircuitIR(3).cu3(0.1, 0.2, 0.3, 0, 1)
+        first = cache.get(c)
+        assert cache.get(c) is first and len(first) == 2
+        c.u(0.4, 0.0, 0.0, 2)  # edited in place: the composed circuit must be rebuilt
+        second = cache.get(c)
+        assert second is not first and len(second) == 3
+        del c, first, second
+        gc.collect()
+        assert len(cache) == 0
+        keep = [CircuitIR(3).id(0) for _ in range(20)]
+        for k in keep:
+            cache.get(k)
+        assert len(cache) <= 8
+        assert _ComposedCircuits(None).get(keep[0]) is keep[0]
+
+    def test_identity_cache_of_the_primitive_front_ends(self):
+        import gc
+
+        from queasars_amd.primitives import _IdentityCache
+
+        class Foreign:
+            pass
+
+        calls = []
+        cache = _IdentityCache(lambda obj: calls.append(id(obj)) or len(calls), limit=4)
+        a = Foreign()
+        assert cache.get(a) == cache.get(a) == 1 and len(calls) == 1
+        del a
+        gc.collect()
+        assert len(cache) == 0
+        tuples = [(i,) for i in range(10)]  # tuples cannot be weakly referenced: bounded strong table
+        for t in tuples:
+            cache.get(t)
+        assert len(cache) <= 4
+
+    def test_vectorised_cvar_equals_the_reference_loop(self):
+        """The product's vectorised CVaR accumulation against the oracle's literal restatement of the reference's
+        loop (expectation_calculation.py:14-32), including distributions whose mass falls short of alpha."""
+        from queasars_amd.circuit_evaluation.expectation_calculation import _get_expectation
+
+        rng = np.random.default_rng(11)
+        for trial in range(200):
+            m = int(rng.integers(1, 12))
+            p = rng.random(m)
+            p = p / p.sum() * (1.0 if trial % 3 else 0.9)
+            values = rng.normal(size=m).round(1 if trial % 2 else 6)  # ties now and then
+            alpha = float(rng.choice([1.0, 0.95, 0.5, 0.2, 0.01]))
+            items = [(i, float(pi), float(vi)) for i, (pi, vi) in enumerate(zip(p, values))]
+            assert abs(_get_expectation(items, alpha) - so.cvar_expectation(items, alpha)) < 1e-12
