@@ -390,6 +390,9 @@ class _ComposedCircuits:
     def __len__(self) -> int:
         return len(self._entries)
 
+    def __reduce__(self):  # a cache travels empty (evaluators are pickled to process-based executors)
+        return (_ComposedCircuits, (self._initial, self._limit))
+
     def get(self, circuit: CircuitIR) -> CircuitIR:
         if self._initial is None:
             return circuit

@@ -341,3 +341,33 @@ def test_config4_three_by_three_jssp_end_to_end():
     exact = OperatorCircuitEvaluator(op, statevector_device=dev).evaluate_circuits([prep], [[]])[0]
     assert abs(exact - 5.0625) < 1e-9
     assert result.eigenvalue >= exact - 1e-9 and result.eigenvalue < exact + 1.0
+
+
+def test_three_by_three_contended_jssp_end_to_end():
+    """A 3 x 3 instance whose all-zero state is NOT a schedule (two jobs start on the same machine; optimum: makespan
+    5, energy 36.708 by exhaustive search over the 2^18 basis states).  EVQE with the notebook's settings must end on
+    a valid schedule -- no penalty term active, so an energy far below the penalties (275 / 319)."""
+    import jssp_instances as inst
+    from queasars_amd.circuit_evaluation import OperatorSamplerCircuitEvaluator
+    from queasars_amd.evqe.solver import (
+        SPSA, BestIndividualRelativeChangeTolerance, EVQEMinimumEigensolver, EVQEMinimumEigensolverConfiguration, SPSATerminationChecker,
+    )
+    from queasars_amd.job_shop_scheduling import JSSPDomainWallHamiltonianEncoder
+
+    enc = JSSPDomainWallHamiltonianEncoder(inst.three_by_three_contended(), makespan_limit=5, **inst.NOTEBOOK_PENALTIES)
+    evaluator = OperatorSamplerCircuitEvaluator(512, enc.get_problem_hamiltonian(), alpha=0.5, seed=0)
+    cfg = EVQEMinimumEigensolverConfiguration(
+        optimizer=SPSA(maxiter=33, perturbation=0.35, learning_rate=0.43, trust_region=True,
+                       termination_checker=SPSATerminationChecker(0.01, 2)),
+        population_size=10, max_generations=8, termination_criterion=BestIndividualRelativeChangeTolerance(0.01, 1),
+        random_seed=0, n_initial_layers=2, randomize_initial_population_parameters=True,
+        speciation_genetic_distance_threshold=1, use_tournament_selection=True, tournament_size=2,
+        selection_alpha_penalty=0.15, selection_beta_penalty=0.02, parameter_search_probability=0.39,
+        topological_search_probability=0.79, layer_removal_probability=0.02,
+    )
+    result = EVQEMinimumEigensolver(cfg).compute_minimum_eigenvalue(evaluator)
+    best = result.best_individual
+    probs = evaluator.statevector_device.probabilities(best.get_parameterized_quantum_circuit(), list(best.parameter_values))
+    schedule = enc.translate_result_bitstring(format(int(np.argmax(probs)), f"0{enc.n_qubits}b"))
+    assert schedule.is_valid and schedule.makespan == 5
+    assert 36.7 < result.eigenvalue < 100.0

@@ -350,3 +350,12 @@ class TestUnpinnedCaches:
             alpha = float(rng.choice([1.0, 0.95, 0.5, 0.2, 0.01]))
             items = [(i, float(pi), float(vi)) for i, (pi, vi) in enumerate(zip(p, values))]
             assert abs(_get_expectation(items, alpha) - so.cvar_expectation(items, alpha)) < 1e-12
+
+    def test_composed_circuit_cache_pickles_empty(self):
+        from queasars_amd.circuit_evaluation.circuit_evaluation import _ComposedCircuits
+
+        cache = _ComposedCircuits(CircuitIR(2).u(0.1, 0.2, 0.3, 0), limit=16)
+        c = CircuitIR(2).id(1)
+        cache.get(c)
+        clone = pickle.loads(pickle.dumps(cache))
+        assert len(clone) == 0 and len(clone.get(c)) == 2
