@@ -30,6 +30,30 @@ from pathlib import Path
 
 OUT = Path(__file__).resolve().parent / "gate_loop_gen.inc"
 
+# Amplitude e of a thread lives in FOUR FIXED vector registers, v[AMP0 + 4e .. AMP0 + 4e + 3] = (re lo, re hi, im lo,
+# im hi), in every assembly block (explicit "{v[a:b]}" constraints): a global_load/store_dwordx4 or an LDS access then
+# reads or writes an amplitude where it lives -- left to the register allocator, real and imaginary parts ended up in
+# separate pairs and every load, store and exchange was followed by 32 moves -- and the lane swaps can name the
+# 32-bit halves directly.
+AMP0 = 8
+
+
+def amp_re(e: int) -> str:
+    return f"v[{AMP0 + 4 * e}:{AMP0 + 4 * e + 1}]"
+
+
+def amp_im(e: int) -> str:
+    return f"v[{AMP0 + 4 * e + 2}:{AMP0 + 4 * e + 3}]"
+
+
+def amp_operands(nr: int) -> list[str]:
+    outs = []
+    for e in range(nr):
+        outs.append(f'"+{{{amp_re(e)}}}"(amp[{e}].re)')
+        outs.append(f'"+{{{amp_im(e)}}}"(amp[{e}].im)')
+    return outs
+
+
 # hard-coded scalar registers (all inside one clobbered window)
 MAT = {"A": 40, "B": 56}  # 16 SGPRs each: 8 doubles
 DESC = {"A": 72, "B": 76}  # w0, ct, cg, op
@@ -71,7 +95,7 @@ def gate(lines: list[str], r: int, x: str, tag: str) -> None:
             if e0 & (1 << j):
                 continue
             e1 = e0 | (1 << j)
-            a0r, a0i, a1r, a1i = f"%[a{e0}r]", f"%[a{e0}i]", f"%[a{e1}r]", f"%[a{e1}i]"
+            a0r, a0i, a1r, a1i = amp_re(e0), amp_im(e0), amp_re(e1), amp_im(e1)
             e(f"s_bitcmp1_b32 {w0}, {16 + pair}")
             e(f"s_cbranch_scc0 Ln{j}_{pair}{tag}_%=")
             e(f"v_mul_f64 %[u], {m01r}, {a1r}")
@@ -151,10 +175,7 @@ def emit(r: int) -> str:
     out.append("        asm volatile(")
     for line in loop_body(r):
         out.append(f'            "{line}\\n\\t"')
-    outs = []
-    for e in range(nr):
-        outs.append(f'[a{e}r] "+v"(amp[{e}].re)')
-        outs.append(f'[a{e}i] "+v"(amp[{e}].im)')
+    outs = amp_operands(nr)
     outs += ['[u] "=&v"(u)', '[w] "=&v"(w)', '[p] "=&v"(p)', '[q] "=&v"(q)', '[vt] "=&v"(vt)']
     out.append("            : " + ",\n              ".join(outs))
     out.append('            : [rp] "s"(rp), [mp] "s"(mp), [n] "s"(n_gates), [base] "s"(base), [tid] "v"(tid)')
@@ -166,14 +187,105 @@ def emit(r: int) -> str:
     return "\n".join(out)
 
 
+# ---- lane swaps (plan.hpp "swap" rounds; kernels.hip swap_reg_lane is the C++ statement of the same thing) ---------
+# One assembly block over the fixed amplitude registers; the (register bit V, lane bit U) case is picked by a binary
+# tree of scalar compares, so no amplitude register is ever copied (written with builtins in C++, hipcc kept a second
+# copy of all amplitudes alive across the dispatch: 48 moves around 16 swaps and 64 more VGPRs).  Wait states: a DPP or permlane read needs 2 wait states after a VALU
+# write of the register it reads; every case starts with s_nop 1 (the block's inputs may just have been written) and the
+# DPP cases keep two pairs in flight so that a temporary is read three instructions after it was written.
+def swap_case(lines: list[str], r: int, v: int, u: int) -> None:
+    e = lines.append
+    pairs = [(e0, e0 | (1 << v)) for e0 in range(1 << r) if not e0 & (1 << v)]
+    # (A, B) dword pairs: the four 32-bit halves of both component planes
+    regs = [(f"v{AMP0 + 4 * a + d}", f"v{AMP0 + 4 * b + d}") for a, b in pairs for d in range(4)]
+    e("s_nop 1")
+    if u >= 4:
+        op = "v_permlane32_swap_b32" if u == 5 else "v_permlane16_swap_b32"
+        for a, b in regs:
+            e(f"{op} {a}, {b}")
+    elif u >= 2:
+        n = 1 << u
+        upper, lower = ("0xa", "0x5") if u == 2 else ("0xc", "0x3")
+        for i in range(0, len(regs), 2):
+            chunk = regs[i : i + 2]
+            temps = ["%[t0]", "%[t1]"]
+            for (a, _b), t in zip(chunk, temps):
+                e(f"v_mov_b32 {t}, {a}")
+            for (a, b), _t in zip(chunk, temps):
+                e(f"v_mov_b32_dpp {a}, {b} row_shr:{n} row_mask:0xf bank_mask:{upper}")
+            for (_a, b), t in zip(chunk, temps):
+                e(f"v_mov_b32_dpp {b}, {t} row_shl:{n} row_mask:0xf bank_mask:{lower}")
+    else:
+        perm = "quad_perm:[1,0,3,2]" if u == 0 else "quad_perm:[2,3,0,1]"
+        e(f"v_and_b32 %[t0], {1 << u}, %[lane]")
+        e("v_cmp_ne_u32 vcc, 0, %[t0]")  # vcc = lanes whose bit U is set
+        for i in range(0, len(regs), 2):
+            chunk = regs[i : i + 2]
+            temps = ["%[t0]", "%[t1]"]
+            for (_a, b), t in zip(chunk, temps):
+                e(f"v_mov_b32_dpp {t}, {b} {perm} row_mask:0xf bank_mask:0xf")  # the partner's B
+            for (a, b), _t in zip(chunk, temps):
+                e(f"v_cndmask_b32_dpp {b}, {a}, {b}, vcc {perm} row_mask:0xf bank_mask:0xf")  # upper ? B : partner's A
+            for (a, _b), t in zip(chunk, temps):
+                e(f"v_cndmask_b32 {a}, {a}, {t}, vcc")  # upper ? partner's B : A
+
+
+def dispatch_tree(lines: list[str], lo: int, hi: int, labels: list[str], tag: str) -> None:
+    """Binary decision tree over %[sel] in [lo, hi): about log2(hi - lo) compare + branch pairs on any path."""
+    if hi - lo == 1:
+        lines.append(f"s_branch {labels[lo]}")
+        return
+    mid = (lo + hi) // 2
+    lines.append(f"s_cmp_lt_u32 %[sel], {mid}")
+    lines.append(f"s_cbranch_scc1 Lt{tag}{lo}_{mid}_%=")
+    dispatch_tree(lines, mid, hi, labels, tag)
+    lines.append(f"Lt{tag}{lo}_{mid}_%=:")
+    dispatch_tree(lines, lo, mid, labels, tag)
+
+
+def emit_swap(r: int) -> str:
+    nr = 1 << r
+    lines: list[str] = []
+    e = lines.append
+    cases = [(v, u) for v in range(r) for u in range(6)]
+    labels = [f"Lc{v}_{u}_%=" for v, u in cases]
+    dispatch_tree(lines, 0, len(cases), labels, "s")
+    for (v, u), label in zip(cases, labels):
+        e(f"{label}:")
+        swap_case(lines, r, v, u)
+        e("s_branch Lend_%=")
+    e("Lend_%=:")
+    out = []
+    out.append(f"// R = {r}: lane swap of the {nr} amplitudes of a thread, both component planes (sel = 6 V + U < {6 * r})")
+    out.append("template <>")
+    out.append(f"struct SwapF64<{r}> {{")
+    out.append(f"    static __device__ __forceinline__ void run(cx<double> (&amp)[{nr}], uint32_t sel, uint32_t lane) {{")
+    out.append("        sel = __builtin_amdgcn_readfirstlane(sel);")
+    out.append("        uint32_t t0, t1;")
+    out.append("        asm volatile(")
+    for line in lines:
+        out.append(f'            "{line}\\n\\t"')
+    outs = amp_operands(nr) + ['[t0] "=&v"(t0)', '[t1] "=&v"(t1)']
+    out.append("            : " + ",\n              ".join(outs))
+    out.append('            : [sel] "s"(sel), [lane] "v"(lane)')
+    out.append('            : "vcc", "scc");')
+    out.append("    }")
+    out.append("};")
+    return "\n".join(out)
+
+
 def render() -> str:
     head = (
         "// GENERATED by gen_gate_loop.py -- do not edit; regenerate with `python gen_gate_loop.py`.\n"
         "// fp64 gate loop of pass_kernel in gfx950 assembly: see the generator's docstring for the design.\n"
         "// Included inside namespace qsv by kernels.hip, after cx<> is defined.\n\n"
-        "template <int R>\nstruct GateLoopF64;  // specialised below for R = 1, 2, 3\n\n"
+        "template <int R>\nstruct GateLoopF64;  // specialised below for R = 1 .. 4\n\n"
     )
-    return head + "\n\n".join(emit(r) for r in (1, 2, 3)) + "\n"
+    swap_head = (
+        "\n\n// Lane swaps (plan.hpp \"swap\" rounds), see gen_gate_loop.py.\n"
+        "template <int R>\nstruct SwapF64;  // specialised below for R = 1 .. 4\n\n"
+    )
+    return (head + "\n\n".join(emit(r) for r in (1, 2, 3, 4)) + swap_head + "\n\n".join(emit_swap(r) for r in (1, 2, 3, 4)) + "\n")
 
 
 if __name__ == "__main__":

@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 
 #include <type_traits>
+#include <utility>
 
 namespace qsv {
 
@@ -80,20 +81,6 @@ __device__ __forceinline__ uint32_t gray_step(int i, uint32_t off, cu32p reg_col
     return i == 0 ? off : off ^ reg_cols[__builtin_ctz(i)];
 }
 
-// Spread a tile number around the tile's bit positions: the fixed (non-tile) index bits of that tile.
-// The block always holds kMaxTileBits positions; the unused ones are kPosPad (a no-op insert).
-__device__ __forceinline__ uint64_t tile_base(uint32_t tile, cu32p pos) {
-    uint32_t ps[kMaxTileBits];
-    load_words<int(kMaxTileBits)>(pos, ps);
-    uint64_t base = tile;
-#pragma unroll
-    for (int j = 0; j < int(kMaxTileBits); ++j) {
-        const uint32_t p = ps[j];
-        base = ((base >> p) << (p + 1)) | (base & ((uint64_t(1) << p) - 1));
-    }
-    return base;
-}
-
 // 2x2 butterfly with a u-type matrix (m00 is real: 14 multiply-adds per amplitude pair instead of 16).
 // m = {m00, Re m01, Im m01, Re m10, Im m10, Re m11, Im m11}.  J = target register bit, C = control register bit
 // (-1: none): both compile-time, so a controlled gate touches exactly the 2^(R-2) pairs it must and there is no
@@ -143,6 +130,90 @@ struct ButterflyDispatch<real, R, -1> {
 };
 
 #include "gate_loop_gen.inc"
+
+// ---- lane swaps (plan.hpp, "swap" rounds) ---------------------------------------------------------------------
+// Transposition of the tile bit under register bit V with the one under lane bit U: element (lane, e) with lane bit U
+// != register bit V of e trades places with (lane ^ 2^U, e ^ 2^V).  For a register pair A = amp[e0] (bit V clear),
+// B = amp[e0 | 2^V] that is: A's lanes with bit U set receive B from their partner lane, B's lanes with bit U clear
+// receive A from theirs -- per 32-bit half
+//   U = 5: v_permlane32_swap_b32 A, B  (lanes 32-63 of vdst trade with lanes 0-31 of src)
+//   U = 4: v_permlane16_swap_b32 A, B  (odd rows of vdst trade with even rows of src; a row = 16 lanes)
+//   U = 3, 2: two DPP moves, a row shift by 8 / 4 lanes each way under a bank mask that selects the receiving lanes
+//   U = 1, 0: two DPP quad permutes (every lane reads its partner) and two selects
+// No LDS, no barrier; 16 (U >= 4) to about 64 vector instructions per transposition at 8 fp64 amplitudes per thread.
+template <int U>
+__device__ __forceinline__ void swap_words(uint32_t& a, uint32_t& b) {
+    if constexpr (U == 5) {
+        const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+        a = r[0];
+        b = r[1];
+    } else if constexpr (U == 4) {
+        const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+        a = r[0];
+        b = r[1];
+    } else if constexpr (U <= 1) {
+        // quad_perm [1,0,3,2] / [2,3,0,1]: every lane reads its partner; the lanes with bit U set keep their b and
+        // take the partner's b into a, the others keep a and take the partner's a into b
+        constexpr int ctrl = U == 0 ? 0xB1 : 0x4E;
+        const uint32_t pb = uint32_t(__builtin_amdgcn_update_dpp(0, int(b), ctrl, 0xF, 0xF, true));
+        const uint32_t pa = uint32_t(__builtin_amdgcn_update_dpp(0, int(a), ctrl, 0xF, 0xF, true));
+        const bool upper = (__lane_id() >> U) & 1u;
+        a = upper ? pb : a;
+        b = upper ? b : pa;
+    } else {
+        // row_shr:n (0x110 + n): lane i reads lane i - n of its row; row_shl:n (0x100 + n): lane i reads lane i + n.
+        // bank b of a row = its lanes 4b .. 4b+3: lane bit 2 = bank bit 0, lane bit 3 = bank bit 1.
+        constexpr int n = 1 << U;                         // 4 or 8
+        constexpr int upper = U == 2 ? 0xA : 0xC;         // banks whose lanes have bit U set
+        constexpr int lower = U == 2 ? 0x5 : 0x3;
+        const uint32_t na = uint32_t(__builtin_amdgcn_update_dpp(int(a), int(b), 0x110 + n, 0xF, upper, false));
+        const uint32_t nb = uint32_t(__builtin_amdgcn_update_dpp(int(b), int(a), 0x100 + n, 0xF, lower, false));
+        a = na;
+        b = nb;
+    }
+}
+
+template <int U>
+__device__ __forceinline__ void swap_reals(double& a, double& b) {
+    uint32_t alo = uint32_t(__double2loint(a)), ahi = uint32_t(__double2hiint(a));
+    uint32_t blo = uint32_t(__double2loint(b)), bhi = uint32_t(__double2hiint(b));
+    swap_words<U>(alo, blo);
+    swap_words<U>(ahi, bhi);
+    a = __hiloint2double(int(ahi), int(alo));
+    b = __hiloint2double(int(bhi), int(blo));
+}
+template <int U>
+__device__ __forceinline__ void swap_reals(float& a, float& b) {
+    uint32_t x = __float_as_uint(a), y = __float_as_uint(b);
+    swap_words<U>(x, y);
+    a = __uint_as_float(x);
+    b = __uint_as_float(y);
+}
+
+template <typename real, int R, int V, int U>
+__device__ __forceinline__ void swap_reg_lane(cx<real> (&amp)[1 << R]) {
+#pragma unroll
+    for (int e0 = 0; e0 < (1 << R); ++e0) {
+        if (e0 & (1 << V)) continue;
+        swap_reals<U>(amp[e0].re, amp[e0 | (1 << V)].re);
+        swap_reals<U>(amp[e0].im, amp[e0 | (1 << V)].im);
+    }
+}
+
+// sel = V * 6 + U
+template <typename real, int R, int SEL>
+struct SwapDispatch {
+    static __device__ __forceinline__ void run(int sel, cx<real> (&amp)[1 << R]) {
+        if (sel == SEL)
+            swap_reg_lane<real, R, SEL / 6, SEL % 6>(amp);
+        else
+            SwapDispatch<real, R, SEL - 1>::run(sel, amp);
+    }
+};
+template <typename real, int R>
+struct SwapDispatch<real, R, -1> {
+    static __device__ __forceinline__ void run(int, cx<real> (&)[1 << R]) {}
+};
 
 // Diagnostic build only (-DQSV_STAMPS, scripts/stamps.sh): per-phase shader-cycle counters of the pass kernel,
 // summed over waves.  The shipped library compiles every QSV_STAMP to nothing.
@@ -265,6 +336,9 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE>::waves_per_simd))
     // synthesis tables of this evaluation (see prepare_kernel): thread factors, then tile factors
     cf64p thread_factor = vecs + 4 * size_t(n_qubits) + kMatPadDoubles;
     cf64p tile_factor = thread_factor + (size_t(2) << t);
+    // this pass's TileInfo table (prepare_kernel): one 16-byte record per tile number
+    cu32p tile_info = reinterpret_cast<cu32p>(tile_factor + (size_t(2) << (n_qubits - uint32_t(k))) +
+                                              size_t(a.pass_index) * (size_t(2) << (n_qubits - uint32_t(k))));
     // loaded once: a load inside the tile loop would make pass 0 wait for the previous tile's stores (same counter)
     double ttr = 1.0, tti = 0.0;
     if (synth && active) {
@@ -292,17 +366,10 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE>::waves_per_simd))
 
     QSV_STAMP(0);
     for (uint32_t j = 0; j < n_tiles; ++j) {
-        uint64_t base;
-        if (cstore) {
-            // the tile of control pattern x: its "outer bits" are the pattern's bits at the control qubits' positions
-            uint32_t cp8[kMaxCompactBits];
-            load_words<int(kMaxCompactBits)>(pp + kPassCompactOffset, cp8);
-            base = 0;
-#pragma unroll
-            for (int b = 0; b < int(kMaxCompactBits); ++b) base |= uint64_t(((tile0 + j * tile_step) >> b) & 1u) << cp8[b];
-        } else {
-            base = tile_base(tile0 + j * tile_step, pos);
-        }
+        // what depends on the tile number comes from prepare_kernel's table: one scalar load
+        uint32_t ti[4];
+        load_words<4>(tile_info + 4 * size_t(tile0 + j * tile_step), ti);
+        const uint64_t base = uint64_t(ti[0]) | uint64_t(ti[1]) << 32;
         // Per-element offsets do not depend on the tile, so hipcc would compute all of them once, ahead of the tile
         // loop, and keep (in fact spill) 3 * 2^R registers for them.  Recomputing them costs one v_xor per access:
         // the opaque copies below stop the hoisting.
@@ -334,20 +401,7 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE>::waves_per_simd))
         } else {
             // Input of a later pass: the tile's amplitudes from the state -- or, behind a compact pass 0, the table
             // entry W[..] (same load code, other base / thread offset / register columns) times the tile factor F[..].
-            uint32_t wbase = 0, fbase = 0;
-            if (cload) {
-                // index parts of this tile: XOR of the columns of the set bits of its tile number (scalar)
-                uint32_t wb[kMaxOuterBits], fb[kMaxOuterBits];
-                load_words<int(kMaxOuterBits)>(pp + kPassCompactWBase, wb);
-                load_words<int(kMaxOuterBits)>(pp + kPassCompactFBase, fb);
-                const uint32_t tile_number = __builtin_amdgcn_readfirstlane(tile0 + j * tile_step);  // uniform: keep this scalar
-#pragma unroll
-                for (int b = 0; b < int(kMaxOuterBits); ++b) {
-                    const bool on = (tile_number >> b) & 1u;
-                    wbase ^= on ? wb[b] : 0u;
-                    fbase ^= on ? fb[b] : 0u;
-                }
-            }
+            const uint32_t wbase = ti[2], fbase = ti[3];  // (zero unless this is a COMPACT_LOAD pass)
             if (active) {
                 if (!wide || cload) {
                     const unsigned char* tile = reinterpret_cast<const unsigned char*>(cload ? wt0 : st0 + base);
@@ -356,7 +410,12 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE>::waves_per_simd))
 #pragma unroll
                     for (int i = 0; i < NR; ++i) {
                         if (i) ob ^= rcols[__builtin_ctz(i)] << ASH;
+#ifndef QSV_ABL_NOLOAD
                         amp[gray_index(i)] = *reinterpret_cast<const cxr*>(tile + ob);
+#else
+                        amp[gray_index(i)].re = real(ob);
+                        amp[gray_index(i)].im = real(i);
+#endif
                     }
                 } else {
                     uint32_t off = tgv;
@@ -366,6 +425,7 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE>::waves_per_simd))
                         amp[gray_index(i)] = st0[base + off];
                     }
                 }
+#ifndef QSV_ABL_NOF
                 if (cload) {
                     // times F: two halves (register budget), each walking its 2^(R-1) elements in Gray-code order
                     const unsigned char* ftab = reinterpret_cast<const unsigned char*>(
@@ -391,6 +451,7 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE>::waves_per_simd))
                         }
                     }
                 }
+#endif
                 // Wait for the loads HERE, inside the branch: at the join with the synthesis path hipcc would otherwise
                 // place this wait before the first use for both paths, and on the synthesis path (pass 0, which loads
                 // nothing) it would then wait for the previous tile's STORES, which share the counter.
@@ -533,11 +594,33 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE>::waves_per_simd))
                 }
                 lds_dirty = true;
                 cross_pending = cross_pending || !intra;
+            } else if ((rh >> 18) & 1u) {
+                // relayout by lane swaps (plan.hpp): no LDS, no barrier
+                QSV_STAMP(2);
+                // (one dispatch site: the loop must not be unrolled, every case is a few dozen instructions)
+#pragma nounroll
+                for (int i = 0; i < int(kMaxSwaps); ++i) {
+                    const uint32_t w = rp[i];
+                    if (w == kSwapPad) break;
+                    const uint32_t sel = (w & 0xffu) * 6u + ((w >> 8) & 0xffu);
+#ifndef QSV_ABL_NOSWAP
+                    if constexpr (std::is_same<real, double>::value && R <= 4)
+                        SwapF64<R>::run(amp, sel, tid & 63u);  // generated assembly (gate_loop_gen.inc)
+                    else
+                        SwapDispatch<real, R, 6 * R - 1>::run(int(sel), amp);
+#else
+                    (void)sel;
+#endif
+                }
+                rp += kMaxSwaps;
+                QSV_STAMP(9);
             }
-            if constexpr (std::is_same<real, double>::value && R <= 3) {
+            if constexpr (std::is_same<real, double>::value && R <= 4) {
                 // fp64: the gate loop is the generated assembly block (gate_loop_gen.inc); amplitudes never move
                 if (n_gates > 0) {
+#ifndef QSV_ABL_NOGATES  // (ablation builds, scripts/ablate.py: timing experiments with wrong results)
                     if (active) GateLoopF64<R>::run(amp, rp, mp, uint32_t(n_gates), uint32_t(base), tid);
+#endif
                     rp += size_t(n_gates) * kGateWords;
                     mp += size_t(n_gates) * 8;
                 }
@@ -588,7 +671,11 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE>::waves_per_simd))
 #pragma unroll
                     for (int i = 0; i < NR; ++i) {
                         if (i) ob ^= gsr[__builtin_ctz(i)] << 3;
+#ifndef QSV_ABL_NODIAG
                         dv[gray_index(i)] = *reinterpret_cast<const double*>(dtile + ob);
+#else
+                        dv[gray_index(i)] = double(ob);
+#endif
                     }
 #pragma unroll
                     for (int e = 0; e < NR; ++e) {
@@ -834,6 +921,37 @@ __global__ void __launch_bounds__(256) prepare_kernel(const uint32_t* __restrict
         const double2 f = product(base, all_qubits & ~tile_mask);
         tile_factor[2 * size_t(tile)] = f.x;
         tile_factor[2 * size_t(tile) + 1] = f.y;
+    }
+    // Per pass and tile: what the pass kernel needs to know about its tile number (kernels.hpp TileInfo).
+    TileInfo* info_all = reinterpret_cast<TileInfo*>(tile_factor + (size_t(2) << (n_qubits - uint32_t(k))));
+    for (uint32_t p = 0; p < n_passes; ++p) {
+        const uint32_t* __restrict__ ph = cp + cp[kCircuitHeaderWords + p];
+        const uint32_t* __restrict__ ppos = ph + kPassHeaderWords;
+        const uint32_t flags = ph[2];
+        const bool cstore = flags & kPassCompactStore, cload = flags & kPassCompactLoad;
+        const uint32_t count = cstore ? 1u << ((flags >> 8) & 0xffu) : n_tiles;
+        TileInfo* info = info_all + size_t(p) * n_tiles;
+        for (uint32_t tile = threadIdx.x; tile < count; tile += blockDim.x) {
+            uint64_t base;
+            if (cstore) {
+                base = 0;
+                for (uint32_t b = 0; b < kMaxCompactBits; ++b) base |= uint64_t((tile >> b) & 1u) << ph[kPassCompactOffset + b];
+            } else {
+                base = tile;
+                for (int j = 0; j < k; ++j) {
+                    const uint32_t ps = ppos[j];
+                    base = ((base >> ps) << (ps + 1)) | (base & ((uint64_t(1) << ps) - 1));
+                }
+            }
+            uint32_t wbase = 0, fbase = 0;
+            if (cload)
+                for (uint32_t b = 0; b < kMaxOuterBits; ++b)
+                    if ((tile >> b) & 1u) {
+                        wbase ^= ph[kPassCompactWBase + b];
+                        fbase ^= ph[kPassCompactFBase + b];
+                    }
+            info[tile] = TileInfo{uint32_t(base), uint32_t(base >> 32), wbase, fbase};
+        }
     }
 }
 

@@ -46,13 +46,26 @@ struct PassArgs {
 constexpr int kStampPasses = 8, kStampPhases = 16;
 hipError_t read_stamps(unsigned long long* out, int reset);  // hipErrorNotSupported in the shipped build
 
-// doubles an evaluation's matrix region occupies for a circuit with n_real scheduled gates on n qubits
+// doubles an evaluation's matrix region occupies for a circuit with n_real scheduled gates in n_passes passes on n qubits
 // (gate matrices | 4 doubles per qubit: initial factors | kMatPadDoubles | thread factors: 2 * 2^t | tile factors:
-// 2 * 2^(n-k)); t = thread bits, n - k = bits outside a tile -- the synthesis tables prepare_kernel fills for pass 0
+// 2 * 2^(n-k) | tile info: n_passes * 2 * 2^(n-k)); t = thread bits, n - k = bits outside a tile.  prepare_kernel
+// fills all of it: the synthesis tables for pass 0 and, per pass and tile, one TileInfo record, so that a workgroup
+// of the pass kernel fetches what depends on its tile number with ONE scalar load instead of decoding it (every
+// wave redid ~190 scalar and ~40 vector instructions per tile for that, and the masks it kept cost ~40 SGPRs).
 constexpr uint32_t kMatPadDoubles = 16;
-inline size_t mat_region_doubles(uint32_t n_real, uint32_t n_qubits, int thread_bits, int outer_bits) {
+struct TileInfo {     // 16 bytes = 2 doubles
+    uint32_t base_lo, base_hi;  // amplitude index of the tile's element 0: the tile number spread over the outer
+                                // qubits (a compact pass 0: the pattern number spread over its control qubits)
+    uint32_t wbase, fbase;      // COMPACT_LOAD pass: the tile's part of the W index / of the tile-factor index
+};
+inline size_t mat_region_doubles(uint32_t n_real, uint32_t n_qubits, int thread_bits, int outer_bits, int n_passes) {
     return size_t(8) * n_real + size_t(4) * n_qubits + kMatPadDoubles + (size_t(2) << thread_bits) +
-           (size_t(2) << outer_bits);
+           (size_t(2) << outer_bits) + size_t(n_passes > 0 ? n_passes : 0) * (size_t(2) << outer_bits);
+}
+// offset (in doubles, from the start of the region) of pass p's TileInfo table
+inline __host__ __device__ size_t tile_info_offset(uint32_t n_real, uint32_t n_qubits, int thread_bits, int outer_bits, uint32_t p) {
+    return size_t(8) * n_real + size_t(4) * n_qubits + kMatPadDoubles + (size_t(2) << thread_bits) +
+           (size_t(2) << outer_bits) + size_t(p) * (size_t(2) << outer_bits);
 }
 
 // Angles -> gate matrices, initial product-state factors and synthesis tables, one workgroup per evaluation.

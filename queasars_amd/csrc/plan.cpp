@@ -2,6 +2,8 @@
 #include "plan.hpp"
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <array>
 #include <cstring>
 #include <map>
@@ -393,9 +395,10 @@ CircuitPlan build_plan(int n, const std::vector<GateIn>& all_gates, const std::v
             pass.rounds.push_back(std::move(round));
             first = false;
         }
+        // (with lane swaps the encoder appends a restoring swap round itself where the last layout needs one)
         bool low_in_regs = false;
         for (int b : pass.rounds.back().regbits) low_in_regs |= (b < cl);
-        if (low_in_regs) {
+        if (low_in_regs && !cfg.swaps) {
             RoundPlan tail;
             tail.regbits = default_regs;
             pass.rounds.push_back(std::move(tail));
@@ -441,6 +444,7 @@ CircuitPlan build_plan(int n, const std::vector<GateIn>& all_gates, const std::v
     for (size_t pi = 0; pi < passes.size(); ++pi) {
         PassPlan& pass = passes[pi];
         w[off_table + pi] = uint32_t(w.size());
+        const size_t pass_header_at = w.size();
         w.push_back(uint32_t(k) | uint32_t(r) << 8 | uint32_t(t) << 16 | uint32_t(pass.rounds.size()) << 24);
         w.push_back(uint32_t(schedule.size()));
         // COMPACT (plan.hpp): pass 0 over the patterns of its outer control qubits, pass 1 reading W x F
@@ -478,7 +482,11 @@ CircuitPlan build_plan(int n, const std::vector<GateIn>& all_gates, const std::v
         std::vector<Layout> layouts;
         std::vector<char> intra(n_rounds_pass, 0);
         std::vector<std::vector<int>> wave_sets(n_rounds_pass);
+        std::vector<std::vector<std::pair<int, int>>> swaps(n_rounds_pass);  // (register bit, lane bit) transpositions
+        std::vector<char> by_swap(n_rounds_pass, 0);                          // the round's relayout needs no LDS
         std::vector<int> prev_w;
+        // does any later round of this pass target tile bit b?
+        auto targeted_later = [&](int b, size_t m) { return next_use(b, m) <= int(n_rounds_pass); };
         for (size_t m = 0; m < n_rounds_pass; ++m) {
             RoundPlan& rd = pass.rounds[m];
             const bool edge = m == 0 || m + 1 == n_rounds_pass;
@@ -489,6 +497,59 @@ CircuitPlan build_plan(int n, const std::vector<GateIn>& all_gates, const std::v
             for (int gi : rd.gates) {
                 const int cb = gates[gi].control >= 0 ? tile_bit(gates[gi].control) : -1;
                 if (cb >= 0 && !contains(must, cb) && !contains(ctrl, cb)) ctrl.push_back(cb);
+            }
+            // SWAP relayout (plan.hpp): every target of the round already sits in a register or on one of the lane
+            // bits a swap can reach; the last layout of a pass must also leave the low tile bits on the low lanes
+            // (swaps never move those, so it is enough that the previous layout has them there).
+            if (m > 0 && cfg.swaps) {
+                const Layout& cur = layouts.back();
+                bool ok = true;
+                std::vector<std::pair<int, int>> want;  // (tile bit, lane bit it sits on)
+                for (int b : must) {
+                    if (contains(cur.reg, b)) continue;
+                    int u = -1;
+                    for (size_t i = 0; i < cur.thr.size(); ++i)
+                        if (cur.thr[i] == b) u = int(i);
+                    if (u < kSwapLaneLo || u >= kSwapLaneHi || u >= t) ok = false;
+                    want.push_back({b, u});
+                }
+                if (ok && want.size() <= kMaxSwaps) {
+                    Layout nl = cur;
+                    std::vector<char> taken(nl.reg.size(), 0);
+                    for (const auto& wb : want) {
+                        // victim: a register whose bit this round does not target; rather not a control of the
+                        // round's gates (a register-held control halves a gate's work), then the bit needed latest
+                        int best = -1;
+                        for (size_t v = 0; v < nl.reg.size(); ++v) {
+                            if (taken[v] || contains(must, nl.reg[v])) continue;
+                            if (best < 0) {
+                                best = int(v);
+                                continue;
+                            }
+                            const bool cv = contains(ctrl, nl.reg[v]), cb = contains(ctrl, nl.reg[size_t(best)]);
+                            if (cv != cb) {
+                                if (!cv) best = int(v);
+                                continue;
+                            }
+                            if (next_use(nl.reg[v], m) > next_use(nl.reg[size_t(best)], m)) best = int(v);
+                        }
+                        if (best < 0) {
+                            ok = false;
+                            break;
+                        }
+                        taken[size_t(best)] = 1;
+                        swaps[m].push_back({best, wb.second});
+                        std::swap(nl.reg[size_t(best)], nl.thr[size_t(wb.second)]);
+                    }
+                    if (ok) {
+                        rd.regbits = nl.reg;
+                        layouts.push_back(nl);
+                        by_swap[m] = 1;
+                        wave_sets[m] = prev_w;
+                        continue;
+                    }
+                    swaps[m].clear();
+                }
             }
             // Spare registers go to controls first: a register-held control halves the gate's work, whereas a
             // control on a lane bit only masks lanes (the full butterfly still issues).
@@ -503,6 +564,11 @@ CircuitPlan build_plan(int n, const std::vector<GateIn>& all_gates, const std::v
                 for (int b = cl; b < k; ++b)
                     if (!contains(regs, b)) cand.push_back(b);
                 std::stable_sort(cand.begin(), cand.end(), [&](int x, int y) {
+                    if (cfg.swaps) {
+                        // wave-index bits are the only ones a swap cannot reach: bits no later round targets go first
+                        const bool lx = targeted_later(x, m), ly = targeted_later(y, m);
+                        if (lx != ly) return !lx;
+                    }
                     const bool cx = contains(ctrl, x), cy = contains(ctrl, y);
                     if (cx != cy) return cx;
                     const bool px = contains(prev_w, x), py = contains(prev_w, y);
@@ -534,6 +600,41 @@ CircuitPlan build_plan(int n, const std::vector<GateIn>& all_gates, const std::v
             intra[m] = m > 0 && (nw == 0 || (int(wset.size()) == nw && wset == prev_w));
             wave_sets[m] = wset;
             prev_w = wset;
+        }
+        // The last layout faces global memory again: the low `cl` tile bits must be back on the low lanes.  Swaps may
+        // have taken them away (a gate targeted one of them): a final gate-less round of swaps brings them home --
+        // from a register in one transposition, from another lane in two (through any register).
+        if (cfg.swaps) {
+            Layout fin = layouts.back();
+            std::vector<std::pair<int, int>> fix;
+            for (int u = 0; u < cl && u < int(fin.thr.size()); ++u) {
+                if (fin.thr[size_t(u)] == u) continue;
+                auto in_reg = std::find(fin.reg.begin(), fin.reg.end(), u);
+                if (in_reg == fin.reg.end()) {
+                    size_t u2 = 0;
+                    while (fin.thr[u2] != u) ++u2;
+                    if (int(u2) >= 6) throw std::logic_error("a low tile bit ended on a wave-index bit");
+                    size_t v = 0;  // any register that does not hold another low bit waiting to go home
+                    while (v + 1 < fin.reg.size() && fin.reg[v] < cl) ++v;
+                    fix.push_back({int(v), int(u2)});
+                    std::swap(fin.reg[v], fin.thr[u2]);
+                    in_reg = fin.reg.begin() + long(v);
+                }
+                fix.push_back({int(in_reg - fin.reg.begin()), u});
+                std::swap(*in_reg, fin.thr[size_t(u)]);
+            }
+            if (!fix.empty()) {
+                if (fix.size() > kMaxSwaps) throw std::logic_error("too many restoring swaps");
+                pass.rounds.emplace_back();
+                pass.rounds.back().regbits = fin.reg;
+                layouts.push_back(fin);
+                swaps.push_back(fix);
+                by_swap.push_back(1);
+                intra.push_back(0);
+                wave_sets.push_back(prev_w);
+                needed.emplace_back();
+                w[pass_header_at] = uint32_t(k) | uint32_t(r) << 8 | uint32_t(t) << 16 | uint32_t(pass.rounds.size()) << 24;
+            }
         }
         // one layout's columns in the fixed shape: kMaxThreadBits thread columns, kMaxRegBits register columns
         auto push_cols = [&](const Layout& l, auto&& col) {
@@ -584,8 +685,16 @@ CircuitPlan build_plan(int n, const std::vector<GateIn>& all_gates, const std::v
         for (size_t m = 0; m < pass.rounds.size(); ++m) {
             const RoundPlan& rd = pass.rounds[m];
             const Layout& lay = layouts[m];
-            const bool exch = m > 0;
-            w.push_back(uint32_t(rd.gates.size()) | (exch ? 1u << 16 : 0u) | (exch && intra[m] ? 1u << 17 : 0u));
+            const bool swap_round = by_swap[m] && !swaps[m].empty();
+            const bool exch = m > 0 && !by_swap[m];
+            w.push_back(uint32_t(rd.gates.size()) | (exch ? 1u << 16 : 0u) | (exch && intra[m] ? 1u << 17 : 0u) |
+                        (swap_round ? 1u << 18 : 0u));
+            if (swap_round) {
+                for (uint32_t i = 0; i < kMaxSwaps; ++i)
+                    w.push_back(i < swaps[m].size() ? uint32_t(swaps[m][i].first) | uint32_t(swaps[m][i].second) << 8 : kSwapPad);
+                out.stats.n_swap_rounds += 1;
+                out.stats.n_swaps += int(swaps[m].size());
+            }
             if (exch) {
                 const SwizzleChoice sw =
                     choose_swizzle(layouts[m - 1], lay, k, cfg.elem_bytes, intra[m] ? wave_sets[m] : std::vector<int>{});

@@ -42,6 +42,8 @@ struct PlanConfig {
     int xmode = 2;       // LDS exchange mode (kernels.hip): 0 whole element, 1 two resident planes, 2 one plane buffer
     bool fold = true;    // absorb leading gates into the synthesised initial product state
     bool compact = true; // (needs fold) pass 0 computes one tile per pattern of its outer control qubits, see below
+    bool swaps = true;   // relayouts that only trade register bits for lane bits 2..5 run as in-register lane swaps
+                         // (v_permlane16/32_swap, DPP row shifts) instead of an LDS exchange, see "round" below
 };
 
 struct GateIn {
@@ -65,6 +67,8 @@ struct PlanStats {
     int n_rounds = 0;
     int n_exchanges = 0;
     int n_intra_wave_exchanges = 0;  // exchanges that stay inside each wave (no barrier)
+    int n_swap_rounds = 0;           // relayouts done by lane swaps instead of an LDS exchange
+    int n_swaps = 0;                 // ... and the (register bit, lane bit) transpositions they took
     int compact_bits = -1;           // >= 0: pass 0 is compact over this many outer control qubits
     int n_real_gates = 0;
     int n_folded_gates = 0;   // u gates absorbed into the initial product state
@@ -109,10 +113,19 @@ struct CircuitPlan {
 //          2^(n-k) and writes them back to back at the start of the state slot (W[x][t] at x * 2^k + t); the
 //          COMPACT_LOAD pass 1 builds its input from W and F (both cache resident) instead of reading the state:
 //          no full-state write and read between the first two passes.
-// round:   [0] n_gates | has_exchange<<16 | intra_wave<<17 (the exchange moves data only inside each wave: the wave-
+// round:   [0] n_gates | has_exchange<<16 | intra_wave<<17 | swap<<18 (the exchange moves data only inside each wave: the wave-
 //              index thread bits hold the same tile bits before and after, so the kernel skips the barriers)
 //          if has_exchange: [1 .. 14) LDS write columns (previous layout), [14 .. 27) LDS read columns (this
 //                           layout), each kMaxThreadBits + kMaxRegBits entries, ELEMENT units, same swizzle
+//          else if swap (bit 18 of the header word): [1 .. 5) up to kMaxSwaps transpositions v | u << 8 (pad
+//                           0xFFFFFFFF): the tile bit under register bit v trades places with the one under lane bit u
+//                           (u < 6), applied in the order listed.  No LDS, no barrier: v_permlane32_swap /
+//                           v_permlane16_swap for u = 5 / 4, DPP row shifts under a bank mask for u = 3 / 2, DPP quad
+//                           permutes + selects for u = 1 / 0.  The scheduler takes this form whenever the round's
+//                           targets already sit in registers or on lane bits (the wave-index bits can only be
+//                           reached through LDS).  The first and the last layout of a pass keep the low tile bits on
+//                           the low lanes, where global memory wants them: a gate-less round of swaps at the end of a
+//                           pass brings them back when gates on those qubits took them away.
 //          then 4 words per gate: [0] target register bit | control register bit<<8 (0xFF: none) | pair mask<<16
 //                                     (bit p: the p-th amplitude pair, register indices with the target bit
 //                                     clear in ascending order, takes part)
@@ -139,6 +152,8 @@ constexpr uint32_t kPassCompactFBase = kPassCompactWBase + kMaxOuterBits;       
 constexpr uint32_t kPassRoundsOffset = kPassCompactFBase + kMaxOuterBits;       // 117
 constexpr uint32_t kPassCompactStore = 1u, kPassCompactLoad = 2u;               // flags word
 constexpr uint32_t kExchangeWords = 2 * kColumnWords;                           // after the round's header word
+constexpr uint32_t kMaxSwaps = 4, kSwapPad = 0xFFFFFFFFu;                       // swap round: kMaxSwaps words
+constexpr int kSwapLaneLo = 0, kSwapLaneHi = 6;                                 // lane bits a swap may use: [lo, hi)
 constexpr uint32_t kPosPad = 62;  // inserting a zero bit at position 62 leaves every index below 2^62 unchanged
 constexpr uint32_t kGateWords = 4;
 constexpr uint32_t kAngleEntryWords = 9;

@@ -201,6 +201,7 @@ PlanConfig resolve_config(const qsv_plan_config* cfg, int dtype) {
     if (const char* e = getenv("QSV_LANE_BITS")) pc.lane_bits = atoi(e);
     if (const char* e = getenv("QSV_FOLD")) pc.fold = atoi(e) != 0;
     if (const char* e = getenv("QSV_COMPACT")) pc.compact = atoi(e) != 0;
+    if (const char* e = getenv("QSV_SWAPS")) pc.swaps = atoi(e) != 0;
     if (cfg) {
         if (cfg->tile_bits > 0) pc.tile_bits = cfg->tile_bits;
         if (cfg->reg_bits > 0) pc.reg_bits = cfg->reg_bits;
@@ -372,7 +373,8 @@ int batch_layout(qsv_t* h, const std::vector<Circuit*>& circs, const std::vector
             return fail(h, QSV_E_ARG, "circuit needs " + std::to_string(circs[i]->n_params) + " parameter values, got " +
                                           std::to_string(n_params[i]));
         total_params += size_t(n_params[i]);
-        total_mats += mat_region_doubles(uint32_t(circs[i]->plan.stats.n_real_gates), uint32_t(h->n), h->geo.t, h->n - h->geo.k);
+        total_mats += mat_region_doubles(uint32_t(circs[i]->plan.stats.n_real_gates), uint32_t(h->n), h->geo.t, h->n - h->geo.k,
+                                         circs[i]->plan.stats.n_passes);
     }
     if (total_params >= (size_t(1) << 31) || total_mats >= (size_t(1) << 31))
         return fail(h, QSV_E_ARG, "batch too large");
@@ -393,7 +395,7 @@ int batch_layout(qsv_t* h, const std::vector<Circuit*>& circs, const std::vector
         b.param_base[i] = uint32_t(pcur);
         b.n_params[i] = uint32_t(n_params[i]);
         pcur += size_t(n_params[i]);
-        mcur += mat_region_doubles(uint32_t(c.plan.stats.n_real_gates), uint32_t(h->n), h->geo.t, h->n - h->geo.k);
+        mcur += mat_region_doubles(uint32_t(c.plan.stats.n_real_gates), uint32_t(h->n), h->geo.t, h->n - h->geo.k, c.plan.stats.n_passes);
         h->prof.n_gates += uint64_t(c.n_gates);
     }
     // (no copy here: prepare_kernel reads descriptors and parameters from this pinned buffer and writes the device

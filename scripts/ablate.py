@@ -1,0 +1,56 @@
+"""Ablation builds of libqsv (timing experiments; results are wrong by construction): each variant switches one part of
+the gate-pass kernel off so that its cost in the whole launch can be read from the per-kernel launch times.
+
+    python scripts/ablate.py build                 # here: queasars_amd/libqsv_abl_<name>.so for every variant
+    python scripts/ablate.py run [n P]             # on the GPU box: one line per variant
+"""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+VARIANTS = {
+    "base": (),
+    "nogates": ("QSV_ABL_NOGATES",),
+    "noswap": ("QSV_ABL_NOSWAP",),
+    "noload": ("QSV_ABL_NOLOAD",),
+    "nof": ("QSV_ABL_NOF",),
+    "nodiag": ("QSV_ABL_NODIAG",),
+    "noload_nof_nodiag": ("QSV_ABL_NOLOAD", "QSV_ABL_NOF", "QSV_ABL_NODIAG"),
+    "nothing_but_memory": ("QSV_ABL_NOGATES", "QSV_ABL_NOSWAP"),
+    "nothing_but_gates": ("QSV_ABL_NOLOAD", "QSV_ABL_NOF", "QSV_ABL_NODIAG", "QSV_ABL_NOSWAP"),
+}
+
+
+def lib_of(name):
+    return ROOT / "queasars_amd" / f"libqsv_abl_{name}.so"
+
+
+def main():
+    if sys.argv[1] == "build":
+        from queasars_amd import _build
+
+        for name, defines in VARIANTS.items():
+            if name == "base":
+                continue
+            print(_build.build(force=True, defines=defines, lib_path=lib_of(name)))
+        return
+    n, pop = (sys.argv[2:4] + ["20", "64"][len(sys.argv[2:4]):])
+    for name in VARIANTS:
+        env = dict(os.environ, QSV_BENCH_QUBITS=n, QSV_BENCH_POP=pop)
+        if name != "base":
+            env["QSV_LIBRARY"] = str(lib_of(name))
+        res = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--no-extras", "--no-cpu-baseline", "--steps", "10", "--warmup", "3"],
+                             env=env, capture_output=True, text=True)
+        if res.returncode != 0:
+            print(name, "FAILED", res.stderr[-400:])
+            continue
+        d = json.loads(res.stdout.strip().splitlines()[-1])
+        print(f"{name:22s} {d['value']:10.0f} evals/s  kernels us: " + "  ".join(f"{k['avg_launch_us']:.1f}" for k in d["roofline"]["kernels"]), flush=True)
+
+
+if __name__ == "__main__":
+    main()

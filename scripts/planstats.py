@@ -10,7 +10,7 @@ from queasars_amd.planning import build_plan_words
 cases = [(12, 4), (16, 4), (20, 4), (20, 8), (24, 4)] if len(sys.argv) < 2 else [tuple(int(x) for x in a.split(",")) for a in sys.argv[1:]]
 P = 16
 for n, L in cases:
-    keys = ["passes", "rounds", "exchanges", "intra", "conflicts", "gates", "u", "ctrl_global", "ctrl_wave", "ctrl_lane", "ctrl_reg", "units"]
+    keys = ["passes", "rounds", "exchanges", "swap_rounds", "swaps", "intra", "conflicts", "gates", "u", "ctrl_global", "ctrl_wave", "ctrl_lane", "ctrl_reg", "units"]
     tot = dict.fromkeys(keys, 0.0)
     _, circuits, _ = helpers.population_circuits(n, L, P, seed=0)
     for c in circuits:
@@ -20,6 +20,7 @@ for n, L in cases:
             t = ps["t"]
             tot["rounds"] += len(ps["rounds"])
             for rd in ps["rounds"]:
+                tot["swap_rounds"] += bool(rd["swaps"]); tot["swaps"] += len(rd["swaps"])
                 if rd["write_cols"] is not None:
                     tot["exchanges"] += 1
                     tot["intra"] += rd["intra_wave"]

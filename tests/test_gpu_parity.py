@@ -35,6 +35,7 @@ def test_statevector_matches_oracle(n_qubits, n_layers):
         dict(tile_bits=11, reg_bits=4, low_bits=4),
         dict(tile_bits=9, reg_bits=2, low_bits=2),
         dict(tile_bits=12, reg_bits=4, low_bits=2),
+        dict(tile_bits=13, reg_bits=4, low_bits=2),
         dict(tile_bits=12, reg_bits=3, exchange=2),
         dict(tile_bits=12, reg_bits=3, exchange=3),
         dict(tile_bits=11, reg_bits=2, exchange=3, group=2),
