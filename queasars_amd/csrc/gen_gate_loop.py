@@ -122,15 +122,24 @@ def gate(lines: list[str], r: int, x: str, tag: str) -> None:
 
 
 def loop_body(r: int) -> list[str]:
-    a, b = MAT["A"], MAT["B"]
-    da, db = DESC["A"], DESC["B"]
     rp, mp = sreg2(RP), sreg2(MP)
-    n = f"s{N}"
     lines: list[str] = []
     e = lines.append
     e(f"s_mov_b64 {rp}, %[rp]")
     e(f"s_mov_b64 {mp}, %[mp]")
-    e(f"s_mov_b32 {n}, %[n]")
+    e(f"s_mov_b32 s{N}, %[n]")
+    gate_loop_core(lines, r)
+    return lines
+
+
+def gate_loop_core(lines: list[str], r: int) -> None:
+    """The gate loop proper; expects the descriptor pointer in s[RP:RP+1], the matrix pointer in s[MP:MP+1] and the
+    gate count (> 0) in s[N].  Leaves the pointers somewhere inside the gate list (the caller keeps its own)."""
+    a, b = MAT["A"], MAT["B"]
+    da, db = DESC["A"], DESC["B"]
+    rp, mp = sreg2(RP), sreg2(MP)
+    n = f"s{N}"
+    e = lines.append
     e(f"s_load_dwordx4 s[{da}:{da + 3}], {rp}, 0x0")
     e(f"s_load_dwordx16 s[{a}:{a + 15}], {mp}, 0x0")
     e("Lloop_%=:")
@@ -154,7 +163,6 @@ def loop_body(r: int) -> list[str]:
     e("s_cbranch_scc1 Lloop_%=")
     e("Ldone_%=:")
     e("s_waitcnt lgkmcnt(0)")  # the last prefetch must land before the compiler may reuse these registers
-    return lines
 
 
 def emit(r: int) -> str:
@@ -274,6 +282,207 @@ def emit_swap(r: int) -> str:
     return "\n".join(out)
 
 
+# ---- the whole round loop of a tile (exchange mode 2) ---------------------------------------------------------------
+# kernels.hip states the same loop in C++ (used for fp32 and the other exchange modes).  Around the separate assembly
+# blocks of that version hipcc carries the amplitudes through temporaries -- 16 v_mov_b64 into the fixed registers
+# before every block and 16 out after it -- because their definitions alternate between its own code (LDS reads) and
+# the blocks.  Here rounds, LDS exchanges, lane swaps and gates are ONE block per tile and nothing moves.
+RH, ROUNDS, FLAGS, T1, T2, T3 = 89, 90, 91, 83, 92, 93
+SAVE2 = "s[94:95]"
+NEXT_RP, NEXT_MP = "s[92:93]", "s[94:95]"  # (the gate loop's exit values; T2 / T3 / SAVE2 are free while gates run)
+ROUND_CLOBBERS = range(40, 96)
+WC, RC = 40, 56  # scalar registers of the LDS write / read columns during an exchange (9 thread + 4 register columns)
+K_THREAD_COLS = 9
+
+
+def emit_rounds(r: int) -> str:
+    nr = 1 << r
+    rp, mp = sreg2(RP), sreg2(MP)
+    lines: list[str] = []
+    e = lines.append
+    e(f"s_mov_b64 {rp}, %[rp]")
+    e(f"s_mov_b64 {mp}, %[mp]")
+    e(f"s_mov_b32 s{ROUNDS}, %[rounds]")
+    e(f"s_mov_b32 s{FLAGS}, %[flags]")
+    e("Lround_%=:")
+    e(f"s_load_dword s{RH}, {rp}, 0x0")
+    e("s_waitcnt lgkmcnt(0)")
+    e(f"s_bitcmp1_b32 s{RH}, 16")
+    e("s_cbranch_scc1 Lexch_%=")
+    e(f"s_bitcmp1_b32 s{RH}, 18")
+    e("s_cbranch_scc1 Lswap_%=")
+    e(f"s_add_u32 s{RP}, s{RP}, 4")
+    e(f"s_addc_u32 s{RP + 1}, s{RP + 1}, 0")
+    e("Lgates_%=:")
+    e(f"s_and_b32 s{N}, s{RH}, 0xffff")
+    e(f"s_cmp_eq_u32 s{N}, 0")
+    e("s_cbranch_scc1 Lnext_%=")
+    # where the pointers stand after this round's gates: 16 bytes of descriptor, 64 bytes of matrix per gate
+    e(f"s_lshl_b32 s{T1}, s{N}, 4")
+    e(f"s_add_u32 s92, s{RP}, s{T1}")
+    e(f"s_addc_u32 s93, s{RP + 1}, 0")
+    e(f"s_lshl_b32 s{T1}, s{N}, 6")
+    e(f"s_add_u32 s94, s{MP}, s{T1}")
+    e(f"s_addc_u32 s95, s{MP + 1}, 0")
+    gate_loop_core(lines, r)
+    e(f"s_mov_b64 {rp}, {NEXT_RP}")
+    e(f"s_mov_b64 {mp}, {NEXT_MP}")
+    e("Lnext_%=:")
+    e(f"s_sub_u32 s{ROUNDS}, s{ROUNDS}, 1")
+    e(f"s_cmp_lg_u32 s{ROUNDS}, 0")
+    e("s_cbranch_scc1 Lround_%=")
+    e("s_branch Lfinish_%=")
+
+    # ---- lane swaps: up to four words, always taken from s40
+    e("Lswap_%=:")
+    e(f"s_load_dwordx4 s[40:43], {rp}, 0x4")
+    e(f"s_add_u32 s{RP}, s{RP}, 20")
+    e(f"s_addc_u32 s{RP + 1}, s{RP + 1}, 0")
+    e("s_waitcnt lgkmcnt(0)")
+    e("Lswapnext_%=:")
+    e("s_cmp_eq_u32 s40, -1")
+    e("s_cbranch_scc1 Lgates_%=")
+    e(f"s_and_b32 {T0}, s40, 0xff")
+    e(f"s_mul_i32 {T0}, {T0}, 6")
+    e(f"s_bfe_u32 s{T1}, s40, 0x80008")
+    e(f"s_add_u32 {T0}, {T0}, s{T1}")
+    cases = [(v, u) for v in range(r) for u in range(6)]
+    labels = [f"Lc{v}_{u}_%=" for v, u in cases]
+    tree: list[str] = []
+    dispatch_tree(tree, 0, len(cases), labels, "r")
+    lines.extend(x.replace("%[sel]", T0) for x in tree)
+    for (v, u), label in zip(cases, labels):
+        e(f"{label}:")
+        swap_case(lines, r, v, u)
+        e("s_branch Lswapdone_%=")
+    e("Lswapdone_%=:")
+    e("s_mov_b32 s40, s41")
+    e("s_mov_b32 s41, s42")
+    e("s_mov_b32 s42, s43")
+    e("s_mov_b32 s43, -1")
+    e("s_branch Lswapnext_%=")
+
+    # ---- LDS exchange (mode 2: real plane, then imaginary plane, through one plane buffer)
+    e("Lexch_%=:")
+    for base, off in ((WC, 4), (RC, 4 + 52)):
+        e(f"s_load_dwordx8 s[{base}:{base + 7}], {rp}, {hex(off)}")
+        e(f"s_load_dwordx4 s[{base + 8}:{base + 11}], {rp}, {hex(off + 32)}")
+        e(f"s_load_dword s{base + 12}, {rp}, {hex(off + 48)}")
+    e(f"s_add_u32 s{RP}, s{RP}, {4 + 104}")
+    e(f"s_addc_u32 s{RP + 1}, s{RP + 1}, 0")
+    # a barrier first if some wave may still be reading what the previous exchange left in LDS: after an exchange
+    # that stayed inside each wave only this wave's own reads matter, and they have completed
+    e(f"s_bitcmp1_b32 s{RH}, 17")
+    e(f"s_cselect_b32 s{T2}, 2, 1")
+    e(f"s_and_b32 s{T2}, s{FLAGS}, s{T2}")
+    e("s_cbranch_scc0 Lnobar_%=")
+    e("s_waitcnt lgkmcnt(0)")
+    e("s_barrier")
+    e(f"s_andn2_b32 s{FLAGS}, s{FLAGS}, 2")
+    e("Lnobar_%=:")
+    e("s_waitcnt lgkmcnt(0)")
+    # thread parts of the two LDS offsets: lane bits on the vector unit, wave-index bits on the scalar unit
+    e("v_mov_b32 %[vt], 0")
+    e("v_mov_b32 %[t0], 0")
+    for u in range(6):
+        e(f"v_bfe_i32 %[t2], %[tid], {u}, 1")
+        e(f"v_and_b32 %[t3], s{WC + u}, %[t2]")
+        e("v_xor_b32 %[vt], %[vt], %[t3]")
+        e(f"v_and_b32 %[t3], s{RC + u}, %[t2]")
+        e("v_xor_b32 %[t0], %[t0], %[t3]")
+    e(f"s_mov_b32 s{T2}, 0")
+    e(f"s_mov_b32 s{T3}, 0")
+    for u in range(6, K_THREAD_COLS):
+        e(f"s_bitcmp1_b32 %[wave], {u - 6}")
+        e(f"s_cselect_b32 s94, s{WC + u}, 0")
+        e(f"s_cselect_b32 s95, s{RC + u}, 0")
+        e(f"s_xor_b32 s{T2}, s{T2}, s94")
+        e(f"s_xor_b32 s{T3}, s{T3}, s95")
+    e(f"v_xor_b32 %[vt], s{T2}, %[vt]")
+    e(f"v_xor_b32 %[t0], s{T3}, %[t0]")
+    e("v_lshlrev_b32 %[vt], 3, %[vt]")
+    e("v_lshlrev_b32 %[t0], 3, %[t0]")
+    e("v_add_u32 %[vt], %[lds], %[vt]")
+    e("v_add_u32 %[t0], %[lds], %[t0]")
+    for v in range(r):
+        e(f"s_lshl_b32 s{WC + K_THREAD_COLS + v}, s{WC + K_THREAD_COLS + v}, 3")
+        e(f"s_lshl_b32 s{RC + K_THREAD_COLS + v}, s{RC + K_THREAD_COLS + v}, 3")
+
+    def gray(i: int) -> int:
+        return i ^ (i >> 1)
+
+    def ctz(i: int) -> int:
+        return (i & -i).bit_length() - 1
+
+    def barrier_unless_intra(tag: str) -> None:
+        e(f"s_bitcmp1_b32 s{RH}, 17")
+        e(f"s_cbranch_scc1 Lib{tag}_%=")
+        e("s_waitcnt lgkmcnt(0)")
+        e("s_barrier")
+        e(f"Lib{tag}_%=:")
+
+    for plane, reg in (("re", amp_re), ("im", amp_im)):
+        # write (threads of the tile only), barrier, read
+        e(f"s_mov_b64 {SAVE2}, exec")
+        e(f"s_and_b64 exec, exec, %[active]")
+        e("v_mov_b32 %[t1], %[vt]")
+        for i in range(nr):
+            if i:
+                e(f"v_xor_b32 %[t1], s{WC + K_THREAD_COLS + ctz(i)}, %[t1]")
+            e(f"ds_write_b64 %[t1], {reg(gray(i))}")
+        e(f"s_mov_b64 exec, {SAVE2}")
+        barrier_unless_intra("w" + plane)
+        e("v_mov_b32 %[t1], %[t0]")
+        for i in range(nr):
+            if i:
+                e(f"v_xor_b32 %[t1], s{RC + K_THREAD_COLS + ctz(i)}, %[t1]")
+            e(f"ds_read_b64 {reg(gray(i))}, %[t1]")
+        if plane == "re":
+            barrier_unless_intra("r" + plane)
+    e("s_waitcnt lgkmcnt(0)")
+    e(f"s_or_b32 s{FLAGS}, s{FLAGS}, 1")
+    e(f"s_bitcmp1_b32 s{RH}, 17")
+    e("s_cbranch_scc1 Lgates_%=")
+    e(f"s_or_b32 s{FLAGS}, s{FLAGS}, 2")
+    e("s_branch Lgates_%=")
+
+    e("Lfinish_%=:")
+    e(f"s_mov_b32 %[flags], s{FLAGS}")
+
+    out = []
+    out.append(f"// R = {r}: every round of a tile (LDS exchanges in mode 2, lane swaps, gates)")
+    out.append("template <>")
+    out.append(f"struct RoundLoopF64<{r}> {{")
+    out.append(
+        f"    static __device__ __forceinline__ void run(cx<double> (&amp)[{nr}], cu32p rp, cf64p mp, uint32_t n_rounds,\n"
+        "                                               uint32_t base, uint32_t tid, uint32_t wave, uint64_t active,\n"
+        "                                               uint32_t lds, uint32_t& flags) {"
+    )
+    out.append("        base = __builtin_amdgcn_readfirstlane(base);")
+    out.append("        n_rounds = __builtin_amdgcn_readfirstlane(n_rounds);")
+    out.append("        wave = __builtin_amdgcn_readfirstlane(wave);")
+    out.append("        lds = __builtin_amdgcn_readfirstlane(lds);")
+    out.append("        uint32_t fl = __builtin_amdgcn_readfirstlane(flags);")
+    out.append("        double u, w, p, q;")
+    out.append("        uint32_t vt, t0, t1, t2, t3;")
+    out.append("        asm volatile(")
+    for line in lines:
+        out.append(f'            "{line}\\n\\t"')
+    outs = amp_operands(nr)
+    outs += ['[u] "=&v"(u)', '[w] "=&v"(w)', '[p] "=&v"(p)', '[q] "=&v"(q)', '[vt] "=&v"(vt)', '[t0] "=&v"(t0)',
+             '[t1] "=&v"(t1)', '[t2] "=&v"(t2)', '[t3] "=&v"(t3)', '[flags] "+s"(fl)']
+    out.append("            : " + ",\n              ".join(outs))
+    out.append('            : [rp] "s"(rp), [mp] "s"(mp), [rounds] "s"(n_rounds), [base] "s"(base), [tid] "v"(tid), [wave] "s"(wave),\n'
+               '              [active] "s"(active), [lds] "s"(lds), [lane] "v"(tid & 63u)')
+    clob = ['"vcc"', '"scc"', '"memory"'] + [f'"s{i}"' for i in ROUND_CLOBBERS]
+    rows = [", ".join(clob[i : i + 12]) for i in range(0, len(clob), 12)]
+    out.append("            : " + ",\n              ".join(rows) + ");")
+    out.append("        flags = fl;")
+    out.append("    }")
+    out.append("};")
+    return "\n".join(out)
+
+
 def render() -> str:
     head = (
         "// GENERATED by gen_gate_loop.py -- do not edit; regenerate with `python gen_gate_loop.py`.\n"
@@ -285,7 +494,12 @@ def render() -> str:
         "\n\n// Lane swaps (plan.hpp \"swap\" rounds), see gen_gate_loop.py.\n"
         "template <int R>\nstruct SwapF64;  // specialised below for R = 1 .. 4\n\n"
     )
-    return (head + "\n\n".join(emit(r) for r in (1, 2, 3, 4)) + swap_head + "\n\n".join(emit_swap(r) for r in (1, 2, 3, 4)) + "\n")
+    rounds_head = (
+        "\n\n// The whole round loop of a tile (exchange mode 2), see gen_gate_loop.py.\n"
+        "template <int R>\nstruct RoundLoopF64;  // specialised below for R = 1 .. 4\n\n"
+    )
+    return (head + "\n\n".join(emit(r) for r in (1, 2, 3, 4)) + swap_head + "\n\n".join(emit_swap(r) for r in (1, 2, 3, 4))
+            + rounds_head + "\n\n".join(emit_rounds(r) for r in (1, 2, 3, 4)) + "\n")
 
 
 if __name__ == "__main__":

@@ -361,6 +361,8 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE>::waves_per_simd))
     }
     cxr amp[NR];
     double acc = 0.0;
+    uint32_t xflags = 0;         // the same two flags for the assembly round loop: bit 0 lds_dirty, bit 1 cross_pending
+    const uint64_t active_mask = __ballot(active);
     bool lds_dirty = false;      // LDS holds exchange data some wave may still be reading
     bool cross_pending = false;  // ... and that wave may be another one (the last exchange crossed waves)
 
@@ -462,6 +464,19 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE>::waves_per_simd))
         QSV_STAMP(1);
         cu32p rp = rounds0;
         cf64p mp = mats0;
+#ifndef QSV_STAMPS
+        // fp64, exchange mode 2 (the production configuration): every round of the tile is ONE generated assembly block
+        // (gate_loop_gen.inc, RoundLoopF64).  The C++ loop below states the same thing and serves fp32, the other
+        // exchange modes and the stamped diagnostic build.
+        constexpr bool kAsmRounds = std::is_same<real, double>::value && XMODE == 2 && R <= 4;
+#else
+        constexpr bool kAsmRounds = false;
+#endif
+        if constexpr (kAsmRounds) {
+            if (n_rounds > 0)
+                RoundLoopF64<R>::run(amp, rp, mp, uint32_t(n_rounds), uint32_t(base), tid, wave, active_mask,
+                                     uint32_t(uintptr_t(lds_raw)), xflags);
+        } else
         for (int m = 0; m < n_rounds; ++m) {
             const uint32_t rh = rp[0];
             const int n_gates = rh & 0xffff;
@@ -498,7 +513,7 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE>::waves_per_simd))
                         }
                     }
                     if (!intra) lds_barrier();
-                    if (active) {
+                    {  // (every thread reads: see the gate loop below)
 {
                             uint32_t o = rt;
 #pragma unroll
@@ -524,7 +539,7 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE>::waves_per_simd))
                         }
                     }
                     if (!intra) lds_barrier();
-                    if (active) {
+                    {  // (every thread reads: see the gate loop below)
 {
                             uint32_t o = rt;
 #pragma unroll
@@ -551,7 +566,7 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE>::waves_per_simd))
                     QSV_STAMP(3);
                     if (!intra) lds_barrier();
                     QSV_STAMP(4);
-                    if (active) {
+                    {  // (every thread reads: see the gate loop below)
 {
                             uint32_t o = rt;
 #pragma unroll
@@ -579,7 +594,7 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE>::waves_per_simd))
                     QSV_STAMP(7);
                     if (!intra) lds_barrier();
                     QSV_STAMP(8);
-                    if (active) {
+                    {  // (every thread reads: see the gate loop below)
 {
                             uint32_t o = rt;
 #pragma unroll
@@ -619,7 +634,10 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE>::waves_per_simd))
                 // fp64: the gate loop is the generated assembly block (gate_loop_gen.inc); amplitudes never move
                 if (n_gates > 0) {
 #ifndef QSV_ABL_NOGATES  // (ablation builds, scripts/ablate.py: timing experiments with wrong results)
-                    if (active) GateLoopF64<R>::run(amp, rp, mp, uint32_t(n_gates), uint32_t(base), tid);
+                    // (not under `if (active)`: threads beyond 2^t only exist in tiles smaller than a wave, their
+                    // registers hold nothing anyone reads, and a conditional here makes hipcc carry the amplitudes
+                    // through temporaries -- 16 v_mov_b64 into the block's fixed registers and 16 out, every round)
+                    GateLoopF64<R>::run(amp, rp, mp, uint32_t(n_gates), uint32_t(base), tid);
 #endif
                     rp += size_t(n_gates) * kGateWords;
                     mp += size_t(n_gates) * 8;
