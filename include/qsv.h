@@ -119,6 +119,12 @@ int qsv_set_operator(qsv_t* h, int n_terms, const uint64_t* x_mask, const uint64
 
 /* Register a circuit structure once; evaluations then send only parameter values. */
 int qsv_circuit_create(qsv_t* h, int n_ops, const qsv_op* ops, int n_params, int* out_circuit_id);
+/* The same for many structures at once (circuit i = ops[op_offsets[i] .. op_offsets[i+1]), n_params[i] parameters):
+ * the pass scheduler runs on several host threads.  What a generation of EVQE needs after topological search or layer
+ * removal, when a whole population of new structures arrives together (reference: one fresh QuantumCircuit per
+ * individual, queasars/minimum_eigensolvers/evqe/evolutionary_algorithm/selection.py:75-82). */
+int qsv_circuits_create(qsv_t* h, int n_circuits, const int64_t* op_offsets, const qsv_op* ops, const int* n_params,
+                        int* out_circuit_ids);
 int qsv_circuit_destroy(qsv_t* h, int circuit_id);
 
 /*
@@ -128,6 +134,17 @@ int qsv_circuit_destroy(qsv_t* h, int circuit_id);
  */
 int qsv_eval_circuits(qsv_t* h, int n_evals, const int* circuit_ids, const int64_t* param_offsets,
                       const double* params, double* out_expectations);
+
+/*
+ * ONE evaluation, merged with the evaluations other host threads ask for at the same time: the first caller collects
+ * the requests that arrive within `window_us` microseconds (0 = library default; it stops earlier once as many
+ * callers as last time have arrived, or nobody new comes), runs them as one batch and every caller gets its value.
+ * This is the native form of the reference's BatchingMutexPrimitiveJobRunner (a 0.1 s collection window in front of a
+ * primitive that is not thread safe, queasars/circuit_evaluation/mutex_primitives.py:67-199) for its calling pattern:
+ * population_size threads, one circuit per call (selection.py:75-82, mutation.py:63-75).
+ */
+int qsv_eval_coalesced(qsv_t* h, int circuit_id, const double* params, int n_params, double window_us,
+                       double* out_expectation);
 
 /*
  * Streaming form of qsv_eval_circuits, for callers whose parameter vectors become available (or are converted)

@@ -74,8 +74,10 @@ SIGNATURES = {
     "qsv_n_qubits": (C.c_int, [_P]),
     "qsv_set_operator": (C.c_int, [_P, C.c_int, _P, _P, _P, _P]),
     "qsv_circuit_create": (C.c_int, [_P, C.c_int, _P, C.c_int, C.POINTER(C.c_int)]),
+    "qsv_circuits_create": (C.c_int, [_P, C.c_int, _P, _P, _P, _P]),
     "qsv_circuit_destroy": (C.c_int, [_P, C.c_int]),
     "qsv_eval_circuits": (C.c_int, [_P, C.c_int, _P, _P, _P, _P]),
+    "qsv_eval_coalesced": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_double, C.POINTER(C.c_double)]),
     "qsv_eval_begin": (C.c_int, [_P, C.c_int, _P, _P]),
     "qsv_eval_push": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "qsv_eval_end": (C.c_int, [_P, _P]),

@@ -40,7 +40,7 @@ from queasars_amd.circuit_evaluation.expectation_calculation import (
     get_expectation_with_bitstring_evaluator,
     get_expectation_with_operator,
 )
-from queasars_amd.ir import CircuitIR, PauliOperator
+from queasars_amd.ir import QSV_OP_DTYPE, CircuitIR, PauliOperator
 
 
 class CircuitEvaluatorException(Exception):
@@ -205,6 +205,31 @@ class StatevectorDevice:
                 weakref.finalize(circuit, StatevectorDevice._release, weakref.ref(self), cid)
         return cid
 
+    def _register_many(self, fresh: Sequence[CircuitIR]) -> None:
+        """Register several new circuit structures with ONE library call (``qsv_circuits_create``: the pass scheduler
+        runs on several host threads).  A generation of EVQE brings up to a population of new structures at once."""
+        fresh = list({id(c): c for c in fresh}.values())
+        if len(fresh) < 2:
+            return
+        for c in fresh:
+            if c.n_qubits != self._n_qubits:
+                raise ValueError(f"circuit has {c.n_qubits} qubits, the evaluator {self._n_qubits}")
+        with self._reg_lock:
+            fresh = [c for c in fresh if self._serial not in c._registered]
+            if len(fresh) < 2:
+                return
+            blobs = [bytes(c._bytes) for c in fresh]
+            ops = np.frombuffer(b"".join(blobs), dtype=QSV_OP_DTYPE) if any(blobs) else np.zeros(1, dtype=QSV_OP_DTYPE)
+            offsets = np.zeros(len(fresh) + 1, dtype=np.int64)
+            np.cumsum([len(c) for c in fresh], out=offsets[1:])
+            counts = np.asarray([c.num_parameters for c in fresh], dtype=np.int32)
+            out = np.zeros(len(fresh), dtype=np.int32)
+            self._check(self._lib.qsv_circuits_create(self._handle, len(fresh), _lib.as_ptr(offsets), _lib.as_ptr(ops),
+                                                      _lib.as_ptr(counts), _lib.as_ptr(out)))
+            for c, cid in zip(fresh, out):
+                c._registered[self._serial] = int(cid)
+                weakref.finalize(c, StatevectorDevice._release, weakref.ref(self), int(cid))
+
     @staticmethod
     def _release(device_ref, cid: int) -> None:
         device = device_ref()
@@ -230,6 +255,7 @@ class StatevectorDevice:
         if self._dead:
             with self._reg_lock:
                 self._reap()
+        self._register_many([c for c in circuits if self._serial not in c._registered])
         ids = np.fromiter((self.circuit_id(c) for c in circuits), dtype=np.int32, count=n)
         need = np.fromiter((c.num_parameters for c in circuits), dtype=np.int64, count=n)
         self._last_batch = ((CircuitIR.edits_of_registered, *map(id, circuits)), list(circuits), ids, need)
@@ -293,6 +319,23 @@ class StatevectorDevice:
             raise (ValueError if rc == _lib.QSV_E_ARG else CircuitEvaluatorException)(msg)
         self._check(rc_end)
         return out
+
+    def expectation_value_coalesced(self, circuit: CircuitIR, parameter_values: Sequence[float], window_us: float = 0.0) -> float:
+        """One evaluation, merged inside the library with the evaluations other threads ask for at the same time
+        (``qsv_eval_coalesced``).  The call blocks in C with the GIL released, so population_size Python threads calling
+        with one circuit each (the reference's selection operator) are answered from one batch."""
+        cid = circuit._registered.get(self._serial)
+        if cid is None:
+            cid = self.circuit_id(circuit)
+        if len(parameter_values) < circuit.num_parameters:
+            raise ValueError(f"circuit needs {circuit.num_parameters} parameter values, got {len(parameter_values)}")
+        packed = array("d", parameter_values) if type(parameter_values) is list else array("d", list(parameter_values))
+        out = C.c_double(0.0)
+        address = packed.buffer_info()[0] if len(packed) else None
+        rc = self._lib.qsv_eval_coalesced(self._handle, cid, address, len(packed), float(window_us), C.byref(out))
+        if rc != _lib.QSV_OK:
+            self._check(rc)
+        return out.value
 
     def statevector(self, circuit: CircuitIR, parameter_values: Sequence[float]) -> np.ndarray:
         cid = self.circuit_id(circuit)

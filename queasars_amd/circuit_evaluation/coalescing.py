@@ -34,12 +34,18 @@ class _Ticket:
 
 
 class CoalescingCircuitEvaluator(BaseCircuitEvaluator):
-    """Wraps any :class:`BaseCircuitEvaluator`; concurrent calls are answered from merged batches, in input order."""
+    """Wraps any :class:`BaseCircuitEvaluator`; concurrent calls are answered from merged batches, in input order.
 
-    def __init__(self, evaluator: BaseCircuitEvaluator, window_s: float = 2e-4, max_batch: int = 4096):
+    One-circuit calls on an exact :class:`OperatorCircuitEvaluator` (no initial state, no noise) take the native path:
+    ``qsv_eval_coalesced`` merges the callers inside the library while their threads wait in C with the GIL released
+    (the Python scheme below costs several thread hand-overs under the GIL per call).  The wrapped evaluator's device
+    must then not be shared with evaluators of other operators."""
+
+    def __init__(self, evaluator: BaseCircuitEvaluator, window_s: float = 2e-4, max_batch: int = 4096, native: bool = True):
         if window_s < 0 or max_batch < 1:
             raise ValueError("window_s must be >= 0 and max_batch >= 1")
         self._evaluator = evaluator
+        self._native = bool(native) and self._native_capable(evaluator)
         self._window_s = float(window_s)
         self._max_batch = int(max_batch)
         self._lock = threading.Lock()
@@ -51,11 +57,22 @@ class CoalescingCircuitEvaluator(BaseCircuitEvaluator):
     def n_qubits(self) -> int:
         return self._evaluator.n_qubits
 
+    @staticmethod
+    def _native_capable(evaluator) -> bool:
+        from queasars_amd.circuit_evaluation.circuit_evaluation import OperatorCircuitEvaluator
+
+        return (type(evaluator) is OperatorCircuitEvaluator and evaluator._initial_state_circuit is None
+                and evaluator._precision == 0)
+
     def evaluate_circuits(self, circuits: Sequence, parameter_values: Sequence[Sequence[float]]) -> list[float]:
         if len(circuits) != len(parameter_values):
             raise ValueError("circuits and parameter_values must have the same length")
         if not circuits:
             return []
+        if self._native and len(circuits) == 1 and circuits[0] is not None and parameter_values[0] is not None:
+            device = self._evaluator._device
+            if device._operator is self._evaluator._operator:
+                return [device.expectation_value_coalesced(circuits[0], parameter_values[0], self._window_s * 1e6)]
         ticket = _Ticket(circuits, parameter_values)
         with self._lock:
             self._queue.append(ticket)

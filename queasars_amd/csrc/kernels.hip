@@ -258,10 +258,13 @@ struct PassScalars {
 // 13 / 7.2 / 5.8 / 4.7 cycles per instruction at 1 / 2 / 4 / 8 waves per SIMD), so the kernel is compiled for
 // 6 waves per SIMD (<= 80 VGPRs) in mode 2: three 512-thread workgroups per CU.  Four (8 waves per SIMD, 64 VGPRs)
 // fit too since the gate loop is assembly, but measured 3-4% slower (twice): fewer scalar registers, more spills.
+#ifndef QSV_WAVES_PER_SIMD
+#define QSV_WAVES_PER_SIMD 6
+#endif
 template <int R, int XMODE>
 struct Occupancy {
     // 2^R amplitudes = 4 * 2^R VGPRs: R = 3 fits the 80-VGPR budget of 6 waves per SIMD, R = 4 needs the 128 of 4
-    static constexpr int waves_per_simd = R >= 4 ? 4 : (XMODE == 2 ? 6 : 4);
+    static constexpr int waves_per_simd = R >= 4 ? 4 : (XMODE == 2 ? QSV_WAVES_PER_SIMD : 4);
 };
 
 template <typename T>

@@ -3,9 +3,13 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <condition_variable>
 #include <cstring>
+#include <functional>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -44,6 +48,73 @@ struct DeviceBuffer {
 
 }  // namespace
 
+// Persistent host threads for scheduling many circuit structures at once (a generation of EVQE brings up to a
+// population of new structures): spawning threads per call would cost more than the plans.
+class WorkerPool {
+public:
+    explicit WorkerPool(unsigned n_threads) {
+        for (unsigned i = 0; i < n_threads; ++i) threads_.emplace_back([this]() { loop(); });
+    }
+    ~WorkerPool() {
+        {
+            std::lock_guard<std::mutex> lock(mu_);
+            stop_ = true;
+        }
+        wake_.notify_all();
+        for (std::thread& t : threads_) t.join();
+    }
+    // run fn(0 .. count-1), the calling thread takes part; returns when every index is done
+    void run(size_t count, const std::function<void(size_t)>& fn) {
+        if (count == 0) return;
+        {
+            std::lock_guard<std::mutex> lock(mu_);
+            fn_ = &fn;
+            count_ = count;
+            next_.store(0);
+            pending_ = count;
+            ++generation_;
+        }
+        wake_.notify_all();
+        work();
+        std::unique_lock<std::mutex> lock(mu_);
+        done_.wait(lock, [this]() { return pending_ == 0; });
+        fn_ = nullptr;
+    }
+
+private:
+    void work() {
+        for (;;) {
+            const size_t i = next_.fetch_add(1);
+            if (i >= count_) return;
+            (*fn_)(i);
+            std::lock_guard<std::mutex> lock(mu_);
+            if (--pending_ == 0) done_.notify_all();
+        }
+    }
+    void loop() {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lock(mu_);
+                wake_.wait(lock, [&]() { return stop_ || generation_ != seen; });
+                if (stop_) return;
+                seen = generation_;
+                if (!fn_) continue;
+            }
+            work();
+        }
+    }
+    std::vector<std::thread> threads_;
+    std::mutex mu_;
+    std::condition_variable wake_, done_;
+    const std::function<void(size_t)>* fn_ = nullptr;
+    std::atomic<size_t> count_{0};
+    size_t pending_ = 0;
+    std::atomic<size_t> next_{0};
+    uint64_t generation_ = 0;
+    bool stop_ = false;
+};
+
 struct qsv_handle {
     int n = 0, dtype = 0, device = 0;
     PlanConfig cfg;
@@ -73,6 +144,25 @@ struct qsv_handle {
     std::unordered_map<int, Circuit> circuits;
     int next_circuit_id = 1;
     std::unordered_map<std::string, int> inline_cache;
+    std::unique_ptr<WorkerPool> pool;  // created on first use (qsv_circuits_create, qsv_eval_batch)
+    std::mutex pool_mu;
+
+    // qsv_eval_coalesced: requests of concurrent callers waiting to be merged into one batch
+    struct CoalesceRequest {
+        int circuit_id = 0;
+        const double* params = nullptr;
+        int n_params = 0;
+        double value = 0.0;
+        int rc = QSV_OK;
+        std::string err;
+        bool done = false;
+    };
+    std::mutex cq_mu;
+    std::condition_variable cq_cv;
+    std::vector<CoalesceRequest*> cq;
+    std::atomic<size_t> cq_count{0};   // = cq.size(), readable without the lock (the collecting caller spins on it)
+    bool cq_collecting = false;        // some caller is collecting or evaluating a batch
+    size_t cq_expected = 0;            // size of the previous batch: how many callers to expect
 
     // device memory
     DeviceBuffer d_arena;  // plans (uint32 words)
@@ -190,9 +280,16 @@ std::vector<GateIn> gates_of(const qsv_op* ops, int n_ops, std::vector<AngleSour
     return gates;
 }
 
-PlanConfig resolve_config(const qsv_plan_config* cfg, int dtype) {
+PlanConfig resolve_config(const qsv_plan_config* cfg, int dtype, int n_qubits) {
     PlanConfig pc;
     pc.amp_bytes = dtype == QSV_F64 ? 16 : 8;
+    // Tile geometry by size (fp64; measured on MI355X with the EVQE benchmark family, scripts/gpu_k.sh): 16 amplitudes
+    // per thread halve the per-amplitude cost of decoding the plan from n = 20 on, and 13 tile qubits save a pass
+    // from n = 21 on (n = 24: 3 -> 2.25 passes on average, +33 % evaluations per second).
+    if (dtype == QSV_F64 && n_qubits >= 20) {
+        pc.reg_bits = 4;
+        pc.tile_bits = n_qubits >= 21 ? 13 : 12;
+    }
     if (dtype != QSV_F64) pc.xmode = 0;  // fp32: one 8-byte complex element per LDS access
     if (const char* e = getenv("QSV_XMODE")) pc.xmode = atoi(e);
     if (const char* e = getenv("QSV_TILE_BITS")) pc.tile_bits = atoi(e);
@@ -238,6 +335,34 @@ int build_circuit(qsv_t* h, int n_ops, const qsv_op* ops, int n_params, bool fol
         return QSV_E_ARG;
     }
     return QSV_OK;
+}
+
+// Schedule `count` structures, in parallel when there are several.  build(i) fills circuits[i]; the first failure is
+// reported.  Needs no handle lock (build_circuit reads only immutable parts of the handle).
+struct BuiltCircuit {
+    Circuit circuit;
+    std::string err;
+    int rc = QSV_OK;
+};
+void build_many(qsv_t* h, size_t count, const std::function<void(size_t, BuiltCircuit&)>& build, std::vector<BuiltCircuit>& out) {
+    out.resize(count);
+    if (count < 4) {
+        for (size_t i = 0; i < count; ++i) build(i, out[i]);
+        return;
+    }
+    WorkerPool* pool;
+    {
+        std::lock_guard<std::mutex> lock(h->pool_mu);
+        if (!h->pool) {
+            const unsigned hw = std::max(2u, std::min(16u, std::thread::hardware_concurrency()));
+            h->pool.reset(new WorkerPool(hw - 1));
+        }
+        pool = h->pool.get();
+    }
+    // one job at a time per pool: callers on several threads take turns
+    static std::mutex job_mu;
+    std::lock_guard<std::mutex> job(job_mu);
+    pool->run(count, [&](size_t i) { build(i, out[i]); });
 }
 
 // (caller holds h->mu)
@@ -711,7 +836,7 @@ int qsv_create(int n_qubits, int dtype, int device, const qsv_plan_config* cfg, 
     PlanConfig pc;
     Geometry geo;
     try {
-        pc = resolve_config(cfg, dtype);
+        pc = resolve_config(cfg, dtype, n_qubits);
         geo = make_geometry(n_qubits, pc);
     } catch (const std::exception& e) {
         return fail(nullptr, QSV_E_ARG, e.what());
@@ -911,6 +1036,24 @@ int qsv_circuit_create(qsv_t* h, int n_ops, const qsv_op* ops, int n_params, int
     return QSV_OK;
 }
 
+int qsv_circuits_create(qsv_t* h, int n_circuits, const int64_t* op_offsets, const qsv_op* ops, const int* n_params,
+                        int* out_circuit_ids) {
+    if (!h) return QSV_E_ARG;
+    if (n_circuits < 0 || (n_circuits > 0 && (!op_offsets || !n_params || !out_circuit_ids)))
+        return fail(h, QSV_E_ARG, "bad arguments");
+    for (int i = 0; i < n_circuits; ++i)
+        if (op_offsets[i + 1] < op_offsets[i] || n_params[i] < 0) return fail(h, QSV_E_ARG, "bad offsets or parameter counts");
+    std::vector<BuiltCircuit> built;
+    build_many(h, size_t(n_circuits), [&](size_t i, BuiltCircuit& b) {
+        b.rc = build_circuit(h, int(op_offsets[i + 1] - op_offsets[i]), ops + op_offsets[i], n_params[i], true, &b.circuit, &b.err);
+    }, built);
+    for (int i = 0; i < n_circuits; ++i)
+        if (built[size_t(i)].rc) return fail(h, built[size_t(i)].rc, built[size_t(i)].err + " (circuit " + std::to_string(i) + ")");
+    std::lock_guard<std::mutex> lock(h->mu);
+    for (int i = 0; i < n_circuits; ++i) out_circuit_ids[i] = insert_circuit(h, std::move(built[size_t(i)].circuit));
+    return QSV_OK;
+}
+
 int qsv_circuit_destroy(qsv_t* h, int circuit_id) {
     if (!h) return QSV_E_ARG;
     std::lock_guard<std::mutex> lock(h->mu);
@@ -935,6 +1078,97 @@ int qsv_eval_circuits(qsv_t* h, int n_evals, const int* circuit_ids, const int64
     }
     static const double dummy = 0.0;
     return eval_all(h, circs, param_offsets, params ? params : &dummy, out);
+}
+
+// Collect the requests of concurrent callers for a moment, evaluate them as ONE batch, hand every caller its value.
+// (caller holds h->cq_mu through `lock`; returns with it held)
+static void coalesce_lead(qsv_t* h, std::unique_lock<std::mutex>& lock, double window_us) {
+    using clock = std::chrono::steady_clock;
+    const double window = window_us > 0 ? window_us : 300.0, quiet = 40.0;
+    // A batch is complete when as many callers as last time have arrived, or nobody new came for `quiet` us, or the
+    // window is over.  The collector spins (no timed sleep is shorter than the kernel's timer slack of ~50 us).
+    lock.unlock();
+    const auto t0 = clock::now();
+    auto last_arrival = t0;
+    size_t seen = h->cq_count.load();
+    for (;;) {
+        const auto now = clock::now();
+        const size_t count = h->cq_count.load();
+        if (count != seen) {
+            seen = count;
+            last_arrival = now;
+        }
+        const double since_start = std::chrono::duration<double, std::micro>(now - t0).count();
+        const double since_arrival = std::chrono::duration<double, std::micro>(now - last_arrival).count();
+        if ((h->cq_expected > 1 && count >= h->cq_expected) || since_arrival >= quiet || since_start >= window) break;
+        __builtin_ia32_pause();
+    }
+    lock.lock();
+    std::vector<qsv_handle::CoalesceRequest*> batch;
+    batch.swap(h->cq);
+    h->cq_count.store(0);
+    lock.unlock();
+    {
+        std::lock_guard<std::mutex> hl(h->mu);
+        std::vector<Circuit*> circs;
+        std::vector<int64_t> offsets{0};
+        std::vector<double> params;
+        std::vector<qsv_handle::CoalesceRequest*> valid;
+        for (auto* r : batch) {
+            auto it = h->circuits.find(r->circuit_id);
+            if (it == h->circuits.end() || r->n_params < it->second.n_params) {
+                r->rc = QSV_E_ARG;
+                r->err = it == h->circuits.end() ? "unknown circuit id " + std::to_string(r->circuit_id)
+                                                 : "circuit needs " + std::to_string(it->second.n_params) + " parameter values";
+                continue;
+            }
+            circs.push_back(&it->second);
+            params.insert(params.end(), r->params, r->params + r->n_params);
+            offsets.push_back(int64_t(params.size()));
+            valid.push_back(r);
+        }
+        if (!valid.empty()) {
+            std::vector<double> values(valid.size(), 0.0);
+            params.push_back(0.0);
+            int rc = hipSetDevice(h->device) == hipSuccess ? QSV_OK : QSV_E_DEVICE;
+            if (!rc) rc = eval_all(h, circs, offsets.data(), params.data(), values.data());
+            const std::string err = rc ? g_handle_error : std::string();
+            for (size_t i = 0; i < valid.size(); ++i) {
+                valid[i]->rc = rc;
+                valid[i]->err = err;
+                valid[i]->value = values[i];
+            }
+        }
+    }
+    lock.lock();
+    h->cq_expected = batch.size();
+    for (auto* r : batch) r->done = true;
+    h->cq_collecting = false;
+    h->cq_cv.notify_all();
+}
+
+int qsv_eval_coalesced(qsv_t* h, int circuit_id, const double* params, int n_params, double window_us, double* out) {
+    if (!h) return QSV_E_ARG;
+    if (!out || n_params < 0 || (n_params > 0 && !params)) return fail(h, QSV_E_ARG, "bad arguments");
+    qsv_handle::CoalesceRequest req;
+    req.circuit_id = circuit_id;
+    req.params = params;
+    req.n_params = n_params;
+    std::unique_lock<std::mutex> lock(h->cq_mu);
+    h->cq.push_back(&req);
+    h->cq_count.fetch_add(1);
+    while (!req.done) {
+        if (!h->cq_collecting) {
+            h->cq_collecting = true;  // nobody is collecting: this caller does, for everyone queued with it
+            coalesce_lead(h, lock, window_us);
+        } else {
+            h->cq_cv.wait(lock);
+        }
+    }
+    lock.unlock();
+    if (req.rc) return fail(h, req.rc, req.err);
+    *out = req.value;
+    return QSV_OK;
 }
 
 int qsv_eval_begin(qsv_t* h, int n_evals, const int* circuit_ids, const int64_t* param_counts) {
@@ -1042,23 +1276,16 @@ int qsv_eval_batch(qsv_t* h, int n_evals, const int64_t* op_offsets, const qsv_o
     // pass 2: schedule the new structures, on several host threads when there are many (a generation of EVQE brings
     // up to a population of new structures at once)
     if (!fresh.empty()) {
-        auto build_one = [&](Fresh& f) {
-            const int i = f.first_eval;
-            const int64_t b = op_offsets[i], e = op_offsets[i + 1];
-            f.rc = build_circuit(h, int(e - b), ops + b, int(param_offsets[i + 1] - param_offsets[i]), true, &f.circuit, &f.err);
-        };
-        const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-        const size_t n_threads = std::min<size_t>(hw, fresh.size() / 2);
-        if (n_threads >= 2) {
-            std::atomic<size_t> next{0};
-            std::vector<std::thread> pool;
-            for (size_t t = 0; t < n_threads; ++t)
-                pool.emplace_back([&]() {
-                    for (size_t j = next.fetch_add(1); j < fresh.size(); j = next.fetch_add(1)) build_one(fresh[j]);
-                });
-            for (std::thread& t : pool) t.join();
-        } else {
-            for (Fresh& f : fresh) build_one(f);
+        std::vector<BuiltCircuit> built;
+        build_many(h, fresh.size(), [&](size_t j, BuiltCircuit& b) {
+            const int i = fresh[j].first_eval;
+            const int64_t ob = op_offsets[i], oe = op_offsets[i + 1];
+            b.rc = build_circuit(h, int(oe - ob), ops + ob, int(param_offsets[i + 1] - param_offsets[i]), true, &b.circuit, &b.err);
+        }, built);
+        for (size_t j = 0; j < fresh.size(); ++j) {
+            fresh[j].rc = built[j].rc;
+            fresh[j].err = std::move(built[j].err);
+            fresh[j].circuit = std::move(built[j].circuit);
         }
         for (Fresh& f : fresh)
             if (f.rc) return fail(h, f.rc, f.err + " (evaluation " + std::to_string(f.first_eval) + ")");
@@ -1299,7 +1526,7 @@ int qsv_plan_build(int n_qubits, int dtype, int n_ops, const qsv_op* ops, const 
     int rc = validate_ops(nullptr, n_qubits, n_ops, ops, 1 << 30);
     if (rc) return rc;
     try {
-        PlanConfig pc = resolve_config(cfg, dtype);
+        PlanConfig pc = resolve_config(cfg, dtype, n_qubits);
         std::vector<AngleSource> angles;
         std::vector<GateIn> gates = gates_of(ops, n_ops, &angles);
         CircuitPlan plan = build_plan(n_qubits, gates, angles, pc);

@@ -19,6 +19,7 @@ conversion.
 
 from __future__ import annotations
 
+import struct
 from dataclasses import dataclass
 from typing import Iterable, Optional, Sequence, Union
 
@@ -44,6 +45,8 @@ QSV_OP_DTYPE = np.dtype(
     align=True,
 )
 assert QSV_OP_DTYPE.itemsize == 40
+_ROW = struct.Struct("<BBBBiiiddd")  # the same record, for appending one op at a time
+assert _ROW.size == 40
 
 
 @dataclass(frozen=True)
@@ -70,6 +73,7 @@ class CircuitIR:
             raise ValueError("n_qubits must be in [1, 34]")
         self._n_qubits = int(n_qubits)
         self._rows: list[tuple] = []
+        self._bytes = bytearray()  # the rows as qsv_op records (what packed() hands to the library)
         self._n_parameters = 0
         self._packed: Optional[np.ndarray] = None
         self._version = 0  # bumped by every edit (caches of derived circuits compare it)
@@ -87,6 +91,7 @@ class CircuitIR:
     def __deepcopy__(self, memo) -> "CircuitIR":
         out = CircuitIR(self._n_qubits)
         out._rows = list(self._rows)  # rows are immutable tuples
+        out._bytes = bytearray(self._bytes)
         out._n_parameters = self._n_parameters
         memo[id(self)] = out
         return out
@@ -110,7 +115,9 @@ class CircuitIR:
 
     def _append(self, kind: int, target: int, control: int, theta: Angle, phi: Angle, lam: Angle) -> "CircuitIR":
         (it, vt), (ip, vp), (il, vl) = self._angle(theta), self._angle(phi), self._angle(lam)
-        self._rows.append((kind, target, control, 0, it, ip, il, vt, vp, vl))
+        row = (kind, target, control, 0, it, ip, il, vt, vp, vl)
+        self._rows.append(row)
+        self._bytes += _ROW.pack(*row)
         self._packed = None
         self._version += 1
         if self._registered:
@@ -150,6 +157,7 @@ class CircuitIR:
             raise ValueError("qubit counts differ")
         out = CircuitIR(self._n_qubits)
         out._rows = list(self._rows) + list(other._rows)
+        out._bytes = self._bytes + other._bytes
         out._n_parameters = max(self._n_parameters, other._n_parameters)
         return out
 
@@ -172,7 +180,7 @@ class CircuitIR:
     def packed(self) -> np.ndarray:
         """The ops as a contiguous ``qsv_op`` array (cached)."""
         if self._packed is None:
-            self._packed = np.array(self._rows, dtype=QSV_OP_DTYPE) if self._rows else np.zeros(0, dtype=QSV_OP_DTYPE)
+            self._packed = np.frombuffer(bytes(self._bytes), dtype=QSV_OP_DTYPE)
         return self._packed
 
     def bound_ops(self, parameter_values: Sequence[float]) -> list[tuple]:

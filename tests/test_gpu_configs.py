@@ -371,3 +371,78 @@ def test_three_by_three_contended_jssp_end_to_end():
     schedule = enc.translate_result_bitstring(format(int(np.argmax(probs)), f"0{enc.n_qubits}b"))
     assert schedule.is_valid and schedule.makespan == 5
     assert 36.7 < result.eigenvalue < 100.0
+
+
+def test_many_structures_registered_in_one_call():
+    """``qsv_circuits_create``: a population of new structures is scheduled by several host threads in one call; a bad
+    circuit among them fails the call and names the circuit."""
+    n = 12
+    _, circuits, params = helpers.population_circuits(n, 3, 40, seed=23)
+    op = helpers.random_ising_operator(n, seed=3)
+    with RawHandle(n) as raw:
+        raw.set_operator(op)
+        ops = np.concatenate([c.packed() for c in circuits])
+        offsets = np.zeros(len(circuits) + 1, dtype=np.int64)
+        np.cumsum([len(c) for c in circuits], out=offsets[1:])
+        counts = np.asarray([c.num_parameters for c in circuits], dtype=np.int32)
+        ids = np.zeros(len(circuits), dtype=np.int32)
+        raw.check(raw.lib.qsv_circuits_create(raw.h, len(circuits), _lib.as_ptr(offsets), _lib.as_ptr(ops), _lib.as_ptr(counts), _lib.as_ptr(ids)))
+        assert len(set(ids.tolist())) == len(circuits)
+        flat = np.concatenate([np.asarray(p) for p in params])
+        poffsets = np.zeros(len(circuits) + 1, dtype=np.int64)
+        np.cumsum([len(p) for p in params], out=poffsets[1:])
+        out = np.zeros(len(circuits))
+        raw.check(raw.lib.qsv_eval_circuits(raw.h, len(circuits), _lib.as_ptr(ids), _lib.as_ptr(poffsets), _lib.as_ptr(flat), _lib.as_ptr(out)))
+        ref = np.asarray([helpers.oracle_expectation(c, p, op) for c, p in zip(circuits[:6], params[:6])])
+        assert np.abs(out[:6] - ref).max() < EXP_TOL
+        bad = ops.copy()
+        bad["target"][int(offsets[17])] = 99
+        assert raw.lib.qsv_circuits_create(raw.h, len(circuits), _lib.as_ptr(offsets), _lib.as_ptr(bad), _lib.as_ptr(counts), _lib.as_ptr(ids)) == _lib.QSV_E_ARG
+        assert b"circuit 17" in raw.lib.qsv_last_error(raw.h)
+    # the Python layer takes the same path for a batch of unknown circuits: same bits as one-by-one registration
+    ev = OperatorCircuitEvaluator(op)
+    together = ev.evaluate_circuits(circuits, params)
+    fresh = helpers.population_circuits(n, 3, 40, seed=23)[1]
+    ev2 = OperatorCircuitEvaluator(op)
+    one_by_one = [ev2.evaluate_circuits([c], [p])[0] for c, p in zip(fresh, params)]
+    assert together == one_by_one and np.abs(np.asarray(together) - out).max() == 0.0
+
+
+def test_native_coalescing_of_concurrent_one_circuit_calls():
+    """The reference's calling pattern -- population_size threads, one circuit per call (selection.py:75-82) -- through
+    ``qsv_eval_coalesced``: callers are merged inside the library; every caller gets exactly the value a batched call
+    gives, and a caller's bad request fails that caller alone."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from queasars_amd.circuit_evaluation import CoalescingCircuitEvaluator
+
+    n, P = 13, 48
+    _, circuits, params = helpers.population_circuits(n, 3, P, seed=31)
+    op = helpers.random_ising_operator(n, seed=9)
+    ev = OperatorCircuitEvaluator(op)
+    want = ev.evaluate_circuits(circuits, params)
+    merged = CoalescingCircuitEvaluator(ev)
+    assert merged._native
+    with ThreadPoolExecutor(max_workers=P) as pool:
+        for _ in range(5):
+            got = list(pool.map(lambda j: merged.evaluate_circuits([circuits[j]], [params[j]])[0], range(P)))
+            assert got == want
+
+        def bad_or_good(j):
+            if j == 7:
+                try:
+                    merged.evaluate_circuits([circuits[j]], [params[j][:-1]])
+                except ValueError:
+                    return "refused"
+                return "accepted"
+            return merged.evaluate_circuits([circuits[j]], [params[j]])[0]
+
+        mixed = list(pool.map(bad_or_good, range(P)))
+        assert mixed[7] == "refused" and mixed[:7] == want[:7] and mixed[8:] == want[8:]
+    # raw ABI: an unknown circuit id is refused with the library's message
+    dev = ev.statevector_device
+    out = C.c_double(0.0)
+    assert dev._lib.qsv_eval_coalesced(dev._handle, 10**6, None, 0, 0.0, C.byref(out)) == _lib.QSV_E_ARG
+    assert b"unknown circuit id" in dev._lib.qsv_last_error(dev._handle)
+    # two-circuit calls still go through the Python merger and agree
+    assert merged.evaluate_circuits(circuits[:2], params[:2]) == want[:2]
