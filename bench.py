@@ -42,8 +42,13 @@ POP_PER_GPU = int(os.environ.get("QSV_BENCH_POP", 64))
 N_LAYERS = int(os.environ.get("QSV_BENCH_LAYERS", 4))
 HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measured copy rate)
 FP64_PEAK_TFLOPS = 78.6     # vector fp64, half the 157.3 TFLOP/s fp32 vector rate of MI355X_MICROARCH.md (spec)
-KERNEL_NAMES = ("qsv::pass_kernel<double, 3, 2, true> (pass 0: synthesises the product state, writes only)",
-                "qsv::pass_kernel<double, 3, 2, false> (later passes; the last one fuses the diagonal expectation and only reads)")
+
+
+def kernel_names(n_qubits: int):
+    """The two instantiations of the gate-pass kernel at this size (register bits by size: qsv_api.hip resolve_config)."""
+    r = 4 if n_qubits >= 20 else 3
+    return (f"qsv::pass_kernel<double, {r}, 2, true> (pass 0: synthesises the product state, writes only)",
+            f"qsv::pass_kernel<double, {r}, 2, false> (later passes; the last one fuses the diagonal expectation and only reads)")
 
 
 def ising_operator(n_qubits: int, seed: int):
@@ -149,7 +154,7 @@ def kernel_rooflines(device, step, profiled_steps: int, traffic: dict):
         flops = acc["kernel_flops"][kind] / launches
         measured = traffic.get("kernels", {}).get(str(kind), {}).get("hbm_bytes_per_launch")
         entry = {
-            "kernel": KERNEL_NAMES[kind],
+            "kernel": kernel_names(N_QUBITS)[kind],
             "launches": launches,
             "states_per_launch": acc["kernel_states"][kind] / launches,
             "avg_launch_us": avg_ms * 1e3,
