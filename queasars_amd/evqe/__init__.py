@@ -17,6 +17,7 @@ from queasars_amd.evqe.genome import (  # noqa: F401
     sorted_parameter_rank,
 )
 from queasars_amd.evqe.solver import (  # noqa: F401,E402
+    NFT,
     SPSA,
     BestIndividualRelativeChangeTolerance,
     EVQEMinimumEigensolver,

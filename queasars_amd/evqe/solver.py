@@ -82,6 +82,9 @@ class SPSA:
     def n_circuit_evaluations(self) -> int:
         return 2 * self.maxiter
 
+    def new_run(self, x0: Sequence[float], seed: Optional[int]) -> "_SPSARun":
+        return _SPSARun(self, x0, seed)
+
 
 class _SPSARun:
     """State of one SPSA minimisation; the driver advances many of them in lock-step."""
@@ -121,18 +124,84 @@ class _SPSARun:
         self.done = stop
 
 
-def _minimize_batched(evaluator, jobs: list[tuple[object, _SPSARun]]) -> None:
-    """Advance every (circuit, run) pair to completion; one evaluate_circuits call per SPSA iteration."""
+@dataclass
+class NFT:
+    """Nakanishi-Fujii-Todo sequential minimisation (Phys. Rev. Research 2, 043158): with every other angle fixed, the
+    expectation value is a sinusoid of period 2 pi in one gate angle, f(t) = c + a cos(t - b), so three values --
+    f(t0), f(t0 + pi/2), f(t0 - pi/2) -- determine it and the parameter jumps to the exact minimiser t = b + pi.
+    Parameters are visited cyclically; the fitted minimum c - a is reused as the next f(t0) and re-evaluated every
+    ``reset_interval`` iterations.  This is the optimiser of the reference's own test harness
+    (test/minimum_eigensolvers/evqe/solver.py:28-36: ``NFT(maxfev=40)``); restated from the paper, the reference takes
+    it from qiskit-algorithms."""
+
+    maxfev: int = 40
+    maxiter: Optional[int] = None
+    reset_interval: int = 32
+
+    @property
+    def n_circuit_evaluations(self) -> int:
+        return self.maxfev
+
+    def new_run(self, x0: Sequence[float], seed: Optional[int]) -> "_NFTRun":
+        return _NFTRun(self, x0)
+
+
+class _NFTRun:
+    """State of one NFT minimisation, advanced in lock-step with the others like :class:`_SPSARun`."""
+
+    def __init__(self, config: NFT, x0: Sequence[float]):
+        self.config = config
+        self.x = np.asarray(x0, dtype=np.float64).copy()
+        self.nfev = 0
+        self.iteration = 0
+        self.done = self.x.size == 0 or config.maxfev <= 0
+        self._recycled: Optional[float] = None
+        self._needs_base = True
+
+    def propose(self) -> list[np.ndarray]:
+        cfg = self.config
+        j = self.iteration % self.x.size
+        if cfg.reset_interval > 0 and self.iteration % cfg.reset_interval == 0:
+            self._recycled = None
+        self._needs_base = self._recycled is None
+        plus, minus = self.x.copy(), self.x.copy()
+        plus[j] += 0.5 * math.pi
+        minus[j] -= 0.5 * math.pi
+        return ([self.x.copy()] if self._needs_base else []) + [plus, minus]
+
+    def accept(self, *values: float) -> None:
+        cfg = self.config
+        self.nfev += len(values)
+        z0 = values[0] if self._needs_base else self._recycled
+        z1, z3 = values[-2], values[-1]
+        j = self.iteration % self.x.size
+        # f(t) = c + a cos(t - b):  z0 - c = a cos(t0 - b),  (z3 - z1) / 2 = a sin(t0 - b)
+        c = 0.5 * (z1 + z3)
+        cos_part, sin_part = z0 - c, 0.5 * (z3 - z1)
+        a = math.hypot(cos_part, sin_part)
+        if a > 0.0:
+            self.x[j] = self.x[j] - math.atan2(sin_part, cos_part) + math.pi
+        self._recycled = c - a
+        self.iteration += 1
+        self.done = self.nfev >= cfg.maxfev or (cfg.maxiter is not None and self.iteration >= cfg.maxiter)
+
+
+def _minimize_batched(evaluator, jobs: list) -> None:
+    """Advance every (circuit, run) pair to completion; one evaluate_circuits call per optimiser iteration of the whole
+    set (SPSA proposes two points per run and iteration, NFT two or three)."""
     active = [job for job in jobs if not job[1].done]
     while active:
-        circuits, params = [], []
+        circuits, params, counts = [], [], []
         for circuit, run in active:
-            plus, minus = run.propose()
-            circuits += [circuit, circuit]
-            params += [plus.tolist(), minus.tolist()]
+            points = run.propose()
+            counts.append(len(points))
+            circuits += [circuit] * len(points)
+            params += [p.tolist() for p in points]
         values = evaluator.evaluate_circuits(circuits, params)
-        for i, (_, run) in enumerate(active):
-            run.accept(values[2 * i], values[2 * i + 1])
+        cur = 0
+        for (_, run), k in zip(active, counts):
+            run.accept(*values[cur : cur + k])
+            cur += k
         active = [job for job in active if not job[1].done]
 
 
@@ -168,7 +237,7 @@ class BestIndividualRelativeChangeTolerance:
 class EVQEMinimumEigensolverConfiguration:
     """The solver knobs of queasars/minimum_eigensolvers/evqe/evqe.py:34-177 that do not concern primitives/executors."""
 
-    optimizer: SPSA
+    optimizer: object  # SPSA or NFT: anything with new_run(x0, seed) and n_circuit_evaluations
     population_size: int
     max_generations: Optional[int] = None
     max_circuit_evaluations: Optional[int] = None
@@ -240,7 +309,7 @@ class EVQEMinimumEigensolver:
         jobs = []
         for individual, layer_id, seed in zip(individuals, layer_ids, seeds):
             circuit = individual.get_partially_parameterized_quantum_circuit({layer_id})
-            run = _SPSARun(self.configuration.optimizer, individual.get_layer_parameter_values(layer_id), seed)
+            run = self.configuration.optimizer.new_run(individual.get_layer_parameter_values(layer_id), seed)
             jobs.append((circuit, run))
         _minimize_batched(evaluator, jobs)
         out, nfev = [], 0

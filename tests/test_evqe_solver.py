@@ -136,3 +136,49 @@ def test_spsa_run_matches_a_plain_sequential_spsa():
             break
     assert np.array_equal(run.x, x) and run.nfev == nfev
     assert f(run.x) < f(x0)
+
+
+# ---- NFT (the optimiser of the reference's own test harness, test/minimum_eigensolvers/evqe/solver.py:28-36) ----------
+
+
+def test_nft_fits_a_sinusoid_exactly():
+    """With every other angle fixed the expectation value is c + a cos(t - b): one NFT step lands on its minimum."""
+    from queasars_amd.evqe.solver import NFT, _NFTRun
+
+    def f(x):
+        return 2.0 + 1.5 * np.cos(x[0] - 0.7) + 0.5 * np.cos(x[1] + 1.1)
+
+    run = _NFTRun(NFT(maxfev=5), [0.2, -0.4])
+    points = run.propose()
+    assert len(points) == 3  # f(x), f(x + pi/2 e_0), f(x - pi/2 e_0)
+    run.accept(*[f(p) for p in points])
+    assert abs(np.cos(run.x[0] - 0.7) + 1.0) < 1e-12 and run.x[1] == -0.4
+    points = run.propose()
+    assert len(points) == 2  # the fitted minimum is reused as f(x)
+    run.accept(*[f(p) for p in points])
+    assert run.done and run.nfev == 5
+    assert abs(f(run.x) - (2.0 - 1.5 - 0.5)) < 1e-12
+
+
+def test_nft_mutation_lowers_the_sum_of_expectation_values():
+    """Mirrors the reference's operator test ("sum of expectation values decreased",
+    test/minimum_eigensolvers/evqe/test_evqe_operators.py:91-93) for the last-layer parameter search with NFT(maxfev=40),
+    and checks the evaluation accounting; the gate angles really are sinusoidal parameters of <H>."""
+    from queasars_amd.evqe.solver import NFT
+
+    op = xy_hamiltonian()
+    ev = OracleEvaluator(op)
+    population = EVQEPopulation.random_population(4, 2, 6, False, 0)  # zero angles, as the reference's fixture
+    solver = EVQEMinimumEigensolver(make_config(optimizer=NFT(maxfev=40), population_size=6))
+
+    def total(pop):
+        return sum(helpers.oracle_expectation(i.get_parameterized_quantum_circuit(), list(i.parameter_values), op) for i in pop.individuals)
+
+    before = total(population)
+    searched, nfev = solver._last_layer_search(ev, population)
+    after = total(searched)
+    assert after < before - 1.0
+    assert nfev == ev.evaluations and 6 * 40 <= nfev <= 6 * 42
+    # and end to end: the solver with NFT finds x = 0, y = 3 too
+    result = EVQEMinimumEigensolver(make_config(optimizer=NFT(maxfev=40))).compute_minimum_eigenvalue(OracleEvaluator(op))
+    assert result.eigenvalue < -8.5

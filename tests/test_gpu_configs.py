@@ -446,3 +446,35 @@ def test_native_coalescing_of_concurrent_one_circuit_calls():
     assert b"unknown circuit id" in dev._lib.qsv_last_error(dev._handle)
     # two-circuit calls still go through the Python merger and agree
     assert merged.evaluate_circuits(circuits[:2], params[:2]) == want[:2]
+
+
+def test_nft_last_layer_search_on_the_device():
+    """The reference's operator test with its own optimiser (NFT, maxfev = 40; test/minimum_eigensolvers/evqe/solver.py:28-36,
+    test_evqe_operators.py:91-93: "sum of expectation values decreased") on the GPU evaluator, n = 10."""
+    from queasars_amd.evqe import EVQEPopulation
+    from queasars_amd.evqe.solver import NFT, EVQEMinimumEigensolver, EVQEMinimumEigensolverConfiguration
+
+    n = 10
+    op = helpers.random_ising_operator(n, seed=12)
+    ev = OperatorCircuitEvaluator(op)
+    population = EVQEPopulation.random_population(n, 2, 8, False, 0)
+    cfg = EVQEMinimumEigensolverConfiguration(
+        optimizer=NFT(maxfev=40), population_size=8, max_generations=1, random_seed=0, n_initial_layers=2,
+        randomize_initial_population_parameters=False, speciation_genetic_distance_threshold=2, use_tournament_selection=True,
+        tournament_size=2, selection_alpha_penalty=0.1, selection_beta_penalty=0.1, parameter_search_probability=0.3,
+        topological_search_probability=0.4, layer_removal_probability=0.05,
+    )
+    solver = EVQEMinimumEigensolver(cfg)
+
+    def total(pop):
+        cs = [i.get_parameterized_quantum_circuit() for i in pop.individuals]
+        return sum(ev.evaluate_circuits(cs, [list(i.parameter_values) for i in pop.individuals]))
+
+    before = total(population)
+    searched, nfev = solver._last_layer_search(ev, population)
+    after = total(searched)
+    assert after < before and 8 * 40 <= nfev <= 8 * 42
+    # every individual's value is what the oracle says for its new parameters
+    ind = searched.individuals[3]
+    got = ev.evaluate_circuits([ind.get_parameterized_quantum_circuit()], [list(ind.parameter_values)])[0]
+    assert abs(got - helpers.oracle_expectation(ind.get_parameterized_quantum_circuit(), list(ind.parameter_values), op)) < EXP_TOL
