@@ -1046,25 +1046,44 @@ __global__ void __launch_bounds__(256) pauli_groups_kernel(const cx<real>* __res
                                                            const double* __restrict__ term_coef,
                                                            const uint32_t* __restrict__ term_odd,
                                                            double* __restrict__ partials) {
+    // The group's terms are staged in LDS once per workgroup, kChunk at a time (z mask, and the coefficient filed under
+    // "weight of Re" or "weight of Im"): the pair loop then reads them by broadcast instead of going back to global
+    // memory for every amplitude pair.
+    constexpr uint32_t kChunk = 256;
     __shared__ double red[4];
+    __shared__ uint64_t sz[kChunk];
+    __shared__ double s_re[kChunk], s_im[kChunk];
     const PauliGroup g = groups[blockIdx.y];
     const int slot = blockIdx.z;
     const cx<real>* __restrict__ st = states + uint64_t(slot) * state_stride;
     const uint64_t low_mask = (uint64_t(1) << g.pivot) - 1;
     double acc = 0.0;
     const uint64_t stride = uint64_t(gridDim.x) * 256;
-    for (uint64_t p = uint64_t(blockIdx.x) * 256 + threadIdx.x; p < n_pairs; p += stride) {
-        const uint64_t i = ((p & ~low_mask) << 1) | (p & low_mask);  // bit `pivot` of i is 0
-        const uint64_t j = i ^ g.x;
-        const cx<real> a = st[i], b = st[j];
-        const double re = double(a.re) * double(b.re) + double(a.im) * double(b.im);
-        const double im = double(a.re) * double(b.im) - double(a.im) * double(b.re);
-        double w_re = 0.0, w_im = 0.0;
-        for (uint32_t k = g.first; k < g.first + g.count; ++k) {
-            const double c = (__popcll(i & term_z[k]) & 1) ? -term_coef[k] : term_coef[k];
-            if (term_odd[k]) w_im += c; else w_re += c;
+    for (uint32_t c0 = 0; c0 < g.count; c0 += kChunk) {
+        const uint32_t nc = min(kChunk, g.count - c0);
+        __syncthreads();  // (the previous chunk is no longer read)
+        if (threadIdx.x < nc) {
+            const uint32_t k = g.first + c0 + threadIdx.x;
+            const double c = term_coef[k];
+            sz[threadIdx.x] = term_z[k];
+            s_re[threadIdx.x] = term_odd[k] ? 0.0 : c;
+            s_im[threadIdx.x] = term_odd[k] ? c : 0.0;
         }
-        acc += w_re * re + w_im * im;
+        __syncthreads();
+        for (uint64_t p = uint64_t(blockIdx.x) * 256 + threadIdx.x; p < n_pairs; p += stride) {
+            const uint64_t i = ((p & ~low_mask) << 1) | (p & low_mask);  // bit `pivot` of i is 0
+            const uint64_t j = i ^ g.x;
+            const cx<real> a = st[i], b = st[j];
+            const double re = double(a.re) * double(b.re) + double(a.im) * double(b.im);
+            const double im = double(a.re) * double(b.im) - double(a.im) * double(b.re);
+            double w_re = 0.0, w_im = 0.0;
+            for (uint32_t k = 0; k < nc; ++k) {
+                const bool minus = __popcll(i & sz[k]) & 1;
+                w_re += minus ? -s_re[k] : s_re[k];
+                w_im += minus ? -s_im[k] : s_im[k];
+            }
+            acc += w_re * re + w_im * im;
+        }
     }
     const double total = block_sum_256(2.0 * acc, red);
     if (threadIdx.x == 0) partials[(size_t(slot) * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = total;
