@@ -14,6 +14,7 @@ from pathlib import Path
 PKG_DIR = Path(__file__).resolve().parent
 CSRC = PKG_DIR / "csrc"
 LIB_PATH = PKG_DIR / "libqsv.so"
+PYHELP_PATH = PKG_DIR / "_qsvpyhelp.so"  # CPython-API helper of the Python layer (csrc/pyhelp.c), optional
 SOURCES = ["kernels.hip", "qsv_api.hip", "plan.cpp"]
 HEADERS = ["kernels.hpp", "plan.hpp", "../../include/qsv.h"]
 ARCH = "gfx950"
@@ -34,6 +35,27 @@ def have_hipcc() -> bool:
         return False
 
 
+def build_pyhelp(force: bool = False) -> "Path | None":
+    """gcc csrc/pyhelp.c against this interpreter's headers; returns None when they (or gcc) are not there -- the Python
+    layer then packs parameter vectors with array.fromlist."""
+    import sysconfig
+
+    src = CSRC / "pyhelp.c"
+    if PYHELP_PATH.exists() and not force and PYHELP_PATH.stat().st_mtime >= src.stat().st_mtime:
+        return PYHELP_PATH
+    include = sysconfig.get_paths().get("include")
+    gcc = shutil.which("gcc")
+    if not gcc or not include or not (Path(include) / "Python.h").exists():
+        return None
+    tmp = PYHELP_PATH.with_suffix(".so.tmp")
+    res = subprocess.run([gcc, "-O2", "-shared", "-fPIC", f"-I{include}", str(src), "-o", str(tmp)],
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if res.returncode != 0:
+        return None
+    os.replace(tmp, PYHELP_PATH)
+    return PYHELP_PATH
+
+
 def needs_build() -> bool:
     if not LIB_PATH.exists():
         return True
@@ -45,6 +67,8 @@ def build(force: bool = False, verbose: bool = False, defines: tuple = (), lib_p
     """Compile every HIP source for gfx950 into queasars_amd/libqsv.so and return its path.
 
     ``defines`` / ``lib_path`` build a diagnostic variant next to it (scripts/stamps.py: -DQSV_STAMPS)."""
+    if not defines:
+        build_pyhelp(force)
     if not force and not defines and not needs_build():
         return LIB_PATH
     obj_dir = PKG_DIR / ("build" if not defines else "build_" + "_".join(defines).lower())

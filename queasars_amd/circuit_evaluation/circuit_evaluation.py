@@ -64,6 +64,40 @@ _device_serial = count(1)
 _PROCESS_TOKEN = uuid.uuid4().hex  # registrations are process-local: a pickled circuit must not match here by accident
 
 
+_pyhelp = None
+
+
+def _load_pyhelp():
+    """csrc/pyhelp.c through ctypes.PyDLL (the GIL stays held: it walks Python lists); None when it was not built."""
+    global _pyhelp
+    if _pyhelp is None:
+        from queasars_amd import _build
+
+        _pyhelp = False
+        try:
+            path = _build.PYHELP_PATH if _build.PYHELP_PATH.exists() else _build.build_pyhelp()
+            if path is not None:
+                lib = C.PyDLL(str(path))
+                lib.qsv_pack_vectors.restype = C.c_ssize_t
+                lib.qsv_pack_vectors.argtypes = [C.py_object, C.c_ssize_t, C.c_ssize_t, C.c_void_p, C.c_ssize_t]
+                _pyhelp = lib
+        except OSError:
+            _pyhelp = False
+    return _pyhelp or None
+
+
+def _pack_slice(vectors: Sequence[Sequence[float]], first: int, last: int, total: int) -> np.ndarray:
+    """The parameter vectors ``vectors[first:last]`` back to back as one float64 array of ``total`` values."""
+    helper = _load_pyhelp()
+    if helper is None:
+        return _pack_doubles(vectors[first:last], total)
+    out = np.empty(max(total, 1), dtype=np.float64)
+    n = helper.qsv_pack_vectors(vectors, first, last - first, out.ctypes.data, total)
+    if n != total:
+        raise ValueError("parameter vectors changed length while they were being packed")
+    return out
+
+
 def _pack_doubles(vectors: Sequence[Sequence[float]], total: int) -> np.ndarray:
     """Parameter vectors back to back as one float64 array.  ``array.fromlist`` is the fastest way CPython offers to
     turn lists of floats into doubles (about 15 ns per value, 40% less than ``np.fromiter`` over a chain)."""
@@ -282,17 +316,16 @@ class StatevectorDevice:
         self._check(lib.qsv_eval_begin(handle, n, _lib.as_ptr(ids), _lib.as_ptr(counts)))
         rc = _lib.QSV_OK
         try:
-            # Several pushes per population: packing the later ones overlaps the GPU work on the earlier ones, and the
-            # library alternates pushes between two HIP streams.  A small first push (an eighth) gets the GPU going
-            # early, the rest goes in two equal pushes (measured: scripts/sweep.sh with QSV_PUSH_PLAN); never more
-            # than a launch group per push.
+            # Two pushes per population: packing the second half overlaps the GPU work on the first, and the library
+            # runs consecutive pushes on two HIP streams, so that the tail of one launch overlaps the next.  (While
+            # packing cost 15 ns per value a small first push paid off; with the CPython-API packer it does not.)
+            # Never more than a launch group per push.
             step = min(self._group * max(1, self._push_groups), max(8, (n + 1) // 2))
             if self._push_evals:
                 step = self._push_evals
             bounds = list(range(0, n, step)) + [n]
             if not self._push_evals and not self._push_plan and 32 <= n <= self._group:
-                head = n // 8
-                bounds = [0, head, head + (n - head + 1) // 2, n]
+                bounds = [0, (n + 1) // 2, n]  # two halves, one per stream (measured: scripts/gpu_h.sh)
             if self._push_plan:
                 bounds, acc = [0], 0
                 for size in self._push_plan:
@@ -303,13 +336,12 @@ class StatevectorDevice:
             for first, last in zip(bounds[:-1], bounds[1:]):
                 if last <= first:
                     continue
-                chunk = parameter_values[first:last]
                 total = int(counts[first:last].sum())
                 if total:
-                    values = _pack_doubles(chunk, total)
-                    rc = lib.qsv_eval_push(handle, first, len(chunk), _lib.as_ptr(values))
+                    values = _pack_slice(parameter_values, first, last, total)
+                    rc = lib.qsv_eval_push(handle, first, last - first, _lib.as_ptr(values))
                 else:
-                    rc = lib.qsv_eval_push(handle, first, len(chunk), None)
+                    rc = lib.qsv_eval_push(handle, first, last - first, None)
                 if rc != _lib.QSV_OK:
                     break
         finally:
@@ -374,7 +406,7 @@ class StatevectorDevice:
             raise ValueError(f"circuit {i} needs {int(need[i])} parameter values, got {int(counts[i])}")
         offsets = np.zeros(n + 1, dtype=np.int64)
         np.cumsum(counts, out=offsets[1:])
-        flat = _pack_doubles(parameter_values, int(offsets[-1])) if offsets[-1] else np.zeros(1)
+        flat = _pack_slice(parameter_values, 0, n, int(offsets[-1])) if offsets[-1] else np.zeros(1)
         self._check(
             self._lib.qsv_sample_batch(
                 self._handle, n, _lib.as_ptr(ids), _lib.as_ptr(offsets), _lib.as_ptr(flat), int(shots),

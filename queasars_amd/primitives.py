@@ -7,9 +7,9 @@ GPU backend (SURVEY.md 8(b) "protocol B").
     sampler.run(pubs=((circuit, values), ...), shots=s).result()                   -> iterable of r with
                                                                                       r.data["meas"].get_counts()
 
-(circuit_evaluation.py:204-215 and :50-59).  The classes below answer exactly that, duck-typed: they do not subclass
-Qiskit's ``BaseEstimatorV2`` / ``BaseSamplerV2`` (Qiskit is not a dependency), which the reference's evaluators do not
-check.  Circuits may be :class:`~queasars_amd.ir.CircuitIR` or Qiskit ``QuantumCircuit`` objects, operators
+(circuit_evaluation.py:204-215 and :50-59).  The classes below answer exactly that.  Where Qiskit is importable they
+subclass ``BaseEstimatorV2`` / ``BaseSamplerV2``; where it is not (this repository's environment) they are plain classes
+of the same shape, which is all the reference's evaluators rely on.  Circuits may be :class:`~queasars_amd.ir.CircuitIR` or Qiskit ``QuantumCircuit`` objects, operators
 :class:`~queasars_amd.ir.PauliOperator` or ``SparsePauliOp`` (converted by ``queasars_amd.qiskit_adapter`` and cached
 per object).
 """
@@ -26,6 +26,15 @@ import numpy as np
 from queasars_amd import qiskit_adapter
 from queasars_amd.circuit_evaluation.circuit_evaluation import OperatorCircuitEvaluator, StatevectorDevice
 from queasars_amd.ir import CircuitIR, PauliOperator
+
+
+# On a host that has Qiskit the two front ends ARE Qiskit V2 primitives (subclasses of the abstract bases, so that
+# isinstance checks and type annotations of user code hold); without Qiskit they are plain classes of the same shape.
+try:  # pragma: no cover - Qiskit is not installable in this repository's environment
+    from qiskit.primitives import BaseEstimatorV2 as _EstimatorBase
+    from qiskit.primitives import BaseSamplerV2 as _SamplerBase
+except Exception:  # ModuleNotFoundError here
+    _EstimatorBase = _SamplerBase = object
 
 
 class _Job:
@@ -89,7 +98,7 @@ def _operator_key(op: PauliOperator) -> tuple:
     return (op.num_qubits, op.x_mask.tobytes(), op.z_mask.tobytes(), op.coeffs.tobytes())
 
 
-class GpuEstimator:
+class GpuEstimator(_EstimatorBase):
     """``run(pubs, precision=...)`` over exact statevector expectation values; ``precision`` other than 0 / None adds
     Gaussian noise of that standard deviation (what an estimator's target precision means to the reference).
 
@@ -153,7 +162,7 @@ class _BitArray:
         return {int(v): int(c) for v, c in zip(values, counts)}
 
 
-class GpuSampler:
+class GpuSampler(_SamplerBase):
     """``run(pubs, shots=...)``: seeded inverse-CDF sampling of every qubit on the device; results expose
     ``data["meas"].get_counts()`` with Qiskit's bitstring convention (leftmost character = highest qubit)."""
 
@@ -163,7 +172,8 @@ class GpuSampler:
         self._seed = int(seed)
         self._calls = 0
 
-    def run(self, pubs: Iterable[Sequence[Any]], *, shots: int = 1024) -> _Job:
+    def run(self, pubs: Iterable[Sequence[Any]], *, shots: Optional[int] = None) -> _Job:
+        shots = 1024 if shots is None else int(shots)
         pubs = [tuple(pub) for pub in pubs]
         circuits = [self._convert.circuit(pub[0]) for pub in pubs]
         values = [list(np.ravel(pub[1])) if len(pub) > 1 and pub[1] is not None else [] for pub in pubs]

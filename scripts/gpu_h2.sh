@@ -11,16 +11,16 @@ print("$label", round(d["value"]), "evals/s", [(round(k["avg_launch_us"],1), k["
 PY
 }
 run default A=1
-run plan_16_24_24 QSV_PUSH_PLAN=16,24,24
-run plan_8_24_32 QSV_PUSH_PLAN=8,24,32
-run plan_12_20_32 QSV_PUSH_PLAN=12,20,32
-run plan_8_16_40 QSV_PUSH_PLAN=8,16,40
-run plan_16_48 QSV_PUSH_PLAN=16,48
-run plan_8_56 QSV_PUSH_PLAN=8,56
-run plan_64 QSV_PUSH_PLAN=64
-run plan_32_32 QSV_PUSH_PLAN=32,32
-run plan_16x4 QSV_PUSH_PLAN=16,16,16,16
-run plan_8_8_16_32 QSV_PUSH_PLAN=8,8,16,32
-run plan_4_12_16_32 QSV_PUSH_PLAN=4,12,16,32
-run plan_24_40 QSV_PUSH_PLAN=24,40
-python scripts/hosttime2.py 2>&1 | grep -v amdgpu.ids
+run default_again A=1
+run plan_28_36 QSV_PUSH_PLAN=28,36
+run plan_36_28 QSV_PUSH_PLAN=36,28
+run plan_20_44 QSV_PUSH_PLAN=20,44
+run tpb1 QSV_TILES_PER_BLOCK=1
+run tpb4 QSV_TILES_PER_BLOCK=4
+run streams1 QSV_STREAMS=1
+run n24 QSV_BENCH_QUBITS=24 QSV_BENCH_POP=32
+run n24_64 QSV_BENCH_QUBITS=24 QSV_BENCH_POP=64
+run n24_tpb1 QSV_BENCH_QUBITS=24 QSV_BENCH_POP=32 QSV_TILES_PER_BLOCK=1
+run n24_tpb4 QSV_BENCH_QUBITS=24 QSV_BENCH_POP=32 QSV_TILES_PER_BLOCK=4
+run n24_g16 QSV_BENCH_QUBITS=24 QSV_BENCH_POP=32 QSV_GROUP=16
+run n24_g4 QSV_BENCH_QUBITS=24 QSV_BENCH_POP=32 QSV_GROUP=4

@@ -93,3 +93,50 @@ def test_single_process_falls_back_to_local_evaluation():
     ev = _OracleEvaluator(op)
     values = evaluate_population_sharded(ev, circuits, params)
     assert ev.seen == 3 and len(values) == 3
+
+
+# ---- the same path on RCCL, when the box has two GPUs ----------------------------------------------------------------
+
+
+def _nccl_worker(rank: int, world: int, port: int, n_individuals: int, out_dir: str):
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+
+    import helpers
+    from queasars_amd.circuit_evaluation import OperatorCircuitEvaluator
+    from queasars_amd.distributed import evaluate_population_sharded
+
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    try:
+        n = 12
+        _, circuits, params = helpers.population_circuits(n, 3, n_individuals, seed=42)
+        evaluator = OperatorCircuitEvaluator(helpers.random_ising_operator(n, seed=7), device=rank)
+        values = evaluate_population_sharded(evaluator, circuits, params)
+        np.save(os.path.join(out_dir, f"rank{rank}.npy"), np.asarray(values))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_rank_sharded_evaluation_on_rccl(tmp_path):
+    """World size 2 over RCCL (backend "nccl"), one process per GPU: every rank ends with all fitness values, equal
+    to a single-GPU evaluation bit for bit.  Skipped on a one-GPU box."""
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    world, n_individuals = 2, 9
+    mp.spawn(_nccl_worker, args=(world, _free_port(), n_individuals, str(tmp_path)), nprocs=world, join=True)
+    import helpers
+    from queasars_amd.circuit_evaluation import OperatorCircuitEvaluator
+
+    _, circuits, params = helpers.population_circuits(12, 3, n_individuals, seed=42)
+    want = np.asarray(OperatorCircuitEvaluator(helpers.random_ising_operator(12, seed=7)).evaluate_circuits(circuits, params))
+    for rank in range(world):
+        got = np.load(tmp_path / f"rank{rank}.npy")
+        assert np.array_equal(got, want)
