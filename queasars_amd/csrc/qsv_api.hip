@@ -707,6 +707,14 @@ int eval_push(qsv_t* h, size_t first, size_t count, const double* values) {
             QSV_HIP(h, stamp(h, b.exp_events, false));
         }
     }
+    if (h->diagonal) {
+        // This push's evaluations are reduced on the push's own stream, straight into the pinned result buffer: no
+        // cross-stream join in front of one final reduction (the join alone cost 15-30 us at the end of every call).
+        QSV_HIP(h, stamp(h, b.exp_events, true));
+        QSV_HIP(h, launch_reduce_partials(static_cast<const double*>(h->d_partials.ptr) + first * size_t(partials_per_state(h)),
+                                          partials_per_state(h), int(count), h->h_out + first, ws(h)));
+        QSV_HIP(h, stamp(h, b.exp_events, false));
+    }
     b.pushed = first + count;
     return QSV_OK;
 }
@@ -716,22 +724,18 @@ int eval_end(qsv_t* h, double* out) {
     const size_t n_evals = b.circs.size();
     if (b.pushed != n_evals) return fail(h, QSV_E_STATE, "not every evaluation of the batch was pushed");
     if (n_evals == 0) return QSV_OK;
-    if (b.used2) {
+    const bool used2 = b.used2;
+    if (used2 && h->profiling) {  // (only so that ev1 below marks the end of BOTH streams' work)
         QSV_HIP(h, hipEventRecord(h->ev_join, h->stream2));
         QSV_HIP(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
-        b.used2 = false;
     }
-    if (h->diagonal) {
-        QSV_HIP(h, stamp(h, b.exp_events, true));
-        // the reduction writes its n_evals doubles straight into the pinned result buffer: no D2H copy to wait for
-        QSV_HIP(h, launch_reduce_partials(static_cast<const double*>(h->d_partials.ptr), partials_per_state(h),
-                                          int(n_evals), h->h_out, h->stream));
-        QSV_HIP(h, stamp(h, b.exp_events, false));
-    }
+    b.used2 = false;
     if (h->profiling) QSV_HIP(h, hipEventRecord(b.ev1, h->stream));
     if (!h->diagonal)
         QSV_HIP(h, hipMemcpyAsync(h->h_out, h->d_out.ptr, n_evals * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    // (polling hipStreamQuery instead was measured: no faster, and it slowed concurrent callers down threefold)
     QSV_HIP(h, hipStreamSynchronize(h->stream));
+    if (used2) QSV_HIP(h, hipStreamSynchronize(h->stream2));
     std::memcpy(out, h->h_out, n_evals * sizeof(double));
     if (h->profiling) {
         float ms = 0.f;
@@ -747,9 +751,9 @@ int eval_end(qsv_t* h, double* out) {
                 h->prof.kernel_ms[kind] += ms;
             }
         // wall-clock window of the gate passes: with two streams the per-push intervals above overlap
-        if (!b.pass_events.empty() && !b.exp_events.empty()) {
-            QSV_HIP(h, hipEventElapsedTime(&ms, b.pass_events.front().first, b.exp_events.front().first));
-            h->prof.pass_window_ms = ms;
+        for (auto& p : b.pass_events) {
+            QSV_HIP(h, hipEventElapsedTime(&ms, b.pass_events.front().first, p.second));
+            h->prof.pass_window_ms = std::max(h->prof.pass_window_ms, double(ms));
         }
         for (auto& p : b.exp_events) {
             QSV_HIP(h, hipEventElapsedTime(&ms, p.first, p.second));
