@@ -41,15 +41,18 @@ def build_pyhelp(force: bool = False) -> "Path | None":
     import sysconfig
 
     src = CSRC / "pyhelp.c"
-    if PYHELP_PATH.exists() and not force and PYHELP_PATH.stat().st_mtime >= src.stat().st_mtime:
+    if (PYHELP_PATH.exists() and not force and PYHELP_PATH.stat().st_mtime >= src.stat().st_mtime
+            and (not LIB_PATH.exists() or PYHELP_PATH.stat().st_mtime >= LIB_PATH.stat().st_mtime)):
         return PYHELP_PATH
     include = sysconfig.get_paths().get("include")
     gcc = shutil.which("gcc")
     if not gcc or not include or not (Path(include) / "Python.h").exists():
         return None
     tmp = PYHELP_PATH.with_suffix(".so.tmp")
-    res = subprocess.run([gcc, "-O2", "-shared", "-fPIC", f"-I{include}", str(src), "-o", str(tmp)],
-                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if not LIB_PATH.exists():
+        return None  # the helper links against libqsv.so (it drives qsv_eval_begin / push / end itself)
+    res = subprocess.run([gcc, "-O2", "-shared", "-fPIC", f"-I{include}", str(src), "-o", str(tmp), f"-L{PKG_DIR}", "-lqsv",
+                          "-Wl,-rpath,$ORIGIN"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if res.returncode != 0:
         return None
     os.replace(tmp, PYHELP_PATH)
@@ -67,9 +70,8 @@ def build(force: bool = False, verbose: bool = False, defines: tuple = (), lib_p
     """Compile every HIP source for gfx950 into queasars_amd/libqsv.so and return its path.
 
     ``defines`` / ``lib_path`` build a diagnostic variant next to it (scripts/stamps.py: -DQSV_STAMPS)."""
-    if not defines:
-        build_pyhelp(force)
     if not force and not defines and not needs_build():
+        build_pyhelp(False)
         return LIB_PATH
     obj_dir = PKG_DIR / ("build" if not defines else "build_" + "_".join(defines).lower())
     obj_dir.mkdir(exist_ok=True)
@@ -100,6 +102,8 @@ def build(force: bool = False, verbose: bool = False, defines: tuple = (), lib_p
     if res.returncode != 0:
         raise RuntimeError(f"link failed:\n{res.stdout}")
     os.replace(tmp, lib_path)
+    if not defines:
+        build_pyhelp(True)
     return lib_path
 
 

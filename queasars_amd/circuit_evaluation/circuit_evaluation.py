@@ -80,6 +80,9 @@ def _load_pyhelp():
                 lib = C.PyDLL(str(path))
                 lib.qsv_pack_vectors.restype = C.c_ssize_t
                 lib.qsv_pack_vectors.argtypes = [C.py_object, C.c_ssize_t, C.c_ssize_t, C.c_void_p, C.c_ssize_t]
+                lib.qsv_py_expectation_values.restype = C.c_int
+                lib.qsv_py_expectation_values.argtypes = [C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_void_p, C.py_object,
+                                                          C.c_void_p, C.c_void_p]
                 _pyhelp = lib
         except OSError:
             _pyhelp = False
@@ -313,6 +316,14 @@ class StatevectorDevice:
             raise ValueError(f"circuit {i} needs {int(need[i])} parameter values, got {int(counts[i])}")
         out = np.empty(n, dtype=np.float64)
         lib, handle = self._lib, self._handle
+        helper = None if (self._push_evals or self._push_plan or os.environ.get("QSV_LIBRARY")) else _load_pyhelp()
+        if helper is not None:
+            # the whole begin / pack / push / end sequence in one call of the CPython-API helper (csrc/pyhelp.c)
+            scratch = np.empty(int(counts.sum()) + 1, dtype=np.float64)
+            rc = helper.qsv_py_expectation_values(handle, n, ids.ctypes.data, counts.ctypes.data, parameter_values,
+                                                  scratch.ctypes.data, out.ctypes.data)
+            self._check(rc)
+            return out
         self._check(lib.qsv_eval_begin(handle, n, _lib.as_ptr(ids), _lib.as_ptr(counts)))
         rc = _lib.QSV_OK
         try:
@@ -535,15 +546,19 @@ class OperatorCircuitEvaluator(BaseCircuitEvaluator):
         return self._composed.get(circuit)
 
     def evaluate_circuits(self, circuits: list[CircuitIR], parameter_values: list[list[float]]) -> list[float]:
-        pairs = [(c, p) for c, p in zip(circuits, parameter_values) if c is not None and p is not None]
+        if None in circuits or None in parameter_values:
+            pairs = [(c, p) for c, p in zip(circuits, parameter_values) if c is not None and p is not None]
+            circuits, parameter_values = [c for c, _ in pairs], [p for _, p in pairs]
+        if self._initial_state_circuit is not None:
+            circuits = [self._with_initial_state(c) for c in circuits]
         # evaluators may share one device: "is it my operator? else set it" and the evaluation are one critical section
         with self._device.operator_lock:
             if self._device._operator is not self._operator:
                 self._device.set_operator(self._operator)
-            values = self._device.expectation_values([self._with_initial_state(c) for c, _ in pairs], [p for _, p in pairs])
+            values = self._device.expectation_values(circuits, parameter_values)
         if self._precision > 0:
             values = values + self._rng.normal(0.0, self._precision, size=values.shape)
-        return [float(v) for v in values]
+        return values.tolist()
 
     @property
     def n_qubits(self) -> int:

@@ -5,6 +5,8 @@
 #define PY_SSIZE_T_CLEAN
 #include <Python.h>
 
+#include "../../include/qsv.h"
+
 /* out[0 .. n) = the values of vectors[first], vectors[first + 1], .. vectors[first + count - 1] back to back.
  * Returns n, or -1 with a Python exception set (called through ctypes.PyDLL, which re-raises it). */
 Py_ssize_t qsv_pack_vectors(PyObject* vectors, Py_ssize_t first, Py_ssize_t count, double* out, Py_ssize_t capacity) {
@@ -44,4 +46,45 @@ Py_ssize_t qsv_pack_vectors(PyObject* vectors, Py_ssize_t first, Py_ssize_t coun
     }
     Py_DECREF(outer);
     return n;
+}
+
+/* The whole of StatevectorDevice.expectation_values after its argument checks, in one call: lay the batch out, pack and
+ * push it in two halves (one per HIP stream of the library; a population that does not fit a launch group goes in
+ * group-sized pushes), wait for the results.  The GIL is released while the call waits for the handle and for the GPU.
+ * In Python the same sequence costs five ctypes calls and a dozen NumPy temporaries per population: about 90 us of a
+ * 345 us step on the benchmark workload.
+ * Returns the library's status (0 or QSV_E_*); -100 with a Python exception set when a parameter vector is malformed.
+ * `values` is scratch for sum(counts) doubles. */
+int qsv_py_expectation_values(qsv_t* h, Py_ssize_t n, const int* ids, const int64_t* counts, PyObject* vectors,
+                              double* values, double* out) {
+    int rc;
+    Py_BEGIN_ALLOW_THREADS
+    rc = qsv_eval_begin(h, (int)n, ids, counts);
+    Py_END_ALLOW_THREADS
+    if (rc) return rc;
+    const Py_ssize_t group = qsv_group_size(h) > 0 ? qsv_group_size(h) : 1;
+    Py_ssize_t step = (n + 1) / 2 > 8 ? (n + 1) / 2 : 8;
+    if (step > group) step = group;
+    int failed = 0, py_error = 0;
+    Py_ssize_t offset = 0;
+    for (Py_ssize_t first = 0; first < n && !failed; first += step) {
+        const Py_ssize_t count = first + step <= n ? step : n - first;
+        Py_ssize_t total = 0;
+        for (Py_ssize_t i = first; i < first + count; ++i) total += (Py_ssize_t)counts[i];
+        if (total > 0 && qsv_pack_vectors(vectors, first, count, values + offset, total) != total) {
+            if (!PyErr_Occurred()) PyErr_SetString(PyExc_ValueError, "parameter vectors changed length while they were being packed");
+            failed = py_error = 1;
+            break;
+        }
+        rc = qsv_eval_push(h, (int)first, (int)count, total > 0 ? values + offset : NULL);
+        if (rc) failed = 1;
+        offset += total;
+    }
+    int rc_end;
+    Py_BEGIN_ALLOW_THREADS
+    rc_end = qsv_eval_end(h, out);  /* must be called even after a failed push: it releases the handle */
+    Py_END_ALLOW_THREADS
+    if (py_error) return -100;
+    if (failed) return rc;
+    return rc_end;
 }
