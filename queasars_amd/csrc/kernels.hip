@@ -261,10 +261,13 @@ struct PassScalars {
 #ifndef QSV_WAVES_PER_SIMD
 #define QSV_WAVES_PER_SIMD 6
 #endif
+#ifndef QSV_WAVES_R4
+#define QSV_WAVES_R4 4
+#endif
 template <int R, int XMODE>
 struct Occupancy {
     // 2^R amplitudes = 4 * 2^R VGPRs: R = 3 fits the 80-VGPR budget of 6 waves per SIMD, R = 4 needs the 128 of 4
-    static constexpr int waves_per_simd = R >= 4 ? 4 : (XMODE == 2 ? QSV_WAVES_PER_SIMD : 4);
+    static constexpr int waves_per_simd = R >= 4 ? QSV_WAVES_R4 : (XMODE == 2 ? QSV_WAVES_PER_SIMD : 4);
 };
 
 template <typename T>
@@ -790,15 +793,18 @@ static hipError_t pass_dispatch_r(int op, int r, dim3 grid, int threads, size_t 
 static hipError_t pass_dispatch(int op, int dtype, int r, int xmode, dim3 grid, int threads, size_t lds_bytes,
                                 hipStream_t stream, const PassArgs* args) {
     if (threads > 512) return hipErrorInvalidValue;
-#ifdef QSV_PROBE_ONLY  // scripts/isa_probe.sh: compile just the default instantiation to read its ISA quickly
+#ifdef QSV_PROBE_ONLY  // scripts/isa_probe.sh: compile just one instantiation (-DQSV_PROBE_R=3|4) to read its ISA quickly
+#ifndef QSV_PROBE_R
+#define QSV_PROBE_R 4
+#endif
     if (op) return hipSuccess;
     const PassScalars sc{args->state_stride, args->wtab_stride, args->pass_index, args->mode, args->tiles_per_block};
     if (args->pass_index == 0 && (args->mode & kModeSynthFirst))
-        hipLaunchKernelGGL((pass_kernel<double, 3, 2, true>), grid, dim3(threads), lds_bytes, stream, args->plan,
+        hipLaunchKernelGGL((pass_kernel<double, QSV_PROBE_R, 2, true>), grid, dim3(threads), lds_bytes, stream, args->plan,
                            args->mats, args->evals, reinterpret_cast<cx<double>*>(args->states),
                            reinterpret_cast<cx<double>*>(args->wtab), args->diag, args->partials, sc);
     else
-    hipLaunchKernelGGL((pass_kernel<double, 3, 2, false>), grid, dim3(threads), lds_bytes, stream, args->plan,
+    hipLaunchKernelGGL((pass_kernel<double, QSV_PROBE_R, 2, false>), grid, dim3(threads), lds_bytes, stream, args->plan,
                        args->mats, args->evals, reinterpret_cast<cx<double>*>(args->states),
                        reinterpret_cast<cx<double>*>(args->wtab), args->diag, args->partials, sc);
     return hipGetLastError();

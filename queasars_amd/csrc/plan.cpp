@@ -306,6 +306,18 @@ CircuitPlan build_plan(int n, const std::vector<GateIn>& all_gates, const std::v
     std::vector<int> default_regs;
     for (int b = k - r; b < k; ++b) default_regs.push_back(b);
 
+    // One scheduling attempt.  try_no = 0 is the plain first-come rule; later attempts decline, with probability 1/7, to
+    // give a new qubit a place in the tile when its first gate comes by (a deterministic pseudo-random sequence per
+    // attempt), which reaches tile sets the greedy rule cannot.  build_plan keeps the attempt with the fewest passes:
+    // a pass is a full sweep of the state, and at n = 24 one circuit in six needs three passes under the greedy rule
+    // where two suffice.
+    auto attempt_schedule = [&](int try_no) {
+    uint32_t lcg = 0x2545F491u * uint32_t(try_no + 1);
+    auto decline = [&]() {
+        if (try_no == 0) return false;
+        lcg = lcg * 1664525u + 1013904223u;
+        return (lcg >> 16) % 7u == 0u;
+    };
     std::vector<char> done(gates.size(), 0);
     size_t n_done = 0;
     std::vector<PassPlan> passes;
@@ -329,7 +341,7 @@ CircuitPlan build_plan(int n, const std::vector<GateIn>& all_gates, const std::v
                 const GateIn& g = gates[i];
                 bool ok = blk.allows(g);
                 if (ok && !in_tile[g.target]) {
-                    if (tile_count < k) {
+                    if (tile_count < k && !decline()) {
                         in_tile[g.target] = 1;
                         ++tile_count;
                     } else {
@@ -407,9 +419,20 @@ CircuitPlan build_plan(int n, const std::vector<GateIn>& all_gates, const std::v
             done[s] = 1;
             ++n_done;
         }
-        if (selected.empty() && n_done < gates.size()) throw std::logic_error("scheduler made no progress");
+        if (selected.empty() && n_done < gates.size()) {
+            if (try_no == 0) throw std::logic_error("scheduler made no progress");
+            return std::vector<PassPlan>();  // (an attempt that declined everything: discarded)
+        }
         passes.push_back(std::move(pass));
     }
+    return passes;
+    };
+    std::vector<PassPlan> passes = attempt_schedule(0);
+    if (cfg.retries > 0 && n > k && passes.size() > 2)
+        for (int attempt = 1; attempt <= cfg.retries && passes.size() > 2; ++attempt) {
+            std::vector<PassPlan> other = attempt_schedule(attempt);
+            if (!other.empty() && other.size() < passes.size()) passes = std::move(other);
+        }
 
     // ---- 3. encode ---------------------------------------------------------------------------------------
     std::vector<uint32_t>& w = out.words;

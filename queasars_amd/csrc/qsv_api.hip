@@ -299,6 +299,7 @@ PlanConfig resolve_config(const qsv_plan_config* cfg, int dtype, int n_qubits) {
     if (const char* e = getenv("QSV_FOLD")) pc.fold = atoi(e) != 0;
     if (const char* e = getenv("QSV_COMPACT")) pc.compact = atoi(e) != 0;
     if (const char* e = getenv("QSV_SWAPS")) pc.swaps = atoi(e) != 0;
+    if (const char* e = getenv("QSV_RETRIES")) pc.retries = atoi(e);
     if (cfg) {
         if (cfg->tile_bits > 0) pc.tile_bits = cfg->tile_bits;
         if (cfg->reg_bits > 0) pc.reg_bits = cfg->reg_bits;
