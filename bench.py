@@ -292,7 +292,8 @@ def config3_block(world: int, rank: int, local_rank: int, steps: int = 2):
     assert len(values) == total and all(np.isfinite(values))
     per_rank = [Timed.own_s / steps]
     if world > 1:
-        t = torch.tensor([elapsed, Timed.own_s / steps], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed, Timed.own_s / steps], dtype=torch.float64,
+                         device="cuda" if dist.get_backend() == "nccl" else "cpu")
         gathered = [torch.empty_like(t) for _ in range(world)]
         dist.all_gather(gathered, t)
         elapsed = max(float(g[0]) for g in gathered)
@@ -324,9 +325,19 @@ def main() -> None:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
+    # Rehearsal on a box with fewer GPUs than ranks (QSV_BENCH_REHEARSE=1): every rank uses the visible GPU
+    # local_rank % device_count, so RCCL (one rank per device) is out and the collectives run over gloo on CPU tensors.
+    # The driver's multi-GPU runs never set it.
+    rehearse = os.environ.get("QSV_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    comm_device = "cpu" if (rehearse and world > 1) else "cuda"
 
     from queasars_amd.circuit_evaluation import OperatorCircuitEvaluator
     from queasars_amd.distributed import evaluate_population_sharded, shard_bounds
@@ -368,7 +379,7 @@ def main() -> None:
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=comm_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

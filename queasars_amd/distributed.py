@@ -44,14 +44,43 @@ def evaluate_population_sharded(evaluator, circuits: Sequence, parameter_values:
     width = -(-n // world)  # every rank contributes a fixed-size slot so one all_gather_into_tensor suffices
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
-    send = torch.full((width,), float("nan"), dtype=torch.float64, device=device)
+    send_host, send, recv, recv_host = _buffers(world, width, torch.device(device))
+    send_host.fill_(float("nan"))
     if local:
-        send[: len(local)] = torch.as_tensor(np.asarray(local, dtype=np.float64), device=device)
-    recv = torch.empty(world * width, dtype=torch.float64, device=device)
+        send_host[: len(local)] = torch.as_tensor(np.asarray(local, dtype=np.float64))
+    # pinned staging buffers and device tensors are kept between calls: the collective moves a few hundred bytes and
+    # is latency bound, so every allocation and every synchronous pageable copy on its path counts
+    send.copy_(send_host, non_blocking=True)
     dist.all_gather_into_tensor(recv, send, group=group)
-    recv = recv.cpu().numpy().reshape(world, width)
+    recv_host.copy_(recv, non_blocking=True)
+    if recv.is_cuda:
+        torch.cuda.current_stream(recv.device).synchronize()
+    table = recv_host.numpy().reshape(world, width)
     out: list[float] = []
     for r in range(world):
         rlo, rhi = shard_bounds(n, world, r)
-        out.extend(float(v) for v in recv[r, : rhi - rlo])
+        out.extend(table[r, : rhi - rlo].tolist())
     return out
+
+
+_BUFFERS: dict = {}
+
+
+def _buffers(world: int, width: int, device):
+    """(pinned send staging, device send, device receive, pinned receive staging) for one (world, width, device)."""
+    import torch
+
+    key = (world, width, str(device))
+    hit = _BUFFERS.get(key)
+    if hit is None:
+        pin = device.type == "cuda"
+        send_host = torch.empty(width, dtype=torch.float64, pin_memory=pin)
+        recv_host = torch.empty(world * width, dtype=torch.float64, pin_memory=pin)
+        if device.type == "cuda":
+            send = torch.empty(width, dtype=torch.float64, device=device)
+            recv = torch.empty(world * width, dtype=torch.float64, device=device)
+        else:
+            send, recv = send_host, recv_host
+        hit = (send_host, send, recv, recv_host)
+        _BUFFERS[key] = hit
+    return hit
