@@ -336,7 +336,7 @@ class StatevectorDevice:
                 step = self._push_evals
             bounds = list(range(0, n, step)) + [n]
             if not self._push_evals and not self._push_plan and 32 <= n <= self._group:
-                bounds = [0, (n + 1) // 2, n]  # two halves, one per stream (measured: scripts/gpu_h.sh)
+                bounds = [0, (n + 1) // 2, n]  # two halves, one per stream (measured: scripts/push_plan_sweep.sh)
             if self._push_plan:
                 bounds, acc = [0], 0
                 for size in self._push_plan:

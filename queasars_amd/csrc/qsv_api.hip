@@ -283,7 +283,7 @@ std::vector<GateIn> gates_of(const qsv_op* ops, int n_ops, std::vector<AngleSour
 PlanConfig resolve_config(const qsv_plan_config* cfg, int dtype, int n_qubits) {
     PlanConfig pc;
     pc.amp_bytes = dtype == QSV_F64 ? 16 : 8;
-    // Tile geometry by size (fp64; measured on MI355X with the EVQE benchmark family, scripts/gpu_k.sh): 16 amplitudes
+    // Tile geometry by size (fp64; measured on MI355X with the EVQE benchmark family, scripts/geometry_sweep.sh): 16 amplitudes
     // per thread halve the per-amplitude cost of decoding the plan from n = 20 on, and 13 tile qubits save a pass
     // from n = 21 on (n = 24: 3 -> 2.25 passes on average, +33 % evaluations per second).
     if (dtype == QSV_F64 && n_qubits >= 20) {

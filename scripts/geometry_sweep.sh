@@ -3,10 +3,10 @@ cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 run() {
   label=$1; shift
-  env "$@" timeout -k 10 100 python bench.py --no-extras --no-cpu-baseline --steps 10 --warmup 3 > gpurun_out/k_$label.json 2> gpurun_out/k_$label.err || { echo "$label failed"; tail -3 gpurun_out/k_$label.err; return 1; }
+  env "$@" timeout -k 10 100 python bench.py --no-extras --no-cpu-baseline --steps 10 --warmup 3 > gpurun_out/geo_$label.json 2> gpurun_out/geo_$label.err || { echo "$label failed"; tail -3 gpurun_out/geo_$label.err; return 1; }
   python - <<PY
 import json
-d=json.load(open("gpurun_out/k_$label.json"))
+d=json.load(open("gpurun_out/geo_$label.json"))
 print("$label", round(d["value"]), "evals/s", [(round(k["avg_launch_us"],1), k["launches"]) for k in d["roofline"]["kernels"]])
 PY
 }
