@@ -603,6 +603,24 @@ def _cvar_of_samples(values: np.ndarray, alpha: float) -> float:
     return total / mass
 
 
+def _cvar_of_sample_matrix(values: np.ndarray, alpha: float) -> list[float]:
+    """:func:`_cvar_of_samples` for every row of ``values`` (one row of ``shots`` sample values per circuit) at once: one
+    sort of the whole matrix instead of one NumPy call chain per circuit (5 us each: as much as the device took to
+    produce the samples)."""
+    if values.size == 0:
+        return []
+    shots = values.shape[1]
+    if np.isclose(alpha, 1):
+        return values.mean(axis=1).tolist()
+    ordered = np.sort(values, axis=1)
+    mass = alpha * shots
+    whole = int(np.floor(mass + 1e-12))
+    total = ordered[:, :whole].sum(axis=1)
+    if whole < shots and mass - whole > 1e-12:
+        total = total + (mass - whole) * ordered[:, whole]
+    return (total / mass).tolist()
+
+
 class OperatorSamplerCircuitEvaluator(BaseCircuitEvaluator):
     """Expectation / CVaR_alpha of a diagonal operator from ``sampler_shots`` measurements (reference [94-161])."""
 
@@ -650,7 +668,7 @@ class OperatorSamplerCircuitEvaluator(BaseCircuitEvaluator):
             _, values = self._device.sample_batch(
                 [c for c, _ in pairs], [p for _, p in pairs], self._shots, int(self._rng.integers(0, 2**63 - 1)), with_values=True
             )
-        return [_cvar_of_samples(row, self._alpha) for row in values]
+        return _cvar_of_sample_matrix(values, self._alpha)
 
     @property
     def n_qubits(self) -> int:

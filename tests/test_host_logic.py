@@ -359,3 +359,15 @@ class TestUnpinnedCaches:
         cache.get(c)
         clone = pickle.loads(pickle.dumps(cache))
         assert len(clone) == 0 and len(clone.get(c)) == 2
+
+
+def test_cvar_of_a_sample_matrix_equals_the_row_by_row_form():
+    from queasars_amd.circuit_evaluation.circuit_evaluation import _cvar_of_sample_matrix, _cvar_of_samples
+
+    rng = np.random.default_rng(5)
+    values = rng.normal(size=(7, 512)).round(2)
+    for alpha in (1.0, 0.5, 0.3, 0.123, 1 / 512, 0.999):
+        want = [_cvar_of_samples(row, alpha) for row in values]
+        got = _cvar_of_sample_matrix(values, alpha)
+        assert np.allclose(got, want, rtol=0, atol=1e-12)
+    assert _cvar_of_sample_matrix(np.zeros((0, 512)), 0.5) == []
