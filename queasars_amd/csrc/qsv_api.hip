@@ -162,7 +162,8 @@ struct qsv_handle {
     std::vector<CoalesceRequest*> cq;
     std::atomic<size_t> cq_count{0};   // = cq.size(), readable without the lock (the collecting caller spins on it)
     bool cq_collecting = false;        // some caller is collecting or evaluating a batch
-    size_t cq_expected = 0;            // size of the previous batch: how many callers to expect
+    size_t cq_expected = 0;            // size of recent batches: how many callers to expect
+    uint64_t cq_batches = 0;           // batches evaluated so far (diagnostic)
 
     // device memory
     DeviceBuffer d_arena;  // plans (uint32 words)
@@ -904,6 +905,8 @@ int qsv_create(int n_qubits, int dtype, int device, const qsv_plan_config* cfg, 
 
 void qsv_destroy(qsv_t* h) {
     if (!h) return;
+    if (getenv("QSV_COALESCE_DEBUG") && h->cq_batches)
+        fprintf(stderr, "qsv_eval_coalesced: %llu batches, last expectation %zu\n", (unsigned long long)h->cq_batches, h->cq_expected);
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->stream2) {
@@ -1089,7 +1092,8 @@ int qsv_eval_circuits(qsv_t* h, int n_evals, const int* circuit_ids, const int64
 // (caller holds h->cq_mu through `lock`; returns with it held)
 static void coalesce_lead(qsv_t* h, std::unique_lock<std::mutex>& lock, double window_us) {
     using clock = std::chrono::steady_clock;
-    const double window = window_us > 0 ? window_us : 300.0, quiet = 40.0;
+    const double window = window_us > 0 ? window_us : 300.0;
+    const double quiet = getenv("QSV_COALESCE_QUIET_US") ? atof(getenv("QSV_COALESCE_QUIET_US")) : 60.0;
     // A batch is complete when as many callers as last time have arrived, or nobody new came for `quiet` us, or the
     // window is over.  The collector spins (no timed sleep is shorter than the kernel's timer slack of ~50 us).
     lock.unlock();
@@ -1146,7 +1150,10 @@ static void coalesce_lead(qsv_t* h, std::unique_lock<std::mutex>& lock, double w
         }
     }
     lock.lock();
-    h->cq_expected = batch.size();
+    // how many callers to expect next time: a high-water mark that decays slowly (a batch cut short by a pause in the
+    // arrivals must not teach the next collector to stop early as well)
+    h->cq_expected = std::max(batch.size(), h->cq_expected * 7 / 8);
+    h->cq_batches += 1;
     for (auto* r : batch) r->done = true;
     h->cq_collecting = false;
     h->cq_cv.notify_all();
