@@ -106,12 +106,16 @@ class GpuEstimator(_EstimatorBase):
     changes); operators are recognised by content, not identity, and at most ``max_operators`` evaluators are kept."""
 
     def __init__(self, dtype: str = "fp64", device: int = 0, seed: Optional[int] = None, max_operators: int = 8):
-        self._dtype, self._device_index = dtype, device
+        self._dtype, self._device_index, self._seed = dtype, device, seed
         self._rng = np.random.default_rng(seed)
         self._convert = _Converter()
         self._devices: dict[int, StatevectorDevice] = {}
         self._evaluators: "OrderedDict[tuple, OperatorCircuitEvaluator]" = OrderedDict()
         self._max_operators = max(1, int(max_operators))
+
+    def backend_options(self) -> dict:
+        """dtype / device / seed, for ``configured_primitives.evaluator_for``."""
+        return {"dtype": self._dtype, "device": self._device_index, "seed": self._seed}
 
     def _evaluator(self, operator: PauliOperator) -> OperatorCircuitEvaluator:
         key = _operator_key(operator)
@@ -168,9 +172,14 @@ class GpuSampler(_SamplerBase):
 
     def __init__(self, n_qubits: int, dtype: str = "fp64", device: int = 0, seed: int = 0):
         self._device = StatevectorDevice(n_qubits, dtype=dtype, device=device)
+        self._options = {"dtype": dtype, "device": device, "seed": int(seed)}
         self._convert = _Converter()
         self._seed = int(seed)
         self._calls = 0
+
+    def backend_options(self) -> dict:
+        """dtype / device / seed, for ``configured_primitives.evaluator_for``."""
+        return dict(self._options)
 
     def run(self, pubs: Iterable[Sequence[Any]], *, shots: Optional[int] = None) -> _Job:
         shots = 1024 if shots is None else int(shots)

@@ -175,6 +175,41 @@ def test_primitive_shaped_front_ends():
     assert abs(res.get(top, 0) / shots - probs[top]) < 6 * np.sqrt(probs[top] * (1 - probs[top]) / shots) + 2 / shots
 
 
+def test_evaluators_from_configured_primitives():
+    """configured_primitives.evaluator_for: the three evaluators a solver configured the reference's way gets
+    (evolving_ansatz_minimum_eigensolver.py builds them from ConfiguredEstimatorV2 / ConfiguredSamplerV2)."""
+    from queasars_amd.circuit_evaluation import (
+        BitstringCircuitEvaluator,
+        BitstringEvaluator,
+        ConfiguredEstimatorV2,
+        ConfiguredSamplerV2,
+        OperatorSamplerCircuitEvaluator,
+        evaluator_for,
+    )
+    from queasars_amd.primitives import GpuEstimator, GpuSampler
+
+    n = 8
+    _, circuits, params = helpers.population_circuits(n, 2, 4, seed=21)
+    op = helpers.random_ising_operator(n, seed=4)
+    exact = evaluator_for(ConfiguredEstimatorV2(GpuEstimator(), 0.0), operator=op)
+    assert isinstance(exact, OperatorCircuitEvaluator)
+    ref = [helpers.oracle_expectation(c, p, op) for c, p in zip(circuits, params)]
+    assert np.abs(np.asarray(exact.evaluate_circuits(circuits, params)) - np.asarray(ref)).max() < EXP_TOL
+    configured = ConfiguredSamplerV2(GpuSampler(n, seed=11), 20000)
+    sampled = evaluator_for(configured, operator=op)
+    assert isinstance(sampled, OperatorSamplerCircuitEvaluator)
+    spread = float(np.abs(op.coeffs).sum())
+    got = sampled.evaluate_circuits(circuits, params)
+    assert np.abs(np.asarray(got) - np.asarray(ref)).max() < 6 * spread / np.sqrt(20000)
+    ones = evaluator_for(configured, bitstring_evaluator=BitstringEvaluator(n, lambda b: float(b.count("1"))))
+    assert isinstance(ones, BitstringCircuitEvaluator)
+    want = [
+        float(np.dot(np.abs(helpers.oracle_state(c, p)) ** 2, [bin(i).count("1") for i in range(1 << n)]))
+        for c, p in zip(circuits, params)
+    ]
+    assert np.abs(np.asarray(ones.evaluate_circuits(circuits, params)) - np.asarray(want)).max() < 6 * n / np.sqrt(20000)
+
+
 def test_zero_angles_known_answer():
     """u(0,0,0) = cu3(0,0,0) = I: the state stays |0..0>, <H> = sum of the I/Z-only coefficients."""
     n = 6

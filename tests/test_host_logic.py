@@ -371,3 +371,34 @@ def test_cvar_of_a_sample_matrix_equals_the_row_by_row_form():
         got = _cvar_of_sample_matrix(values, alpha)
         assert np.allclose(got, want, rtol=0, atol=1e-12)
     assert _cvar_of_sample_matrix(np.zeros((0, 512)), 0.5) == []
+
+
+class TestConfiguredPrimitives:
+    """queasars_amd.circuit_evaluation.configured_primitives (reference: configured_primitives.py:9-22)."""
+
+    def test_the_two_pairs_hold_their_option_and_refuse_nonsense(self):
+        from queasars_amd.circuit_evaluation import ConfiguredEstimatorV2, ConfiguredSamplerV2
+
+        sampler, estimator = object(), object()
+        s = ConfiguredSamplerV2(sampler=sampler, shots=128)
+        e = ConfiguredEstimatorV2(estimator=estimator, precision=0.0)
+        assert s.sampler is sampler and s.shots == 128 and e.estimator is estimator and e.precision == 0.0
+        assert s == ConfiguredSamplerV2(sampler, 128)  # plain dataclasses, as in the reference
+        with pytest.raises(ValueError):
+            ConfiguredSamplerV2(sampler, 0)
+        with pytest.raises(ValueError):
+            ConfiguredEstimatorV2(estimator, -1e-3)
+
+    def test_evaluator_for_checks_its_arguments_before_touching_a_device(self):
+        from queasars_amd.circuit_evaluation import ConfiguredEstimatorV2, ConfiguredSamplerV2, evaluator_for
+
+        op = PauliOperator(["ZI"])
+        ev = BitstringEvaluator(2, lambda b: 0.0)
+        with pytest.raises(ValueError):
+            evaluator_for(ConfiguredSamplerV2(object(), 8))
+        with pytest.raises(ValueError):
+            evaluator_for(ConfiguredSamplerV2(object(), 8), operator=op, bitstring_evaluator=ev)
+        with pytest.raises(ValueError):
+            evaluator_for(ConfiguredEstimatorV2(object(), 0.0), bitstring_evaluator=ev)
+        with pytest.raises(TypeError):
+            evaluator_for(object(), operator=op)
