@@ -73,7 +73,7 @@ def build(force: bool = False, verbose: bool = False, defines: tuple = (), lib_p
     if not force and not defines and not needs_build():
         build_pyhelp(False)
         return LIB_PATH
-    obj_dir = PKG_DIR / ("build" if not defines else "build_" + "_".join(defines).lower())
+    obj_dir = PKG_DIR / ("build" if not defines else "build_" + "".join(c if c.isalnum() else "_" for c in "_".join(defines).lower()))
     obj_dir.mkdir(exist_ok=True)
     hipcc = _hipcc()
     common = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]

@@ -12,10 +12,9 @@ Per gate (descriptor = 4 words w0, ct, cg, op; matrix = 8 doubles m00 m01 m10 m1
     mask lanes whose thread-held control bit is 0                  (tid & ct) == ct               exec
     J = w0 & 0xff picks the target register bit; for each of the 2^(R-1) amplitude pairs p, bit 16 + p of w0 says
     whether the pair takes part (a register-held control switches half of them off)                 scalar
-    pair update, 14 fp64 operations, in place:
-        u = m01r a1r - m01i a1i      w = m01r a1i + m01i a1r
-        p = m11r a1r - m11i a1i + m10r a0r      q = m11r a1i + m11i a1r + m10r a0i
-        a1r' = p - m10i a0i    a1i' = q + m10i a0r    a0r' = m00 a0r + u    a0i' = m00 a0i + w
+    pair update, 14 fp64 operations, in place, as four chains issued round-robin (p, q, u, w):
+        a1r' = ((m10r a0r - m10i a0i) + m11r a1r) - m11i a1i      a1i' = ((m10r a0i + m10i a0r) + m11i a1r) + m11r a1i
+        a0r' = (m00 a0r + m01r a1r) - m01i a1i                    a0i' = (m00 a0i + m01r a1i) + m01i a1r
 
 Descriptor and matrix of gate g + 1 are fetched with scalar loads while gate g runs (two register sets, loop unrolled
 by two).  Scalar registers are hard-coded and declared as clobbers; amplitudes and temporaries are operands.
@@ -29,6 +28,14 @@ import sys
 from pathlib import Path
 
 OUT = Path(__file__).resolve().parent / "gate_loop_gen.inc"
+
+# Timing experiments (scripts/ablate.py): QSV_GEN_ABL=name[,name..] leaves parts of the block out.  The results of such
+# a build are wrong by construction; the shipped gate_loop_gen.inc is generated with the variable unset.
+#   gatevalu  the 14 operations of a pair update          pairtest  the per-pair "takes part" test
+#   swapvalu  the moves of a lane swap                     gateloop  the whole gate loop (descriptor fetches too)
+import os
+
+ABL = set(filter(None, os.environ.get("QSV_GEN_ABL", "").split(",")))
 
 # Amplitude e of a thread lives in FOUR FIXED vector registers, v[AMP0 + 4e .. AMP0 + 4e + 3] = (re lo, re hi, im lo,
 # im hi), in every assembly block (explicit "{v[a:b]}" constraints): a global_load/store_dwordx4 or an LDS access then
@@ -96,22 +103,27 @@ def gate(lines: list[str], r: int, x: str, tag: str) -> None:
                 continue
             e1 = e0 | (1 << j)
             a0r, a0i, a1r, a1i = amp_re(e0), amp_im(e0), amp_re(e1), amp_im(e1)
-            e(f"s_bitcmp1_b32 {w0}, {16 + pair}")
-            e(f"s_cbranch_scc0 Ln{j}_{pair}{tag}_%=")
-            e(f"v_mul_f64 %[u], {m01r}, {a1r}")
-            e(f"v_mul_f64 %[w], {m01r}, {a1i}")
-            e(f"v_mul_f64 %[p], {m11r}, {a1r}")
-            e(f"v_mul_f64 %[q], {m11r}, {a1i}")
-            e(f"v_fma_f64 %[u], -{m01i}, {a1i}, %[u]")
-            e(f"v_fma_f64 %[w], {m01i}, {a1r}, %[w]")
-            e(f"v_fma_f64 %[p], -{m11i}, {a1i}, %[p]")
-            e(f"v_fma_f64 %[q], {m11i}, {a1r}, %[q]")
-            e(f"v_fma_f64 %[p], {m10r}, {a0r}, %[p]")
-            e(f"v_fma_f64 %[q], {m10r}, {a0i}, %[q]")
-            e(f"v_fma_f64 {a1r}, -{m10i}, {a0i}, %[p]")
-            e(f"v_fma_f64 {a1i}, {m10i}, {a0r}, %[q]")
-            e(f"v_fma_f64 {a0r}, {m00}, {a0r}, %[u]")
-            e(f"v_fma_f64 {a0i}, {m00}, {a0i}, %[w]")
+            if "pairtest" not in ABL:
+                e(f"s_bitcmp1_b32 {w0}, {16 + pair}")
+                e(f"s_cbranch_scc0 Ln{j}_{pair}{tag}_%=")
+            # four accumulation chains taken round-robin: every operation is four issue slots behind the one it
+            # depends on (the dependent issue of v_fma_f64 is longer than two slots), and every amplitude register
+            # is overwritten only after its last reader
+            if "gatevalu" not in ABL:
+                e(f"v_mul_f64 %[p], {m10r}, {a0r}")
+                e(f"v_mul_f64 %[q], {m10r}, {a0i}")
+                e(f"v_mul_f64 %[u], {m00}, {a0r}")
+                e(f"v_mul_f64 %[w], {m00}, {a0i}")
+                e(f"v_fma_f64 %[p], -{m10i}, {a0i}, %[p]")
+                e(f"v_fma_f64 %[q], {m10i}, {a0r}, %[q]")
+                e(f"v_fma_f64 %[u], {m01r}, {a1r}, %[u]")
+                e(f"v_fma_f64 %[w], {m01r}, {a1i}, %[w]")
+                e(f"v_fma_f64 %[p], {m11r}, {a1r}, %[p]")
+                e(f"v_fma_f64 %[q], {m11i}, {a1r}, %[q]")
+                e(f"v_fma_f64 {a0r}, -{m01i}, {a1i}, %[u]")
+                e(f"v_fma_f64 {a0i}, {m01i}, {a1r}, %[w]")
+                e(f"v_fma_f64 {a1r}, -{m11i}, {a1i}, %[p]")
+                e(f"v_fma_f64 {a1i}, {m11r}, {a1i}, %[q]")
             e(f"Ln{j}_{pair}{tag}_%=:")
             pair += 1
         if pos + 1 < len(order):
@@ -207,6 +219,8 @@ def swap_case(lines: list[str], r: int, v: int, u: int) -> None:
     # (A, B) dword pairs: the four 32-bit halves of both component planes
     regs = [(f"v{AMP0 + 4 * a + d}", f"v{AMP0 + 4 * b + d}") for a, b in pairs for d in range(4)]
     e("s_nop 1")
+    if "swapvalu" in ABL:
+        return
     if u >= 4:
         op = "v_permlane32_swap_b32" if u == 5 else "v_permlane16_swap_b32"
         for a, b in regs:
@@ -324,7 +338,8 @@ def emit_rounds(r: int) -> str:
     e(f"s_lshl_b32 s{T1}, s{N}, 6")
     e(f"s_add_u32 s94, s{MP}, s{T1}")
     e(f"s_addc_u32 s95, s{MP + 1}, 0")
-    gate_loop_core(lines, r)
+    if "gateloop" not in ABL:
+        gate_loop_core(lines, r)
     e(f"s_mov_b64 {rp}, {NEXT_RP}")
     e(f"s_mov_b64 {mp}, {NEXT_MP}")
     e("Lnext_%=:")
@@ -506,5 +521,8 @@ if __name__ == "__main__":
     text = render()
     if len(sys.argv) > 1 and sys.argv[1] == "--check":
         sys.exit(0 if OUT.exists() and OUT.read_text() == text else 1)
-    OUT.write_text(text)
-    print(f"wrote {OUT} ({len(text.splitlines())} lines)")
+    out = Path(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[1] == "--out" else OUT
+    if ABL and out == OUT:
+        sys.exit("QSV_GEN_ABL is set: refusing to overwrite the shipped gate_loop_gen.inc (use --out)")
+    out.write_text(text)
+    print(f"wrote {out} ({len(text.splitlines())} lines)")

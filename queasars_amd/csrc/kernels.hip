@@ -129,7 +129,11 @@ struct ButterflyDispatch<real, R, -1> {
     static __device__ __forceinline__ void run(int, cx<real> (&)[1 << R], const real (&)[7]) {}
 };
 
+#ifdef QSV_GATE_LOOP_INC  // (timing experiments, scripts/ablate.py: a variant of the generated block)
+#include QSV_GATE_LOOP_INC
+#else
 #include "gate_loop_gen.inc"
+#endif
 
 // ---- lane swaps (plan.hpp, "swap" rounds) ---------------------------------------------------------------------
 // Transposition of the tile bit under register bit V with the one under lane bit U: element (lane, e) with lane bit U
@@ -247,6 +251,7 @@ struct PassScalars {
     uint32_t pass_index;
     uint32_t mode;
     uint32_t tiles_per_block;
+    uint32_t partial_chunks;
 };
 
 // XMODE selects how a tile is transposed through LDS:
@@ -264,10 +269,15 @@ struct PassScalars {
 #ifndef QSV_WAVES_R4
 #define QSV_WAVES_R4 4
 #endif
-template <int R, int XMODE>
+#ifndef QSV_WAVES_R4_FIRST
+#define QSV_WAVES_R4_FIRST 5
+#endif
+template <int R, int XMODE, bool FIRST>
 struct Occupancy {
-    // 2^R amplitudes = 4 * 2^R VGPRs: R = 3 fits the 80-VGPR budget of 6 waves per SIMD, R = 4 needs the 128 of 4
-    static constexpr int waves_per_simd = R >= 4 ? QSV_WAVES_R4 : (XMODE == 2 ? QSV_WAVES_PER_SIMD : 4);
+    // 2^R amplitudes = 4 * 2^R VGPRs: R = 3 fits the 80-VGPR budget of 6 waves per SIMD, R = 4 needs the 128 of 4 --
+    // except in the synthesising pass 0, which has no load phase (its peak) and fits the 96 of 5
+    static constexpr int waves_per_simd =
+        R >= 4 ? (FIRST && XMODE == 2 ? QSV_WAVES_R4_FIRST : QSV_WAVES_R4) : (XMODE == 2 ? QSV_WAVES_PER_SIMD : 4);
 };
 
 template <typename T>
@@ -278,7 +288,7 @@ template <> struct Log2Size<double> { static constexpr int value = 3; };
 // FIRST = the pass synthesises its input (pass 0 of an evaluation from |0..0>): two instantiations, so that neither
 // carries the other's load path through register allocation.
 template <typename real, int R, int XMODE, bool FIRST>
-__global__ void __launch_bounds__(512, (Occupancy<R, XMODE>::waves_per_simd))
+__global__ void __launch_bounds__(512, (Occupancy<R, XMODE, FIRST>::waves_per_simd))
     pass_kernel(const uint32_t* __restrict__ plan_arena, const double* __restrict__ mats_all,
                 const EvalDesc* __restrict__ evals, cx<real>* __restrict__ states, cx<real>* __restrict__ wtabs,
                 const double* __restrict__ diag, double* __restrict__ partials, const PassScalars a) {
@@ -470,7 +480,7 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE>::waves_per_simd))
         QSV_STAMP(1);
         cu32p rp = rounds0;
         cf64p mp = mats0;
-#ifndef QSV_STAMPS
+#if !defined(QSV_STAMPS) || defined(QSV_STAMPS_ASM)  // (QSV_STAMPS_ASM: stamps around the production block)
         // fp64, exchange mode 2 (the production configuration): every round of the tile is ONE generated assembly block
         // (gate_loop_gen.inc, RoundLoopF64).  The C++ loop below states the same thing and serves fp32, the other
         // exchange modes and the stamped diagnostic build.
@@ -482,6 +492,7 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE>::waves_per_simd))
             if (n_rounds > 0)
                 RoundLoopF64<R>::run(amp, rp, mp, uint32_t(n_rounds), uint32_t(base), tid, wave, active_mask,
                                      uint32_t(uintptr_t(lds_raw)), xflags);
+            QSV_STAMP(10);
         } else
         for (int m = 0; m < n_rounds; ++m) {
             const uint32_t rh = rp[0];
@@ -730,7 +741,13 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE>::waves_per_simd))
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
         const uint32_t n_waves = blockDim.x >> 6;
-        if ((tid & 63u) == 0) partials[(size_t(ev.out_index) * gridDim.x + blockIdx.x) * n_waves + wave] = acc;
+        // a launch with fewer workgroups than the reducer's shape also clears the slots nobody owns
+        const uint32_t slots = a.partial_chunks ? a.partial_chunks : gridDim.x;
+        if ((tid & 63u) == 0) {
+            double* mine = partials + size_t(ev.out_index) * slots * n_waves + wave;
+            mine[size_t(blockIdx.x) * n_waves] = acc;
+            for (uint32_t b2 = blockIdx.x + gridDim.x; b2 < slots; b2 += gridDim.x) mine[size_t(b2) * n_waves] = 0.0;
+        }
     }
 #ifdef QSV_STAMPS
     QSV_STAMP(12);
@@ -755,7 +772,8 @@ template <typename real, int R, int XMODE>
 static hipError_t launch_pass_t(dim3 grid, int threads, size_t lds_bytes, hipStream_t stream, const PassArgs& args) {
     // the block reduction at the end needs one double per wave (and the diagnostic build a table of counters)
     const size_t lds = lds_bytes < 256 ? 256 : lds_bytes;
-    const PassScalars sc{args.state_stride, args.wtab_stride, args.pass_index, args.mode, args.tiles_per_block};
+    const PassScalars sc{args.state_stride, args.wtab_stride, args.pass_index, args.mode, args.tiles_per_block,
+                         args.partial_chunks};
     cx<real>* st = reinterpret_cast<cx<real>*>(args.states);
     const bool first = args.pass_index == 0 && (args.mode & kModeSynthFirst);
     if (first)
@@ -798,7 +816,8 @@ static hipError_t pass_dispatch(int op, int dtype, int r, int xmode, dim3 grid, 
 #define QSV_PROBE_R 4
 #endif
     if (op) return hipSuccess;
-    const PassScalars sc{args->state_stride, args->wtab_stride, args->pass_index, args->mode, args->tiles_per_block};
+    const PassScalars sc{args->state_stride, args->wtab_stride, args->pass_index, args->mode, args->tiles_per_block,
+                         args->partial_chunks};
     if (args->pass_index == 0 && (args->mode & kModeSynthFirst))
         hipLaunchKernelGGL((pass_kernel<double, QSV_PROBE_R, 2, true>), grid, dim3(threads), lds_bytes, stream, args->plan,
                            args->mats, args->evals, reinterpret_cast<cx<double>*>(args->states),

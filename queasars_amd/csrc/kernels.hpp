@@ -31,12 +31,14 @@ struct PassArgs {
     void* states;          // slot s starts at s * state_stride amplitudes
     void* wtab;            // compact tables (plan.hpp COMPACT): slot s starts at s * wtab_stride amplitudes
     const double* diag;    // D[i] for the diagonal fast path (may be null)
-    double* partials;      // [out_index][gridDim.x]
+    double* partials;      // [out_index][partial_chunks][waves of a workgroup]
     uint64_t state_stride;
     uint64_t wtab_stride;
     uint32_t pass_index;
     uint32_t mode;
     uint32_t tiles_per_block;  // consecutive tiles each workgroup sweeps
+    uint32_t partial_chunks;   // workgroup slots per evaluation in `partials` (>= gridDim.x; 0 means gridDim.x): launches
+                               // of one batch may use different grids (pass 0 / later passes), the reducer sees one shape
 };
 
 // Diagnostic stamps (only in a -DQSV_STAMPS build): [pass][phase] shader cycles summed over WAVES; the last phase

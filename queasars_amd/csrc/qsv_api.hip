@@ -125,10 +125,10 @@ struct qsv_handle {
     bool own_stream = false;
     // Second stream for the streaming evaluation: consecutive pushes alternate between the two, so that the
     // compute-bound first pass of one push runs beside the memory-bound later passes of the other.
-    hipStream_t stream2 = nullptr;
+    std::vector<hipStream_t> side_streams;  // (own, non-blocking); pushes cycle over `stream` and these
     hipStream_t work = nullptr;  // stream of the push being issued (null: `stream`)
     hipEvent_t ev_join = nullptr;
-    bool dual_streams = true;
+    int n_streams = 2;           // streams a batch cycles over (QSV_STREAMS, 1 .. 4)
     mutable std::mutex mu;
     std::atomic<std::thread::id> batch_owner{};  // thread that holds `mu` between qsv_eval_begin and qsv_eval_end
 
@@ -173,7 +173,8 @@ struct qsv_handle {
     uint64_t wtab_stride = 0; // amplitudes per slot
     DeviceBuffer d_batch;     // [EvalDesc x B][parameter vectors]
     DeviceBuffer d_mats;      // per evaluation: gate matrices in schedule order + product-state factors
-    int tiles_per_block = 1;
+    int tiles_per_block = 1;        // pass 0 (and the only pass of a small circuit)
+    int tiles_per_block_later = 1;  // passes 1.. (a multiple of tiles_per_block)
     DeviceBuffer d_partials;  // [B][blocks_per_state]
     DeviceBuffer d_out;       // [B]
     DeviceBuffer d_scratch;   // probabilities / converted state
@@ -195,8 +196,8 @@ struct qsv_handle {
         std::vector<std::pair<hipEvent_t, hipEvent_t>> pass_events, exp_events;
         std::vector<std::pair<hipEvent_t, hipEvent_t>> launch_events[2];  // per launch: [0] first pass, [1] later passes
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
-        bool dual = false;   // this batch alternates pushes between the two streams
-        bool used2 = false;  // ... and the second one has work in flight
+        int ways = 1;           // streams this batch cycles over
+        unsigned used_mask = 0; // side streams (bit i = side_streams[i]) with work of this batch in flight
         size_t n_pushes = 0;
     } batch;
     std::unique_lock<std::mutex> batch_lock;  // held from begin to end
@@ -232,7 +233,8 @@ inline hipStream_t ws(const qsv_t* h) { return h->work ? h->work : h->stream; }
 // Nothing on either stream may still be using a buffer that is about to be replaced.
 hipError_t sync_streams(qsv_t* h) {
     hipError_t e = h->stream ? hipStreamSynchronize(h->stream) : hipSuccess;
-    if (e == hipSuccess && h->stream2) e = hipStreamSynchronize(h->stream2);
+    for (hipStream_t st : h->side_streams)
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
     return e;
 }
 
@@ -447,9 +449,9 @@ int upload_plans(qsv_t* h, const std::vector<Circuit*>& circs) {
                               hipMemcpyHostToDevice, h->stream));
     h->arena_used_words += need;
     // launches on the second stream read the arena too: they wait for this copy
-    if (h->stream2) {
+    if (!h->side_streams.empty()) {
         QSV_HIP(h, hipEventRecord(h->ev_join, h->stream));
-        QSV_HIP(h, hipStreamWaitEvent(h->stream2, h->ev_join, 0));
+        for (hipStream_t st : h->side_streams) QSV_HIP(h, hipStreamWaitEvent(st, h->ev_join, 0));
     }
     return QSV_OK;
 }
@@ -586,11 +588,19 @@ int run_group(qsv_t* h, const std::vector<Circuit*>& circs, size_t first, size_t
     a.partials = static_cast<double*>(h->d_partials.ptr);
     a.state_stride = uint64_t(1) << h->n;
     a.mode = mode;
+    // Pass 0 and the later passes have their own grids (tiles per workgroup): a compact pass 0 has few tiles and wants
+    // them spread, a later pass sweeps all of them and amortises its set-up over more.  Which grid an evaluation's
+    // LAST pass runs on depends on its own pass count only, so its partial sums are laid out (and added) the same
+    // way in any batch.
     const unsigned chunks = chunks_per_state(h);
-    a.tiles_per_block = h->geo.blocks_per_state / chunks;
-    dim3 grid(chunks, unsigned(count));
+    const unsigned tpb_later = unsigned(std::min<uint32_t>(uint32_t(h->tiles_per_block_later), h->geo.blocks_per_state));
+    const unsigned chunks_later = std::max(1u, std::min(chunks, h->geo.blocks_per_state / std::max(1u, tpb_later)));
+    a.partial_chunks = chunks;
     const uint64_t sweep = (uint64_t(1) << h->n) * h->amp_bytes;
     for (int p = 0; p < max_passes; ++p) {
+        const unsigned chunks_p = p == 0 ? chunks : chunks_later;
+        a.tiles_per_block = (h->geo.blocks_per_state + chunks_p - 1) / chunks_p;
+        dim3 grid(chunks_p, unsigned(count));
         a.pass_index = uint32_t(p);
         const int kind = (p == 0 && (mode & kModeSynthFirst)) ? 0 : 1;  // which instantiation of the kernel runs
         if (h->stamping) QSV_HIP(h, stamp(h, h->batch.launch_events[kind], true));
@@ -646,8 +656,10 @@ int eval_begin(qsv_t* h, const std::vector<Circuit*>& circs, const std::vector<i
     // Measured alternative: pass 0 of every push on one stream and the later passes on the other (compute-bound
     // beside memory-bound by construction) is 10 % slower: two resident kernels mostly take workgroup slots from
     // each other.
-    b.dual = h->dual_streams && h->diagonal && h->group >= 2 && n_evals >= 2;
-    b.used2 = false;
+    b.ways = 1;
+    if (h->diagonal && n_evals >= 2)
+        b.ways = std::max(1, std::min({h->n_streams, int(h->side_streams.size()) + 1, h->group}));
+    b.used_mask = 0;
     b.n_pushes = 0;
     return QSV_OK;
 }
@@ -669,13 +681,13 @@ int eval_push(qsv_t* h, size_t first, size_t count, const double* values) {
     } guard{h};
     h->stamping = h->profiling;
     EvalDesc* hd = static_cast<EvalDesc*>(h->h_batch);  // pinned; prepare_kernel reads it after this point
-    if (b.dual) {
-        const size_t half = G / 2, side = b.n_pushes & 1;
-        for (size_t j = 0; j < count; ++j) hd[first + j].state_slot = uint32_t(side * half + j % half);
-        G = half;
+    if (b.ways > 1) {
+        const size_t share = G / size_t(b.ways), side = size_t(b.n_pushes) % size_t(b.ways);
+        for (size_t j = 0; j < count; ++j) hd[first + j].state_slot = uint32_t(side * share + j % share);
+        G = share;
         if (side) {
-            h->work = h->stream2;
-            b.used2 = true;
+            h->work = h->side_streams[side - 1];
+            b.used_mask |= 1u << (side - 1);
         }
     } else {
         // every launch group of this push occupies slots 0 .. count-1 in order (the expectation kernels of the
@@ -726,18 +738,21 @@ int eval_end(qsv_t* h, double* out) {
     const size_t n_evals = b.circs.size();
     if (b.pushed != n_evals) return fail(h, QSV_E_STATE, "not every evaluation of the batch was pushed");
     if (n_evals == 0) return QSV_OK;
-    const bool used2 = b.used2;
-    if (used2 && h->profiling) {  // (only so that ev1 below marks the end of BOTH streams' work)
-        QSV_HIP(h, hipEventRecord(h->ev_join, h->stream2));
-        QSV_HIP(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
-    }
-    b.used2 = false;
+    const unsigned used_mask = b.used_mask;
+    if (h->profiling)  // (only so that ev1 below marks the end of EVERY stream's work)
+        for (size_t i = 0; i < h->side_streams.size(); ++i)
+            if (used_mask >> i & 1u) {
+                QSV_HIP(h, hipEventRecord(h->ev_join, h->side_streams[i]));
+                QSV_HIP(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
+            }
+    b.used_mask = 0;
     if (h->profiling) QSV_HIP(h, hipEventRecord(b.ev1, h->stream));
     if (!h->diagonal)
         QSV_HIP(h, hipMemcpyAsync(h->h_out, h->d_out.ptr, n_evals * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     // (polling hipStreamQuery instead was measured: no faster, and it slowed concurrent callers down threefold)
     QSV_HIP(h, hipStreamSynchronize(h->stream));
-    if (used2) QSV_HIP(h, hipStreamSynchronize(h->stream2));
+    for (size_t i = 0; i < h->side_streams.size(); ++i)
+        if (used_mask >> i & 1u) QSV_HIP(h, hipStreamSynchronize(h->side_streams[i]));
     std::memcpy(out, h->h_out, n_evals * sizeof(double));
     if (h->profiling) {
         float ms = 0.f;
@@ -780,7 +795,8 @@ void eval_close(qsv_t* h) {
     b.ev0 = b.ev1 = nullptr;
     b.circs.clear();
     b.open = false;
-    b.dual = b.used2 = false;
+    b.ways = 1;
+    b.used_mask = 0;
     h->work = nullptr;
 }
 
@@ -880,7 +896,9 @@ int qsv_create(int n_qubits, int dtype, int device, const qsv_plan_config* cfg, 
         const uint64_t tiles_per_launch = uint64_t(geo.blocks_per_state) * uint64_t(group);
         h->tiles_per_block = (tiles_per_launch >= 4096 && geo.blocks_per_state >= 2) ? 2 : 1;
     }
-    if (const char* env = getenv("QSV_TILES_PER_BLOCK")) h->tiles_per_block = std::max(1, atoi(env));
+    h->tiles_per_block_later = h->tiles_per_block;
+    if (const char* env = getenv("QSV_TILES_PER_BLOCK")) h->tiles_per_block = h->tiles_per_block_later = std::max(1, atoi(env));
+    if (const char* env = getenv("QSV_TILES_PER_BLOCK_LATER")) h->tiles_per_block_later = std::max(1, atoi(env));
     auto bail = [&](hipError_t err, const char* what) {
         std::string msg = std::string(what) + ": " + hipGetErrorString(err);
         qsv_destroy(h);
@@ -888,9 +906,13 @@ int qsv_create(int n_qubits, int dtype, int device, const qsv_plan_config* cfg, 
     };
     if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
     h->own_stream = true;
-    if ((e = hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
+    if (const char* env = getenv("QSV_STREAMS")) h->n_streams = std::max(1, std::min(4, atoi(env)));
+    for (int i = 1; i < std::max(2, h->n_streams); ++i) {
+        hipStream_t st = nullptr;
+        if ((e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
+        h->side_streams.push_back(st);
+    }
     if ((e = hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
-    if (const char* env = getenv("QSV_STREAMS")) h->dual_streams = atoi(env) >= 2;
     if ((e = hipMalloc(&h->d_states.ptr, state_bytes * size_t(group))) != hipSuccess) return bail(e, "hipMalloc(states)");
     h->d_states.bytes = state_bytes * size_t(group);
     // compact tables: at most 2^kMaxCompactBits tiles per slot, never more than a state
@@ -909,9 +931,9 @@ void qsv_destroy(qsv_t* h) {
         fprintf(stderr, "qsv_eval_coalesced: %llu batches, last expectation %zu\n", (unsigned long long)h->cq_batches, h->cq_expected);
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    if (h->stream2) {
-        (void)hipStreamSynchronize(h->stream2);
-        (void)hipStreamDestroy(h->stream2);
+    for (hipStream_t st : h->side_streams) {
+        (void)hipStreamSynchronize(st);
+        (void)hipStreamDestroy(st);
     }
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     for (DeviceBuffer* b : {&h->d_z, &h->d_cre, &h->d_diag, &h->d_term_partials, &h->d_groups, &h->d_term_odd, &h->d_arena,
@@ -1226,8 +1248,7 @@ int qsv_eval_end(qsv_t* h, double* out_expectations) {
     int rc = out_expectations || h->batch.circs.empty() ? eval_end(h, out_expectations)
                                                         : fail(h, QSV_E_ARG, "out is null");
     if (rc) {  // nothing of the failed batch may still be running
-        (void)hipStreamSynchronize(h->stream);
-        (void)hipStreamSynchronize(h->stream2);
+        (void)sync_streams(h);
     }
     eval_close(h);
     h->batch_owner.store(std::thread::id());
@@ -1476,7 +1497,7 @@ static int bench_ops_locked(qsv_t* h, int n_ops, const qsv_op* ops, int reps, do
     a.state_stride = uint64_t(1) << h->n;
     a.mode = kModeFinalStore;  // read-modify-write of the resident state, no synthesis
     const unsigned chunks = chunks_per_state(h);
-    a.tiles_per_block = h->geo.blocks_per_state / chunks;
+    a.tiles_per_block = (h->geo.blocks_per_state + chunks - 1) / chunks;
     dim3 grid(chunks, 1);
     const int n_passes = c.plan.stats.n_passes;
     auto sweep = [&]() -> hipError_t {

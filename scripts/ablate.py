@@ -23,6 +23,18 @@ VARIANTS = {
     "nothing_but_memory": ("QSV_ABL_NOGATES", "QSV_ABL_NOSWAP"),
     "nothing_but_gates": ("QSV_ABL_NOLOAD", "QSV_ABL_NOF", "QSV_ABL_NODIAG", "QSV_ABL_NOSWAP"),
 }
+# variants of the GENERATED assembly round loop (production path): parts left out by gen_gate_loop.py (QSV_GEN_ABL)
+ASM_VARIANTS = {
+    "asm_gatevalu": "gatevalu",
+    "asm_pairtest": "pairtest",
+    "asm_swapvalu": "swapvalu",
+    "asm_gateloop": "gateloop",
+    "asm_gatevalu_swapvalu": "gatevalu,swapvalu",
+    "asm_gateloop_swapvalu": "gateloop,swapvalu",
+    # the skeleton: no gates, no swaps, no memory -- what the launch, the set-up and the loop structure cost by themselves
+    "asm_skeleton": ("gateloop,swapvalu", ("QSV_ABL_NOLOAD", "QSV_ABL_NOF", "QSV_ABL_NODIAG")),
+    "asm_nomem": ("", ("QSV_ABL_NOLOAD", "QSV_ABL_NOF", "QSV_ABL_NODIAG")),
+}
 
 
 def lib_of(name):
@@ -33,13 +45,25 @@ def main():
     if sys.argv[1] == "build":
         from queasars_amd import _build
 
+        only = set(sys.argv[2:])
         for name, defines in VARIANTS.items():
-            if name == "base":
+            if name == "base" or (only and name not in only):
                 continue
             print(_build.build(force=True, defines=defines, lib_path=lib_of(name)))
+        csrc = ROOT / "queasars_amd" / "csrc"
+        for name, abl in ASM_VARIANTS.items():
+            if only and name not in only:
+                continue
+            abl, extra = abl if isinstance(abl, tuple) else (abl, ())
+            inc = csrc / f"gate_loop_{name}.inc"
+            subprocess.run([sys.executable, str(csrc / "gen_gate_loop.py"), "--out", str(inc)],
+                           env=dict(os.environ, QSV_GEN_ABL=abl), check=True)
+            print(_build.build(force=True, defines=(f'QSV_GATE_LOOP_INC="{inc.name}"', *extra), lib_path=lib_of(name)))
+            inc.unlink()
         return
     n, pop = (sys.argv[2:4] + ["20", "64"][len(sys.argv[2:4]):])
-    for name in VARIANTS:
+    names = [v for v in list(VARIANTS) + list(ASM_VARIANTS) if v == "base" or lib_of(v).exists()]
+    for name in names:
         env = dict(os.environ, QSV_BENCH_QUBITS=n, QSV_BENCH_POP=pop)
         if name != "base":
             env["QSV_LIBRARY"] = str(lib_of(name))

@@ -14,7 +14,7 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
-STAMP_LIB = ROOT / "queasars_amd" / "libqsv_stamps.so"
+STAMP_LIB = Path(os.environ.get("QSV_STAMP_LIB", ROOT / "queasars_amd" / "libqsv_stamps.so"))
 PHASES = ["setup", "load/synth", "x-wait", "x-wr-re", "x-bar1", "x-rd-re", "x-bar2", "x-wr-im", "x-bar3", "x-rd-im", "gates",
           "store/red", "epilogue"]
 
@@ -23,7 +23,9 @@ def main() -> None:
     if sys.argv[1] == "build":
         from queasars_amd import _build
 
-        print(_build.build(force=True, defines=("QSV_STAMPS",), lib_path=STAMP_LIB))
+        # "build asm": stamps around the production assembly round loop (all of it charged to "gates")
+        defines = ("QSV_STAMPS", "QSV_STAMPS_ASM") if "asm" in sys.argv[2:] else ("QSV_STAMPS",)
+        print(_build.build(force=True, defines=defines, lib_path=STAMP_LIB))
         return
     os.environ["QSV_LIBRARY"] = str(STAMP_LIB)
     import numpy as np
