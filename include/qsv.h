@@ -81,17 +81,20 @@ typedef struct qsv_profile {
     double pass_window_ms;     /* wall-clock window from the first gate-pass launch to the end of the last one */
     uint64_t moved_bytes;      /* state bytes the launches really moved: less than state_bytes when a compact first pass
                                   replaced the state round trip between the first two passes by a small table */
-    /* The gate-pass kernel has two instantiations; with profiling on, every launch is bracketed by HIP events on the
-       stream it runs on.  [0] = the synthesising first pass (writes only), [1] = every later pass (the last one fuses
-       the diagonal expectation and then only reads).  bytes = algorithmic state bytes at the pass's own price
-       (16 * 2^n per state and direction it has to move), moved = what it really moves (compact tables), flops =
-       24 per amplitude pair the pass updates (4 multiplications + 10 fused multiply-adds). */
-    uint64_t kernel_launches[2];
-    double kernel_ms[2];
-    uint64_t kernel_bytes[2];
-    uint64_t kernel_moved_bytes[2];
-    double kernel_flops[2];
-    uint64_t kernel_states[2]; /* states swept, summed over launches */
+    /* The kernels of the hot path; with profiling on, every launch is bracketed by HIP events on the stream it runs
+       on.  [0] = the synthesising first pass of the gate-pass kernel (writes only; also the one-tile virtual circuits
+       of split evaluations), [1] = every later pass (the last one fuses the diagonal expectation and then only
+       reads), [2] = the contraction kernel of split evaluations (reads the diagonal table once, forms the amplitudes
+       from two small tables).  bytes = algorithmic state bytes at the pass's own price (16 * 2^n per state and
+       direction it has to move; the contraction is priced as the read-only fused pass it replaces), moved = what it
+       really moves (compact tables; for [2] the diagonal table and the side tables), flops = 24 per amplitude pair a
+       pass updates (4 multiplications + 10 fused multiply-adds), for [2] 8 J + 5 per amplitude (J product terms). */
+    uint64_t kernel_launches[3];
+    double kernel_ms[3];
+    uint64_t kernel_bytes[3];
+    uint64_t kernel_moved_bytes[3];
+    double kernel_flops[3];
+    uint64_t kernel_states[3]; /* states swept, summed over launches */
 } qsv_profile;
 
 /* ---- lifetime ---------------------------------------------------------------------------------- */
@@ -211,6 +214,18 @@ int qsv_bench_ops(qsv_t* h, int n_ops, const qsv_op* ops, int reps, double* out_
  */
 int qsv_plan_build(int n_qubits, int dtype, int n_ops, const qsv_op* ops, const qsv_plan_config* cfg,
                    uint32_t* out_words, size_t capacity_words, size_t* n_words);
+
+/*
+ * How the scheduler would split a circuit into two virtual circuits (csrc/split.hpp), without touching any device.
+ * Returns the number of cut keys K (>= 0), or -1 when the circuit keeps its ordinary plan; an argument error is
+ * QSV_E_ARG - 100.  mask_a receives the qubits of side A (the rest is side B).  The virtual circuits come back as op
+ * lists on popcount(side) + K qubits (side qubits in ascending order, then the keys): kind QSV_OP_U / QSV_OP_CU3,
+ * angles as in the input, except that p_theta = -2 / -3 / -4 stands for the fixed matrix diag(1, 0) / [[1,0],[1,0]] / X.
+ * The final states a_kappa, b_kappa of the two circuits give  psi[i] = sum_kappa a[kappa, i|A] * b[kappa, i|B].
+ * Used by the CPU-side tests.
+ */
+int qsv_split_describe(int n_qubits, int n_ops, const qsv_op* ops, int max_side, uint64_t* mask_a, qsv_op* ops_a,
+                       int capacity_a, int* n_ops_a, qsv_op* ops_b, int capacity_b, int* n_ops_b);
 
 /* Library version string. */
 const char* qsv_version(void);

@@ -52,12 +52,12 @@ class QsvProfile(C.Structure):
         ("total_ms", C.c_double),
         ("pass_window_ms", C.c_double),
         ("moved_bytes", C.c_uint64),
-        ("kernel_launches", C.c_uint64 * 2),
-        ("kernel_ms", C.c_double * 2),
-        ("kernel_bytes", C.c_uint64 * 2),
-        ("kernel_moved_bytes", C.c_uint64 * 2),
-        ("kernel_flops", C.c_double * 2),
-        ("kernel_states", C.c_uint64 * 2),
+        ("kernel_launches", C.c_uint64 * 3),
+        ("kernel_ms", C.c_double * 3),
+        ("kernel_bytes", C.c_uint64 * 3),
+        ("kernel_moved_bytes", C.c_uint64 * 3),
+        ("kernel_flops", C.c_double * 3),
+        ("kernel_states", C.c_uint64 * 3),
     ]
 
 
@@ -91,6 +91,10 @@ SIGNATURES = {
     "qsv_get_profile": (C.c_int, [_P, C.POINTER(QsvProfile)]),
     "qsv_bench_gate": (C.c_int, [_P, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.POINTER(C.c_double)]),
     "qsv_bench_ops": (C.c_int, [_P, C.c_int, _P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "qsv_split_describe": (
+        C.c_int,
+        [C.c_int, C.c_int, _P, C.c_int, C.POINTER(C.c_uint64), _P, C.c_int, C.POINTER(C.c_int), _P, C.c_int, C.POINTER(C.c_int)],
+    ),
     "qsv_plan_build": (
         C.c_int,
         [C.c_int, C.c_int, C.c_int, _P, C.POINTER(QsvPlanConfig), _P, C.c_size_t, C.POINTER(C.c_size_t)],

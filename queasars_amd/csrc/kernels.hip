@@ -305,7 +305,10 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, FIRST>::waves_per_si
         ev.mat_base = e[1];
         ev.state_slot = e[2];
         ev.out_index = e[3];
+        ev.flags = e[6];
     }
+    if (ev.flags & kEvalNull) return;
+    const bool side = ev.flags & kEvalSide;  // a virtual circuit of a split evaluation (split.hpp)
     cu32p cp = as_constant(plan_arena) + ev.plan_base;
     const uint32_t n_passes = cp[0];
     if (a.pass_index >= n_passes) return;
@@ -329,12 +332,14 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, FIRST>::waves_per_si
 
     constexpr bool synth = FIRST;  // the launcher picks FIRST = (pass_index == 0 && mode & kModeSynthFirst)
     const bool last = a.pass_index + 1 == n_passes;
-    const bool do_store = !last || (a.mode & kModeFinalStore);
-    const bool do_diag = last && (a.mode & kModeFinalDiag);
-    cxr* __restrict__ st0 = states + uint64_t(ev.state_slot) * a.state_stride;
+    const bool do_store = !last || (a.mode & kModeFinalStore) || side;
+    const bool do_diag = last && (a.mode & kModeFinalDiag) && !side;
     // the compact table of this state slot lives in its own buffer: pass 1 may already be storing the state while
     // other workgroups of the same launch still read the table
     cxr* __restrict__ wt0 = wtabs + uint64_t(ev.state_slot) * a.wtab_stride;
+    // (a side of a split evaluation is one tile: its state goes to the side's half of the slot's table)
+    cxr* __restrict__ st0 = side ? wt0 + ((ev.flags & kEvalSideB) ? a.wtab_stride >> 1 : 0)
+                                 : states + uint64_t(ev.state_slot) * a.state_stride;
     // Global offsets inside a state are XORs of plan columns.  While a state's byte size fits 32 bits (n <= 28 in
     // fp64) they are kept as BYTE offsets in one 32-bit register per element next to a uniform tile pointer (one
     // v_xor per access, scalar-base addressing); larger states take the 64-bit path.
@@ -880,16 +885,39 @@ __device__ __forceinline__ void u_matrix(const Angles& a, double* m) {
     m[6] = cpl * c;  m[7] = spl * c;
 }
 
+// One angle-table entry -> matrix.  Entries with p_theta below -1 are the fixed matrices of split.hpp's virtual circuits.
+__device__ __forceinline__ void entry_matrix(const uint32_t* __restrict__ e, const double* __restrict__ params, double* m) {
+    const int32_t code = int32_t(e[0]);
+    if (code >= -1) {
+        u_matrix(read_angles(e, params), m);
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) m[i] = 0.0;
+    if (code == -2) {         // projector on |0>
+        m[0] = 1.0;
+    } else if (code == -3) {  // |0> -> |0> + |1>
+        m[0] = 1.0;
+        m[4] = 1.0;
+    } else {                  // X
+        m[2] = 1.0;
+        m[4] = 1.0;
+    }
+}
+
 // `host_evals` and `params` point into PINNED HOST memory: the kernel fetches the few hundred bytes an evaluation
 // needs over PCIe itself and leaves a device copy of the descriptor for the pass kernels.  Separate H2D copies in
 // front of it cost two more dependent stream operations (~50 us before the first pass of a step could start).
 __global__ void __launch_bounds__(256) prepare_kernel(const uint32_t* __restrict__ plan,
                                                       const EvalDesc* __restrict__ host_evals,
                                                       EvalDesc* __restrict__ evals,
-                                                      const double* __restrict__ params, double* __restrict__ mats) {
+                                                      const double* __restrict__ params, double* __restrict__ mats,
+                                                      uint32_t region_stride) {
     __shared__ double sv[4 * 32];  // initial factors (v0, v1) of every qubit, n <= 32
-    const EvalDesc ev = host_evals[blockIdx.x];
-    if (threadIdx.x == 0) evals[blockIdx.x] = ev;
+    const size_t slot = size_t(blockIdx.x) + size_t(blockIdx.y) * region_stride;
+    const EvalDesc ev = host_evals[slot];
+    if (threadIdx.x == 0) evals[slot] = ev;
+    if (ev.flags & kEvalNull) return;
     const uint32_t* __restrict__ cp = plan + ev.plan_base;
     const uint32_t n_passes = cp[0], n_real = cp[1], n_qubits = cp[2];
     const uint32_t* __restrict__ table = cp + cp[3];
@@ -898,7 +926,7 @@ __global__ void __launch_bounds__(256) prepare_kernel(const uint32_t* __restrict
     double* __restrict__ out = mats + ev.mat_base;
     for (uint32_t j = threadIdx.x; j < n_real; j += blockDim.x) {
         double m[8];
-        u_matrix(read_angles(table + size_t(j) * kAngleEntryWords, p), m);
+        entry_matrix(table + size_t(j) * kAngleEntryWords, p, m);
 #pragma unroll
         for (int i = 0; i < 8; ++i) out[size_t(j) * 8 + i] = m[i];
     }
@@ -907,7 +935,7 @@ __global__ void __launch_bounds__(256) prepare_kernel(const uint32_t* __restrict
         double v0r = 1.0, v0i = 0.0, v1r = 0.0, v1i = 0.0;
         for (uint32_t i = 0; i < count; ++i) {
             double m[8];
-            u_matrix(read_angles(table + size_t(first + i) * kAngleEntryWords, p), m);
+            entry_matrix(table + size_t(first + i) * kAngleEntryWords, p, m);
             const double a0r = v0r, a0i = v0i, a1r = v1r, a1i = v1i;
             v0r = m[0] * a0r - m[1] * a0i + m[2] * a1r - m[3] * a1i;
             v0i = m[0] * a0i + m[1] * a0r + m[2] * a1i + m[3] * a1r;
@@ -1002,8 +1030,193 @@ __global__ void __launch_bounds__(256) prepare_kernel(const uint32_t* __restrict
 }
 
 hipError_t launch_prepare(const uint32_t* plan, const EvalDesc* host_evals, EvalDesc* evals, const double* params,
-                          double* mats, int n_evals, hipStream_t stream) {
-    hipLaunchKernelGGL(prepare_kernel, dim3(n_evals), dim3(256), 0, stream, plan, host_evals, evals, params, mats);
+                          double* mats, int n_evals, hipStream_t stream, int n_regions, uint32_t region_stride) {
+    hipLaunchKernelGGL(prepare_kernel, dim3(n_evals, n_regions), dim3(256), 0, stream, plan, host_evals, evals, params,
+                       mats, region_stride);
+    return hipGetLastError();
+}
+
+// ---- split evaluations: contraction of the two side tables with the diagonal operator ---------------------------
+// psi[i] = sum_j X_j[x(i)] * Y_j[y(i)]: a rank-J outer product.  A thread owns 32 amplitudes: LX index bits of side X
+// times 5 - LX bits of side Y (LX = 2 where the circuit's partition allows it, see the split block), so it loads
+// 2^LX * J values of X, 2^(5-LX) * J of Y and 32 of D -- independent loads, a few memory latencies per thread instead
+// of one per amplitude -- and spends 8 J + 5 flops per amplitude.  Which index bits are lanes (0 .. 5), wave-index
+// bits, a thread's own bits (together the low 11 + wave bits) and workgroup bits (the top ones) is the same for every
+// circuit; workgroup w of the 1-D grid takes part w mod 8 of D for one evaluation after the other, so every part of D
+// is read by ONE XCD, once from memory and then from its L2 (D used to be re-read from memory for every evaluation).
+// Partial sums as in the pass kernel's fused last pass.
+template <typename real, int J, int LX, int YB>
+__device__ __forceinline__ double contract_block(const unsigned char* __restrict__ bx, const unsigned char* __restrict__ by,
+                                                 const unsigned char* __restrict__ bd, uint32_t ix, uint32_t iy, uint32_t i0,
+                                                 uint32_t bits_x, uint32_t bits_y, const uint32_t (&col)[kSplitLoopBits],
+                                                 const uint32_t (&pos)[kSplitLoopBits]) {
+    // every offset is a 32-bit BYTE offset from a uniform base (tables and D are far below 4 GiB: n <= 28): one VGPR per
+    // address and scalar-base loads; with 64-bit addresses the kernel needed 204 VGPRs and ran two waves per SIMD
+    constexpr int LY = kSplitLoopBits - LX, NX = 1 << LX, NY = 1 << LY;
+    constexpr int ASH = Log2Size<real>::value + 1;
+    double xr[NX][J], xi[NX][J];
+#pragma unroll
+    for (int a = 0; a < NX; ++a) {
+        uint32_t idx = ix;
+#pragma unroll
+        for (int b = 0; b < LX; ++b)
+            if (a >> b & 1) idx ^= col[b];
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const cx<real> v = *reinterpret_cast<const cx<real>*>(bx + (((uint32_t(j) << bits_x) + idx) << ASH));
+            xr[a][j] = double(v.re);
+            xi[a][j] = double(v.im);
+        }
+    }
+    double acc = 0.0;
+    // one chunk of YB values of y per trip, NOT unrolled: hoisted to the top, the loads of every chunk (32 + 12 J per
+    // thread) cost 200+ VGPRs -- two waves per SIMD, or spills under a register cap
+#pragma nounroll
+    for (int y0 = 0; y0 < NY; y0 += YB) {
+        double yr[YB][J], yi[YB][J], d[YB][NX];
+#pragma unroll
+        for (int c = 0; c < YB; ++c) {
+            uint32_t sy = 0, si = 0;  // (uniform: the chunk's part of the offsets)
+#pragma unroll
+            for (int b = 0; b < LY; ++b)
+                if ((y0 + c) >> b & 1) {
+                    sy ^= col[LX + b];
+                    si ^= pos[LX + b];
+                }
+            const uint32_t idx = iy ^ sy, i = i0 ^ si;
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                const cx<real> v = *reinterpret_cast<const cx<real>*>(by + (((uint32_t(j) << bits_y) + idx) << ASH));
+                yr[c][j] = double(v.re);
+                yi[c][j] = double(v.im);
+            }
+#pragma unroll
+            for (int a = 0; a < NX; ++a) {
+                uint32_t ia = i;
+#pragma unroll
+                for (int b = 0; b < LX; ++b)
+                    if (a >> b & 1) ia ^= pos[b];
+                d[c][a] = *reinterpret_cast<const double*>(bd + (ia << 3));
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < YB; ++c)
+#pragma unroll
+            for (int a = 0; a < NX; ++a) {
+                double pr = xr[a][0] * yr[c][0], pi = xr[a][0] * yi[c][0];
+                pr = fma(-xi[a][0], yi[c][0], pr);
+                pi = fma(xi[a][0], yr[c][0], pi);
+#pragma unroll
+                for (int j = 1; j < J; ++j) {
+                    pr = fma(xr[a][j], yr[c][j], fma(-xi[a][j], yi[c][j], pr));
+                    pi = fma(xr[a][j], yi[c][j], fma(xi[a][j], yr[c][j], pi));
+                }
+                acc = fma(fma(pr, pr, pi * pi), d[c][a], acc);
+            }
+    }
+    return acc;
+}
+
+template <typename real, int J>
+__device__ __forceinline__ double contract_by_shape(uint32_t lx, const unsigned char* bx, const unsigned char* by,
+                                                    const unsigned char* bd, uint32_t ix, uint32_t iy, uint32_t i0,
+                                                    uint32_t bits_x, uint32_t bits_y, const uint32_t (&col)[kSplitLoopBits],
+                                                    const uint32_t (&pos)[kSplitLoopBits]) {
+    if (lx == 2) return contract_block<real, J, 2, 4 / J>(bx, by, bd, ix, iy, i0, bits_x, bits_y, col, pos);
+    if (lx == 1) return contract_block<real, J, 1, 8 / J>(bx, by, bd, ix, iy, i0, bits_x, bits_y, col, pos);
+    return contract_block<real, J, 0, 8 / J>(bx, by, bd, ix, iy, i0, bits_x, bits_y, col, pos);
+}
+
+template <typename real>
+__global__ void __launch_bounds__(512, 4) contract_kernel(const uint32_t* __restrict__ plan_arena,
+                                                          const EvalDesc* __restrict__ evals,
+                                                          const cx<real>* __restrict__ wtabs, const double* __restrict__ diag,
+                                                          double* __restrict__ partials, uint64_t wtab_stride,
+                                                          uint32_t n_qubits, uint32_t partial_chunks, uint32_t n_chunks,
+                                                          uint32_t n_evals) {
+    // workgroup -> (evaluation, chunk of the index space): consecutive workgroups go to consecutive XCDs, so chunk c is
+    // handled by XCD c mod 8 for every evaluation (when there are at least 8 chunks)
+    uint32_t chunk, which;
+    if ((n_chunks & 7u) == 0) {
+        const uint32_t xcd = blockIdx.x & 7u, rest = blockIdx.x >> 3;
+        which = rest % n_evals;
+        chunk = (rest / n_evals) * 8u + xcd;
+    } else {
+        which = blockIdx.x % n_evals;
+        chunk = blockIdx.x / n_evals;
+    }
+    EvalDesc ev;
+    {
+        cu32p e = as_constant(reinterpret_cast<const uint32_t*>(evals + which));
+        ev.state_slot = e[2];
+        ev.out_index = e[3];
+        ev.flags = e[6];
+        ev.split_base = e[7];
+    }
+    if (!(ev.flags & kEvalSide)) return;
+    cu32p sp = as_constant(plan_arena) + ev.split_base;
+    const uint32_t n_keys = sp[0];
+    const bool swap = sp[3] & 1u;
+    const uint32_t lx = sp[3] >> 8;
+    const uint32_t bits_x = sp[swap ? 2 : 1], bits_y = sp[swap ? 1 : 2];
+    cu32p colx = sp + (swap ? kSplitColsB : kSplitColsA), coly = sp + (swap ? kSplitColsA : kSplitColsB);
+    cu32p order = sp + kSplitOrder;
+    const cx<real>* __restrict__ ta = wtabs + uint64_t(ev.state_slot) * wtab_stride;
+    const unsigned char* bx = reinterpret_cast<const unsigned char*>(ta + (swap ? wtab_stride >> 1 : 0));
+    const unsigned char* by = reinterpret_cast<const unsigned char*>(ta + (swap ? 0 : wtab_stride >> 1));
+    const unsigned char* bd = reinterpret_cast<const unsigned char*>(diag);
+    const uint32_t tid = threadIdx.x;
+    const uint32_t wave_bits = 25u - uint32_t(__builtin_clz(blockDim.x));  // log2(blockDim / 64)
+    // the index this thread's block starts at: lanes, wave-index bits, then the chunk number spread over its bits
+    uint32_t i0 = tid & 63u;
+    for (uint32_t b = 0; b < wave_bits; ++b) i0 |= ((tid >> (6 + b)) & 1u) << order[6 + b];
+    const uint32_t first_chunk_bit = 6 + wave_bits + kSplitLoopBits;
+    for (uint32_t b = 0; first_chunk_bit + b < n_qubits; ++b) i0 |= ((chunk >> b) & 1u) << order[first_chunk_bit + b];
+    uint32_t ix = 0, iy = 0;
+    for (uint32_t p = 0; p < n_qubits; ++p)
+        if ((i0 >> p) & 1u) {
+            ix |= colx[p];
+            iy |= coly[p];
+        }
+    uint32_t col[kSplitLoopBits], pos[kSplitLoopBits];  // the thread's own bits: first LX of side X, then those of side Y
+#pragma unroll
+    for (int b = 0; b < kSplitLoopBits; ++b) {
+        const uint32_t p = order[6 + wave_bits + b];
+        pos[b] = 1u << p;
+        col[b] = uint32_t(b) < lx ? colx[p] : coly[p];
+    }
+    double acc;
+    if (n_keys == 0)
+        acc = contract_by_shape<real, 1>(lx, bx, by, bd, ix, iy, i0, bits_x, bits_y, col, pos);
+    else if (n_keys == 1)
+        acc = contract_by_shape<real, 2>(lx, bx, by, bd, ix, iy, i0, bits_x, bits_y, col, pos);
+    else
+        acc = contract_by_shape<real, 4>(lx, bx, by, bd, ix, iy, i0, bits_x, bits_y, col, pos);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    const uint32_t n_waves = blockDim.x >> 6, wave = tid >> 6;
+    const uint32_t slots = partial_chunks ? partial_chunks : n_chunks;
+    if ((tid & 63u) == 0) {
+        double* mine = partials + size_t(ev.out_index) * slots * n_waves + wave;
+        mine[size_t(chunk) * n_waves] = acc;
+        for (uint32_t b2 = chunk + n_chunks; b2 < slots; b2 += n_chunks) mine[size_t(b2) * n_waves] = 0.0;
+    }
+}
+
+hipError_t launch_contract(int dtype, unsigned n_chunks, unsigned n_evals, int threads, hipStream_t stream, const PassArgs& a) {
+    const uint32_t n = uint32_t(63 - __builtin_clzll(a.state_stride));
+    if (threads < 64 || threads > 512 || (threads & (threads - 1))) return hipErrorInvalidValue;
+    // every index once: n_chunks workgroups x threads x the 32 amplitudes of a thread's block
+    if (uint64_t(n_chunks) * uint64_t(threads) << kSplitLoopBits != uint64_t(1) << n || n > 28) return hipErrorInvalidValue;
+    const dim3 grid(n_chunks * n_evals);
+    if (dtype == 0)
+        hipLaunchKernelGGL(contract_kernel<double>, grid, dim3(threads), 0, stream, a.plan, a.evals,
+                           static_cast<const cx<double>*>(a.wtab), a.diag, a.partials, a.wtab_stride, n, a.partial_chunks,
+                           n_chunks, n_evals);
+    else
+        hipLaunchKernelGGL(contract_kernel<float>, grid, dim3(threads), 0, stream, a.plan, a.evals,
+                           static_cast<const cx<float>*>(a.wtab), a.diag, a.partials, a.wtab_stride, n, a.partial_chunks,
+                           n_chunks, n_evals);
     return hipGetLastError();
 }
 

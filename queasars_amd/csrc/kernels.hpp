@@ -15,8 +15,24 @@ struct EvalDesc {
     uint32_t out_index;   // row of `partials` / entry of the result vector
     uint32_t param_base;  // offset (in doubles) of this evaluation's parameter vector in the parameter buffer
     uint32_t n_params;
-    uint32_t reserved0, reserved1;
+    uint32_t flags;       // kEval* below
+    uint32_t split_base;  // word offset (plan arena) of the split block (kEvalSide descriptors, see split.hpp)
 };
+// A split evaluation (split.hpp) has TWO descriptors, one per virtual circuit: side A where an ordinary evaluation has
+// its own (region 0), side B in a second region of the descriptor array, which holds kEvalNull entries for everybody
+// else.  A side's pass kernel stores its final state in the side's half of the evaluation's compact-table slot.
+constexpr uint32_t kEvalSide = 1u, kEvalSideB = 2u, kEvalNull = 4u;
+// split block: [0] number of keys K  [1] qubits of side A  [2] of side B
+//              [3] bit 0: the contraction's X side is B (else A); bits 8..: LX, how many of a thread's own index bits
+//                  belong to side X (0 .. 2)
+//              [4 .. 36)  index bit p of the full register -> its bit in side A's table index (0 if p is not in A)
+//              [36 .. 68) the same for side B
+//              [68 .. 100) the contraction's use of the index bits, as positions: 6 lane bits (0 .. 5), the wave-index
+//                         bits of a workgroup, LX bits of side X and kSplitLoopBits - LX bits of side Y that every
+//                         thread walks itself -- all of these among the lowest 11 + wave bits, whatever the circuit --
+//                         then the bits numbered by the workgroup index (the top ones, ascending), pad 63
+constexpr uint32_t kSplitBlockWords = 100, kSplitColsA = 4, kSplitColsB = 36, kSplitOrder = 68;
+constexpr int kSplitLoopBits = 5, kSplitMaxLoopX = 2;
 
 enum PassMode : uint32_t {
     kModeSynthFirst = 1u,  // pass 0 synthesises |0..0> instead of reading the state
@@ -72,8 +88,15 @@ inline __host__ __device__ size_t tile_info_offset(uint32_t n_real, uint32_t n_q
 
 // Angles -> gate matrices, initial product-state factors and synthesis tables, one workgroup per evaluation.
 // host_evals / params are pinned host memory read by the kernel; evals receives the device copy of the descriptors.
+// n_regions = 2: also descriptors [region_stride + i] (the second descriptors of split evaluations).
 hipError_t launch_prepare(const uint32_t* plan, const EvalDesc* host_evals, EvalDesc* evals, const double* params,
-                          double* mats, int n_evals, hipStream_t stream);
+                          double* mats, int n_evals, hipStream_t stream, int n_regions = 1, uint32_t region_stride = 0);
+
+// Split evaluations (split.hpp): <psi|D|psi> with psi[i] = sum_kappa A_kappa[a(i)] B_kappa[b(i)] formed on the fly from
+// the two side tables; grid and partial-sum layout as the pass kernel's fused last pass (PassArgs: plan, evals, wtab,
+// wtab_stride, diag, partials, partial_chunks; state_stride = 2^n).  Descriptors without kEvalSide return at once.
+// n_chunks workgroups per evaluation (n_chunks * threads * 32 = 2^n), n_evals evaluations.
+hipError_t launch_contract(int dtype, unsigned n_chunks, unsigned n_evals, int threads, hipStream_t stream, const PassArgs& args);
 
 // dtype: 0 = fp64, 1 = fp32.  r = register bits (1..4).  xmode = LDS exchange mode (see kernels.hip).
 // Returns hipSuccess or the launch error.

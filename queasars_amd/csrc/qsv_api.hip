@@ -19,6 +19,7 @@
 #include "../../include/qsv.h"
 #include "kernels.hpp"
 #include "plan.hpp"
+#include "split.hpp"
 
 using namespace qsv;
 
@@ -32,10 +33,23 @@ thread_local std::string g_create_error;
 thread_local std::string g_handle_error;
 thread_local const void* g_handle_error_owner = nullptr;
 
+// A circuit the scheduler could split (split.hpp): the plans of the two virtual circuits and the contraction's index
+// maps follow the ordinary plan in `plan.words` (offsets relative to it, like everything in a plan).
+struct SplitInfo {
+    bool ok = false;
+    int n_keys = 0;
+    PlanStats stats[2];
+    int t[2] = {0, 0};              // thread bits of the two one-tile plans
+    int n_virtual[2] = {0, 0};      // qubits of the virtual circuits
+    uint32_t off_side[2] = {0, 0};  // word offsets of the side plans
+    uint32_t off_block = 0;         // ... and of the split block (kernels.hpp)
+};
+
 struct Circuit {
     int n_params = 0;
     int n_gates = 0;                // non-identity ops
     CircuitPlan plan;
+    SplitInfo split;
     bool uploaded = false;
     bool staged = false;            // scratch flag of upload_plans (a circuit may appear several times in a batch)
     uint32_t plan_base = 0;         // word offset in the device arena
@@ -129,6 +143,7 @@ struct qsv_handle {
     hipStream_t work = nullptr;  // stream of the push being issued (null: `stream`)
     hipEvent_t ev_join = nullptr;
     int n_streams = 2;           // streams a batch cycles over (QSV_STREAMS, 1 .. 4)
+    bool split_enabled = true;   // weakly entangled circuits run as two virtual circuits + a contraction (split.hpp)
     mutable std::mutex mu;
     std::atomic<std::thread::id> batch_owner{};  // thread that holds `mu` between qsv_eval_begin and qsv_eval_end
 
@@ -194,8 +209,10 @@ struct qsv_handle {
         size_t desc_bytes = 0;
         size_t pushed = 0;                 // evaluations launched so far
         std::vector<std::pair<hipEvent_t, hipEvent_t>> pass_events, exp_events;
-        std::vector<std::pair<hipEvent_t, hipEvent_t>> launch_events[2];  // per launch: [0] first pass, [1] later passes
+        std::vector<std::pair<hipEvent_t, hipEvent_t>> launch_events[3];  // per launch: [0] first pass, [1] later passes, [2] contraction
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        bool split_any = false; // some evaluation of the batch runs split: the descriptor array has a second region
+        std::vector<char> split;  // per evaluation
         int ways = 1;           // streams this batch cycles over
         unsigned used_mask = 0; // side streams (bit i = side_streams[i]) with work of this batch in flight
         size_t n_pushes = 0;
@@ -262,7 +279,8 @@ int validate_ops(qsv_t* h, int n, int n_ops, const qsv_op* ops, int n_params) {
             return fail(h, QSV_E_ARG, "bad control qubit at op " + std::to_string(i));
         if (o.kind != QSV_OP_ID)
             for (int32_t p : {o.p_theta, o.p_phi, o.p_lambda})
-                if (p >= n_params) return fail(h, QSV_E_ARG, "parameter index out of range at op " + std::to_string(i));
+                if (p >= n_params || p < -1)  // (below -1: the scheduler's own fixed matrices, split.hpp)
+                    return fail(h, QSV_E_ARG, "parameter index out of range at op " + std::to_string(i));
     }
     return QSV_OK;
 }
@@ -334,6 +352,95 @@ int build_circuit(qsv_t* h, int n_ops, const qsv_op* ops, int n_params, bool fol
         PlanConfig pc = h->cfg;
         pc.fold = pc.fold && fold;
         out->plan = build_plan(h->n, gates, angles, pc);
+        if (h->split_enabled && pc.fold && h->n > h->geo.k) {
+            const SplitCircuits sc = find_split(h->n, gates, angles, h->geo.k);
+            if (sc.ok) {
+                SplitInfo& sp = out->split;
+                std::vector<uint32_t>& w = out->plan.words;
+                bool fits = true;
+                for (int s = 0; s < 2 && fits; ++s) {
+                    PlanConfig side = pc;
+                    sp.n_virtual[s] = sc.n_side[s] + sc.n_keys;
+                    side.tile_bits = sp.n_virtual[s];  // one tile
+                    side.reg_bits = h->geo.r;
+                    fits = sp.n_virtual[s] > side.reg_bits;
+                    if (!fits) break;
+                    const CircuitPlan p = build_plan(sp.n_virtual[s], sc.gates[s], sc.angles[s], side);
+                    fits = p.stats.n_passes == 1;
+                    sp.stats[s] = p.stats;
+                    sp.t[s] = sp.n_virtual[s] - side.reg_bits;
+                    sp.off_side[s] = uint32_t(w.size());
+                    w.insert(w.end(), p.words.begin(), p.words.end());
+                }
+                // the contraction kernel's use of the index bits (kernels.hpp, split block): 6 lanes, the wave-index bits of
+                // a workgroup, 2 bits of one side and 3 of the other for each thread's own block, the rest for the grid
+                const int wave_bits = h->geo.t > 6 ? h->geo.t - 6 : 0;
+                std::vector<uint32_t> order;
+                bool swap_xy = false;
+                int loop_x = 0;
+                const int middle_end = 6 + wave_bits + kSplitLoopBits;  // lanes, wave bits and a thread's own bits: [0, end)
+                fits = fits && h->n >= middle_end;
+                if (fits) {
+                    // of a thread's five own bits as many as possible (up to 2) come from one side, the rest from the other
+                    auto middle_bits = [&](int side) {
+                        return __builtin_popcountll((sc.mask[side] >> 6) & ((uint64_t(1) << (middle_end - 6)) - 1));
+                    };
+                    bool found = false;
+                    for (int lx = kSplitMaxLoopX; lx >= 0 && !found; --lx)
+                        for (int sx = 0; sx < 2 && !found; ++sx)
+                            if (middle_bits(sx) >= lx && middle_bits(1 - sx) >= kSplitLoopBits - lx) {
+                                found = true;
+                                loop_x = lx;
+                                swap_xy = sx == 1;
+                            }
+                    fits = found;
+                }
+                if (fits) {
+                    std::vector<char> used(size_t(h->n), 0);
+                    for (int p = 0; p < 6; ++p) {
+                        order.push_back(uint32_t(p));
+                        used[size_t(p)] = 1;
+                    }
+                    std::vector<uint32_t> loops;
+                    const int sx = swap_xy ? 1 : 0;
+                    for (int which = 0; which < 2; ++which) {
+                        const int side = which == 0 ? sx : 1 - sx, want = which == 0 ? loop_x : kSplitLoopBits - loop_x;
+                        for (int p = 6, got = 0; p < middle_end && got < want; ++p)
+                            if (sc.mask[side] >> p & 1u) {
+                                loops.push_back(uint32_t(p));
+                                used[size_t(p)] = 1;
+                                ++got;
+                            }
+                    }
+                    for (int p = 6; p < middle_end; ++p)
+                        if (!used[size_t(p)]) order.push_back(uint32_t(p));  // the wave-index bits
+                    order.insert(order.end(), loops.begin(), loops.end());
+                    for (int p = middle_end; p < h->n; ++p) order.push_back(uint32_t(p));
+                }
+                if (fits) {
+                    sp.off_block = uint32_t(w.size());
+                    w.resize(w.size() + kSplitBlockWords, 0);
+                    uint32_t* blk = w.data() + sp.off_block;
+                    blk[0] = uint32_t(sc.n_keys);
+                    blk[1] = uint32_t(sc.n_side[0]);
+                    blk[2] = uint32_t(sc.n_side[1]);
+                    blk[3] = (swap_xy ? 1u : 0u) | uint32_t(loop_x) << 8;
+                    int ca = 0, cb = 0;
+                    for (int q = 0; q < h->n; ++q) {
+                        if (sc.mask[0] >> q & 1u)
+                            blk[kSplitColsA + q] = 1u << ca++;
+                        else
+                            blk[kSplitColsB + q] = 1u << cb++;
+                    }
+                    for (uint32_t j = 0; j < 32; ++j) blk[kSplitOrder + j] = j < order.size() ? order[j] : 63u;
+                    sp.n_keys = sc.n_keys;
+                    sp.ok = true;
+                } else {
+                    w.resize(sp.off_side[0] ? sp.off_side[0] : w.size());
+                    sp = SplitInfo{};
+                }
+            }
+        }
     } catch (const std::exception& e) {
         if (err) *err = std::string("plan: ") + e.what();
         return QSV_E_ARG;
@@ -491,23 +598,37 @@ struct EventPair {
 // group-aligned slices: each push ships that slice's parameter values, turns them into matrices on the device and
 // launches the slice's gate passes, all asynchronously, so the host can prepare the next slice meanwhile.
 
-int batch_layout(qsv_t* h, const std::vector<Circuit*>& circs, const std::vector<int64_t>& n_params) {
+// doubles of an evaluation's matrix region(s): one for the ordinary plan, or one per virtual circuit when it runs split
+size_t mat_doubles_of(const qsv_t* h, const Circuit& c, bool split, int side) {
+    if (!split)
+        return mat_region_doubles(uint32_t(c.plan.stats.n_real_gates), uint32_t(h->n), h->geo.t, h->n - h->geo.k,
+                                  c.plan.stats.n_passes);
+    return mat_region_doubles(uint32_t(c.split.stats[side].n_real_gates), uint32_t(c.split.n_virtual[side]), c.split.t[side], 0, 1);
+}
+
+// allow_split: the caller only wants <D> of the final states (fused diagonal expectation), so a circuit that has a
+// split form (split.hpp) may run as its two virtual circuits + the contraction kernel.
+int batch_layout(qsv_t* h, const std::vector<Circuit*>& circs, const std::vector<int64_t>& n_params, bool allow_split = false) {
     qsv_handle::Batch& b = h->batch;
     const size_t n_evals = circs.size();
     int rc;
     if ((rc = upload_plans(h, circs))) return rc;
     size_t total_params = 0, total_mats = 0;
+    b.split.assign(n_evals, 0);
+    b.split_any = false;
     for (size_t i = 0; i < n_evals; ++i) {
         if (n_params[i] < circs[i]->n_params)
             return fail(h, QSV_E_ARG, "circuit needs " + std::to_string(circs[i]->n_params) + " parameter values, got " +
                                           std::to_string(n_params[i]));
         total_params += size_t(n_params[i]);
-        total_mats += mat_region_doubles(uint32_t(circs[i]->plan.stats.n_real_gates), uint32_t(h->n), h->geo.t, h->n - h->geo.k,
-                                         circs[i]->plan.stats.n_passes);
+        const bool split = allow_split && circs[i]->split.ok;
+        b.split[i] = split;
+        b.split_any |= split;
+        total_mats += mat_doubles_of(h, *circs[i], split, 0) + (split ? mat_doubles_of(h, *circs[i], true, 1) : 0);
     }
     if (total_params >= (size_t(1) << 31) || total_mats >= (size_t(1) << 31))
         return fail(h, QSV_E_ARG, "batch too large");
-    b.desc_bytes = ((sizeof(EvalDesc) * n_evals + 63) / 64) * 64;
+    b.desc_bytes = ((sizeof(EvalDesc) * n_evals * (b.split_any ? 2 : 1) + 63) / 64) * 64;
     const size_t bytes = b.desc_bytes + (total_params + 1) * sizeof(double);
     if ((rc = ensure_host_batch(h, bytes))) return rc;
     if ((rc = ensure(h, h->d_batch, bytes))) return rc;
@@ -519,12 +640,23 @@ int batch_layout(qsv_t* h, const std::vector<Circuit*>& circs, const std::vector
     size_t pcur = 0, mcur = 0;
     for (size_t i = 0; i < n_evals; ++i) {
         const Circuit& c = *circs[i];
-        hd[i] = EvalDesc{c.plan_base, uint32_t(mcur), uint32_t(i % size_t(h->group)), uint32_t(i), uint32_t(pcur),
-                         uint32_t(n_params[i]), 0, 0};
+        const uint32_t slot = uint32_t(i % size_t(h->group));
+        if (!b.split[i]) {
+            hd[i] = EvalDesc{c.plan_base, uint32_t(mcur), slot, uint32_t(i), uint32_t(pcur), uint32_t(n_params[i]), 0, 0};
+            mcur += mat_doubles_of(h, c, false, 0);
+            if (b.split_any) hd[n_evals + i] = EvalDesc{0, 0, slot, uint32_t(i), 0, 0, kEvalNull, 0};
+        } else {
+            // one descriptor per virtual circuit: side A here, side B in the second region
+            for (int s = 0; s < 2; ++s) {
+                hd[size_t(s) * n_evals + i] =
+                    EvalDesc{c.plan_base + c.split.off_side[s], uint32_t(mcur), slot, uint32_t(i), uint32_t(pcur),
+                             uint32_t(n_params[i]), kEvalSide | (s ? kEvalSideB : 0u), c.plan_base + c.split.off_block};
+                mcur += mat_doubles_of(h, c, true, s);
+            }
+        }
         b.param_base[i] = uint32_t(pcur);
         b.n_params[i] = uint32_t(n_params[i]);
         pcur += size_t(n_params[i]);
-        mcur += mat_region_doubles(uint32_t(c.plan.stats.n_real_gates), uint32_t(h->n), h->geo.t, h->n - h->geo.k, c.plan.stats.n_passes);
         h->prof.n_gates += uint64_t(c.n_gates);
     }
     // (no copy here: prepare_kernel reads descriptors and parameters from this pinned buffer and writes the device
@@ -547,7 +679,7 @@ int batch_ship(qsv_t* h, size_t first, size_t count, const double* values) {
     const EvalDesc* host_evals = static_cast<const EvalDesc*>(h->h_batch);
     QSV_HIP(h, launch_prepare(static_cast<const uint32_t*>(h->d_arena.ptr), host_evals + first,
                               static_cast<EvalDesc*>(h->d_batch.ptr) + first, hp, static_cast<double*>(h->d_mats.ptr),
-                              int(count), ws(h)));
+                              int(count), ws(h), b.split_any ? 2 : 1, uint32_t(b.circs.size())));
     return QSV_OK;
 }
 
@@ -575,8 +707,15 @@ hipError_t stamp(qsv_t* h, std::vector<std::pair<hipEvent_t, hipEvent_t>>& list,
 
 // Run the gate passes of evaluations [first, first+count) of the current batch (one launch group).
 int run_group(qsv_t* h, const std::vector<Circuit*>& circs, size_t first, size_t count, uint32_t mode) {
+    const qsv_handle::Batch& b = h->batch;
+    const bool batch_split = b.split_any && b.split.size() == circs.size();
     int max_passes = 0;
-    for (size_t i = 0; i < count; ++i) max_passes = std::max(max_passes, circs[first + i]->plan.stats.n_passes);
+    bool any_split = false;
+    for (size_t i = 0; i < count; ++i) {
+        const bool split = batch_split && b.split[first + i];
+        any_split |= split;
+        max_passes = std::max(max_passes, split ? 1 : circs[first + i]->plan.stats.n_passes);
+    }
     PassArgs a{};
     a.plan = static_cast<const uint32_t*>(h->d_arena.ptr);
     a.mats = static_cast<const double*>(h->d_mats.ptr);
@@ -613,6 +752,7 @@ int run_group(qsv_t* h, const std::vector<Circuit*>& circs, size_t first, size_t
         // synthesising pass 0 does not read and a fused last pass does not write.  What it really moves is less when
         // a compact pass 0 writes, and pass 1 reads, a table of 2^cb tiles instead of the state.
         for (size_t i = 0; i < count; ++i) {
+            if (batch_split && b.split[first + i]) continue;  // (accounted with the contraction below)
             const PlanStats& st = circs[first + i]->plan.stats;
             if (p >= st.n_passes) continue;
             const bool reads = !(p == 0 && (mode & kModeSynthFirst));
@@ -628,6 +768,41 @@ int run_group(qsv_t* h, const std::vector<Circuit*>& circs, size_t first, size_t
             h->prof.kernel_moved_bytes[kind] += moved;
             h->prof.kernel_states[kind] += 1;
             if (size_t(p) < st.pass_pairs.size()) h->prof.kernel_flops[kind] += 24.0 * st.pass_pairs[size_t(p)];
+        }
+    }
+    if (any_split) {
+        // side B of the split evaluations (their side A ran in the launch of pass 0 above), then the contraction
+        a.evals = batch_evals(h) + circs.size() + first;
+        a.pass_index = 0;
+        a.tiles_per_block = 1;
+        if (h->stamping) QSV_HIP(h, stamp(h, h->batch.launch_events[0], true));
+        QSV_HIP(h, launch_pass(h->dtype, h->geo.r, h->cfg.xmode, dim3(1, unsigned(count)), h->geo.threads_launch,
+                               h->geo.lds_bytes, ws(h), a));
+        if (h->stamping) QSV_HIP(h, stamp(h, h->batch.launch_events[0], false));
+        h->prof.n_pass_launches += 1;
+        h->prof.kernel_launches[0] += 1;
+        a.evals = batch_evals(h) + first;
+        if (h->stamping) QSV_HIP(h, stamp(h, h->batch.launch_events[2], true));
+        const unsigned contract_chunks = unsigned((uint64_t(1) << h->n) / (uint64_t(h->geo.threads_launch) << kSplitLoopBits));
+        QSV_HIP(h, launch_contract(h->dtype, contract_chunks, unsigned(count), h->geo.threads_launch, ws(h), a));
+        if (h->stamping) QSV_HIP(h, stamp(h, h->batch.launch_events[2], false));
+        h->prof.kernel_launches[2] += 1;
+        for (size_t i = 0; i < count; ++i) {
+            if (!b.split[first + i]) continue;
+            const SplitInfo& sp = circs[first + i]->split;
+            // the contraction reads D once (8 * 2^n bytes) and the two side tables; priced as the read-only fused pass it
+            // replaces (16 * 2^n bytes per state) in kernel_bytes, what it really touches in moved_bytes
+            h->prof.state_bytes += sweep;
+            h->prof.kernel_bytes[2] += sweep;
+            const uint64_t moved = (uint64_t(8) << h->n) + ((uint64_t(1) << sp.n_virtual[0]) + (uint64_t(1) << sp.n_virtual[1])) * h->amp_bytes;
+            h->prof.moved_bytes += moved;
+            h->prof.kernel_moved_bytes[2] += moved;
+            h->prof.kernel_states[2] += 1;
+            h->prof.kernel_flops[2] += double(uint64_t(1) << h->n) * (8.0 * double(1u << sp.n_keys) + 5.0);
+            for (int s = 0; s < 2; ++s) {
+                h->prof.kernel_states[0] += 1;
+                if (!sp.stats[s].pass_pairs.empty()) h->prof.kernel_flops[0] += 24.0 * sp.stats[s].pass_pairs[0];
+            }
         }
     }
     return QSV_OK;
@@ -647,7 +822,7 @@ int eval_begin(qsv_t* h, const std::vector<Circuit*>& circs, const std::vector<i
         QSV_HIP(h, hipEventCreate(&h->batch.ev1));
         QSV_HIP(h, hipEventRecord(h->batch.ev0, h->stream));
     }
-    if ((rc = batch_layout(h, circs, n_params))) return rc;
+    if ((rc = batch_layout(h, circs, n_params, h->diagonal))) return rc;
     qsv_handle::Batch& b = h->batch;
     // Two streams: consecutive pushes alternate between them, so that kernels of different pushes share the chip
     // (+15 % on the benchmark population).  Each stream owns one half of the state slots (eval_push assigns them),
@@ -684,6 +859,8 @@ int eval_push(qsv_t* h, size_t first, size_t count, const double* values) {
     if (b.ways > 1) {
         const size_t share = G / size_t(b.ways), side = size_t(b.n_pushes) % size_t(b.ways);
         for (size_t j = 0; j < count; ++j) hd[first + j].state_slot = uint32_t(side * share + j % share);
+        if (b.split_any)
+            for (size_t j = 0; j < count; ++j) hd[b.circs.size() + first + j].state_slot = hd[first + j].state_slot;
         G = share;
         if (side) {
             h->work = h->side_streams[side - 1];
@@ -693,6 +870,8 @@ int eval_push(qsv_t* h, size_t first, size_t count, const double* values) {
         // every launch group of this push occupies slots 0 .. count-1 in order (the expectation kernels of the
         // general-operator path index states by position in the group), wherever the push starts in the batch
         for (size_t j = 0; j < count; ++j) hd[first + j].state_slot = uint32_t(j % G);
+        if (b.split_any)
+            for (size_t j = 0; j < count; ++j) hd[b.circs.size() + first + j].state_slot = hd[first + j].state_slot;
     }
     b.n_pushes += 1;
     int rc = batch_ship(h, first, count, values);
@@ -762,7 +941,7 @@ int eval_end(qsv_t* h, double* out) {
             QSV_HIP(h, hipEventElapsedTime(&ms, p.first, p.second));
             h->prof.pass_ms += ms;
         }
-        for (int kind = 0; kind < 2; ++kind)
+        for (int kind = 0; kind < 3; ++kind)
             for (auto& p : b.launch_events[kind]) {
                 QSV_HIP(h, hipEventElapsedTime(&ms, p.first, p.second));
                 h->prof.kernel_ms[kind] += ms;
@@ -783,7 +962,7 @@ int eval_end(qsv_t* h, double* out) {
 // Releases whatever a batch holds (events) and marks it closed; safe to call on error paths.
 void eval_close(qsv_t* h) {
     qsv_handle::Batch& b = h->batch;
-    for (auto* list : {&b.pass_events, &b.exp_events, &b.launch_events[0], &b.launch_events[1]}) {
+    for (auto* list : {&b.pass_events, &b.exp_events, &b.launch_events[0], &b.launch_events[1], &b.launch_events[2]}) {
         for (auto& p : *list) {
             if (p.first) (void)hipEventDestroy(p.first);
             if (p.second) (void)hipEventDestroy(p.second);
@@ -906,6 +1085,7 @@ int qsv_create(int n_qubits, int dtype, int device, const qsv_plan_config* cfg, 
     };
     if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
     h->own_stream = true;
+    if (const char* env = getenv("QSV_SPLIT")) h->split_enabled = atoi(env) != 0;
     if (const char* env = getenv("QSV_STREAMS")) h->n_streams = std::max(1, std::min(4, atoi(env)));
     for (int i = 1; i < std::max(2, h->n_streams); ++i) {
         hipStream_t st = nullptr;
@@ -1549,6 +1729,37 @@ int qsv_bench_gate(qsv_t* h, int target, int control, double theta, double phi, 
     op.phi = phi;
     op.lambda = lambda;
     return bench_ops_locked(h, 1, &op, reps, out_ms_per_sweep, nullptr);
+}
+
+int qsv_split_describe(int n_qubits, int n_ops, const qsv_op* ops, int max_side, uint64_t* mask_a, qsv_op* ops_a,
+                       int capacity_a, int* n_ops_a, qsv_op* ops_b, int capacity_b, int* n_ops_b) {
+    if (!mask_a || !n_ops_a || !n_ops_b) return fail(nullptr, QSV_E_ARG, "null output") - 100;
+    if (n_qubits < 1 || n_qubits > 32) return fail(nullptr, QSV_E_ARG, "n_qubits must be in [1, 32]") - 100;
+    if (validate_ops(nullptr, n_qubits, n_ops, ops, 1 << 30)) return QSV_E_ARG - 100;
+    std::vector<AngleSource> angles;
+    const std::vector<GateIn> gates = gates_of(ops, n_ops, &angles);
+    const SplitCircuits sc = find_split(n_qubits, gates, angles, max_side);
+    if (!sc.ok) return -1;
+    *mask_a = sc.mask[0];
+    qsv_op* outs[2] = {ops_a, ops_b};
+    const int caps[2] = {capacity_a, capacity_b};
+    int* counts[2] = {n_ops_a, n_ops_b};
+    for (int s = 0; s < 2; ++s) {
+        *counts[s] = int(sc.gates[s].size());
+        if (!outs[s] || caps[s] < *counts[s]) continue;
+        for (size_t i = 0; i < sc.gates[s].size(); ++i) {
+            const GateIn& g = sc.gates[s][i];
+            const AngleSource& a = sc.angles[s][size_t(g.op)];
+            qsv_op o{};
+            o.kind = g.control < 0 ? QSV_OP_U : QSV_OP_CU3;
+            o.target = uint8_t(g.target);
+            o.control = g.control < 0 ? uint8_t(QSV_NO_CONTROL) : uint8_t(g.control);
+            o.p_theta = a.p_theta; o.p_phi = a.p_phi; o.p_lambda = a.p_lambda;
+            o.theta = a.theta; o.phi = a.phi; o.lambda = a.lambda;
+            outs[s][i] = o;
+        }
+    }
+    return sc.n_keys;
 }
 
 int qsv_plan_build(int n_qubits, int dtype, int n_ops, const qsv_op* ops, const qsv_plan_config* cfg,

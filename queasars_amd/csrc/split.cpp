@@ -1,0 +1,210 @@
+// Register splitting (split.hpp): partition search and construction of the two virtual circuits.  Pure C++.
+#include "split.hpp"
+
+#include <algorithm>
+#include <array>
+#include <cstdlib>
+
+namespace qsv {
+
+namespace {
+
+struct Key {
+    int control;
+    std::vector<int> targets;  // distinct targets of the key's gates
+};
+
+struct UnionFind {
+    std::array<int8_t, 64> parent;
+    explicit UnionFind(int n) {
+        for (int i = 0; i < n; ++i) parent[size_t(i)] = int8_t(i);
+    }
+    int find(int x) {
+        while (parent[size_t(x)] != x) {
+            parent[size_t(x)] = parent[size_t(parent[size_t(x)])];
+            x = parent[size_t(x)];
+        }
+        return x;
+    }
+    void join(int a, int b) { parent[size_t(find(a))] = int8_t(find(b)); }
+};
+
+}  // namespace
+
+SplitCircuits find_split(int n, const std::vector<GateIn>& all_gates, const std::vector<AngleSource>& op_angles,
+                         int max_side, int max_keys) {
+    SplitCircuits out;
+    if (n > 60 || n <= max_side || 2 * max_side < n) return out;
+
+    // ---- which gates act at all, and the keys -------------------------------------------------------------------
+    // (the drop rule of build_plan: a cu3 whose control nobody has targeted yet acts on |0> and is the identity)
+    std::vector<char> touched(size_t(n), 0);
+    std::vector<int> epoch(size_t(n), 0);           // gates that have targeted the qubit so far
+    std::vector<int> key_of(all_gates.size(), -1);  // per gate: its key (cu3 that act), -1 otherwise
+    std::vector<char> dropped(all_gates.size(), 0);
+    std::vector<Key> keys;
+    std::vector<std::pair<int, int>> key_id;  // (control, epoch) of keys[i]
+    for (size_t i = 0; i < all_gates.size(); ++i) {
+        const GateIn& g = all_gates[i];
+        if (g.control >= 0) {
+            if (!touched[size_t(g.control)]) {
+                dropped[i] = 1;
+                continue;
+            }
+            const std::pair<int, int> id{g.control, epoch[size_t(g.control)]};
+            int ki = -1;
+            for (size_t j = keys.size(); j-- > 0;)
+                if (key_id[j] == id) {
+                    ki = int(j);
+                    break;
+                }
+            if (ki < 0) {
+                ki = int(keys.size());
+                keys.push_back(Key{g.control, {}});
+                key_id.push_back(id);
+            }
+            key_of[i] = ki;
+            std::vector<int>& ts = keys[size_t(ki)].targets;
+            if (std::find(ts.begin(), ts.end(), g.target) == ts.end()) ts.push_back(g.target);
+        }
+        touched[size_t(g.target)] = 1;
+        epoch[size_t(g.target)] += 1;
+    }
+    const int nk = int(keys.size());
+
+    // ---- partition: the fewest cut keys such that both virtual circuits fit a tile --------------------------------
+    // Remove a set R of keys (|R| = 0, 1, 2, ..), take the connected components of what is left and pack them into
+    // two bins (subset sum over the component sizes, as balanced as the size limit allows).
+    uint64_t side_a = 0;
+    bool found = false;
+    auto try_without = [&](int r0, int r1) {
+        UnionFind uf(n);
+        for (int j = 0; j < nk; ++j) {
+            if (j == r0 || j == r1) continue;
+            for (int t : keys[size_t(j)].targets) uf.join(keys[size_t(j)].control, t);
+        }
+        // components in order of their lowest qubit
+        std::array<int8_t, 64> comp_of{};
+        std::vector<int> size;
+        std::vector<uint64_t> members;
+        for (int q = 0; q < n; ++q) {
+            const int root = uf.find(q);
+            if (root == q) {
+                comp_of[size_t(q)] = int8_t(size.size());
+                size.push_back(0);
+                members.push_back(0);
+            }
+        }
+        // (roots are not necessarily the lowest member: number them in a second sweep)
+        for (int q = 0; q < n; ++q) {
+            const int c = comp_of[size_t(uf.find(q))];
+            size[size_t(c)] += 1;
+            members[size_t(c)] |= uint64_t(1) << q;
+        }
+        const int removed = (r0 >= 0) + (r1 >= 0);
+        const int lo = n - max_side + removed, hi = max_side - removed;  // admissible |A|
+        if (lo > hi) return false;
+        // subset sums: choice[s] = set of components (bit mask) with total size s, component 0 always in A
+        std::vector<uint64_t> choice(size_t(n) + 1, 0);
+        std::vector<char> reach(size_t(n) + 1, 0);
+        reach[size_t(size[0])] = 1;
+        choice[size_t(size[0])] = 1;
+        for (size_t c = 1; c < size.size(); ++c)
+            for (int s = n - size[c]; s >= 0; --s)
+                if (reach[size_t(s)] && !reach[size_t(s + size[c])]) {
+                    reach[size_t(s + size[c])] = 1;
+                    choice[size_t(s + size[c])] = choice[size_t(s)] | uint64_t(1) << c;
+                }
+        int best = -1;
+        for (int s = lo; s <= hi; ++s)
+            if (reach[size_t(s)] && (best < 0 || std::abs(2 * s - n) < std::abs(2 * best - n))) best = s;
+        if (best < 0) return false;
+        side_a = 0;
+        for (size_t c = 0; c < size.size(); ++c)
+            if (choice[size_t(best)] >> c & 1u) side_a |= members[c];
+        return true;
+    };
+    found = try_without(-1, -1);
+    for (int r0 = 0; !found && max_keys >= 1 && r0 < nk; ++r0) found = try_without(r0, -1);
+    for (int r0 = 0; !found && max_keys >= 2 && r0 < nk; ++r0)
+        for (int r1 = r0 + 1; !found && r1 < nk; ++r1) found = try_without(r0, r1);
+    if (!found) return out;
+
+    // ---- the keys this partition really cuts ----------------------------------------------------------------------
+    auto side_of = [&](int q) { return int(!(side_a >> q & 1u)); };  // 0 = A, 1 = B
+    std::vector<int> cut_index(size_t(nk), -1);
+    int n_cut = 0;
+    for (int j = 0; j < nk; ++j) {
+        bool cut = false;
+        for (int t : keys[size_t(j)].targets) cut |= side_of(t) != side_of(keys[size_t(j)].control);
+        if (cut) cut_index[size_t(j)] = n_cut++;
+    }
+    out.mask[0] = side_a;
+    out.mask[1] = ~side_a & ((uint64_t(1) << n) - 1);
+    for (int s = 0; s < 2; ++s) out.n_side[s] = __builtin_popcountll(out.mask[s]);
+    if (n_cut > max_keys || out.n_side[0] + n_cut > max_side || out.n_side[1] + n_cut > max_side) return out;
+    out.n_keys = n_cut;
+
+    // ---- the two virtual circuits -------------------------------------------------------------------------------------
+    std::vector<int> local(size_t(n), 0);
+    {
+        int ca = 0, cb = 0;
+        for (int q = 0; q < n; ++q) local[size_t(q)] = side_of(q) == 0 ? ca++ : cb++;
+    }
+    auto fixed = [](int32_t code) { return AngleSource{code, -1, -1, 0.0, 0.0, 0.0}; };
+    for (int s = 0; s < 2; ++s) {
+        std::vector<GateIn>& vg = out.gates[s];
+        std::vector<AngleSource>& va = out.angles[s];
+        for (int j = 0; j < n_cut; ++j) {  // every key qubit starts as (1, 1)
+            va.push_back(fixed(kFixedOnes));
+            vg.push_back(GateIn{out.n_side[s] + j, -1, int(va.size()) - 1});
+        }
+    }
+    std::vector<char> projected(size_t(nk), 0);
+    for (size_t i = 0; i < all_gates.size(); ++i) {
+        if (dropped[i]) continue;
+        const GateIn& g = all_gates[i];
+        const int st = side_of(g.target);
+        const int key = key_of[i] >= 0 ? cut_index[size_t(key_of[i])] : -1;
+        if (g.control < 0 || side_of(g.control) == st) {
+            // a gate of one side -- but the first use of a cut key projects its control first, also when this
+            // particular gate of the key stays inside the side
+            if (key >= 0 && !projected[size_t(key_of[i])]) {
+                projected[size_t(key_of[i])] = 1;
+                std::vector<GateIn>& vg = out.gates[st];
+                std::vector<AngleSource>& va = out.angles[st];
+                const int c = local[size_t(g.control)], kq = out.n_side[st] + key;
+                va.push_back(fixed(kFixedX));
+                vg.push_back(GateIn{c, kq, int(va.size()) - 1});
+                va.push_back(fixed(kFixedProj0));
+                vg.push_back(GateIn{c, -1, int(va.size()) - 1});
+                va.push_back(fixed(kFixedX));
+                vg.push_back(GateIn{c, kq, int(va.size()) - 1});
+            }
+            out.angles[st].push_back(op_angles[size_t(g.op)]);
+            out.gates[st].push_back(GateIn{local[size_t(g.target)], g.control < 0 ? -1 : local[size_t(g.control)],
+                                           int(out.angles[st].size()) - 1});
+            continue;
+        }
+        // cross gate: control on the other side
+        const int sc = 1 - st;
+        if (!projected[size_t(key_of[i])]) {
+            projected[size_t(key_of[i])] = 1;
+            std::vector<GateIn>& vg = out.gates[sc];
+            std::vector<AngleSource>& va = out.angles[sc];
+            const int c = local[size_t(g.control)], kq = out.n_side[sc] + key;
+            va.push_back(fixed(kFixedX));
+            vg.push_back(GateIn{c, kq, int(va.size()) - 1});
+            va.push_back(fixed(kFixedProj0));
+            vg.push_back(GateIn{c, -1, int(va.size()) - 1});
+            va.push_back(fixed(kFixedX));
+            vg.push_back(GateIn{c, kq, int(va.size()) - 1});
+        }
+        out.angles[st].push_back(op_angles[size_t(g.op)]);
+        out.gates[st].push_back(GateIn{local[size_t(g.target)], out.n_side[st] + key, int(out.angles[st].size()) - 1});
+    }
+    out.ok = true;
+    return out;
+}
+
+}  // namespace qsv

@@ -39,7 +39,7 @@ def test_struct_layouts_match_the_header():
         assert QSV_OP_DTYPE.fields[field][1] == offset
         assert getattr(_lib.QsvOp, field).offset == offset
     assert C.sizeof(_lib.QsvPlanConfig) == 20
-    assert C.sizeof(_lib.QsvProfile) == 5 * 8 + 4 * 8 + 8 + 6 * 16
+    assert C.sizeof(_lib.QsvProfile) == 5 * 8 + 4 * 8 + 8 + 6 * 24  # six per-kernel arrays of three
 
 
 def test_argument_errors_without_a_device():
