@@ -252,6 +252,7 @@ struct PassScalars {
     uint32_t mode;
     uint32_t tiles_per_block;
     uint32_t partial_chunks;
+    uint32_t region_stride;
 };
 
 // XMODE selects how a tile is transposed through LDS:
@@ -300,7 +301,7 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, FIRST>::waves_per_si
 
     EvalDesc ev;
     {
-        cu32p e = as_constant(reinterpret_cast<const uint32_t*>(evals + blockIdx.y));
+        cu32p e = as_constant(reinterpret_cast<const uint32_t*>(evals + blockIdx.y + size_t(blockIdx.z) * a.region_stride));
         ev.plan_base = e[0];
         ev.mat_base = e[1];
         ev.state_slot = e[2];
@@ -778,7 +779,7 @@ static hipError_t launch_pass_t(dim3 grid, int threads, size_t lds_bytes, hipStr
     // the block reduction at the end needs one double per wave (and the diagnostic build a table of counters)
     const size_t lds = lds_bytes < 256 ? 256 : lds_bytes;
     const PassScalars sc{args.state_stride, args.wtab_stride, args.pass_index, args.mode, args.tiles_per_block,
-                         args.partial_chunks};
+                         args.partial_chunks, args.region_stride};
     cx<real>* st = reinterpret_cast<cx<real>*>(args.states);
     const bool first = args.pass_index == 0 && (args.mode & kModeSynthFirst);
     if (first)
@@ -822,7 +823,7 @@ static hipError_t pass_dispatch(int op, int dtype, int r, int xmode, dim3 grid, 
 #endif
     if (op) return hipSuccess;
     const PassScalars sc{args->state_stride, args->wtab_stride, args->pass_index, args->mode, args->tiles_per_block,
-                         args->partial_chunks};
+                         args->partial_chunks, args->region_stride};
     if (args->pass_index == 0 && (args->mode & kModeSynthFirst))
         hipLaunchKernelGGL((pass_kernel<double, QSV_PROBE_R, 2, true>), grid, dim3(threads), lds_bytes, stream, args->plan,
                            args->mats, args->evals, reinterpret_cast<cx<double>*>(args->states),

@@ -53,6 +53,8 @@ struct PassArgs {
     uint32_t pass_index;
     uint32_t mode;
     uint32_t tiles_per_block;  // consecutive tiles each workgroup sweeps
+    uint32_t region_stride;    // gridDim.z = 2: blockIdx.z = 1 takes descriptor evals[region_stride + blockIdx.y] (side B of
+                               // split evaluations, kEvalNull for the others)
     uint32_t partial_chunks;   // workgroup slots per evaluation in `partials` (>= gridDim.x; 0 means gridDim.x): launches
                                // of one batch may use different grids (pass 0 / later passes), the reducer sees one shape
 };

@@ -213,6 +213,7 @@ struct qsv_handle {
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
         bool split_any = false; // some evaluation of the batch runs split: the descriptor array has a second region
         std::vector<char> split;  // per evaluation
+        std::vector<uint32_t> eval_at;  // descriptor position -> evaluation (a push puts its split evaluations first)
         int ways = 1;           // streams this batch cycles over
         unsigned used_mask = 0; // side streams (bit i = side_streams[i]) with work of this batch in flight
         size_t n_pushes = 0;
@@ -616,6 +617,8 @@ int batch_layout(qsv_t* h, const std::vector<Circuit*>& circs, const std::vector
     size_t total_params = 0, total_mats = 0;
     b.split.assign(n_evals, 0);
     b.split_any = false;
+    b.eval_at.resize(n_evals);
+    for (size_t i = 0; i < n_evals; ++i) b.eval_at[i] = uint32_t(i);
     for (size_t i = 0; i < n_evals; ++i) {
         if (n_params[i] < circs[i]->n_params)
             return fail(h, QSV_E_ARG, "circuit needs " + std::to_string(circs[i]->n_params) + " parameter values, got " +
@@ -709,13 +712,19 @@ hipError_t stamp(qsv_t* h, std::vector<std::pair<hipEvent_t, hipEvent_t>>& list,
 int run_group(qsv_t* h, const std::vector<Circuit*>& circs, size_t first, size_t count, uint32_t mode) {
     const qsv_handle::Batch& b = h->batch;
     const bool batch_split = b.split_any && b.split.size() == circs.size();
+    // descriptor position -> evaluation (eval_push put the push's split evaluations first)
+    auto eval_of = [&](size_t pos) { return batch_split ? size_t(b.eval_at[pos]) : pos; };
+    size_t n_split = 0;
     int max_passes = 0;
-    bool any_split = false;
     for (size_t i = 0; i < count; ++i) {
-        const bool split = batch_split && b.split[first + i];
-        any_split |= split;
-        max_passes = std::max(max_passes, split ? 1 : circs[first + i]->plan.stats.n_passes);
+        const size_t e = eval_of(first + i);
+        if (batch_split && b.split[e])
+            n_split = i + 1;  // (split evaluations lead each push, so also each group of it)
+        else
+            max_passes = std::max(max_passes, circs[e]->plan.stats.n_passes);
     }
+    const bool any_split = n_split > 0;
+    const size_t n_plain = count - n_split;
     PassArgs a{};
     a.plan = static_cast<const uint32_t*>(h->d_arena.ptr);
     a.mats = static_cast<const double*>(h->d_mats.ptr);
@@ -735,25 +744,37 @@ int run_group(qsv_t* h, const std::vector<Circuit*>& circs, size_t first, size_t
     const unsigned tpb_later = unsigned(std::min<uint32_t>(uint32_t(h->tiles_per_block_later), h->geo.blocks_per_state));
     const unsigned chunks_later = std::max(1u, std::min(chunks, h->geo.blocks_per_state / std::max(1u, tpb_later)));
     a.partial_chunks = chunks;
+    a.region_stride = uint32_t(circs.size());
     const uint64_t sweep = (uint64_t(1) << h->n) * h->amp_bytes;
-    for (int p = 0; p < max_passes; ++p) {
+    if (any_split) {
+        // both virtual circuits of every split evaluation: one tile, one workgroup each (second descriptor region: z = 1)
+        a.pass_index = 0;
+        a.tiles_per_block = 1;
+        if (h->stamping) QSV_HIP(h, stamp(h, h->batch.launch_events[0], true));
+        QSV_HIP(h, launch_pass(h->dtype, h->geo.r, h->cfg.xmode, dim3(1, unsigned(n_split), 2), h->geo.threads_launch,
+                               h->geo.lds_bytes, ws(h), a));
+        if (h->stamping) QSV_HIP(h, stamp(h, h->batch.launch_events[0], false));
+        h->prof.n_pass_launches += 1;
+        h->prof.kernel_launches[0] += 1;
+    }
+    a.evals = batch_evals(h) + first + n_split;
+    for (int p = 0; p < max_passes && n_plain > 0; ++p) {
         const unsigned chunks_p = p == 0 ? chunks : chunks_later;
         a.tiles_per_block = (h->geo.blocks_per_state + chunks_p - 1) / chunks_p;
-        dim3 grid(chunks_p, unsigned(count));
+        dim3 grid(chunks_p, unsigned(n_plain));
         a.pass_index = uint32_t(p);
         const int kind = (p == 0 && (mode & kModeSynthFirst)) ? 0 : 1;  // which instantiation of the kernel runs
         if (h->stamping) QSV_HIP(h, stamp(h, h->batch.launch_events[kind], true));
         QSV_HIP(h, launch_pass(h->dtype, h->geo.r, h->cfg.xmode, grid, h->geo.threads_launch, h->geo.lds_bytes, ws(h), a));
         if (h->stamping) QSV_HIP(h, stamp(h, h->batch.launch_events[kind], false));
         h->prof.n_pass_launches += 1;
-        h->prof.n_state_passes += count;
+        h->prof.n_state_passes += n_plain;
         h->prof.kernel_launches[kind] += 1;
         // Algorithmic state bytes at this pass's own price: every pass reads and writes the state once, except that a
         // synthesising pass 0 does not read and a fused last pass does not write.  What it really moves is less when
         // a compact pass 0 writes, and pass 1 reads, a table of 2^cb tiles instead of the state.
-        for (size_t i = 0; i < count; ++i) {
-            if (batch_split && b.split[first + i]) continue;  // (accounted with the contraction below)
-            const PlanStats& st = circs[first + i]->plan.stats;
+        for (size_t i = n_split; i < count; ++i) {
+            const PlanStats& st = circs[eval_of(first + i)]->plan.stats;
             if (p >= st.n_passes) continue;
             const bool reads = !(p == 0 && (mode & kModeSynthFirst));
             const bool writes = !(p + 1 == st.n_passes && !(mode & kModeFinalStore));
@@ -771,25 +792,15 @@ int run_group(qsv_t* h, const std::vector<Circuit*>& circs, size_t first, size_t
         }
     }
     if (any_split) {
-        // side B of the split evaluations (their side A ran in the launch of pass 0 above), then the contraction
-        a.evals = batch_evals(h) + circs.size() + first;
-        a.pass_index = 0;
-        a.tiles_per_block = 1;
-        if (h->stamping) QSV_HIP(h, stamp(h, h->batch.launch_events[0], true));
-        QSV_HIP(h, launch_pass(h->dtype, h->geo.r, h->cfg.xmode, dim3(1, unsigned(count)), h->geo.threads_launch,
-                               h->geo.lds_bytes, ws(h), a));
-        if (h->stamping) QSV_HIP(h, stamp(h, h->batch.launch_events[0], false));
-        h->prof.n_pass_launches += 1;
-        h->prof.kernel_launches[0] += 1;
+        // the contraction of the split evaluations
         a.evals = batch_evals(h) + first;
         if (h->stamping) QSV_HIP(h, stamp(h, h->batch.launch_events[2], true));
         const unsigned contract_chunks = unsigned((uint64_t(1) << h->n) / (uint64_t(h->geo.threads_launch) << kSplitLoopBits));
-        QSV_HIP(h, launch_contract(h->dtype, contract_chunks, unsigned(count), h->geo.threads_launch, ws(h), a));
+        QSV_HIP(h, launch_contract(h->dtype, contract_chunks, unsigned(n_split), h->geo.threads_launch, ws(h), a));
         if (h->stamping) QSV_HIP(h, stamp(h, h->batch.launch_events[2], false));
         h->prof.kernel_launches[2] += 1;
-        for (size_t i = 0; i < count; ++i) {
-            if (!b.split[first + i]) continue;
-            const SplitInfo& sp = circs[first + i]->split;
+        for (size_t i = 0; i < n_split; ++i) {
+            const SplitInfo& sp = circs[eval_of(first + i)]->split;
             // the contraction reads D once (8 * 2^n bytes) and the two side tables; priced as the read-only fused pass it
             // replaces (16 * 2^n bytes per state) in kernel_bytes, what it really touches in moved_bytes
             h->prof.state_bytes += sweep;
@@ -872,6 +883,23 @@ int eval_push(qsv_t* h, size_t first, size_t count, const double* values) {
         for (size_t j = 0; j < count; ++j) hd[first + j].state_slot = uint32_t(j % G);
         if (b.split_any)
             for (size_t j = 0; j < count; ++j) hd[b.circs.size() + first + j].state_slot = hd[first + j].state_slot;
+    }
+    if (b.split_any) {
+        // descriptors of the push: split evaluations first, the others behind them (results, partial sums and state
+        // slots go by the descriptor's fields, not by its position), so that the side circuits, the ordinary passes and
+        // the contraction are each launched over the evaluations they concern -- a workgroup that only finds out that
+        // it has nothing to do still costs its dispatch, and a mixed launch was mostly such workgroups
+        const size_t P = b.circs.size();
+        std::vector<EvalDesc> tmp(hd + first, hd + first + count), tmp2(hd + P + first, hd + P + first + count);
+        size_t at = first;
+        for (int pass = 0; pass < 2; ++pass)
+            for (size_t j = 0; j < count; ++j)
+                if (bool(b.split[first + j]) == (pass == 0)) {
+                    hd[at] = tmp[j];
+                    hd[P + at] = tmp2[j];
+                    b.eval_at[at] = uint32_t(first + j);
+                    ++at;
+                }
     }
     b.n_pushes += 1;
     int rc = batch_ship(h, first, count, values);
