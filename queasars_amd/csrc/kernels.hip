@@ -1123,7 +1123,8 @@ __device__ __forceinline__ double contract_by_shape(uint32_t lx, const unsigned 
                                                     const unsigned char* bd, uint32_t ix, uint32_t iy, uint32_t i0,
                                                     uint32_t bits_x, uint32_t bits_y, const uint32_t (&col)[kSplitLoopBits],
                                                     const uint32_t (&pos)[kSplitLoopBits]) {
-    if (lx == 2) return contract_block<real, J, 2, 4 / J>(bx, by, bd, ix, iy, i0, bits_x, bits_y, col, pos);
+    if constexpr (J <= 4)  // (eight terms: the scheduler keeps LX below 2, the values of X alone would fill the registers)
+        if (lx == 2) return contract_block<real, J, 2, 4 / J>(bx, by, bd, ix, iy, i0, bits_x, bits_y, col, pos);
     if (lx == 1) return contract_block<real, J, 1, 8 / J>(bx, by, bd, ix, iy, i0, bits_x, bits_y, col, pos);
     return contract_block<real, J, 0, 8 / J>(bx, by, bd, ix, iy, i0, bits_x, bits_y, col, pos);
 }
@@ -1191,8 +1192,10 @@ __global__ void __launch_bounds__(512, 4) contract_kernel(const uint32_t* __rest
         acc = contract_by_shape<real, 1>(lx, bx, by, bd, ix, iy, i0, bits_x, bits_y, col, pos);
     else if (n_keys == 1)
         acc = contract_by_shape<real, 2>(lx, bx, by, bd, ix, iy, i0, bits_x, bits_y, col, pos);
-    else
+    else if (n_keys == 2)
         acc = contract_by_shape<real, 4>(lx, bx, by, bd, ix, iy, i0, bits_x, bits_y, col, pos);
+    else
+        acc = contract_by_shape<real, 8>(lx, bx, by, bd, ix, iy, i0, bits_x, bits_y, col, pos);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
     const uint32_t n_waves = blockDim.x >> 6, wave = tid >> 6;

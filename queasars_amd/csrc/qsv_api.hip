@@ -39,7 +39,8 @@ struct SplitInfo {
     bool ok = false;
     int n_keys = 0;
     PlanStats stats[2];
-    int t[2] = {0, 0};              // thread bits of the two one-tile plans
+    int t[2] = {0, 0};              // thread bits of the two plans
+    int outer[2] = {0, 0};          // qubits outside a tile (0: the virtual circuit is one tile)
     int n_virtual[2] = {0, 0};      // qubits of the virtual circuits
     uint32_t off_side[2] = {0, 0};  // word offsets of the side plans
     uint32_t off_block = 0;         // ... and of the split block (kernels.hpp)
@@ -353,8 +354,12 @@ int build_circuit(qsv_t* h, int n_ops, const qsv_op* ops, int n_params, bool fol
         PlanConfig pc = h->cfg;
         pc.fold = pc.fold && fold;
         out->plan = build_plan(h->n, gates, angles, pc);
-        if (h->split_enabled && pc.fold && h->n > h->geo.k) {
-            const SplitCircuits sc = find_split(h->n, gates, angles, h->geo.k);
+        if (h->split_enabled && pc.fold && h->n > h->geo.k && h->n <= 28) {  // (28: the contraction's 32-bit byte offsets into D)
+            // a virtual circuit may be up to two qubits larger than a tile (it then takes the pass kernel two passes over
+            // four tiles: nothing next to the 2^n indices of the contraction)
+            // ... but one tile each is what to look for first: no second pass, one workgroup per virtual circuit
+            SplitCircuits sc = find_split(h->n, gates, angles, h->geo.k);
+            if (!sc.ok) sc = find_split(h->n, gates, angles, std::min(h->geo.k + 2, h->n - 1));
             if (sc.ok) {
                 SplitInfo& sp = out->split;
                 std::vector<uint32_t>& w = out->plan.words;
@@ -362,14 +367,15 @@ int build_circuit(qsv_t* h, int n_ops, const qsv_op* ops, int n_params, bool fol
                 for (int s = 0; s < 2 && fits; ++s) {
                     PlanConfig side = pc;
                     sp.n_virtual[s] = sc.n_side[s] + sc.n_keys;
-                    side.tile_bits = sp.n_virtual[s];  // one tile
+                    side.tile_bits = std::min(sp.n_virtual[s], h->geo.k);
                     side.reg_bits = h->geo.r;
-                    fits = sp.n_virtual[s] > side.reg_bits;
+                    side.compact = false;  // (the compact-table buffer is where a side's state lives)
+                    fits = side.tile_bits > side.reg_bits;
                     if (!fits) break;
                     const CircuitPlan p = build_plan(sp.n_virtual[s], sc.gates[s], sc.angles[s], side);
-                    fits = p.stats.n_passes == 1;
                     sp.stats[s] = p.stats;
-                    sp.t[s] = sp.n_virtual[s] - side.reg_bits;
+                    sp.t[s] = side.tile_bits - side.reg_bits;
+                    sp.outer[s] = sp.n_virtual[s] - side.tile_bits;
                     sp.off_side[s] = uint32_t(w.size());
                     w.insert(w.end(), p.words.begin(), p.words.end());
                 }
@@ -387,7 +393,7 @@ int build_circuit(qsv_t* h, int n_ops, const qsv_op* ops, int n_params, bool fol
                         return __builtin_popcountll((sc.mask[side] >> 6) & ((uint64_t(1) << (middle_end - 6)) - 1));
                     };
                     bool found = false;
-                    for (int lx = kSplitMaxLoopX; lx >= 0 && !found; --lx)
+                    for (int lx = sc.n_keys >= 3 ? 1 : kSplitMaxLoopX; lx >= 0 && !found; --lx)
                         for (int sx = 0; sx < 2 && !found; ++sx)
                             if (middle_bits(sx) >= lx && middle_bits(1 - sx) >= kSplitLoopBits - lx) {
                                 found = true;
@@ -604,7 +610,8 @@ size_t mat_doubles_of(const qsv_t* h, const Circuit& c, bool split, int side) {
     if (!split)
         return mat_region_doubles(uint32_t(c.plan.stats.n_real_gates), uint32_t(h->n), h->geo.t, h->n - h->geo.k,
                                   c.plan.stats.n_passes);
-    return mat_region_doubles(uint32_t(c.split.stats[side].n_real_gates), uint32_t(c.split.n_virtual[side]), c.split.t[side], 0, 1);
+    return mat_region_doubles(uint32_t(c.split.stats[side].n_real_gates), uint32_t(c.split.n_virtual[side]), c.split.t[side],
+                              c.split.outer[side], c.split.stats[side].n_passes);
 }
 
 // allow_split: the caller only wants <D> of the final states (fused diagonal expectation), so a circuit that has a
@@ -747,15 +754,28 @@ int run_group(qsv_t* h, const std::vector<Circuit*>& circs, size_t first, size_t
     a.region_stride = uint32_t(circs.size());
     const uint64_t sweep = (uint64_t(1) << h->n) * h->amp_bytes;
     if (any_split) {
-        // both virtual circuits of every split evaluation: one tile, one workgroup each (second descriptor region: z = 1)
-        a.pass_index = 0;
+        // both virtual circuits of every split evaluation (second descriptor region: z = 1): one tile and one pass each,
+        // or up to four tiles and a few passes when a virtual circuit is larger than a tile
+        int side_passes = 1;
+        unsigned side_tiles = 1;
+        for (size_t i = 0; i < n_split; ++i) {
+            const SplitInfo& sp = circs[eval_of(first + i)]->split;
+            for (int s = 0; s < 2; ++s) {
+                side_passes = std::max(side_passes, sp.stats[s].n_passes);
+                side_tiles = std::max(side_tiles, 1u << sp.outer[s]);
+            }
+        }
         a.tiles_per_block = 1;
-        if (h->stamping) QSV_HIP(h, stamp(h, h->batch.launch_events[0], true));
-        QSV_HIP(h, launch_pass(h->dtype, h->geo.r, h->cfg.xmode, dim3(1, unsigned(n_split), 2), h->geo.threads_launch,
-                               h->geo.lds_bytes, ws(h), a));
-        if (h->stamping) QSV_HIP(h, stamp(h, h->batch.launch_events[0], false));
-        h->prof.n_pass_launches += 1;
-        h->prof.kernel_launches[0] += 1;
+        for (int p = 0; p < side_passes; ++p) {
+            a.pass_index = uint32_t(p);
+            const int kind = p == 0 ? 0 : 1;
+            if (h->stamping) QSV_HIP(h, stamp(h, h->batch.launch_events[kind], true));
+            QSV_HIP(h, launch_pass(h->dtype, h->geo.r, h->cfg.xmode, dim3(side_tiles, unsigned(n_split), 2),
+                                   h->geo.threads_launch, h->geo.lds_bytes, ws(h), a));
+            if (h->stamping) QSV_HIP(h, stamp(h, h->batch.launch_events[kind], false));
+            h->prof.n_pass_launches += 1;
+            h->prof.kernel_launches[kind] += 1;
+        }
     }
     a.evals = batch_evals(h) + first + n_split;
     for (int p = 0; p < max_passes && n_plain > 0; ++p) {

@@ -11,9 +11,10 @@
 // where a_kappa / b_kappa are the final states of two VIRTUAL circuits on |A| + K and |B| + K qubits: the side's own
 // gates, plus one extra qubit per key that starts as (1, 1) and is never targeted.  On the target side the cross gate
 // becomes cu3(key -> target); on the control side the key's first use becomes the projector P_kappa(c), written as
-// [X(c) if key] P0(c) [X(c) if key].  Both virtual circuits fit one tile, so the ordinary pass kernel runs each in one
-// workgroup, and one streaming kernel (contract_kernel) forms psi on the fly and reduces <psi|D|psi> -- the only sweep
-// over 2^n indices, with 4 * 2^K + 3 fp64 operations per amplitude instead of a pass of gates.
+// [X(c) if key] P0(c) [X(c) if key].  Both virtual circuits are small (at most two qubits more than a tile), so the
+// ordinary pass kernel runs each in one to four workgroups, and one streaming kernel (contract_kernel) forms psi on the
+// fly and reduces <psi|D|psi> -- the only sweep over 2^n indices, with 4 * 2^K + 3 fp64 operations per amplitude instead
+// of a pass of gates.
 //
 // This generalises the compact first pass (plan.hpp): there only pass 0 worked on a table of tiles, here every gate
 // does.  A circuit that has no such partition (deeper, well entangled circuits) keeps the ordinary multi-pass plan.
@@ -32,7 +33,7 @@ constexpr int32_t kFixedProj0 = -2;  // [[1, 0], [0, 0]]
 constexpr int32_t kFixedOnes = -3;   // [[1, 0], [1, 0]]: applied to |0> it gives (1, 1)
 constexpr int32_t kFixedX = -4;      // [[0, 1], [1, 0]]
 
-constexpr int kMaxSplitKeys = 2;
+constexpr int kMaxSplitKeys = 3;
 
 struct SplitCircuits {
     bool ok = false;
@@ -43,7 +44,7 @@ struct SplitCircuits {
     std::vector<AngleSource> angles[2];
 };
 
-// max_side: most qubits a virtual circuit may have (the tile size).  Deterministic.
+// max_side: most qubits a virtual circuit may have.  Deterministic.
 SplitCircuits find_split(int n_qubits, const std::vector<GateIn>& gates, const std::vector<AngleSource>& op_angles,
                          int max_side, int max_keys = kMaxSplitKeys);
 
