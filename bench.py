@@ -46,10 +46,14 @@ FP64_PEAK_TFLOPS = 78.6     # vector fp64, half the 157.3 TFLOP/s fp32 vector ra
 
 
 def kernel_names(n_qubits: int):
-    """The two instantiations of the gate-pass kernel at this size (register bits by size: qsv_api.hip resolve_config)."""
+    """The kernels of the hot path at this size (register bits by size: qsv_api.hip resolve_config), in the order of
+    qsv_profile's per-kernel arrays."""
     r = 4 if n_qubits >= 20 else 3
-    return (f"qsv::pass_kernel<double, {r}, 2, true> (pass 0: synthesises the product state, writes only)",
-            f"qsv::pass_kernel<double, {r}, 2, false> (later passes; the last one fuses the diagonal expectation and only reads)")
+    return (f"qsv::pass_kernel<double, {r}, 2, true> (pass 0: synthesises a product state, writes only; for a split "
+            "evaluation the two small virtual circuits, one workgroup each)",
+            f"qsv::pass_kernel<double, {r}, 2, false> (later passes; the last one fuses the diagonal expectation and only reads)",
+            "qsv::contract_kernel<double> (split evaluations: forms psi[i] from the two side tables on the fly and reduces "
+            "sum_i D[i] |psi[i]|^2; reads D once per state)")
 
 
 def ising_operator(n_qubits: int, seed: int):
@@ -130,7 +134,7 @@ def aer_baseline(circuits, params, operator):
 
 
 def kernel_rooflines(device, step, profiled_steps: int, traffic: dict):
-    """Per instantiation of the gate-pass kernel: launches, mean launch time (HIP events on the stream each launch runs
+    """Per kernel of the hot path (the two instantiations of the gate-pass kernel, the contraction kernel): launches, mean launch time (HIP events on the stream each launch runs
     on), algorithmic bytes and flops per launch, and the fractions of the two roofs.  Measured in steps of their own,
     after the timed region: the per-launch events cost a few microseconds each."""
     device.set_profiling(True)
@@ -145,7 +149,7 @@ def kernel_rooflines(device, step, profiled_steps: int, traffic: dict):
                 acc[k] = [a + b for a, b in zip(acc[k], v)] if isinstance(v, list) else acc[k] + v
     device.set_profiling(False)
     kernels = []
-    for kind in (0, 1):
+    for kind in (0, 1, 2):
         launches = acc["kernel_launches"][kind]
         if not launches or acc["kernel_ms"][kind] <= 0:
             continue
@@ -418,16 +422,17 @@ def main() -> None:
                 "kernels": kernels,
                 "gates_per_s": prof["n_gates"] / (prof["pass_window_ms"] * 1e-3) if prof["pass_window_ms"] > 0 else None,
                 "pass_window_ms_per_step": prof["pass_window_ms"] / min(args.steps, 10),
-                "note": "top-level fields describe the instantiation with the most GPU time.  achieved = algorithmic state "
-                "bytes per launch (16 * 2^n per state and direction the pass has to move: pass 0 synthesises and only "
-                "writes, a last pass with the fused diagonal expectation only reads, passes in between do both; SURVEY "
-                "8(d)) / mean launch time from HIP events around every launch on its own stream, measured in "
-                "profiled steps after the timed region.  HBM is the roof SURVEY 8(d) names for the path; at n = 20 the "
-                "counters say the launches are bound by dependent latencies and instruction issue instead "
-                "(observed_limiter; the compact first pass keeps most state traffic on chip: traffic << algorithmic "
-                "bytes), so frac_fp64 and frac_hbm_on_measured_traffic are given too.  traffic = 2 x FETCH_SIZE + "
-                "WRITE_SIZE per launch from separate rocprofv3 --pmc passes of this command (profiles/, see "
-                "traffic_source), gfx950 correction of MI355X_MICROARCH.md",
+                "note": "top-level fields describe the kernel with the most GPU time.  Gate-pass kernels: achieved = "
+                "algorithmic state bytes per launch (16 * 2^n per state and direction the pass has to move: pass 0 "
+                "synthesises and only writes, a last pass with the fused diagonal expectation only reads, passes in "
+                "between do both; SURVEY 8(d)) / mean launch time.  Contraction kernel (weakly entangled circuits run as "
+                "two small virtual circuits + one sweep, csrc/split.hpp): algorithmic bytes = what the sweep reads per "
+                "state, 8 * 2^n of the diagonal table + the two side tables; the table is shared by the evaluations of a "
+                "launch and each part of it is handled by one XCD, so it is read from memory once per launch and "
+                "served from L2 afterwards (traffic << algorithmic bytes: observed_limiter says what the counters say).  "
+                "Launch times are HIP events around every launch on its own stream, in profiled steps after the timed "
+                "region.  traffic = 2 x FETCH_SIZE + WRITE_SIZE per launch from separate rocprofv3 --pmc passes of this "
+                "command (profiles/, see traffic_source), gfx950 correction of MI355X_MICROARCH.md",
             }
         result = {
             "metric": "circuit-evals/sec (EVQE population) at n qubits; achieved HBM GB/s vs roofline",

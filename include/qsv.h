@@ -86,9 +86,10 @@ typedef struct qsv_profile {
        of split evaluations), [1] = every later pass (the last one fuses the diagonal expectation and then only
        reads), [2] = the contraction kernel of split evaluations (reads the diagonal table once, forms the amplitudes
        from two small tables).  bytes = algorithmic state bytes at the pass's own price (16 * 2^n per state and
-       direction it has to move; the contraction is priced as the read-only fused pass it replaces), moved = what it
-       really moves (compact tables; for [2] the diagonal table and the side tables), flops = 24 per amplitude pair a
-       pass updates (4 multiplications + 10 fused multiply-adds), for [2] 8 J + 5 per amplitude (J product terms). */
+       direction it has to move; for [2] what the contraction reads per state: the diagonal table, 8 * 2^n, and the two
+       side tables), moved = what a launch really moves (compact tables instead of states; = bytes for [2]), flops = 24
+       per amplitude pair a pass updates (4 multiplications + 10 fused multiply-adds), for [2] 8 J + 5 per amplitude
+       (J product terms). */
     uint64_t kernel_launches[3];
     double kernel_ms[3];
     uint64_t kernel_bytes[3];

@@ -821,11 +821,10 @@ int run_group(qsv_t* h, const std::vector<Circuit*>& circs, size_t first, size_t
         h->prof.kernel_launches[2] += 1;
         for (size_t i = 0; i < n_split; ++i) {
             const SplitInfo& sp = circs[eval_of(first + i)]->split;
-            // the contraction reads D once (8 * 2^n bytes) and the two side tables; priced as the read-only fused pass it
-            // replaces (16 * 2^n bytes per state) in kernel_bytes, what it really touches in moved_bytes
-            h->prof.state_bytes += sweep;
-            h->prof.kernel_bytes[2] += sweep;
+            // what the contraction reads per state: D once (8 * 2^n bytes) and the two side tables
             const uint64_t moved = (uint64_t(8) << h->n) + ((uint64_t(1) << sp.n_virtual[0]) + (uint64_t(1) << sp.n_virtual[1])) * h->amp_bytes;
+            h->prof.state_bytes += moved;
+            h->prof.kernel_bytes[2] += moved;
             h->prof.moved_bytes += moved;
             h->prof.kernel_moved_bytes[2] += moved;
             h->prof.kernel_states[2] += 1;

@@ -39,12 +39,12 @@ stats = {}
 for path in glob.glob(f"{root}/trace/**/*kernel_stats.csv", recursive=True):
     with open(path) as f:
         for r in csv.DictReader(f):
-            if "pass_kernel" in r["Name"]:
+            if "pass_kernel" in r["Name"] or "contract_kernel" in r["Name"]:
                 stats[r["Name"]] = (int(r["Calls"]), float(r["TotalDurationNs"]))
 if stats:
     calls = sum(c for c, _ in stats.values())
     total = sum(t for _, t in stats.values())
-    print("\n== pass_kernel, both instantiations ==")
+    print("\n== pass_kernel (both instantiations) + contract_kernel ==")
     print(f"calls={calls} total_ns={total:.0f} avg_ns={total / calls:.0f}")
 
 # HBM traffic per launch and per instantiation of the gate-pass kernel, corrected as MI355X_MICROARCH.md (HBM section)
@@ -52,9 +52,9 @@ if stats:
 # bench.py reads this file (profiles/traffic.json) for roofline.traffic.
 kernels = {}
 for kern, counters in acc.items():
-    if "pass_kernel" not in kern:
+    if "pass_kernel" not in kern and "contract_kernel" not in kern:
         continue
-    kind = "0" if ", true>" in kern else "1"
+    kind = "2" if "contract_kernel" in kern else ("0" if ", true>" in kern else "1")
     fetch, write = counters.get("FETCH_SIZE", []), counters.get("WRITE_SIZE", [])
     if fetch and write:
         f_mean, w_mean = sum(fetch) / len(fetch), sum(write) / len(write)
