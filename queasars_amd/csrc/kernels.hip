@@ -1038,22 +1038,21 @@ hipError_t launch_prepare(const uint32_t* plan, const EvalDesc* host_evals, Eval
 }
 
 // ---- split evaluations: contraction of the two side tables with the diagonal operator ---------------------------
-// psi[i] = sum_j X_j[x(i)] * Y_j[y(i)]: a rank-J outer product.  A thread owns 32 amplitudes: LX index bits of side X
-// times 5 - LX bits of side Y (LX = 2 where the circuit's partition allows it, see the split block), so it loads
-// 2^LX * J values of X, 2^(5-LX) * J of Y and 32 of D -- independent loads, a few memory latencies per thread instead
-// of one per amplitude -- and spends 8 J + 5 flops per amplitude.  Which index bits are lanes (0 .. 5), wave-index
-// bits, a thread's own bits (together the low 11 + wave bits) and workgroup bits (the top ones) is the same for every
-// circuit; workgroup w of the 1-D grid takes part w mod 8 of D for one evaluation after the other, so every part of D
-// is read by ONE XCD, once from memory and then from its L2 (D used to be re-read from memory for every evaluation).
-// Partial sums as in the pass kernel's fused last pass.
-template <typename real, int J, int LX, int YB>
+// psi[i] = sum_j X_j[x(i)] * Y_j[y(i)]: a rank-J outer product.  A thread owns 32 amplitudes (five index bits, the same
+// positions for every circuit): LX of them belong to side X, the others to side Y, so it loads 2^LX * J values of X,
+// 2^(5-LX) * J of Y and 32 of D -- independent loads, a few memory latencies per thread instead of one per amplitude --
+// and spends 8 J + 5 flops per amplitude.  Lanes are index bits 0 .. 5 (D is read in 512-byte runs), the workgroup
+// number the top bits; workgroup w of the 1-D grid takes part w mod 8 of D for one evaluation after the other, so every
+// part of D is read by ONE XCD, once from memory and then from its L2 (D used to be re-read from memory for every
+// evaluation).  Everything circuit-dependent comes as ready-made pieces of the two table indices (split block,
+// kernels.hpp): one level of loads behind the descriptor.  Partial sums as in the pass kernel's fused last pass.
+template <typename real, int J, int LX, int LY, int YB>
 __device__ __forceinline__ double contract_block(const unsigned char* __restrict__ bx, const unsigned char* __restrict__ by,
                                                  const unsigned char* __restrict__ bd, uint32_t ix, uint32_t iy, uint32_t i0,
-                                                 uint32_t bits_x, uint32_t bits_y, const uint32_t (&col)[kSplitLoopBits],
-                                                 const uint32_t (&pos)[kSplitLoopBits]) {
+                                                 uint32_t bits_x, uint32_t bits_y, const uint32_t* col, const uint32_t* pos) {
     // every offset is a 32-bit BYTE offset from a uniform base (tables and D are far below 4 GiB: n <= 28): one VGPR per
     // address and scalar-base loads; with 64-bit addresses the kernel needed 204 VGPRs and ran two waves per SIMD
-    constexpr int LY = kSplitLoopBits - LX, NX = 1 << LX, NY = 1 << LY;
+    constexpr int NX = 1 << LX, NY = 1 << LY;
     constexpr int ASH = Log2Size<real>::value + 1;
     double xr[NX][J], xi[NX][J];
 #pragma unroll
@@ -1123,12 +1122,25 @@ __device__ __forceinline__ double contract_by_shape(uint32_t lx, const unsigned 
                                                     const unsigned char* bd, uint32_t ix, uint32_t iy, uint32_t i0,
                                                     uint32_t bits_x, uint32_t bits_y, const uint32_t (&col)[kSplitLoopBits],
                                                     const uint32_t (&pos)[kSplitLoopBits]) {
-    if constexpr (J <= 4)  // (eight terms: the scheduler keeps LX below 2, the values of X alone would fill the registers)
-        if (lx == 2) return contract_block<real, J, 2, 4 / J>(bx, by, bd, ix, iy, i0, bits_x, bits_y, col, pos);
-    if (lx == 1) return contract_block<real, J, 1, 8 / J>(bx, by, bd, ix, iy, i0, bits_x, bits_y, col, pos);
-    return contract_block<real, J, 0, 8 / J>(bx, by, bd, ix, iy, i0, bits_x, bits_y, col, pos);
+    if (lx == 2) {
+        if constexpr (J <= 4) {
+            return contract_block<real, J, 2, 3, (J == 1 ? 8 : 4 / J)>(bx, by, bd, ix, iy, i0, bits_x, bits_y, col, pos);
+        } else {
+            // eight terms: the values of X for two bits alone would fill the registers; the second X bit is walked outside
+            double acc = 0.0;
+#pragma nounroll
+            for (int o = 0; o < 2; ++o)
+                acc += contract_block<real, J, 1, 3, 1>(bx, by, bd, o ? ix ^ col[0] : ix, iy, o ? i0 ^ pos[0] : i0, bits_x, bits_y,
+                                                        col + 1, pos + 1);
+            return acc;
+        }
+    }
+    if (lx == 1) return contract_block<real, J, 1, 4, (J == 1 ? 16 : 8 / J)>(bx, by, bd, ix, iy, i0, bits_x, bits_y, col, pos);
+    return contract_block<real, J, 0, 5, (J == 1 ? 16 : 8 / J)>(bx, by, bd, ix, iy, i0, bits_x, bits_y, col, pos);
 }
 
+// (Measured: one launch per number of terms instead of the switch below costs more than it saves -- the classes with
+// several keys hold a few evaluations each and a small launch still takes ten microseconds.)
 template <typename real>
 __global__ void __launch_bounds__(512, 4) contract_kernel(const uint32_t* __restrict__ plan_arena,
                                                           const EvalDesc* __restrict__ evals,
@@ -1157,36 +1169,32 @@ __global__ void __launch_bounds__(512, 4) contract_kernel(const uint32_t* __rest
     }
     if (!(ev.flags & kEvalSide)) return;
     cu32p sp = as_constant(plan_arena) + ev.split_base;
-    const uint32_t n_keys = sp[0];
-    const bool swap = sp[3] & 1u;
-    const uint32_t lx = sp[3] >> 8;
-    const uint32_t bits_x = sp[swap ? 2 : 1], bits_y = sp[swap ? 1 : 2];
-    cu32p colx = sp + (swap ? kSplitColsB : kSplitColsA), coly = sp + (swap ? kSplitColsA : kSplitColsB);
-    cu32p order = sp + kSplitOrder;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t wave_bits = 25u - uint32_t(__builtin_clz(blockDim.x));  // log2(blockDim / 64)
+    // everything circuit-dependent: the header, and this thread's pieces of the two table indices
+    uint32_t hdr[16];
+    load_words<16>(sp, hdr);
+    const uint32_t* lane_entry = plan_arena + ev.split_base + kSplitLaneTable + 2 * (tid & 63u);
+    const uint32_t lane_x = lane_entry[0], lane_y = lane_entry[1];
+    cu32p we = sp + kSplitWaveTable + 2 * wave, c0 = sp + kSplitChunkLow + 2 * (chunk & 127u), c1 = sp + kSplitChunkHigh + 2 * (chunk >> 7);
+    const uint32_t ix = lane_x | we[0] | c0[0] | c1[0], iy = lane_y | we[1] | c0[1] | c1[1];
+    const uint32_t n_keys = hdr[0], bits_x = hdr[1], bits_y = hdr[2];
+    const bool swap = hdr[3] & 1u;
+    const uint32_t lx = hdr[3] >> 8;
+    uint32_t col[kSplitLoopBits], pos[kSplitLoopBits];
+#pragma unroll
+    for (int b = 0; b < kSplitLoopBits; ++b) {
+        col[b] = hdr[kSplitLoopCols + b];
+        pos[b] = hdr[kSplitLoopPos + b];
+    }
     const cx<real>* __restrict__ ta = wtabs + uint64_t(ev.state_slot) * wtab_stride;
     const unsigned char* bx = reinterpret_cast<const unsigned char*>(ta + (swap ? wtab_stride >> 1 : 0));
     const unsigned char* by = reinterpret_cast<const unsigned char*>(ta + (swap ? 0 : wtab_stride >> 1));
     const unsigned char* bd = reinterpret_cast<const unsigned char*>(diag);
-    const uint32_t tid = threadIdx.x;
-    const uint32_t wave_bits = 25u - uint32_t(__builtin_clz(blockDim.x));  // log2(blockDim / 64)
-    // the index this thread's block starts at: lanes, wave-index bits, then the chunk number spread over its bits
-    uint32_t i0 = tid & 63u;
-    for (uint32_t b = 0; b < wave_bits; ++b) i0 |= ((tid >> (6 + b)) & 1u) << order[6 + b];
-    const uint32_t first_chunk_bit = 6 + wave_bits + kSplitLoopBits;
-    for (uint32_t b = 0; first_chunk_bit + b < n_qubits; ++b) i0 |= ((chunk >> b) & 1u) << order[first_chunk_bit + b];
-    uint32_t ix = 0, iy = 0;
-    for (uint32_t p = 0; p < n_qubits; ++p)
-        if ((i0 >> p) & 1u) {
-            ix |= colx[p];
-            iy |= coly[p];
-        }
-    uint32_t col[kSplitLoopBits], pos[kSplitLoopBits];  // the thread's own bits: first LX of side X, then those of side Y
-#pragma unroll
-    for (int b = 0; b < kSplitLoopBits; ++b) {
-        const uint32_t p = order[6 + wave_bits + b];
-        pos[b] = 1u << p;
-        col[b] = uint32_t(b) < lx ? colx[p] : coly[p];
-    }
+    const uint32_t i0 = tid | chunk << (6 + wave_bits + kSplitLoopBits);  // (the thread's own bits start at 0)
+    // chunk sizes by number of terms: one term keeps every load of a thread in flight at once, eight walk the tables in
+    // small steps; all variants fit the same 128 registers
     double acc;
     if (n_keys == 0)
         acc = contract_by_shape<real, 1>(lx, bx, by, bd, ix, iy, i0, bits_x, bits_y, col, pos);
@@ -1198,7 +1206,7 @@ __global__ void __launch_bounds__(512, 4) contract_kernel(const uint32_t* __rest
         acc = contract_by_shape<real, 8>(lx, bx, by, bd, ix, iy, i0, bits_x, bits_y, col, pos);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
-    const uint32_t n_waves = blockDim.x >> 6, wave = tid >> 6;
+    const uint32_t n_waves = blockDim.x >> 6;
     const uint32_t slots = partial_chunks ? partial_chunks : n_chunks;
     if ((tid & 63u) == 0) {
         double* mine = partials + size_t(ev.out_index) * slots * n_waves + wave;

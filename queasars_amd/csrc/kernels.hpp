@@ -22,16 +22,20 @@ struct EvalDesc {
 // its own (region 0), side B in a second region of the descriptor array, which holds kEvalNull entries for everybody
 // else.  A side's pass kernel stores its final state in the side's half of the evaluation's compact-table slot.
 constexpr uint32_t kEvalSide = 1u, kEvalSideB = 2u, kEvalNull = 4u;
-// split block: [0] number of keys K  [1] qubits of side A  [2] of side B
-//              [3] bit 0: the contraction's X side is B (else A); bits 8..: LX, how many of a thread's own index bits
-//                  belong to side X (0 .. 2)
-//              [4 .. 36)  index bit p of the full register -> its bit in side A's table index (0 if p is not in A)
-//              [36 .. 68) the same for side B
-//              [68 .. 100) the contraction's use of the index bits, as positions: 6 lane bits (0 .. 5), the wave-index
-//                         bits of a workgroup, LX bits of side X and kSplitLoopBits - LX bits of side Y that every
-//                         thread walks itself -- all of these among the lowest 11 + wave bits, whatever the circuit --
-//                         then the bits numbered by the workgroup index (the top ones, ascending), pad 63
-constexpr uint32_t kSplitBlockWords = 100, kSplitColsA = 4, kSplitColsB = 36, kSplitOrder = 68;
+// split block (what the contraction kernel needs to know about one split circuit).  The roles of the index bits do not
+// depend on the circuit: bits 0 .. 5 are the lanes, the next W the wave index inside a workgroup (W = log2(threads / 64)),
+// the next kSplitLoopBits a thread's own bits (it walks their 32 combinations itself), the rest the chunk number.  Per
+// circuit: which side each of them belongs to, as ready-made pieces of the two table indices.
+//   [0] number of keys K  [1] index bits of side X's table (without the keys)  [2] of side Y's
+//   [3] bit 0: X is side B (else A); bits 8..: LX, how many of the thread's own bits belong to side X (0 .. 2: X is the
+//       side with fewer of them)
+//   [4 .. 9)    thread's own bit b (X's bits first, then Y's): its bit in the table index of the side it belongs to
+//   [9 .. 14)   ... and its value in the full index (1 << position)
+//   [16 .. 144)  lane l -> (x piece, y piece) of index bits 0 .. 5 = l
+//   [144 .. 160) wave w -> pieces of the wave-index bits
+//   [160 .. 416) chunk & 127 -> pieces of the low seven chunk bits      [416 .. 672) chunk >> 7 -> pieces of the rest
+constexpr uint32_t kSplitLoopCols = 4, kSplitLoopPos = 9, kSplitLaneTable = 16, kSplitWaveTable = 144,
+                   kSplitChunkLow = 160, kSplitChunkHigh = 416, kSplitBlockWords = 672;
 constexpr int kSplitLoopBits = 5, kSplitMaxLoopX = 2;
 
 enum PassMode : uint32_t {

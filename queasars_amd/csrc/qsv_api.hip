@@ -379,67 +379,61 @@ int build_circuit(qsv_t* h, int n_ops, const qsv_op* ops, int n_params, bool fol
                     sp.off_side[s] = uint32_t(w.size());
                     w.insert(w.end(), p.words.begin(), p.words.end());
                 }
-                // the contraction kernel's use of the index bits (kernels.hpp, split block): 6 lanes, the wave-index bits of
-                // a workgroup, 2 bits of one side and 3 of the other for each thread's own block, the rest for the grid
+                // the contraction kernel's view of the circuit (kernels.hpp, split block): ready-made pieces of the two
+                // table indices for the lanes, the wave index, a thread's own five bits and the chunk number
                 const int wave_bits = h->geo.t > 6 ? h->geo.t - 6 : 0;
-                std::vector<uint32_t> order;
-                bool swap_xy = false;
-                int loop_x = 0;
-                const int middle_end = 6 + wave_bits + kSplitLoopBits;  // lanes, wave bits and a thread's own bits: [0, end)
-                fits = fits && h->n >= middle_end;
+                const int loop0 = 6 + wave_bits, chunk0 = loop0 + kSplitLoopBits;
+                fits = fits && h->n >= chunk0 && h->n - chunk0 <= 14;
                 if (fits) {
-                    // of a thread's five own bits as many as possible (up to 2) come from one side, the rest from the other
-                    auto middle_bits = [&](int side) {
-                        return __builtin_popcountll((sc.mask[side] >> 6) & ((uint64_t(1) << (middle_end - 6)) - 1));
-                    };
-                    bool found = false;
-                    for (int lx = sc.n_keys >= 3 ? 1 : kSplitMaxLoopX; lx >= 0 && !found; --lx)
-                        for (int sx = 0; sx < 2 && !found; ++sx)
-                            if (middle_bits(sx) >= lx && middle_bits(1 - sx) >= kSplitLoopBits - lx) {
-                                found = true;
-                                loop_x = lx;
-                                swap_xy = sx == 1;
-                            }
-                    fits = found;
-                }
-                if (fits) {
-                    std::vector<char> used(size_t(h->n), 0);
-                    for (int p = 0; p < 6; ++p) {
-                        order.push_back(uint32_t(p));
-                        used[size_t(p)] = 1;
-                    }
-                    std::vector<uint32_t> loops;
+                    int own_a = 0;  // how many of a thread's own bits belong to side A
+                    for (int b = 0; b < kSplitLoopBits; ++b) own_a += int(sc.mask[0] >> (loop0 + b) & 1u);
+                    const bool swap_xy = own_a > kSplitMaxLoopX;  // X = the side with fewer of them
                     const int sx = swap_xy ? 1 : 0;
-                    for (int which = 0; which < 2; ++which) {
-                        const int side = which == 0 ? sx : 1 - sx, want = which == 0 ? loop_x : kSplitLoopBits - loop_x;
-                        for (int p = 6, got = 0; p < middle_end && got < want; ++p)
-                            if (sc.mask[side] >> p & 1u) {
-                                loops.push_back(uint32_t(p));
-                                used[size_t(p)] = 1;
-                                ++got;
-                            }
+                    const int loop_x = swap_xy ? kSplitLoopBits - own_a : own_a;
+                    // bit of index position p in the table index of the side it belongs to
+                    std::vector<uint32_t> colx(size_t(h->n), 0), coly(size_t(h->n), 0);
+                    {
+                        int cx_ = 0, cy_ = 0;
+                        for (int q = 0; q < h->n; ++q) {
+                            if (sc.mask[sx] >> q & 1u)
+                                colx[size_t(q)] = 1u << cx_++;
+                            else
+                                coly[size_t(q)] = 1u << cy_++;
+                        }
                     }
-                    for (int p = 6; p < middle_end; ++p)
-                        if (!used[size_t(p)]) order.push_back(uint32_t(p));  // the wave-index bits
-                    order.insert(order.end(), loops.begin(), loops.end());
-                    for (int p = middle_end; p < h->n; ++p) order.push_back(uint32_t(p));
-                }
-                if (fits) {
+                    auto pieces = [&](uint64_t index_bits, uint32_t* out) {  // (x piece, y piece) of a set of index bits
+                        out[0] = out[1] = 0;
+                        for (int q = 0; q < h->n; ++q)
+                            if (index_bits >> q & 1u) {
+                                out[0] |= colx[size_t(q)];
+                                out[1] |= coly[size_t(q)];
+                            }
+                    };
                     sp.off_block = uint32_t(w.size());
                     w.resize(w.size() + kSplitBlockWords, 0);
                     uint32_t* blk = w.data() + sp.off_block;
                     blk[0] = uint32_t(sc.n_keys);
-                    blk[1] = uint32_t(sc.n_side[0]);
-                    blk[2] = uint32_t(sc.n_side[1]);
+                    blk[1] = uint32_t(sc.n_side[sx]);
+                    blk[2] = uint32_t(sc.n_side[1 - sx]);
                     blk[3] = (swap_xy ? 1u : 0u) | uint32_t(loop_x) << 8;
-                    int ca = 0, cb = 0;
-                    for (int q = 0; q < h->n; ++q) {
-                        if (sc.mask[0] >> q & 1u)
-                            blk[kSplitColsA + q] = 1u << ca++;
-                        else
-                            blk[kSplitColsB + q] = 1u << cb++;
+                    {
+                        int at = 0;
+                        for (int which = 0; which < 2; ++which)
+                            for (int b = 0; b < kSplitLoopBits; ++b) {
+                                const int q = loop0 + b;
+                                const bool is_x = sc.mask[sx] >> q & 1u;
+                                if (is_x != (which == 0)) continue;
+                                blk[kSplitLoopCols + at] = is_x ? colx[size_t(q)] : coly[size_t(q)];
+                                blk[kSplitLoopPos + at] = 1u << q;
+                                ++at;
+                            }
                     }
-                    for (uint32_t j = 0; j < 32; ++j) blk[kSplitOrder + j] = j < order.size() ? order[j] : 63u;
+                    for (uint32_t l = 0; l < 64; ++l) pieces(l, blk + kSplitLaneTable + 2 * l);
+                    for (uint32_t v = 0; v < (1u << wave_bits); ++v) pieces(uint64_t(v) << 6, blk + kSplitWaveTable + 2 * v);
+                    for (uint32_t c = 0; c < 128; ++c) {
+                        pieces((uint64_t(c) << chunk0) & ((uint64_t(1) << h->n) - 1), blk + kSplitChunkLow + 2 * c);
+                        pieces((uint64_t(c) << (chunk0 + 7)) & ((uint64_t(1) << h->n) - 1), blk + kSplitChunkHigh + 2 * c);
+                    }
                     sp.n_keys = sc.n_keys;
                     sp.ok = true;
                 } else {
@@ -910,15 +904,18 @@ int eval_push(qsv_t* h, size_t first, size_t count, const double* values) {
         // it has nothing to do still costs its dispatch, and a mixed launch was mostly such workgroups
         const size_t P = b.circs.size();
         std::vector<EvalDesc> tmp(hd + first, hd + first + count), tmp2(hd + P + first, hd + P + first + count);
+        // (... and among the split ones those with more keys first: their workgroups of the contraction take longest and
+        // should not be the tail of the launch)
         size_t at = first;
-        for (int pass = 0; pass < 2; ++pass)
-            for (size_t j = 0; j < count; ++j)
-                if (bool(b.split[first + j]) == (pass == 0)) {
-                    hd[at] = tmp[j];
-                    hd[P + at] = tmp2[j];
-                    b.eval_at[at] = uint32_t(first + j);
-                    ++at;
-                }
+        for (int cls = kMaxSplitKeys; cls >= -1; --cls)
+            for (size_t j = 0; j < count; ++j) {
+                const int mine = b.split[first + j] ? b.circs[first + j]->split.n_keys : -1;
+                if (mine != cls) continue;
+                hd[at] = tmp[j];
+                hd[P + at] = tmp2[j];
+                b.eval_at[at] = uint32_t(first + j);
+                ++at;
+            }
     }
     b.n_pushes += 1;
     int rc = batch_ship(h, first, count, values);

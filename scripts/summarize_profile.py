@@ -26,7 +26,7 @@ for path in glob.glob(f"{root}/pmc_*/**/*counter_collection.csv", recursive=True
         for r in csv.DictReader(f):
             acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for kern, counters in acc.items():
-    if "pass_kernel" not in kern and "reduce" not in kern and "prepare" not in kern:
+    if not any(k in kern for k in ("pass_kernel", "contract_kernel", "reduce", "prepare")):
         continue
     print(kern)
     for cname, vals in sorted(counters.items()):
