@@ -1147,71 +1147,78 @@ __global__ void __launch_bounds__(512, 4) contract_kernel(const uint32_t* __rest
                                                           const cx<real>* __restrict__ wtabs, const double* __restrict__ diag,
                                                           double* __restrict__ partials, uint64_t wtab_stride,
                                                           uint32_t n_qubits, uint32_t partial_chunks, uint32_t n_chunks,
-                                                          uint32_t n_evals) {
-    // workgroup -> (evaluation, chunk of the index space): consecutive workgroups go to consecutive XCDs, so chunk c is
-    // handled by XCD c mod 8 for every evaluation (when there are at least 8 chunks)
-    uint32_t chunk, which;
+                                                          uint32_t n_evals, uint32_t evals_per_group) {
+    // workgroup -> (group of evaluations, chunk of the index space): consecutive workgroups go to consecutive XCDs, so
+    // chunk c is handled by XCD c mod 8 for every evaluation (when there are at least 8 chunks).  A workgroup takes
+    // evals_per_group evaluations one after the other (1 unless QSV_CONTRACT_GROUP says otherwise, see launch_contract).
+    const uint32_t n_groups = (n_evals + evals_per_group - 1) / evals_per_group;
+    uint32_t chunk, group;
     if ((n_chunks & 7u) == 0) {
         const uint32_t xcd = blockIdx.x & 7u, rest = blockIdx.x >> 3;
-        which = rest % n_evals;
-        chunk = (rest / n_evals) * 8u + xcd;
+        group = rest % n_groups;
+        chunk = (rest / n_groups) * 8u + xcd;
     } else {
-        which = blockIdx.x % n_evals;
-        chunk = blockIdx.x / n_evals;
+        group = blockIdx.x % n_groups;
+        chunk = blockIdx.x / n_groups;
     }
-    EvalDesc ev;
-    {
-        cu32p e = as_constant(reinterpret_cast<const uint32_t*>(evals + which));
-        ev.state_slot = e[2];
-        ev.out_index = e[3];
-        ev.flags = e[6];
-        ev.split_base = e[7];
-    }
-    if (!(ev.flags & kEvalSide)) return;
-    cu32p sp = as_constant(plan_arena) + ev.split_base;
     const uint32_t tid = threadIdx.x;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t wave_bits = 25u - uint32_t(__builtin_clz(blockDim.x));  // log2(blockDim / 64)
-    // everything circuit-dependent: the header, and this thread's pieces of the two table indices
-    uint32_t hdr[16];
-    load_words<16>(sp, hdr);
-    const uint32_t* lane_entry = plan_arena + ev.split_base + kSplitLaneTable + 2 * (tid & 63u);
-    const uint32_t lane_x = lane_entry[0], lane_y = lane_entry[1];
-    cu32p we = sp + kSplitWaveTable + 2 * wave, c0 = sp + kSplitChunkLow + 2 * (chunk & 127u), c1 = sp + kSplitChunkHigh + 2 * (chunk >> 7);
-    const uint32_t ix = lane_x | we[0] | c0[0] | c1[0], iy = lane_y | we[1] | c0[1] | c1[1];
-    const uint32_t n_keys = hdr[0], bits_x = hdr[1], bits_y = hdr[2];
-    const bool swap = hdr[3] & 1u;
-    const uint32_t lx = hdr[3] >> 8;
-    uint32_t col[kSplitLoopBits], pos[kSplitLoopBits];
-#pragma unroll
-    for (int b = 0; b < kSplitLoopBits; ++b) {
-        col[b] = hdr[kSplitLoopCols + b];
-        pos[b] = hdr[kSplitLoopPos + b];
-    }
-    const cx<real>* __restrict__ ta = wtabs + uint64_t(ev.state_slot) * wtab_stride;
-    const unsigned char* bx = reinterpret_cast<const unsigned char*>(ta + (swap ? wtab_stride >> 1 : 0));
-    const unsigned char* by = reinterpret_cast<const unsigned char*>(ta + (swap ? 0 : wtab_stride >> 1));
-    const unsigned char* bd = reinterpret_cast<const unsigned char*>(diag);
     const uint32_t i0 = tid | chunk << (6 + wave_bits + kSplitLoopBits);  // (the thread's own bits start at 0)
-    // chunk sizes by number of terms: one term keeps every load of a thread in flight at once, eight walk the tables in
-    // small steps; all variants fit the same 128 registers
-    double acc;
-    if (n_keys == 0)
-        acc = contract_by_shape<real, 1>(lx, bx, by, bd, ix, iy, i0, bits_x, bits_y, col, pos);
-    else if (n_keys == 1)
-        acc = contract_by_shape<real, 2>(lx, bx, by, bd, ix, iy, i0, bits_x, bits_y, col, pos);
-    else if (n_keys == 2)
-        acc = contract_by_shape<real, 4>(lx, bx, by, bd, ix, iy, i0, bits_x, bits_y, col, pos);
-    else
-        acc = contract_by_shape<real, 8>(lx, bx, by, bd, ix, iy, i0, bits_x, bits_y, col, pos);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    const unsigned char* bd = reinterpret_cast<const unsigned char*>(diag);
     const uint32_t n_waves = blockDim.x >> 6;
     const uint32_t slots = partial_chunks ? partial_chunks : n_chunks;
-    if ((tid & 63u) == 0) {
-        double* mine = partials + size_t(ev.out_index) * slots * n_waves + wave;
-        mine[size_t(chunk) * n_waves] = acc;
-        for (uint32_t b2 = chunk + n_chunks; b2 < slots; b2 += n_chunks) mine[size_t(b2) * n_waves] = 0.0;
+    const uint32_t last = min(n_evals, (group + 1) * evals_per_group);
+#pragma nounroll
+    for (uint32_t which = group * evals_per_group; which < last; ++which) {
+        EvalDesc ev;
+        {
+            cu32p e = as_constant(reinterpret_cast<const uint32_t*>(evals + which));
+            ev.state_slot = e[2];
+            ev.out_index = e[3];
+            ev.flags = e[6];
+            ev.split_base = e[7];
+        }
+        if (!(ev.flags & kEvalSide)) continue;
+        cu32p sp = as_constant(plan_arena) + ev.split_base;
+        // everything circuit-dependent: the header, and this thread's pieces of the two table indices
+        uint32_t hdr[16];
+        load_words<16>(sp, hdr);
+        const uint32_t* lane_entry = plan_arena + ev.split_base + kSplitLaneTable + 2 * (tid & 63u);
+        const uint32_t lane_x = lane_entry[0], lane_y = lane_entry[1];
+        cu32p we = sp + kSplitWaveTable + 2 * wave, c0 = sp + kSplitChunkLow + 2 * (chunk & 127u),
+              c1 = sp + kSplitChunkHigh + 2 * (chunk >> 7);
+        const uint32_t ix = lane_x | we[0] | c0[0] | c1[0], iy = lane_y | we[1] | c0[1] | c1[1];
+        const uint32_t n_keys = hdr[0], bits_x = hdr[1], bits_y = hdr[2];
+        const bool swap = hdr[3] & 1u;
+        const uint32_t lx = hdr[3] >> 8;
+        uint32_t col[kSplitLoopBits], pos[kSplitLoopBits];
+#pragma unroll
+        for (int b = 0; b < kSplitLoopBits; ++b) {
+            col[b] = hdr[kSplitLoopCols + b];
+            pos[b] = hdr[kSplitLoopPos + b];
+        }
+        const cx<real>* __restrict__ ta = wtabs + uint64_t(ev.state_slot) * wtab_stride;
+        const unsigned char* bx = reinterpret_cast<const unsigned char*>(ta + (swap ? wtab_stride >> 1 : 0));
+        const unsigned char* by = reinterpret_cast<const unsigned char*>(ta + (swap ? 0 : wtab_stride >> 1));
+        // chunk sizes by number of terms: one term keeps every load of a thread in flight at once, eight walk the tables
+        // in small steps; all variants fit the same 128 registers
+        double acc;
+        if (n_keys == 0)
+            acc = contract_by_shape<real, 1>(lx, bx, by, bd, ix, iy, i0, bits_x, bits_y, col, pos);
+        else if (n_keys == 1)
+            acc = contract_by_shape<real, 2>(lx, bx, by, bd, ix, iy, i0, bits_x, bits_y, col, pos);
+        else if (n_keys == 2)
+            acc = contract_by_shape<real, 4>(lx, bx, by, bd, ix, iy, i0, bits_x, bits_y, col, pos);
+        else
+            acc = contract_by_shape<real, 8>(lx, bx, by, bd, ix, iy, i0, bits_x, bits_y, col, pos);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+        if ((tid & 63u) == 0) {
+            double* mine = partials + size_t(ev.out_index) * slots * n_waves + wave;
+            mine[size_t(chunk) * n_waves] = acc;
+            for (uint32_t b2 = chunk + n_chunks; b2 < slots; b2 += n_chunks) mine[size_t(b2) * n_waves] = 0.0;
+        }
     }
 }
 
@@ -1220,15 +1227,21 @@ hipError_t launch_contract(int dtype, unsigned n_chunks, unsigned n_evals, int t
     if (threads < 64 || threads > 512 || (threads & (threads - 1))) return hipErrorInvalidValue;
     // every index once: n_chunks workgroups x threads x the 32 amplitudes of a thread's block
     if (uint64_t(n_chunks) * uint64_t(threads) << kSplitLoopBits != uint64_t(1) << n || n > 28) return hipErrorInvalidValue;
-    const dim3 grid(n_chunks * n_evals);
+    // One evaluation per workgroup.  (QSV_CONTRACT_GROUP = e lets a workgroup take e evaluations in turn -- fewer
+    // workgroups to dispatch; measured slower at n = 20: 44 us per launch of 32 evaluations for e = 1, 47 / 55 / 49 / 60
+    // for e = 2 / 4 / 8 / 16: the evaluations of a workgroup run one after the other, each with its own chain of loads.)
+    static const unsigned env_group = getenv("QSV_CONTRACT_GROUP") ? unsigned(atoi(getenv("QSV_CONTRACT_GROUP"))) : 0u;
+    const unsigned per_group = std::min(std::max(1u, env_group), std::max(1u, n_evals));
+    const unsigned n_groups = (n_evals + per_group - 1) / per_group;
+    const dim3 grid(n_chunks * n_groups);
     if (dtype == 0)
         hipLaunchKernelGGL(contract_kernel<double>, grid, dim3(threads), 0, stream, a.plan, a.evals,
                            static_cast<const cx<double>*>(a.wtab), a.diag, a.partials, a.wtab_stride, n, a.partial_chunks,
-                           n_chunks, n_evals);
+                           n_chunks, n_evals, per_group);
     else
         hipLaunchKernelGGL(contract_kernel<float>, grid, dim3(threads), 0, stream, a.plan, a.evals,
                            static_cast<const cx<float>*>(a.wtab), a.diag, a.partials, a.wtab_stride, n, a.partial_chunks,
-                           n_chunks, n_evals);
+                           n_chunks, n_evals, per_group);
     return hipGetLastError();
 }
 
