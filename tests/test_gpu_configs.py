@@ -478,3 +478,84 @@ def test_nft_last_layer_search_on_the_device():
     ind = searched.individuals[3]
     got = ev.evaluate_circuits([ind.get_parameterized_quantum_circuit()], [list(ind.parameter_values)])[0]
     assert abs(got - helpers.oracle_expectation(ind.get_parameterized_quantum_circuit(), list(ind.parameter_values), op)) < EXP_TOL
+
+
+# ---- (k) register splitting (csrc/split.hpp): the contraction path against the pass path and the oracle ----------------
+
+
+def _split_device(n, split, **kwargs):
+    """A device with register splitting on or off (the library reads QSV_SPLIT when the handle is created)."""
+    import os
+
+    old = os.environ.get("QSV_SPLIT")
+    os.environ["QSV_SPLIT"] = "1" if split else "0"
+    try:
+        return StatevectorDevice(n, **kwargs)
+    finally:
+        if old is None:
+            del os.environ["QSV_SPLIT"]
+        else:
+            os.environ["QSV_SPLIT"] = old
+
+
+def _split_keys(circuit, max_side):
+    ops = circuit.packed()
+    cap = 4 * len(ops) + 64
+    a, b = np.zeros(cap, dtype=QSV_OP_DTYPE), np.zeros(cap, dtype=QSV_OP_DTYPE)
+    na, nb, mask = C.c_int(0), C.c_int(0), C.c_uint64(0)
+    return _lib.load().qsv_split_describe(circuit.n_qubits, len(ops), _lib.as_ptr(ops), max_side, C.byref(mask), _lib.as_ptr(a), cap,
+                                          C.byref(na), _lib.as_ptr(b), cap, C.byref(nb))
+
+
+@pytest.mark.parametrize("n,layers,count", [(14, 5, 24), (16, 6, 32), (20, 4, 64), (20, 5, 32), (22, 5, 16)])
+def test_split_evaluations_agree_with_the_pass_path(n, layers, count):
+    """The same population through the split path (virtual circuits + contraction kernel) and through the ordinary
+    multi-pass path: |dE| <= 1e-10, for circuits without a key, with one to three keys, with virtual circuits larger than
+    a tile, and for circuits that cannot be split at all (deeper ones), mixed in one batch."""
+    _, circuits, params = helpers.population_circuits(n, layers, count, seed=40 + n)
+    op = helpers.random_ising_operator(n, seed=n)
+    tile = 12 if n < 21 else 13
+    keys = [_split_keys(c, tile) for c in circuits]
+    keys = [k if k >= 0 else _split_keys(c, min(tile + 2, n - 1)) for k, c in zip(keys, circuits)]
+    assert max(keys) >= 1 and min(keys) <= 0, keys  # the population exercises keys, and key-less or unsplit circuits
+    split = OperatorCircuitEvaluator(op, statevector_device=_split_device(n, True)).evaluate_circuits(circuits, params)
+    plain = OperatorCircuitEvaluator(op, statevector_device=_split_device(n, False)).evaluate_circuits(circuits, params)
+    assert np.abs(np.asarray(split) - np.asarray(plain)).max() < EXP_TOL
+    # a small sample against the NumPy oracle as well
+    for i in (0, count // 2, count - 1):
+        if n <= 16:
+            assert abs(split[i] - helpers.oracle_expectation(circuits[i], params[i], op)) < EXP_TOL
+
+
+def test_split_results_do_not_depend_on_the_batch(c_oracle):
+    """Bitwise: an evaluation's value is the same alone, in a batch of split evaluations and in a batch mixed with
+    circuits that keep the ordinary plan; and it matches the C oracle at n = 20."""
+    n = 20
+    _, shallow, ps = helpers.population_circuits(n, 4, 12, seed=7)
+    _, deep, pd = helpers.population_circuits(n, 9, 3, seed=8)
+    assert all(_split_keys(c, 12) < 0 and _split_keys(c, 14) < 0 for c in deep)
+    op = helpers.random_ising_operator(n, seed=3)
+    ev = OperatorCircuitEvaluator(op)
+    alone = [ev.evaluate_circuits([c], [p])[0] for c, p in zip(shallow, ps)]
+    together = ev.evaluate_circuits(shallow, ps)
+    mixed = ev.evaluate_circuits(deep[:2] + shallow + deep[2:], pd[:2] + ps + pd[2:])
+    assert together == alone and mixed[2:-1] == alone
+    table = c_oracle.diagonal_table(op)
+    scratch = np.zeros(2 << n)
+    ref = [c_oracle.evaluate(c, p, op, table, scratch) for c, p in zip(shallow[:4], ps[:4])]
+    assert np.abs(np.asarray(alone[:4]) - np.asarray(ref)).max() < EXP_TOL
+
+
+def test_split_fp32_and_general_operators():
+    """fp32 tables through the contraction kernel (within the fp32 bound of the fp64 value); a general operator never
+    takes the split path (it needs the state) and still agrees."""
+    n = 18
+    _, circuits, params = helpers.population_circuits(n, 4, 16, seed=5)
+    op = helpers.random_ising_operator(n, seed=9)
+    want = np.asarray(OperatorCircuitEvaluator(op).evaluate_circuits(circuits, params))
+    got32 = np.asarray(OperatorCircuitEvaluator(op, dtype="fp32").evaluate_circuits(circuits, params))
+    assert np.abs(got32 - want).max() < FP32_REL * float(np.abs(op.coeffs).sum())
+    general = helpers.random_pauli_operator(n, 12, seed=4)
+    a = OperatorCircuitEvaluator(general, statevector_device=_split_device(n, True)).evaluate_circuits(circuits[:4], params[:4])
+    b = OperatorCircuitEvaluator(general, statevector_device=_split_device(n, False)).evaluate_circuits(circuits[:4], params[:4])
+    assert np.abs(np.asarray(a) - np.asarray(b)).max() < EXP_TOL
