@@ -4,6 +4,7 @@
  * one push of the benchmark population, which delayed the later pushes of a step by more than a kernel's length. */
 #define PY_SSIZE_T_CLEAN
 #include <Python.h>
+#include <stdlib.h>
 
 #include "../../include/qsv.h"
 
@@ -63,7 +64,13 @@ int qsv_py_expectation_values(qsv_t* h, Py_ssize_t n, const int* ids, const int6
     Py_END_ALLOW_THREADS
     if (rc) return rc;
     const Py_ssize_t group = qsv_group_size(h) > 0 ? qsv_group_size(h) : 1;
-    Py_ssize_t step = (n + 1) / 2 > 8 ? (n + 1) / 2 : 8;
+    /* (QSV_PUSHES = p: p pushes per population instead of two, for measurements) */
+    static int pushes = 0;
+    if (pushes == 0) {
+        const char* env = getenv("QSV_PUSHES");
+        pushes = env && atoi(env) > 0 ? atoi(env) : 2;
+    }
+    Py_ssize_t step = (n + pushes - 1) / pushes > 8 ? (n + pushes - 1) / pushes : 8;
     if (step > group) step = group;
     int failed = 0, py_error = 0;
     Py_ssize_t offset = 0;
