@@ -49,8 +49,17 @@ struct SplitInfo {
 struct Circuit {
     int n_params = 0;
     int n_gates = 0;                // non-identity ops
-    CircuitPlan plan;
+    CircuitPlan plan;               // words: everything of this circuit that lives in the device arena; stats: of the
+                                    // ordinary multi-pass plan, once it exists
     SplitInfo split;
+    // The ordinary plan of a circuit that has a split form is scheduled when something first needs it (a general
+    // operator, a state read-out, sampling): a population of fresh structures under a diagonal operator never does,
+    // and its scheduling was half the cost of registering a structure.
+    bool has_plan = false;
+    uint32_t off_plan = 0;          // word offset of the ordinary plan inside plan.words
+    bool fold = true;
+    std::vector<GateIn> gates;      // (kept until the ordinary plan is built)
+    std::vector<AngleSource> angles;
     bool uploaded = false;
     bool staged = false;            // scratch flag of upload_plans (a circuit may appear several times in a batch)
     uint32_t plan_base = 0;         // word offset in the device arena
@@ -350,10 +359,10 @@ int build_circuit(qsv_t* h, int n_ops, const qsv_op* ops, int n_params, bool fol
     std::vector<AngleSource> angles;
     std::vector<GateIn> gates = gates_of(ops, n_ops, &angles);
     out->n_gates = int(gates.size());
+    out->fold = fold;
     try {
         PlanConfig pc = h->cfg;
         pc.fold = pc.fold && fold;
-        out->plan = build_plan(h->n, gates, angles, pc);
         if (h->split_enabled && pc.fold && h->n > h->geo.k && h->n <= 28) {  // (28: the contraction's 32-bit byte offsets into D)
             // a virtual circuit may be up to two qubits larger than a tile (it then takes the pass kernel two passes over
             // four tiles: nothing next to the 2^n indices of the contraction)
@@ -442,10 +451,42 @@ int build_circuit(qsv_t* h, int n_ops, const qsv_op* ops, int n_params, bool fol
                 }
             }
         }
+        if (out->split.ok) {
+            out->gates = std::move(gates);
+            out->angles = std::move(angles);
+        } else {
+            const CircuitPlan p = build_plan(h->n, gates, angles, pc);
+            out->off_plan = uint32_t(out->plan.words.size());
+            out->plan.words.insert(out->plan.words.end(), p.words.begin(), p.words.end());
+            out->plan.stats = p.stats;
+            out->has_plan = true;
+        }
     } catch (const std::exception& e) {
         if (err) *err = std::string("plan: ") + e.what();
         return QSV_E_ARG;
     }
+    return QSV_OK;
+}
+
+// The ordinary plan of a circuit registered in split form, on first need (caller holds the handle).
+int ensure_plan(qsv_t* h, Circuit& c) {
+    if (c.has_plan) return QSV_OK;
+    try {
+        PlanConfig pc = h->cfg;
+        pc.fold = pc.fold && c.fold;
+        const CircuitPlan p = build_plan(h->n, c.gates, c.angles, pc);
+        c.off_plan = uint32_t(c.plan.words.size());
+        c.plan.words.insert(c.plan.words.end(), p.words.begin(), p.words.end());
+        c.plan.stats = p.stats;
+    } catch (const std::exception& e) {
+        return fail(h, QSV_E_ARG, std::string("plan: ") + e.what());
+    }
+    c.has_plan = true;
+    c.uploaded = false;  // (the arena copy, if any, lacks the new words)
+    c.gates.clear();
+    c.gates.shrink_to_fit();
+    c.angles.clear();
+    c.angles.shrink_to_fit();
     return QSV_OK;
 }
 
@@ -614,6 +655,8 @@ int batch_layout(qsv_t* h, const std::vector<Circuit*>& circs, const std::vector
     qsv_handle::Batch& b = h->batch;
     const size_t n_evals = circs.size();
     int rc;
+    for (Circuit* c : circs)
+        if (!(allow_split && c->split.ok) && (rc = ensure_plan(h, *c))) return rc;
     if ((rc = upload_plans(h, circs))) return rc;
     size_t total_params = 0, total_mats = 0;
     b.split.assign(n_evals, 0);
@@ -646,7 +689,7 @@ int batch_layout(qsv_t* h, const std::vector<Circuit*>& circs, const std::vector
         const Circuit& c = *circs[i];
         const uint32_t slot = uint32_t(i % size_t(h->group));
         if (!b.split[i]) {
-            hd[i] = EvalDesc{c.plan_base, uint32_t(mcur), slot, uint32_t(i), uint32_t(pcur), uint32_t(n_params[i]), 0, 0};
+            hd[i] = EvalDesc{c.plan_base + c.off_plan, uint32_t(mcur), slot, uint32_t(i), uint32_t(pcur), uint32_t(n_params[i]), 0, 0};
             mcur += mat_doubles_of(h, c, false, 0);
             if (b.split_any) hd[n_evals + i] = EvalDesc{0, 0, slot, uint32_t(i), 0, 0, kEvalNull, 0};
         } else {
