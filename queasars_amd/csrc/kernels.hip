@@ -1168,9 +1168,10 @@ __global__ void __launch_bounds__(512, 4) contract_kernel(const uint32_t* __rest
     const unsigned char* bd = reinterpret_cast<const unsigned char*>(diag);
     const uint32_t n_waves = blockDim.x >> 6;
     const uint32_t slots = partial_chunks ? partial_chunks : n_chunks;
-    const uint32_t last = min(n_evals, (group + 1) * evals_per_group);
+    // (a group's evaluations are taken with stride n_groups: the descriptors are sorted by number of keys, and
+    // neighbours in that order cost the same -- a group of the expensive ones would be the launch's tail)
 #pragma nounroll
-    for (uint32_t which = group * evals_per_group; which < last; ++which) {
+    for (uint32_t which = group; which < n_evals; which += n_groups) {
         EvalDesc ev;
         {
             cu32p e = as_constant(reinterpret_cast<const uint32_t*>(evals + which));
