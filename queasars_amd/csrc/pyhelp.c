@@ -70,8 +70,10 @@ int qsv_py_expectation_values(qsv_t* h, Py_ssize_t n, const int* ids, const int6
         const char* env = getenv("QSV_PUSHES");
         pushes = env && atoi(env) > 0 ? atoi(env) : 2;
     }
+    /* (a push may hold more evaluations than a launch group: the library cuts it into groups itself, and split
+     * evaluations -- which need no resident state -- run in much larger groups than `group`) */
     Py_ssize_t step = (n + pushes - 1) / pushes > 8 ? (n + pushes - 1) / pushes : 8;
-    if (step > group) step = group;
+    (void)group;
     int failed = 0, py_error = 0;
     Py_ssize_t offset = 0;
     for (Py_ssize_t first = 0; first < n && !failed; first += step) {

@@ -196,6 +196,9 @@ struct qsv_handle {
     DeviceBuffer d_states;
     DeviceBuffer d_wtab;      // compact tables of pass 0 (plan.hpp COMPACT), one per state slot
     uint64_t wtab_stride = 0; // amplitudes per slot
+    DeviceBuffer d_side;      // final states of the virtual circuits of split evaluations (split.hpp): two halves per slot
+    uint64_t side_stride = 0; // amplitudes per slot
+    int side_slots = 0;       // a split evaluation needs no state, so many more of them than `group` run side by side
     DeviceBuffer d_batch;     // [EvalDesc x B][parameter vectors]
     DeviceBuffer d_mats;      // per evaluation: gate matrices in schedule order + product-state factors
     int tiles_per_block = 1;        // pass 0 (and the only pass of a small circuit)
@@ -791,6 +794,9 @@ int run_group(qsv_t* h, const std::vector<Circuit*>& circs, size_t first, size_t
     a.region_stride = uint32_t(circs.size());
     const uint64_t sweep = (uint64_t(1) << h->n) * h->amp_bytes;
     if (any_split) {
+        if (n_plain > 0) return fail(h, QSV_E_STATE, "internal: a launch group mixes split and ordinary evaluations");
+        a.wtab = h->d_side.ptr;  // (the side tables' own slots)
+        a.wtab_stride = h->side_stride;
         // both virtual circuits of every split evaluation (second descriptor region: z = 1): one tile and one pass each,
         // or up to four tiles and a few passes when a virtual circuit is larger than a tile
         int side_passes = 1;
@@ -923,29 +929,14 @@ int eval_push(qsv_t* h, size_t first, size_t count, const double* values) {
     } guard{h};
     h->stamping = h->profiling;
     EvalDesc* hd = static_cast<EvalDesc*>(h->h_batch);  // pinned; prepare_kernel reads it after this point
-    if (b.ways > 1) {
-        const size_t share = G / size_t(b.ways), side = size_t(b.n_pushes) % size_t(b.ways);
-        for (size_t j = 0; j < count; ++j) hd[first + j].state_slot = uint32_t(side * share + j % share);
-        if (b.split_any)
-            for (size_t j = 0; j < count; ++j) hd[b.circs.size() + first + j].state_slot = hd[first + j].state_slot;
-        G = share;
-        if (side) {
-            h->work = h->side_streams[side - 1];
-            b.used_mask |= 1u << (side - 1);
-        }
-    } else {
-        // every launch group of this push occupies slots 0 .. count-1 in order (the expectation kernels of the
-        // general-operator path index states by position in the group), wherever the push starts in the batch
-        for (size_t j = 0; j < count; ++j) hd[first + j].state_slot = uint32_t(j % G);
-        if (b.split_any)
-            for (size_t j = 0; j < count; ++j) hd[b.circs.size() + first + j].state_slot = hd[first + j].state_slot;
-    }
+    const size_t ways = size_t(std::max(1, b.ways)), lane = ways > 1 ? size_t(b.n_pushes) % ways : 0;
+    const size_t P = b.circs.size();
+    size_t n_split = 0;
     if (b.split_any) {
-        // descriptors of the push: split evaluations first, the others behind them (results, partial sums and state
-        // slots go by the descriptor's fields, not by its position), so that the side circuits, the ordinary passes and
-        // the contraction are each launched over the evaluations they concern -- a workgroup that only finds out that
-        // it has nothing to do still costs its dispatch, and a mixed launch was mostly such workgroups
-        const size_t P = b.circs.size();
+        // descriptors of the push: split evaluations first, the others behind them (results, partial sums and slots go
+        // by the descriptor's fields, not by its position), so that the side circuits, the ordinary passes and the
+        // contraction are each launched over the evaluations they concern -- a workgroup that only finds out that it
+        // has nothing to do still costs its dispatch, and a mixed launch was mostly such workgroups
         std::vector<EvalDesc> tmp(hd + first, hd + first + count), tmp2(hd + P + first, hd + P + first + count);
         // (... and among the split ones those with more keys first: their workgroups of the contraction take longest and
         // should not be the tail of the launch)
@@ -958,15 +949,45 @@ int eval_push(qsv_t* h, size_t first, size_t count, const double* values) {
                 hd[P + at] = tmp2[j];
                 b.eval_at[at] = uint32_t(first + j);
                 ++at;
+                if (cls >= 0) ++n_split;
             }
+    }
+    // Slots.  Ordinary evaluations: G states are resident together; on one stream the slot of an evaluation is its
+    // position mod G and the stream orders every reuse; with several streams each push takes its stream's share of the
+    // slots.  (The expectation kernels of the general-operator path index states by position in the launch group.)
+    // Split evaluations have no state, only two small tables: their own, much larger set of slots.
+    if (ways > 1) {
+        G = G / ways;
+        if (lane) {
+            h->work = h->side_streams[lane - 1];
+            b.used_mask |= 1u << (lane - 1);
+        }
+    }
+    const size_t SG = h->side_slots > 0 ? std::max<size_t>(1, size_t(h->side_slots) / ways) : 1;
+    for (size_t j = 0; j < n_split; ++j) {
+        const uint32_t slot = uint32_t(lane * SG + j % SG);
+        hd[first + j].state_slot = slot;
+        hd[P + first + j].state_slot = slot;
+    }
+    for (size_t j = n_split; j < count; ++j) {
+        const uint32_t slot = uint32_t(lane * G + (j - n_split) % G);
+        hd[first + j].state_slot = slot;
+        if (b.split_any) hd[P + first + j].state_slot = slot;
     }
     b.n_pushes += 1;
     int rc = batch_ship(h, first, count, values);
     if (rc) return rc;
     const uint32_t mode = kModeSynthFirst | (h->diagonal ? kModeFinalDiag : kModeFinalStore) |
                           (h->has_diag_part ? kModeFinalDiag : 0u);
-    for (size_t g0 = first; g0 < first + count; g0 += G) {
-        const size_t gc = std::min(G, first + count - g0);
+    // launch groups: the split evaluations of the push in groups of SG, then the ordinary ones in groups of G
+    for (size_t g0 = first; g0 < first + count;) {
+        const bool in_split = g0 < first + n_split;
+        const size_t gc = in_split ? std::min(SG, first + n_split - g0) : std::min(G, first + count - g0);
+        struct Advance {
+            size_t& g0;
+            size_t gc;
+            ~Advance() { g0 += gc; }
+        } advance{g0, gc};
         QSV_HIP(h, stamp(h, b.pass_events, true));
         rc = run_group(h, b.circs, g0, gc, mode);
         if (!rc) QSV_HIP(h, stamp(h, b.pass_events, false));
@@ -1187,6 +1208,14 @@ int qsv_create(int n_qubits, int dtype, int device, const qsv_plan_config* cfg, 
     if ((e = hipMalloc(&h->d_wtab.ptr, size_t(h->wtab_stride) * h->amp_bytes * size_t(group))) != hipSuccess)
         return bail(e, "hipMalloc(compact tables)");
     h->d_wtab.bytes = size_t(h->wtab_stride) * h->amp_bytes * size_t(group);
+    if (h->split_enabled && n_qubits > geo.k && n_qubits <= 28) {
+        // side tables of split evaluations: two virtual circuits of at most tile + 2 qubits per slot
+        h->side_stride = uint64_t(2) << (geo.k + 2);
+        h->side_slots = 128;
+        if ((e = hipMalloc(&h->d_side.ptr, size_t(h->side_stride) * h->amp_bytes * size_t(h->side_slots))) != hipSuccess)
+            return bail(e, "hipMalloc(side tables)");
+        h->d_side.bytes = size_t(h->side_stride) * h->amp_bytes * size_t(h->side_slots);
+    }
     if ((e = configure_pass_kernels(dtype, geo.r, pc.xmode, geo.lds_bytes)) != hipSuccess) return bail(e, "hipFuncSetAttribute");
     *out = h;
     return QSV_OK;
@@ -1204,7 +1233,7 @@ void qsv_destroy(qsv_t* h) {
     }
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     for (DeviceBuffer* b : {&h->d_z, &h->d_cre, &h->d_diag, &h->d_term_partials, &h->d_groups, &h->d_term_odd, &h->d_arena,
-                            &h->d_states, &h->d_wtab, &h->d_batch, &h->d_mats, &h->d_partials, &h->d_out, &h->d_scratch})
+                            &h->d_states, &h->d_wtab, &h->d_side, &h->d_batch, &h->d_mats, &h->d_partials, &h->d_out, &h->d_scratch})
         if (b->ptr) (void)hipFree(b->ptr);
     if (h->h_batch) (void)hipHostFree(h->h_batch);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
