@@ -1086,9 +1086,14 @@ __device__ __forceinline__ double contract_block(const unsigned char* __restrict
             const uint32_t idx = iy ^ sy, i = i0 ^ si;
 #pragma unroll
             for (int j = 0; j < J; ++j) {
+#ifndef QSV_ABL_CT_NOTAB
                 const cx<real> v = *reinterpret_cast<const cx<real>*>(by + (((uint32_t(j) << bits_y) + idx) << ASH));
                 yr[c][j] = double(v.re);
                 yi[c][j] = double(v.im);
+#else
+                yr[c][j] = double(idx + uint32_t(j));
+                yi[c][j] = double(idx);
+#endif
             }
 #pragma unroll
             for (int a = 0; a < NX; ++a) {
@@ -1096,7 +1101,11 @@ __device__ __forceinline__ double contract_block(const unsigned char* __restrict
 #pragma unroll
                 for (int b = 0; b < LX; ++b)
                     if (a >> b & 1) ia ^= pos[b];
+#ifndef QSV_ABL_CT_NOD  // (ablation builds, scripts/ablate.py: timing experiments with wrong results)
                 d[c][a] = *reinterpret_cast<const double*>(bd + (ia << 3));
+#else
+                d[c][a] = double(ia);
+#endif
             }
         }
 #pragma unroll
@@ -1111,7 +1120,11 @@ __device__ __forceinline__ double contract_block(const unsigned char* __restrict
                     pr = fma(xr[a][j], yr[c][j], fma(-xi[a][j], yi[c][j], pr));
                     pi = fma(xr[a][j], yi[c][j], fma(xi[a][j], yr[c][j], pi));
                 }
+#ifndef QSV_ABL_CT_NOMATH
                 acc = fma(fma(pr, pr, pi * pi), d[c][a], acc);
+#else
+                acc += d[c][a] + yr[c][0];
+#endif
             }
     }
     return acc;

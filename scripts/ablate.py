@@ -22,6 +22,12 @@ VARIANTS = {
     "noload_nof_nodiag": ("QSV_ABL_NOLOAD", "QSV_ABL_NOF", "QSV_ABL_NODIAG"),
     "nothing_but_memory": ("QSV_ABL_NOGATES", "QSV_ABL_NOSWAP"),
     "nothing_but_gates": ("QSV_ABL_NOLOAD", "QSV_ABL_NOF", "QSV_ABL_NODIAG", "QSV_ABL_NOSWAP"),
+    # the contraction kernel of split evaluations
+    "ct_nod": ("QSV_ABL_CT_NOD",),
+    "ct_notab": ("QSV_ABL_CT_NOTAB",),
+    "ct_nomath": ("QSV_ABL_CT_NOMATH",),
+    "ct_nod_notab": ("QSV_ABL_CT_NOD", "QSV_ABL_CT_NOTAB"),
+    "ct_nothing": ("QSV_ABL_CT_NOD", "QSV_ABL_CT_NOTAB", "QSV_ABL_CT_NOMATH"),
 }
 # variants of the GENERATED assembly round loop (production path): parts left out by gen_gate_loop.py (QSV_GEN_ABL)
 ASM_VARIANTS = {
