@@ -366,7 +366,10 @@ int build_circuit(qsv_t* h, int n_ops, const qsv_op* ops, int n_params, bool fol
     try {
         PlanConfig pc = h->cfg;
         pc.fold = pc.fold && fold;
-        if (h->split_enabled && pc.fold && h->n > h->geo.k && h->n <= 28) {  // (28: the contraction's 32-bit byte offsets into D)
+        // (not under a general operator: every evaluation then needs the state, i.e. the ordinary plan; a circuit registered
+        // now and evaluated under a diagonal operator later simply takes the ordinary path)
+        const bool state_needed = h->n_terms > 0 && !h->diagonal;
+        if (h->split_enabled && !state_needed && pc.fold && h->n > h->geo.k && h->n <= 28) {  // (28: the contraction's 32-bit byte offsets into D)
             // a virtual circuit may be up to two qubits larger than a tile (it then takes the pass kernel two passes over
             // four tiles: nothing next to the 2^n indices of the contraction)
             // ... but one tile each is what to look for first: no second pass, one workgroup per virtual circuit
@@ -658,8 +661,43 @@ int batch_layout(qsv_t* h, const std::vector<Circuit*>& circs, const std::vector
     qsv_handle::Batch& b = h->batch;
     const size_t n_evals = circs.size();
     int rc;
-    for (Circuit* c : circs)
-        if (!(allow_split && c->split.ok) && (rc = ensure_plan(h, *c))) return rc;
+    {
+        // ordinary plans that are needed now and do not exist yet (circuits registered in split form): scheduled on the
+        // host's worker threads when there are several
+        std::vector<Circuit*> missing;
+        for (Circuit* c : circs)
+            if (!(allow_split && c->split.ok) && !c->has_plan && std::find(missing.begin(), missing.end(), c) == missing.end())
+                missing.push_back(c);
+        if (missing.size() >= 4) {
+            std::vector<BuiltCircuit> built;
+            build_many(h, missing.size(), [&](size_t i, BuiltCircuit& out) {
+                Circuit& c = *missing[i];
+                try {
+                    PlanConfig pc = h->cfg;
+                    pc.fold = pc.fold && c.fold;
+                    out.circuit.plan = build_plan(h->n, c.gates, c.angles, pc);
+                } catch (const std::exception& e) {
+                    out.rc = QSV_E_ARG;
+                    out.err = std::string("plan: ") + e.what();
+                }
+            }, built);
+            for (size_t i = 0; i < missing.size(); ++i) {
+                if (built[i].rc) return fail(h, built[i].rc, built[i].err);
+                Circuit& c = *missing[i];
+                const CircuitPlan& p = built[i].circuit.plan;
+                c.off_plan = uint32_t(c.plan.words.size());
+                c.plan.words.insert(c.plan.words.end(), p.words.begin(), p.words.end());
+                c.plan.stats = p.stats;
+                c.has_plan = true;
+                c.uploaded = false;
+                c.gates.clear();
+                c.angles.clear();
+            }
+        } else {
+            for (Circuit* c : missing)
+                if ((rc = ensure_plan(h, *c))) return rc;
+        }
+    }
     if ((rc = upload_plans(h, circs))) return rc;
     size_t total_params = 0, total_mats = 0;
     b.split.assign(n_evals, 0);

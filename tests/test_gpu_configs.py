@@ -559,3 +559,23 @@ def test_split_fp32_and_general_operators():
     a = OperatorCircuitEvaluator(general, statevector_device=_split_device(n, True)).evaluate_circuits(circuits[:4], params[:4])
     b = OperatorCircuitEvaluator(general, statevector_device=_split_device(n, False)).evaluate_circuits(circuits[:4], params[:4])
     assert np.abs(np.asarray(a) - np.asarray(b)).max() < EXP_TOL
+
+
+def test_split_circuits_get_their_ordinary_plan_on_first_need():
+    """A circuit registered in split form has no multi-pass plan until something needs its state: the read-out and the
+    sampler build it then (several at once on the worker threads), and the split evaluation still works afterwards."""
+    n = 16
+    _, circuits, params = helpers.population_circuits(n, 4, 8, seed=11)
+    op = helpers.random_ising_operator(n, seed=2)
+    ev = OperatorCircuitEvaluator(op)
+    dev = ev.statevector_device
+    before = ev.evaluate_circuits(circuits, params)
+    ref = [helpers.oracle_expectation(c, p, op) for c, p in zip(circuits, params)]
+    assert np.abs(np.asarray(before) - np.asarray(ref)).max() < EXP_TOL
+    state = dev.statevector(circuits[0], params[0])
+    assert np.abs(state - helpers.oracle_state(circuits[0], params[0])).max() < 1e-12
+    states, _ = dev.sample_batch(circuits, params, shots=64, seed=5)  # the other seven plans in one go
+    assert np.asarray(states).shape == (8, 64)
+    probs = np.abs(helpers.oracle_state(circuits[3], params[3])) ** 2
+    assert all(probs[int(s)] > 0 for s in np.asarray(states)[3])
+    assert ev.evaluate_circuits(circuits, params) == before
