@@ -41,21 +41,31 @@ def evaluate_population_sharded(evaluator, circuits: Sequence, parameter_values:
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     lo, hi = shard_bounds(n, world, rank)
     local = evaluator.evaluate_circuits(list(circuits[lo:hi]), list(parameter_values[lo:hi])) if hi > lo else []
-    width = -(-n // world)  # every rank contributes a fixed-size slot so one all_gather_into_tensor suffices
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
-    send_host, send, recv, recv_host = _buffers(world, width, torch.device(device))
-    send_host.fill_(float("nan"))
-    if local:
-        send_host[: len(local)] = torch.as_tensor(np.asarray(local, dtype=np.float64))
+    return _gather(local, n, world, rank, group, torch.device(device))
+
+
+def _gather(local: Sequence[float], n: int, world: int, rank: int, group, device) -> list[float]:
+    """All ranks' blocks of fitness values, ordered by population index (``local`` is this rank's block)."""
+    import torch
+    import torch.distributed as dist
+
+    width = -(-n // world)  # every rank contributes a fixed-size slot so one all_gather_into_tensor suffices
+    send_host, send, recv, recv_host = _buffers(world, width, device)
     # pinned staging buffers and device tensors are kept between calls: the collective moves a few hundred bytes and
     # is latency bound, so every allocation and every synchronous pageable copy on its path counts
+    staged = send_host.numpy()
+    staged[: len(local)] = local
+    staged[len(local):] = np.nan
     send.copy_(send_host, non_blocking=True)
     dist.all_gather_into_tensor(recv, send, group=group)
     recv_host.copy_(recv, non_blocking=True)
     if recv.is_cuda:
         torch.cuda.current_stream(recv.device).synchronize()
     table = recv_host.numpy().reshape(world, width)
+    if n == world * width:
+        return table.ravel().tolist()
     out: list[float] = []
     for r in range(world):
         rlo, rhi = shard_bounds(n, world, r)
