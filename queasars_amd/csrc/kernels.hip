@@ -253,6 +253,10 @@ struct PassScalars {
     uint32_t tiles_per_block;
     uint32_t partial_chunks;
     uint32_t region_stride;
+    const EvalDesc* host_evals;
+    EvalDesc* evals_out;
+    const double* host_params;
+    double* mats_out;
 };
 
 // XMODE selects how a tile is transposed through LDS:
@@ -271,12 +275,12 @@ struct PassScalars {
 #define QSV_WAVES_R4 4
 #endif
 #ifndef QSV_WAVES_R4_FIRST
-#define QSV_WAVES_R4_FIRST 5
+#define QSV_WAVES_R4_FIRST 4
 #endif
 template <int R, int XMODE, bool FIRST>
 struct Occupancy {
     // 2^R amplitudes = 4 * 2^R VGPRs: R = 3 fits the 80-VGPR budget of 6 waves per SIMD, R = 4 needs the 128 of 4 --
-    // except in the synthesising pass 0, which has no load phase (its peak) and fits the 96 of 5
+    // (the synthesising pass 0 has no load phase and would fit the 96 of 5 waves; measured: no faster)
     static constexpr int waves_per_simd =
         R >= 4 ? (FIRST && XMODE == 2 ? QSV_WAVES_R4_FIRST : QSV_WAVES_R4) : (XMODE == 2 ? QSV_WAVES_PER_SIMD : 4);
 };
@@ -285,6 +289,169 @@ template <typename T>
 struct Log2Size;
 template <> struct Log2Size<float> { static constexpr int value = 2; };
 template <> struct Log2Size<double> { static constexpr int value = 3; };
+
+// ---- angles -> matrices ---------------------------------------------------------------------------------
+struct Angles {
+    double theta, phi, lam;
+};
+
+__device__ __forceinline__ Angles read_angles(const uint32_t* __restrict__ e, const double* __restrict__ params) {
+    const int32_t pt = int32_t(e[0]), pf = int32_t(e[1]), pl = int32_t(e[2]);
+    Angles a;
+    a.theta = pt >= 0 ? params[pt] : __hiloint2double(int(e[4]), int(e[3]));
+    a.phi = pf >= 0 ? params[pf] : __hiloint2double(int(e[6]), int(e[5]));
+    a.lam = pl >= 0 ? params[pl] : __hiloint2double(int(e[8]), int(e[7]));
+    return a;
+}
+
+// Qiskit UGate: [[cos(t/2), -e^{i lam} sin(t/2)], [e^{i phi} sin(t/2), e^{i(phi+lam)} cos(t/2)]]
+__device__ __forceinline__ void u_matrix(const Angles& a, double* m) {
+    double s, c, sl, cl, sp, cp, spl, cpl;
+    sincos(a.theta * 0.5, &s, &c);
+    sincos(a.lam, &sl, &cl);
+    sincos(a.phi, &sp, &cp);
+    sincos(a.phi + a.lam, &spl, &cpl);
+    m[0] = c;        m[1] = 0.0;
+    m[2] = -cl * s;  m[3] = -sl * s;
+    m[4] = cp * s;   m[5] = sp * s;
+    m[6] = cpl * c;  m[7] = spl * c;
+}
+
+// One angle-table entry -> matrix.  Entries with p_theta below -1 are the fixed matrices of split.hpp's virtual circuits.
+__device__ __forceinline__ void entry_matrix(const uint32_t* __restrict__ e, const double* __restrict__ params, double* m) {
+    const int32_t code = int32_t(e[0]);
+    if (code >= -1) {
+        u_matrix(read_angles(e, params), m);
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) m[i] = 0.0;
+    if (code == -2) {         // projector on |0>
+        m[0] = 1.0;
+    } else if (code == -3) {  // |0> -> |0> + |1>
+        m[0] = 1.0;
+        m[4] = 1.0;
+    } else {                  // X
+        m[2] = 1.0;
+        m[4] = 1.0;
+    }
+}
+
+// What prepare_kernel does for ONE evaluation, by one workgroup (every thread of it calls this; `sv` is scratch in LDS for
+// 128 doubles).  The pass kernel's synthesising instantiation runs it itself for the virtual circuits of split
+// evaluations (one launch and one dependent launch latency less in front of the contraction).
+__device__ __forceinline__ void prepare_eval(const uint32_t* __restrict__ plan, const EvalDesc& ev,
+                                             const double* __restrict__ params, double* __restrict__ mats, double* sv) {
+    const uint32_t* __restrict__ cp = plan + ev.plan_base;
+    const uint32_t n_passes = cp[0], n_real = cp[1], n_qubits = cp[2];
+    const uint32_t* __restrict__ table = cp + cp[3];
+    const uint32_t* __restrict__ fold = cp + cp[4];
+    const double* __restrict__ p = params + ev.param_base;
+    double* __restrict__ out = mats + ev.mat_base;
+    for (uint32_t j = threadIdx.x; j < n_real; j += blockDim.x) {
+        double m[8];
+        entry_matrix(table + size_t(j) * kAngleEntryWords, p, m);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) out[size_t(j) * 8 + i] = m[i];
+    }
+    for (uint32_t q = threadIdx.x; q < n_qubits; q += blockDim.x) {
+        const uint32_t first = fold[2 * q], count = fold[2 * q + 1];
+        double v0r = 1.0, v0i = 0.0, v1r = 0.0, v1i = 0.0;
+        for (uint32_t i = 0; i < count; ++i) {
+            double m[8];
+            entry_matrix(table + size_t(first + i) * kAngleEntryWords, p, m);
+            const double a0r = v0r, a0i = v0i, a1r = v1r, a1i = v1i;
+            v0r = m[0] * a0r - m[1] * a0i + m[2] * a1r - m[3] * a1i;
+            v0i = m[0] * a0i + m[1] * a0r + m[2] * a1i + m[3] * a1r;
+            v1r = m[4] * a0r - m[5] * a0i + m[6] * a1r - m[7] * a1i;
+            v1i = m[4] * a0i + m[5] * a0r + m[6] * a1i + m[7] * a1r;
+        }
+        double* o = out + size_t(n_real) * 8 + size_t(q) * 4;
+        o[0] = v0r; o[1] = v0i; o[2] = v1r; o[3] = v1i;
+        sv[4 * q] = v0r; sv[4 * q + 1] = v0i; sv[4 * q + 2] = v1r; sv[4 * q + 3] = v1i;
+    }
+    double* pad = out + size_t(n_real) * 8 + size_t(n_qubits) * 4;
+    // zero the padding the pass kernel's one-gate-ahead prefetch may read
+    for (uint32_t i = threadIdx.x; i < kMatPadDoubles; i += blockDim.x) pad[i] = 0.0;
+    if (n_passes == 0) return;
+    __syncthreads();
+
+    // Synthesis tables for pass 0 (the pass that writes the initial product state, amplitude(i) = prod_q v_q[i_q]):
+    //   thread_factor[tid] = product over the tile qubits that pass 0's load layout keeps on thread bits
+    //   tile_factor[tile]  = product over the qubits outside the tile
+    // The pass kernel multiplies the two and expands the register-held qubits itself.
+    const uint32_t* __restrict__ pp = cp + cp[kCircuitHeaderWords];
+    const uint32_t hdr = pp[0];
+    const int k = hdr & 0xff, t = (hdr >> 16) & 0xff;
+    const uint32_t* __restrict__ pos = pp + kPassHeaderWords;
+    const uint32_t* __restrict__ cols = pp + kPassLoadColsOffset;
+    uint32_t thread_mask = 0, tile_mask = 0;
+    for (int u = 0; u < t; ++u) thread_mask |= cols[u];
+    for (int j = 0; j < k; ++j) tile_mask |= 1u << pos[j];
+    double* thread_factor = pad + kMatPadDoubles;
+    double* tile_factor = thread_factor + (size_t(2) << t);
+    auto product = [&](uint64_t index, uint32_t qubits) {
+        double fr = 1.0, fi = 0.0;
+        for (uint32_t q = 0; q < n_qubits; ++q) {
+            if (!((qubits >> q) & 1u)) continue;
+            const double* v = sv + 4 * q + 2 * ((index >> q) & 1u);
+            const double nr = fr * v[0] - fi * v[1];
+            fi = fr * v[1] + fi * v[0];
+            fr = nr;
+        }
+        return make_double2(fr, fi);
+    };
+    for (uint32_t i = threadIdx.x; i < (1u << t); i += blockDim.x) {
+        uint32_t off = 0;
+        for (int u = 0; u < t; ++u) off ^= (0u - ((i >> u) & 1u)) & cols[u];
+        const double2 f = product(off, thread_mask);
+        thread_factor[2 * size_t(i)] = f.x;
+        thread_factor[2 * size_t(i) + 1] = f.y;
+    }
+    const uint32_t all_qubits = n_qubits >= 32 ? 0xffffffffu : ((1u << n_qubits) - 1u);
+    const uint32_t n_tiles = 1u << (n_qubits - uint32_t(k));
+    for (uint32_t tile = threadIdx.x; tile < n_tiles; tile += blockDim.x) {
+        uint64_t base = tile;
+        for (int j = 0; j < k; ++j) {
+            const uint32_t ps = pos[j];
+            base = ((base >> ps) << (ps + 1)) | (base & ((uint64_t(1) << ps) - 1));
+        }
+        const double2 f = product(base, all_qubits & ~tile_mask);
+        tile_factor[2 * size_t(tile)] = f.x;
+        tile_factor[2 * size_t(tile) + 1] = f.y;
+    }
+    // Per pass and tile: what the pass kernel needs to know about its tile number (kernels.hpp TileInfo).
+    TileInfo* info_all = reinterpret_cast<TileInfo*>(tile_factor + (size_t(2) << (n_qubits - uint32_t(k))));
+    for (uint32_t p = 0; p < n_passes; ++p) {
+        const uint32_t* __restrict__ ph = cp + cp[kCircuitHeaderWords + p];
+        const uint32_t* __restrict__ ppos = ph + kPassHeaderWords;
+        const uint32_t flags = ph[2];
+        const bool cstore = flags & kPassCompactStore, cload = flags & kPassCompactLoad;
+        const uint32_t count = cstore ? 1u << ((flags >> 8) & 0xffu) : n_tiles;
+        TileInfo* info = info_all + size_t(p) * n_tiles;
+        for (uint32_t tile = threadIdx.x; tile < count; tile += blockDim.x) {
+            uint64_t base;
+            if (cstore) {
+                base = 0;
+                for (uint32_t b = 0; b < kMaxCompactBits; ++b) base |= uint64_t((tile >> b) & 1u) << ph[kPassCompactOffset + b];
+            } else {
+                base = tile;
+                for (int j = 0; j < k; ++j) {
+                    const uint32_t ps = ppos[j];
+                    base = ((base >> ps) << (ps + 1)) | (base & ((uint64_t(1) << ps) - 1));
+                }
+            }
+            uint32_t wbase = 0, fbase = 0;
+            if (cload)
+                for (uint32_t b = 0; b < kMaxOuterBits; ++b)
+                    if ((tile >> b) & 1u) {
+                        wbase ^= ph[kPassCompactWBase + b];
+                        fbase ^= ph[kPassCompactFBase + b];
+                    }
+            info[tile] = TileInfo{uint32_t(base), uint32_t(base >> 32), wbase, fbase};
+        }
+    }
+}
 
 // FIRST = the pass synthesises its input (pass 0 of an evaluation from |0..0>): two instantiations, so that neither
 // carries the other's load path through register allocation.
@@ -300,7 +467,26 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, FIRST>::waves_per_si
     extern __shared__ __align__(16) unsigned char lds_raw[];
 
     EvalDesc ev;
-    {
+    const double* mats_base = mats_all;
+    bool prepared_here = false;
+    if constexpr (FIRST) prepared_here = a.mode & kModeFusedPrepare;
+    if (prepared_here) {
+        // This workgroup does prepare_kernel's work for its evaluation itself (virtual circuits of split evaluations:
+        // one launch and its latency less in front of the contraction): descriptor and parameters from pinned host
+        // memory, matrices and tables into the evaluation's region -- which this workgroup then reads back through the
+        // scalar cache: its stores must have landed, stale lines must go, and no load below may be moved above this
+        // point (the pointer the loads use is only known to the compiler from here on).
+        const size_t slot = size_t(blockIdx.y) + size_t(blockIdx.z) * a.region_stride;
+        ev = a.host_evals[slot];
+        if (ev.flags & kEvalNull) return;
+        if (threadIdx.x == 0 && blockIdx.x == 0) a.evals_out[slot] = ev;
+        prepare_eval(plan_arena, ev, a.host_params, a.mats_out, reinterpret_cast<double*>(lds_raw));
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        __builtin_amdgcn_s_dcache_inv();
+        __builtin_amdgcn_s_waitcnt(0);
+        asm volatile("" : "+s"(mats_base)::"memory");
+    } else {
         cu32p e = as_constant(reinterpret_cast<const uint32_t*>(evals + blockIdx.y + size_t(blockIdx.z) * a.region_stride));
         ev.plan_base = e[0];
         ev.mat_base = e[1];
@@ -328,8 +514,8 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, FIRST>::waves_per_si
     cu32p glr = pp + kPassLoadColsOffset + kMaxThreadBits;   // register columns of the load layout
     cu32p gsr = pp + kPassStoreColsOffset + kMaxThreadBits;  // ... of the store layout
     cu32p rounds0 = pp + kPassRoundsOffset;
-    cf64p mats0 = as_constant(mats_all) + ev.mat_base + size_t(pp[1]) * 8;
-    cf64p vecs = as_constant(mats_all) + ev.mat_base + size_t(n_real) * 8;
+    cf64p mats0 = as_constant(mats_base) + ev.mat_base + size_t(pp[1]) * 8;
+    cf64p vecs = as_constant(mats_base) + ev.mat_base + size_t(n_real) * 8;
 
     constexpr bool synth = FIRST;  // the launcher picks FIRST = (pass_index == 0 && mode & kModeSynthFirst)
     const bool last = a.pass_index + 1 == n_passes;
@@ -453,7 +639,7 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, FIRST>::waves_per_si
                 if (cload) {
                     // times F: two halves (register budget), each walking its 2^(R-1) elements in Gray-code order
                     const unsigned char* ftab = reinterpret_cast<const unsigned char*>(
-                        mats_all + ev.mat_base + size_t(n_real) * 8 + 4 * size_t(n_qubits) + kMatPadDoubles + (size_t(2) << t));
+                        mats_base + ev.mat_base + size_t(n_real) * 8 + 4 * size_t(n_qubits) + kMatPadDoubles + (size_t(2) << t));
                     cu32p frc = pp + kPassCompactFCols + kMaxThreadBits;
                     const uint32_t fo = (fbase ^ fthr) << 4;
                     constexpr int HB = NR > 1 ? NR / 2 : 1;
@@ -779,7 +965,8 @@ static hipError_t launch_pass_t(dim3 grid, int threads, size_t lds_bytes, hipStr
     // the block reduction at the end needs one double per wave (and the diagnostic build a table of counters)
     const size_t lds = lds_bytes < 256 ? 256 : lds_bytes;
     const PassScalars sc{args.state_stride, args.wtab_stride, args.pass_index, args.mode, args.tiles_per_block,
-                         args.partial_chunks, args.region_stride};
+                         args.partial_chunks, args.region_stride, args.host_evals, args.evals_out, args.host_params,
+                         args.mats_out};
     cx<real>* st = reinterpret_cast<cx<real>*>(args.states);
     const bool first = args.pass_index == 0 && (args.mode & kModeSynthFirst);
     if (first)
@@ -823,7 +1010,8 @@ static hipError_t pass_dispatch(int op, int dtype, int r, int xmode, dim3 grid, 
 #endif
     if (op) return hipSuccess;
     const PassScalars sc{args->state_stride, args->wtab_stride, args->pass_index, args->mode, args->tiles_per_block,
-                         args->partial_chunks, args->region_stride};
+                         args->partial_chunks, args->region_stride, args->host_evals, args->evals_out, args->host_params,
+                         args->mats_out};
     if (args->pass_index == 0 && (args->mode & kModeSynthFirst))
         hipLaunchKernelGGL((pass_kernel<double, QSV_PROBE_R, 2, true>), grid, dim3(threads), lds_bytes, stream, args->plan,
                            args->mats, args->evals, reinterpret_cast<cx<double>*>(args->states),
@@ -859,53 +1047,6 @@ hipError_t configure_pass_kernels(int dtype, int r, int xmode, size_t lds_bytes)
     return pass_dispatch(1, dtype, r, xmode, dim3(1), 64, lds_bytes, nullptr, nullptr);
 }
 
-// ---- angles -> matrices ---------------------------------------------------------------------------------
-struct Angles {
-    double theta, phi, lam;
-};
-
-__device__ __forceinline__ Angles read_angles(const uint32_t* __restrict__ e, const double* __restrict__ params) {
-    const int32_t pt = int32_t(e[0]), pf = int32_t(e[1]), pl = int32_t(e[2]);
-    Angles a;
-    a.theta = pt >= 0 ? params[pt] : __hiloint2double(int(e[4]), int(e[3]));
-    a.phi = pf >= 0 ? params[pf] : __hiloint2double(int(e[6]), int(e[5]));
-    a.lam = pl >= 0 ? params[pl] : __hiloint2double(int(e[8]), int(e[7]));
-    return a;
-}
-
-// Qiskit UGate: [[cos(t/2), -e^{i lam} sin(t/2)], [e^{i phi} sin(t/2), e^{i(phi+lam)} cos(t/2)]]
-__device__ __forceinline__ void u_matrix(const Angles& a, double* m) {
-    double s, c, sl, cl, sp, cp, spl, cpl;
-    sincos(a.theta * 0.5, &s, &c);
-    sincos(a.lam, &sl, &cl);
-    sincos(a.phi, &sp, &cp);
-    sincos(a.phi + a.lam, &spl, &cpl);
-    m[0] = c;        m[1] = 0.0;
-    m[2] = -cl * s;  m[3] = -sl * s;
-    m[4] = cp * s;   m[5] = sp * s;
-    m[6] = cpl * c;  m[7] = spl * c;
-}
-
-// One angle-table entry -> matrix.  Entries with p_theta below -1 are the fixed matrices of split.hpp's virtual circuits.
-__device__ __forceinline__ void entry_matrix(const uint32_t* __restrict__ e, const double* __restrict__ params, double* m) {
-    const int32_t code = int32_t(e[0]);
-    if (code >= -1) {
-        u_matrix(read_angles(e, params), m);
-        return;
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) m[i] = 0.0;
-    if (code == -2) {         // projector on |0>
-        m[0] = 1.0;
-    } else if (code == -3) {  // |0> -> |0> + |1>
-        m[0] = 1.0;
-        m[4] = 1.0;
-    } else {                  // X
-        m[2] = 1.0;
-        m[4] = 1.0;
-    }
-}
-
 // `host_evals` and `params` point into PINNED HOST memory: the kernel fetches the few hundred bytes an evaluation
 // needs over PCIe itself and leaves a device copy of the descriptor for the pass kernels.  Separate H2D copies in
 // front of it cost two more dependent stream operations (~50 us before the first pass of a step could start).
@@ -919,115 +1060,7 @@ __global__ void __launch_bounds__(256) prepare_kernel(const uint32_t* __restrict
     const EvalDesc ev = host_evals[slot];
     if (threadIdx.x == 0) evals[slot] = ev;
     if (ev.flags & kEvalNull) return;
-    const uint32_t* __restrict__ cp = plan + ev.plan_base;
-    const uint32_t n_passes = cp[0], n_real = cp[1], n_qubits = cp[2];
-    const uint32_t* __restrict__ table = cp + cp[3];
-    const uint32_t* __restrict__ fold = cp + cp[4];
-    const double* __restrict__ p = params + ev.param_base;
-    double* __restrict__ out = mats + ev.mat_base;
-    for (uint32_t j = threadIdx.x; j < n_real; j += blockDim.x) {
-        double m[8];
-        entry_matrix(table + size_t(j) * kAngleEntryWords, p, m);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) out[size_t(j) * 8 + i] = m[i];
-    }
-    for (uint32_t q = threadIdx.x; q < n_qubits; q += blockDim.x) {
-        const uint32_t first = fold[2 * q], count = fold[2 * q + 1];
-        double v0r = 1.0, v0i = 0.0, v1r = 0.0, v1i = 0.0;
-        for (uint32_t i = 0; i < count; ++i) {
-            double m[8];
-            entry_matrix(table + size_t(first + i) * kAngleEntryWords, p, m);
-            const double a0r = v0r, a0i = v0i, a1r = v1r, a1i = v1i;
-            v0r = m[0] * a0r - m[1] * a0i + m[2] * a1r - m[3] * a1i;
-            v0i = m[0] * a0i + m[1] * a0r + m[2] * a1i + m[3] * a1r;
-            v1r = m[4] * a0r - m[5] * a0i + m[6] * a1r - m[7] * a1i;
-            v1i = m[4] * a0i + m[5] * a0r + m[6] * a1i + m[7] * a1r;
-        }
-        double* o = out + size_t(n_real) * 8 + size_t(q) * 4;
-        o[0] = v0r; o[1] = v0i; o[2] = v1r; o[3] = v1i;
-        sv[4 * q] = v0r; sv[4 * q + 1] = v0i; sv[4 * q + 2] = v1r; sv[4 * q + 3] = v1i;
-    }
-    double* pad = out + size_t(n_real) * 8 + size_t(n_qubits) * 4;
-    // zero the padding the pass kernel's one-gate-ahead prefetch may read
-    for (uint32_t i = threadIdx.x; i < kMatPadDoubles; i += blockDim.x) pad[i] = 0.0;
-    if (n_passes == 0) return;
-    __syncthreads();
-
-    // Synthesis tables for pass 0 (the pass that writes the initial product state, amplitude(i) = prod_q v_q[i_q]):
-    //   thread_factor[tid] = product over the tile qubits that pass 0's load layout keeps on thread bits
-    //   tile_factor[tile]  = product over the qubits outside the tile
-    // The pass kernel multiplies the two and expands the register-held qubits itself.
-    const uint32_t* __restrict__ pp = cp + cp[kCircuitHeaderWords];
-    const uint32_t hdr = pp[0];
-    const int k = hdr & 0xff, t = (hdr >> 16) & 0xff;
-    const uint32_t* __restrict__ pos = pp + kPassHeaderWords;
-    const uint32_t* __restrict__ cols = pp + kPassLoadColsOffset;
-    uint32_t thread_mask = 0, tile_mask = 0;
-    for (int u = 0; u < t; ++u) thread_mask |= cols[u];
-    for (int j = 0; j < k; ++j) tile_mask |= 1u << pos[j];
-    double* thread_factor = pad + kMatPadDoubles;
-    double* tile_factor = thread_factor + (size_t(2) << t);
-    auto product = [&](uint64_t index, uint32_t qubits) {
-        double fr = 1.0, fi = 0.0;
-        for (uint32_t q = 0; q < n_qubits; ++q) {
-            if (!((qubits >> q) & 1u)) continue;
-            const double* v = sv + 4 * q + 2 * ((index >> q) & 1u);
-            const double nr = fr * v[0] - fi * v[1];
-            fi = fr * v[1] + fi * v[0];
-            fr = nr;
-        }
-        return make_double2(fr, fi);
-    };
-    for (uint32_t i = threadIdx.x; i < (1u << t); i += blockDim.x) {
-        uint32_t off = 0;
-        for (int u = 0; u < t; ++u) off ^= (0u - ((i >> u) & 1u)) & cols[u];
-        const double2 f = product(off, thread_mask);
-        thread_factor[2 * size_t(i)] = f.x;
-        thread_factor[2 * size_t(i) + 1] = f.y;
-    }
-    const uint32_t all_qubits = n_qubits >= 32 ? 0xffffffffu : ((1u << n_qubits) - 1u);
-    const uint32_t n_tiles = 1u << (n_qubits - uint32_t(k));
-    for (uint32_t tile = threadIdx.x; tile < n_tiles; tile += blockDim.x) {
-        uint64_t base = tile;
-        for (int j = 0; j < k; ++j) {
-            const uint32_t ps = pos[j];
-            base = ((base >> ps) << (ps + 1)) | (base & ((uint64_t(1) << ps) - 1));
-        }
-        const double2 f = product(base, all_qubits & ~tile_mask);
-        tile_factor[2 * size_t(tile)] = f.x;
-        tile_factor[2 * size_t(tile) + 1] = f.y;
-    }
-    // Per pass and tile: what the pass kernel needs to know about its tile number (kernels.hpp TileInfo).
-    TileInfo* info_all = reinterpret_cast<TileInfo*>(tile_factor + (size_t(2) << (n_qubits - uint32_t(k))));
-    for (uint32_t p = 0; p < n_passes; ++p) {
-        const uint32_t* __restrict__ ph = cp + cp[kCircuitHeaderWords + p];
-        const uint32_t* __restrict__ ppos = ph + kPassHeaderWords;
-        const uint32_t flags = ph[2];
-        const bool cstore = flags & kPassCompactStore, cload = flags & kPassCompactLoad;
-        const uint32_t count = cstore ? 1u << ((flags >> 8) & 0xffu) : n_tiles;
-        TileInfo* info = info_all + size_t(p) * n_tiles;
-        for (uint32_t tile = threadIdx.x; tile < count; tile += blockDim.x) {
-            uint64_t base;
-            if (cstore) {
-                base = 0;
-                for (uint32_t b = 0; b < kMaxCompactBits; ++b) base |= uint64_t((tile >> b) & 1u) << ph[kPassCompactOffset + b];
-            } else {
-                base = tile;
-                for (int j = 0; j < k; ++j) {
-                    const uint32_t ps = ppos[j];
-                    base = ((base >> ps) << (ps + 1)) | (base & ((uint64_t(1) << ps) - 1));
-                }
-            }
-            uint32_t wbase = 0, fbase = 0;
-            if (cload)
-                for (uint32_t b = 0; b < kMaxOuterBits; ++b)
-                    if ((tile >> b) & 1u) {
-                        wbase ^= ph[kPassCompactWBase + b];
-                        fbase ^= ph[kPassCompactFBase + b];
-                    }
-            info[tile] = TileInfo{uint32_t(base), uint32_t(base >> 32), wbase, fbase};
-        }
-    }
+    prepare_eval(plan, ev, params, mats, sv);
 }
 
 hipError_t launch_prepare(const uint32_t* plan, const EvalDesc* host_evals, EvalDesc* evals, const double* params,

@@ -42,6 +42,8 @@ enum PassMode : uint32_t {
     kModeSynthFirst = 1u,  // pass 0 synthesises |0..0> instead of reading the state
     kModeFinalStore = 2u,  // the last pass writes the state back
     kModeFinalDiag = 4u,   // the last pass reduces sum_i |a_i|^2 D[i] into `partials`
+    kModeFusedPrepare = 8u,  // (pass 0 only) every workgroup first does prepare_kernel's work for its evaluation, reading
+                             // the descriptor from host_evals (PassArgs below); no prepare launch ran for these evaluations
 };
 
 struct PassArgs {
@@ -59,6 +61,11 @@ struct PassArgs {
     uint32_t tiles_per_block;  // consecutive tiles each workgroup sweeps
     uint32_t region_stride;    // gridDim.z = 2: blockIdx.z = 1 takes descriptor evals[region_stride + blockIdx.y] (side B of
                                // split evaluations, kEvalNull for the others)
+    // kModeFusedPrepare: where prepare_kernel would read and write (indexed like `evals`)
+    const EvalDesc* host_evals;  // pinned host memory
+    EvalDesc* evals_out;         // device copy of the descriptors (the contraction kernel reads it)
+    const double* host_params;   // pinned host memory
+    double* mats_out;            // = mats
     uint32_t partial_chunks;   // workgroup slots per evaluation in `partials` (>= gridDim.x; 0 means gridDim.x): launches
                                // of one batch may use different grids (pass 0 / later passes), the reducer sees one shape
 };

@@ -757,7 +757,9 @@ const EvalDesc* batch_evals(const qsv_t* h) { return static_cast<const EvalDesc*
 
 // Ship the parameter values of evaluations [first, first+count) (packed back to back in `values`) and prepare
 // their matrices.
-int batch_ship(qsv_t* h, size_t first, size_t count, const double* values) {
+// (The first n_fused evaluations of the range are split evaluations: the pass kernel prepares their virtual circuits
+// itself, kModeFusedPrepare.)
+int batch_ship(qsv_t* h, size_t first, size_t count, const double* values, size_t n_fused = 0) {
     qsv_handle::Batch& b = h->batch;
     if (count == 0) return QSV_OK;
     const size_t p0 = b.param_base[first];
@@ -765,9 +767,10 @@ int batch_ship(qsv_t* h, size_t first, size_t count, const double* values) {
     double* hp = reinterpret_cast<double*>(static_cast<char*>(h->h_batch) + b.desc_bytes);
     if (p1 > p0) std::memcpy(hp + p0, values, (p1 - p0) * sizeof(double));
     const EvalDesc* host_evals = static_cast<const EvalDesc*>(h->h_batch);
-    QSV_HIP(h, launch_prepare(static_cast<const uint32_t*>(h->d_arena.ptr), host_evals + first,
-                              static_cast<EvalDesc*>(h->d_batch.ptr) + first, hp, static_cast<double*>(h->d_mats.ptr),
-                              int(count), ws(h), b.split_any ? 2 : 1, uint32_t(b.circs.size())));
+    if (count > n_fused)
+        QSV_HIP(h, launch_prepare(static_cast<const uint32_t*>(h->d_arena.ptr), host_evals + first + n_fused,
+                                  static_cast<EvalDesc*>(h->d_batch.ptr) + first + n_fused, hp,
+                                  static_cast<double*>(h->d_mats.ptr), int(count - n_fused), ws(h)));
     return QSV_OK;
 }
 
@@ -847,8 +850,14 @@ int run_group(qsv_t* h, const std::vector<Circuit*>& circs, size_t first, size_t
             }
         }
         a.tiles_per_block = 1;
+        // (pass 0 prepares the virtual circuits' matrices and tables itself: no prepare launch ran for them)
+        a.host_evals = static_cast<const EvalDesc*>(h->h_batch) + first;
+        a.evals_out = static_cast<EvalDesc*>(h->d_batch.ptr) + first;
+        a.host_params = reinterpret_cast<const double*>(static_cast<const char*>(h->h_batch) + h->batch.desc_bytes);
+        a.mats_out = static_cast<double*>(h->d_mats.ptr);
         for (int p = 0; p < side_passes; ++p) {
             a.pass_index = uint32_t(p);
+            a.mode = p == 0 ? (mode | kModeFusedPrepare) : mode;
             const int kind = p == 0 ? 0 : 1;
             if (h->stamping) QSV_HIP(h, stamp(h, h->batch.launch_events[kind], true));
             QSV_HIP(h, launch_pass(h->dtype, h->geo.r, h->cfg.xmode, dim3(side_tiles, unsigned(n_split), 2),
@@ -857,6 +866,7 @@ int run_group(qsv_t* h, const std::vector<Circuit*>& circs, size_t first, size_t
             h->prof.n_pass_launches += 1;
             h->prof.kernel_launches[kind] += 1;
         }
+        a.mode = mode;
     }
     a.evals = batch_evals(h) + first + n_split;
     for (int p = 0; p < max_passes && n_plain > 0; ++p) {
@@ -1013,7 +1023,7 @@ int eval_push(qsv_t* h, size_t first, size_t count, const double* values) {
         if (b.split_any) hd[P + first + j].state_slot = slot;
     }
     b.n_pushes += 1;
-    int rc = batch_ship(h, first, count, values);
+    int rc = batch_ship(h, first, count, values, n_split);
     if (rc) return rc;
     const uint32_t mode = kModeSynthFirst | (h->diagonal ? kModeFinalDiag : kModeFinalStore) |
                           (h->has_diag_part ? kModeFinalDiag : 0u);
