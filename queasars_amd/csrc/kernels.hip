@@ -306,11 +306,12 @@ __device__ __forceinline__ Angles read_angles(const uint32_t* __restrict__ e, co
 
 // Qiskit UGate: [[cos(t/2), -e^{i lam} sin(t/2)], [e^{i phi} sin(t/2), e^{i(phi+lam)} cos(t/2)]]
 __device__ __forceinline__ void u_matrix(const Angles& a, double* m) {
-    double s, c, sl, cl, sp, cp, spl, cpl;
+    double s, c, sl, cl, sp, cp;
     sincos(a.theta * 0.5, &s, &c);
     sincos(a.lam, &sl, &cl);
     sincos(a.phi, &sp, &cp);
-    sincos(a.phi + a.lam, &spl, &cpl);
+    // e^{i(phi+lam)} from the two factors (a fourth sincos costs more than everything else in this function)
+    const double cpl = cp * cl - sp * sl, spl = sp * cl + cp * sl;
     m[0] = c;        m[1] = 0.0;
     m[2] = -cl * s;  m[3] = -sl * s;
     m[4] = cp * s;   m[5] = sp * s;
@@ -337,29 +338,56 @@ __device__ __forceinline__ void entry_matrix(const uint32_t* __restrict__ e, con
     }
 }
 
-// What prepare_kernel does for ONE evaluation, by one workgroup (every thread of it calls this; `sv` is scratch in LDS for
-// 128 doubles).  The pass kernel's synthesising instantiation runs it itself for the virtual circuits of split
+// What prepare_kernel does for ONE evaluation, by one workgroup (every thread of it calls this; `scratch` = LDS for
+// kPrepScratchDoubles doubles).  The pass kernel's synthesising instantiation runs it itself for the virtual circuits of split
 // evaluations (one launch and one dependent launch latency less in front of the contraction).
+// LDS scratch of prepare_eval: the qubits' initial factors, the evaluation's parameter vector and the matrices of the
+// folded gates.
+constexpr uint32_t kPrepMaxParams = 1024, kPrepMaxFold = 128;
+constexpr uint32_t kPrepScratchDoubles = 4 * 32 + kPrepMaxParams + 8 * kPrepMaxFold;  // 17 KiB
+static_assert(kPrepScratchDoubles * sizeof(double) == kFusedPrepareLdsBytes, "kernels.hpp: kFusedPrepareLdsBytes");
+
 __device__ __forceinline__ void prepare_eval(const uint32_t* __restrict__ plan, const EvalDesc& ev,
-                                             const double* __restrict__ params, double* __restrict__ mats, double* sv) {
+                                             const double* __restrict__ params, double* __restrict__ mats, double* scratch) {
+    double* sv = scratch;                   // initial factors (v0, v1) of every qubit, n <= 32
+    double* sp = scratch + 4 * 32;          // the parameter vector
+    double* fm = sp + kPrepMaxParams;       // matrices of the fold entries
     const uint32_t* __restrict__ cp = plan + ev.plan_base;
     const uint32_t n_passes = cp[0], n_real = cp[1], n_qubits = cp[2];
     const uint32_t* __restrict__ table = cp + cp[3];
     const uint32_t* __restrict__ fold = cp + cp[4];
-    const double* __restrict__ p = params + ev.param_base;
+    const uint32_t n_fold = cp[5];
+    const double* p = params + ev.param_base;
     double* __restrict__ out = mats + ev.mat_base;
-    for (uint32_t j = threadIdx.x; j < n_real; j += blockDim.x) {
+    // The parameters live in pinned host memory: every read is a trip over PCIe, and a qubit's folded gates used to be
+    // worked through one after the other, each waiting for its own angles and then for its sincos -- 13 of the kernel's
+    // 18 microseconds.  Now: the whole vector comes over in one go, every matrix (scheduled gates and folded ones) is
+    // computed by its own thread, and the per-qubit loop only multiplies 2x2 matrices.
+    const bool staged = ev.n_params <= kPrepMaxParams && n_fold <= kPrepMaxFold;
+    if (staged) {
+        for (uint32_t i = threadIdx.x; i < ev.n_params; i += blockDim.x) sp[i] = p[i];
+        __syncthreads();
+        p = sp;
+    }
+    for (uint32_t j = threadIdx.x; j < n_real + (staged ? n_fold : 0u); j += blockDim.x) {
         double m[8];
         entry_matrix(table + size_t(j) * kAngleEntryWords, p, m);
+        double* dst = j < n_real ? out + size_t(j) * 8 : fm + size_t(j - n_real) * 8;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) out[size_t(j) * 8 + i] = m[i];
+        for (int i = 0; i < 8; ++i) dst[i] = m[i];
     }
+    if (staged) __syncthreads();
     for (uint32_t q = threadIdx.x; q < n_qubits; q += blockDim.x) {
         const uint32_t first = fold[2 * q], count = fold[2 * q + 1];
         double v0r = 1.0, v0i = 0.0, v1r = 0.0, v1i = 0.0;
         for (uint32_t i = 0; i < count; ++i) {
             double m[8];
-            entry_matrix(table + size_t(first + i) * kAngleEntryWords, p, m);
+            if (staged) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) m[e] = fm[size_t(first + i - n_real) * 8 + e];
+            } else {
+                entry_matrix(table + size_t(first + i) * kAngleEntryWords, p, m);
+            }
             const double a0r = v0r, a0i = v0i, a1r = v1r, a1i = v1i;
             v0r = m[0] * a0r - m[1] * a0i + m[2] * a1r - m[3] * a1i;
             v0i = m[0] * a0i + m[1] * a0r + m[2] * a1i + m[3] * a1r;
@@ -1055,12 +1083,12 @@ __global__ void __launch_bounds__(256) prepare_kernel(const uint32_t* __restrict
                                                       EvalDesc* __restrict__ evals,
                                                       const double* __restrict__ params, double* __restrict__ mats,
                                                       uint32_t region_stride) {
-    __shared__ double sv[4 * 32];  // initial factors (v0, v1) of every qubit, n <= 32
+    __shared__ double scratch[kPrepScratchDoubles];
     const size_t slot = size_t(blockIdx.x) + size_t(blockIdx.y) * region_stride;
     const EvalDesc ev = host_evals[slot];
     if (threadIdx.x == 0) evals[slot] = ev;
     if (ev.flags & kEvalNull) return;
-    prepare_eval(plan, ev, params, mats, sv);
+    prepare_eval(plan, ev, params, mats, scratch);
 }
 
 hipError_t launch_prepare(const uint32_t* plan, const EvalDesc* host_evals, EvalDesc* evals, const double* params,

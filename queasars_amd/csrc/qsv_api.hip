@@ -861,7 +861,8 @@ int run_group(qsv_t* h, const std::vector<Circuit*>& circs, size_t first, size_t
             const int kind = p == 0 ? 0 : 1;
             if (h->stamping) QSV_HIP(h, stamp(h, h->batch.launch_events[kind], true));
             QSV_HIP(h, launch_pass(h->dtype, h->geo.r, h->cfg.xmode, dim3(side_tiles, unsigned(n_split), 2),
-                                   h->geo.threads_launch, h->geo.lds_bytes, ws(h), a));
+                                   h->geo.threads_launch, std::max(h->geo.lds_bytes, p == 0 ? kFusedPrepareLdsBytes : size_t(0)),
+                                   ws(h), a));
             if (h->stamping) QSV_HIP(h, stamp(h, h->batch.launch_events[kind], false));
             h->prof.n_pass_launches += 1;
             h->prof.kernel_launches[kind] += 1;
