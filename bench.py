@@ -250,9 +250,15 @@ def cold_and_threaded(operator, n_steps: int = 7):
         for _ in range(reps):
             got = list(pool.map(one, range(POP_PER_GPU)))
         threaded = POP_PER_GPU * reps / (time.perf_counter() - t0)
+        # what this calling pattern can reach on this host whatever the backend: the same 64-thread pool.map with tasks
+        # that do nothing (CPython's executor and thread hand-over are the arrival rate of the real calls)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            list(pool.map(lambda j: j, range(POP_PER_GPU)))
+        noop = POP_PER_GPU * reps / (time.perf_counter() - t0)
     assert got == evaluator.evaluate_circuits(circuits, params)
     evaluator.statevector_device.close()
-    return cold, threaded
+    return cold, threaded, noop
 
 
 def config3_block(world: int, rank: int, local_rank: int, steps: int = 8):
@@ -465,13 +471,16 @@ def main() -> None:
             result["config3"] = config3
         if world == 1 and not args.no_extras:
             result["roofline"]["microbench"] = microbench_block()
-            cold, threaded = cold_and_threaded(operator)
+            cold, threaded, noop = cold_and_threaded(operator)
             result["cold_structure_evals_per_s"] = cold
             result["threaded_b1_evals_per_s"] = threaded
+            result["threaded_b1_noop_tasks_per_s"] = noop
             result["calling_pattern_note"] = (
                 "cold: every step evaluates 64 circuit structures the device has never seen (plan building + upload "
                 "inside the timed region); threaded: 64 host threads, one circuit per call (the reference's selection "
-                "operator, selection.py:75-82) through CoalescingCircuitEvaluator")
+                "operator, selection.py:75-82) through CoalescingCircuitEvaluator; threaded_b1_noop_tasks_per_s: the same "
+                "pool.map with tasks that do nothing, i.e. the rate at which this host's CPython can hand out and collect "
+                "such calls at all")
         if world == 1 and not args.no_cpu_baseline:
             base, ref_values = cpu_baseline(circuits, params, operator)
             result["cpu_baseline"] = base
