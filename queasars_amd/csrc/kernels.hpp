@@ -42,6 +42,7 @@ enum PassMode : uint32_t {
     kModeSynthFirst = 1u,  // pass 0 synthesises |0..0> instead of reading the state
     kModeFinalStore = 2u,  // the last pass writes the state back
     kModeFinalDiag = 4u,   // the last pass reduces sum_i |a_i|^2 D[i] into `partials`
+    kModeStreaming = 16u,    // the states do not fit the Infinity Cache: non-temporal state loads and stores
     kModeFusedPrepare = 8u,  // (pass 0 only) every workgroup first does prepare_kernel's work for its evaluation, reading
                              // the descriptor from host_evals (PassArgs below); no prepare launch ran for these evaluations
 };

@@ -154,6 +154,7 @@ struct qsv_handle {
     hipEvent_t ev_join = nullptr;
     int n_streams = 2;           // streams a batch cycles over (QSV_STREAMS, 1 .. 4)
     bool split_enabled = true;   // weakly entangled circuits run as two virtual circuits + a contraction (split.hpp)
+    uint32_t stream_mode = 0;    // kModeStreaming when a state is larger than the Infinity Cache (256 MiB), else 0
     mutable std::mutex mu;
     std::atomic<std::thread::id> batch_owner{};  // thread that holds `mu` between qsv_eval_begin and qsv_eval_end
 
@@ -823,7 +824,7 @@ int run_group(qsv_t* h, const std::vector<Circuit*>& circs, size_t first, size_t
     a.diag = static_cast<const double*>(h->d_diag.ptr);
     a.partials = static_cast<double*>(h->d_partials.ptr);
     a.state_stride = uint64_t(1) << h->n;
-    a.mode = mode;
+    a.mode = mode | h->stream_mode;
     // Pass 0 and the later passes have their own grids (tiles per workgroup): a compact pass 0 has few tiles and wants
     // them spread, a later pass sweeps all of them and amortises its set-up over more.  Which grid an evaluation's
     // LAST pass runs on depends on its own pass count only, so its partial sums are laid out (and added) the same
@@ -857,7 +858,7 @@ int run_group(qsv_t* h, const std::vector<Circuit*>& circs, size_t first, size_t
         a.mats_out = static_cast<double*>(h->d_mats.ptr);
         for (int p = 0; p < side_passes; ++p) {
             a.pass_index = uint32_t(p);
-            a.mode = p == 0 ? (mode | kModeFusedPrepare) : mode;
+            a.mode = (p == 0 ? (mode | kModeFusedPrepare) : mode) | h->stream_mode;
             const int kind = p == 0 ? 0 : 1;
             if (h->stamping) QSV_HIP(h, stamp(h, h->batch.launch_events[kind], true));
             QSV_HIP(h, launch_pass(h->dtype, h->geo.r, h->cfg.xmode, dim3(side_tiles, unsigned(n_split), 2),
@@ -867,7 +868,7 @@ int run_group(qsv_t* h, const std::vector<Circuit*>& circs, size_t first, size_t
             h->prof.n_pass_launches += 1;
             h->prof.kernel_launches[kind] += 1;
         }
-        a.mode = mode;
+        a.mode = mode | h->stream_mode;
     }
     a.evals = batch_evals(h) + first + n_split;
     for (int p = 0; p < max_passes && n_plain > 0; ++p) {
@@ -1243,6 +1244,8 @@ int qsv_create(int n_qubits, int dtype, int device, const qsv_plan_config* cfg, 
     if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
     h->own_stream = true;
     if (const char* env = getenv("QSV_SPLIT")) h->split_enabled = atoi(env) != 0;
+    h->stream_mode = state_bytes > (size_t(256) << 20) ? uint32_t(kModeStreaming) : 0u;
+    if (const char* env = getenv("QSV_STREAMING")) h->stream_mode = atoi(env) ? uint32_t(kModeStreaming) : 0u;
     if (const char* env = getenv("QSV_STREAMS")) h->n_streams = std::max(1, std::min(4, atoi(env)));
     for (int i = 1; i < std::max(2, h->n_streams); ++i) {
         hipStream_t st = nullptr;
@@ -1840,7 +1843,7 @@ static int bench_ops_locked(qsv_t* h, int n_ops, const qsv_op* ops, int reps, do
     a.wtab = h->d_wtab.ptr;
     a.wtab_stride = h->wtab_stride;
     a.state_stride = uint64_t(1) << h->n;
-    a.mode = kModeFinalStore;  // read-modify-write of the resident state, no synthesis
+    a.mode = kModeFinalStore | h->stream_mode;  // read-modify-write of the resident state, no synthesis
     const unsigned chunks = chunks_per_state(h);
     a.tiles_per_block = (h->geo.blocks_per_state + chunks - 1) / chunks;
     dim3 grid(chunks, 1);
