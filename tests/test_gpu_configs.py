@@ -579,3 +579,33 @@ def test_split_circuits_get_their_ordinary_plan_on_first_need():
     probs = np.abs(helpers.oracle_state(circuits[3], params[3])) ** 2
     assert all(probs[int(s)] > 0 for s in np.asarray(states)[3])
     assert ev.evaluate_circuits(circuits, params) == before
+
+
+@pytest.mark.parametrize("n", [10, 14])
+def test_prepare_without_lds_staging(n):
+    """prepare_eval stages the parameter vector and the folded gates' matrices in LDS when they fit (1024 parameters, 128
+    folded gates); beyond that it reads and computes them one by one.  Both limits exceeded, in the prepare kernel
+    (n = 10) and in the pass kernel's own preparation of a split evaluation's virtual circuits (n = 14)."""
+    rng = np.random.default_rng(n)
+    c = CircuitIR(n)
+    k = 0
+    from queasars_amd.ir import ParamRef
+
+    def angle():
+        nonlocal k
+        k += 1
+        return ParamRef(k - 1)
+
+    for rep in range(20 if n == 10 else 26):  # u gates before anything entangles: 200 / 364 folded gates, 3 parameters each
+        for q in range(n):
+            c.u(angle(), angle(), angle(), q)
+    for q in range(0, n - 1, 2):
+        c.cu3(angle(), angle(), angle(), q, q + 1)
+    for q in range(n):
+        c.u(angle(), angle(), angle(), q)
+    assert c.num_parameters == k and (k > 1024 or n == 10)
+    params = list(rng.uniform(-np.pi, np.pi, size=k))
+    op = helpers.random_ising_operator(n, seed=1)
+    got = OperatorCircuitEvaluator(op).evaluate_circuits([c, c], [params, params[::-1]])
+    ref = [helpers.oracle_expectation(c, p, op) for p in (params, params[::-1])]
+    assert np.abs(np.asarray(got) - np.asarray(ref)).max() < EXP_TOL
