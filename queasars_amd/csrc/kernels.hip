@@ -347,8 +347,16 @@ constexpr uint32_t kPrepMaxParams = 1024, kPrepMaxFold = 128;
 constexpr uint32_t kPrepScratchDoubles = 4 * 32 + kPrepMaxParams + 8 * kPrepMaxFold;  // 17 KiB
 static_assert(kPrepScratchDoubles * sizeof(double) == kFusedPrepareLdsBytes, "kernels.hpp: kFusedPrepareLdsBytes");
 
+#ifdef QSV_STAMPS  // (diagnostic build: phases 2 .. 8 of the stamp table take prepare_eval's steps)
+#define QSV_PSTAMP(ph) do { if (st_acc) { const unsigned long long st_t = qsv_stamp_now(); st_acc[ph] += st_t - *st_last; *st_last = st_t; } } while (0)
+#define QSV_PSTAMP_PARAMS , unsigned long long* st_acc = nullptr, unsigned long long* st_last = nullptr
+#else
+#define QSV_PSTAMP(ph)
+#define QSV_PSTAMP_PARAMS
+#endif
 __device__ __forceinline__ void prepare_eval(const uint32_t* __restrict__ plan, const EvalDesc& ev,
-                                             const double* __restrict__ params, double* __restrict__ mats, double* scratch) {
+                                             const double* __restrict__ params, double* __restrict__ mats,
+                                             double* scratch QSV_PSTAMP_PARAMS) {
     double* sv = scratch;                   // initial factors (v0, v1) of every qubit, n <= 32
     double* sp = scratch + 4 * 32;          // the parameter vector
     double* fm = sp + kPrepMaxParams;       // matrices of the fold entries
@@ -364,11 +372,13 @@ __device__ __forceinline__ void prepare_eval(const uint32_t* __restrict__ plan, 
     // 18 microseconds.  Now: the whole vector comes over in one go, every matrix (scheduled gates and folded ones) is
     // computed by its own thread, and the per-qubit loop only multiplies 2x2 matrices.
     const bool staged = ev.n_params <= kPrepMaxParams && n_fold <= kPrepMaxFold;
+    QSV_PSTAMP(2);  // plan header
     if (staged) {
         for (uint32_t i = threadIdx.x; i < ev.n_params; i += blockDim.x) sp[i] = p[i];
         __syncthreads();
         p = sp;
     }
+    QSV_PSTAMP(3);  // parameters staged
     for (uint32_t j = threadIdx.x; j < n_real + (staged ? n_fold : 0u); j += blockDim.x) {
         double m[8];
         entry_matrix(table + size_t(j) * kAngleEntryWords, p, m);
@@ -377,6 +387,7 @@ __device__ __forceinline__ void prepare_eval(const uint32_t* __restrict__ plan, 
         for (int i = 0; i < 8; ++i) dst[i] = m[i];
     }
     if (staged) __syncthreads();
+    QSV_PSTAMP(4);  // matrices
     for (uint32_t q = threadIdx.x; q < n_qubits; q += blockDim.x) {
         const uint32_t first = fold[2 * q], count = fold[2 * q + 1];
         double v0r = 1.0, v0i = 0.0, v1r = 0.0, v1i = 0.0;
@@ -403,6 +414,7 @@ __device__ __forceinline__ void prepare_eval(const uint32_t* __restrict__ plan, 
     for (uint32_t i = threadIdx.x; i < kMatPadDoubles; i += blockDim.x) pad[i] = 0.0;
     if (n_passes == 0) return;
     __syncthreads();
+    QSV_PSTAMP(5);  // initial factors
 
     // Synthesis tables for pass 0 (the pass that writes the initial product state, amplitude(i) = prod_q v_q[i_q]):
     //   thread_factor[tid] = product over the tile qubits that pass 0's load layout keeps on thread bits
@@ -448,6 +460,7 @@ __device__ __forceinline__ void prepare_eval(const uint32_t* __restrict__ plan, 
         tile_factor[2 * size_t(tile)] = f.x;
         tile_factor[2 * size_t(tile) + 1] = f.y;
     }
+    QSV_PSTAMP(6);  // synthesis tables
     // Per pass and tile: what the pass kernel needs to know about its tile number (kernels.hpp TileInfo).
     TileInfo* info_all = reinterpret_cast<TileInfo*>(tile_factor + (size_t(2) << (n_qubits - uint32_t(k))));
     for (uint32_t p = 0; p < n_passes; ++p) {
@@ -479,6 +492,7 @@ __device__ __forceinline__ void prepare_eval(const uint32_t* __restrict__ plan, 
             info[tile] = TileInfo{uint32_t(base), uint32_t(base >> 32), wbase, fbase};
         }
     }
+    QSV_PSTAMP(7);  // tile info
 }
 
 // FIRST = the pass synthesises its input (pass 0 of an evaluation from |0..0>): two instantiations, so that neither
@@ -494,6 +508,7 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, FIRST>::waves_per_si
     constexpr int LSH = XMODE == 0 ? ASH : ASH - 1;        // log2 of an LDS element's bytes
     extern __shared__ __align__(16) unsigned char lds_raw[];
 
+    QSV_STAMP_DECL
     EvalDesc ev;
     const double* mats_base = mats_all;
     bool prepared_here = false;
@@ -508,12 +523,18 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, FIRST>::waves_per_si
         ev = a.host_evals[slot];
         if (ev.flags & kEvalNull) return;
         if (threadIdx.x == 0 && blockIdx.x == 0) a.evals_out[slot] = ev;
+#ifdef QSV_STAMPS
+        QSV_STAMP(0);  // descriptor
+        prepare_eval(plan_arena, ev, a.host_params, a.mats_out, reinterpret_cast<double*>(lds_raw), st_acc, &st_last);
+#else
         prepare_eval(plan_arena, ev, a.host_params, a.mats_out, reinterpret_cast<double*>(lds_raw));
+#endif
         __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
         __builtin_amdgcn_s_dcache_inv();
         __builtin_amdgcn_s_waitcnt(0);
         asm volatile("" : "+s"(mats_base)::"memory");
+        QSV_STAMP(13);
     } else {
         cu32p e = as_constant(reinterpret_cast<const uint32_t*>(evals + blockIdx.y + size_t(blockIdx.z) * a.region_stride));
         ev.plan_base = e[0];
@@ -568,7 +589,6 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, FIRST>::waves_per_si
     // single-gate sweeps: n = 26 / 27 +3.8 %, 5.23 -> 5.43 TB/s; at n = 24, where the state fits the cache, -28 %)
     const bool streaming = (a.mode & kModeStreaming) && !cload && !cstore && !side;
 
-    QSV_STAMP_DECL
     const uint32_t tg = xor_columns(pp + kPassLoadColsOffset, tid, wave);
     const uint32_t sg = xor_columns(pp + kPassStoreColsOffset, tid, wave);
 

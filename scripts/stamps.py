@@ -16,7 +16,7 @@ sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 STAMP_LIB = Path(os.environ.get("QSV_STAMP_LIB", ROOT / "queasars_amd" / "libqsv_stamps.so"))
 PHASES = ["setup", "load/synth", "x-wait", "x-wr-re", "x-bar1", "x-rd-re", "x-bar2", "x-wr-im", "x-bar3", "x-rd-im", "gates",
-          "store/red", "epilogue"]
+          "store/red", "epilogue", "prepare"]
 
 
 def main() -> None:
