@@ -420,11 +420,18 @@ __device__ __forceinline__ void prepare_eval(const uint32_t* __restrict__ plan, 
     //   thread_factor[tid] = product over the tile qubits that pass 0's load layout keeps on thread bits
     //   tile_factor[tile]  = product over the qubits outside the tile
     // The pass kernel multiplies the two and expands the register-held qubits itself.
-    const uint32_t* __restrict__ pp = cp + cp[kCircuitHeaderWords];
+    // pass 0's header block, copied to LDS with one load per thread: the loops below index it with run-time subscripts,
+    // and straight from memory every such access was a dependent load of its own (4 of the kernel's 10 microseconds)
+    uint32_t* pp = reinterpret_cast<uint32_t*>(fm);  // (the fold matrices are no longer needed)
+    {
+        const uint32_t* __restrict__ src = cp + cp[kCircuitHeaderWords];
+        for (uint32_t i = threadIdx.x; i < kPassLoadColsOffset + kColumnWords; i += blockDim.x) pp[i] = src[i];
+        __syncthreads();
+    }
     const uint32_t hdr = pp[0];
     const int k = hdr & 0xff, t = (hdr >> 16) & 0xff;
-    const uint32_t* __restrict__ pos = pp + kPassHeaderWords;
-    const uint32_t* __restrict__ cols = pp + kPassLoadColsOffset;
+    const uint32_t* pos = pp + kPassHeaderWords;
+    const uint32_t* cols = pp + kPassLoadColsOffset;
     uint32_t thread_mask = 0, tile_mask = 0;
     for (int u = 0; u < t; ++u) thread_mask |= cols[u];
     for (int j = 0; j < k; ++j) tile_mask |= 1u << pos[j];
