@@ -257,6 +257,7 @@ struct PassScalars {
     EvalDesc* evals_out;
     const double* host_params;
     double* mats_out;
+    double* result_out;
 };
 
 // XMODE selects how a tile is transposed through LDS:
@@ -1004,6 +1005,20 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, FIRST>::waves_per_si
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
         const uint32_t n_waves = blockDim.x >> 6;
+        if (a.mode & kModeDirectResult) {
+            // the evaluation is this workgroup alone: its waves' sums are added here, in wave order, and the result goes
+            // straight to the caller's (pinned) buffer -- no partial sums, no reduction launch
+            double* sums = reinterpret_cast<double*>(lds_raw);
+            __syncthreads();  // (whoever still reads the last exchange's data from LDS is done after this)
+            if ((tid & 63u) == 0) sums[wave] = acc;
+            __syncthreads();
+            if (tid == 0) {
+                double total = 0.0;
+                for (uint32_t w = 0; w < n_waves; ++w) total += sums[w];
+                a.result_out[ev.out_index] = total;
+            }
+            return;
+        }
         // a launch with fewer workgroups than the reducer's shape also clears the slots nobody owns
         const uint32_t slots = a.partial_chunks ? a.partial_chunks : gridDim.x;
         if ((tid & 63u) == 0) {
@@ -1037,7 +1052,7 @@ static hipError_t launch_pass_t(dim3 grid, int threads, size_t lds_bytes, hipStr
     const size_t lds = lds_bytes < 256 ? 256 : lds_bytes;
     const PassScalars sc{args.state_stride, args.wtab_stride, args.pass_index, args.mode, args.tiles_per_block,
                          args.partial_chunks, args.region_stride, args.host_evals, args.evals_out, args.host_params,
-                         args.mats_out};
+                         args.mats_out, args.result_out};
     cx<real>* st = reinterpret_cast<cx<real>*>(args.states);
     const bool first = args.pass_index == 0 && (args.mode & kModeSynthFirst);
     if (first)
@@ -1082,7 +1097,7 @@ static hipError_t pass_dispatch(int op, int dtype, int r, int xmode, dim3 grid, 
     if (op) return hipSuccess;
     const PassScalars sc{args->state_stride, args->wtab_stride, args->pass_index, args->mode, args->tiles_per_block,
                          args->partial_chunks, args->region_stride, args->host_evals, args->evals_out, args->host_params,
-                         args->mats_out};
+                         args->mats_out, args->result_out};
     if (args->pass_index == 0 && (args->mode & kModeSynthFirst))
         hipLaunchKernelGGL((pass_kernel<double, QSV_PROBE_R, 2, true>), grid, dim3(threads), lds_bytes, stream, args->plan,
                            args->mats, args->evals, reinterpret_cast<cx<double>*>(args->states),

@@ -42,6 +42,8 @@ enum PassMode : uint32_t {
     kModeSynthFirst = 1u,  // pass 0 synthesises |0..0> instead of reading the state
     kModeFinalStore = 2u,  // the last pass writes the state back
     kModeFinalDiag = 4u,   // the last pass reduces sum_i |a_i|^2 D[i] into `partials`
+    kModeDirectResult = 32u, // every evaluation of the launch is ONE workgroup (gridDim.x = 1, one tile): the fused last pass
+                             // adds its waves' sums itself (fixed order) and writes result_out[out_index]; no partials
     kModeStreaming = 16u,    // the states do not fit the Infinity Cache: non-temporal state loads and stores
     kModeFusedPrepare = 8u,  // (pass 0 only) every workgroup first does prepare_kernel's work for its evaluation, reading
                              // the descriptor from host_evals (PassArgs below); no prepare launch ran for these evaluations
@@ -67,6 +69,7 @@ struct PassArgs {
     EvalDesc* evals_out;         // device copy of the descriptors (the contraction kernel reads it)
     const double* host_params;   // pinned host memory
     double* mats_out;            // = mats
+    double* result_out;          // kModeDirectResult: one double per evaluation (pinned host memory)
     uint32_t partial_chunks;   // workgroup slots per evaluation in `partials` (>= gridDim.x; 0 means gridDim.x): launches
                                // of one batch may use different grids (pass 0 / later passes), the reducer sees one shape
 };

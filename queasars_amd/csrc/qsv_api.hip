@@ -775,6 +775,13 @@ int batch_ship(qsv_t* h, size_t first, size_t count, const double* values, size_
     return QSV_OK;
 }
 
+// One workgroup per evaluation (the register fits one tile) under a diagonal operator: the pass kernel prepares the
+// evaluation itself and writes the expectation value straight to the result buffer -- one launch per push instead of three.
+bool single_workgroup_path(const qsv_t* h, uint32_t mode) {
+    return h->geo.blocks_per_state == 1 && h->diagonal && (mode & kModeFinalDiag) && !(mode & kModeFinalStore) &&
+           (mode & kModeSynthFirst) && !getenv("QSV_NO_DIRECT");
+}
+
 unsigned chunks_per_state(const qsv_t* h) {
     const unsigned tpb = unsigned(std::min<uint32_t>(uint32_t(h->tiles_per_block), h->geo.blocks_per_state));
     return h->geo.blocks_per_state / tpb;
@@ -871,6 +878,15 @@ int run_group(qsv_t* h, const std::vector<Circuit*>& circs, size_t first, size_t
         a.mode = mode | h->stream_mode;
     }
     a.evals = batch_evals(h) + first + n_split;
+    const bool direct = mode & kModeDirectResult;  // (eval_push decides, for the whole push)
+    if (direct) {
+        a.mode |= kModeFusedPrepare;
+        a.host_evals = static_cast<const EvalDesc*>(h->h_batch) + first + n_split;
+        a.evals_out = static_cast<EvalDesc*>(h->d_batch.ptr) + first + n_split;
+        a.host_params = reinterpret_cast<const double*>(static_cast<const char*>(h->h_batch) + h->batch.desc_bytes);
+        a.mats_out = static_cast<double*>(h->d_mats.ptr);
+        a.result_out = h->h_out;
+    }
     for (int p = 0; p < max_passes && n_plain > 0; ++p) {
         const unsigned chunks_p = p == 0 ? chunks : chunks_later;
         a.tiles_per_block = (h->geo.blocks_per_state + chunks_p - 1) / chunks_p;
@@ -878,7 +894,8 @@ int run_group(qsv_t* h, const std::vector<Circuit*>& circs, size_t first, size_t
         a.pass_index = uint32_t(p);
         const int kind = (p == 0 && (mode & kModeSynthFirst)) ? 0 : 1;  // which instantiation of the kernel runs
         if (h->stamping) QSV_HIP(h, stamp(h, h->batch.launch_events[kind], true));
-        QSV_HIP(h, launch_pass(h->dtype, h->geo.r, h->cfg.xmode, grid, h->geo.threads_launch, h->geo.lds_bytes, ws(h), a));
+        QSV_HIP(h, launch_pass(h->dtype, h->geo.r, h->cfg.xmode, grid, h->geo.threads_launch,
+                               std::max(h->geo.lds_bytes, direct ? kFusedPrepareLdsBytes : size_t(0)), ws(h), a));
         if (h->stamping) QSV_HIP(h, stamp(h, h->batch.launch_events[kind], false));
         h->prof.n_pass_launches += 1;
         h->prof.n_state_passes += n_plain;
@@ -1025,10 +1042,13 @@ int eval_push(qsv_t* h, size_t first, size_t count, const double* values) {
         if (b.split_any) hd[P + first + j].state_slot = slot;
     }
     b.n_pushes += 1;
-    int rc = batch_ship(h, first, count, values, n_split);
-    if (rc) return rc;
     const uint32_t mode = kModeSynthFirst | (h->diagonal ? kModeFinalDiag : kModeFinalStore) |
                           (h->has_diag_part ? kModeFinalDiag : 0u);
+    bool direct = single_workgroup_path(h, mode);
+    for (size_t j = 0; direct && j < count; ++j) direct = b.circs[first + j]->plan.stats.n_passes == 1;
+    int rc = batch_ship(h, first, count, values, direct ? count : n_split);
+    if (rc) return rc;
+    const uint32_t group_mode = mode | (direct ? uint32_t(kModeDirectResult) : 0u);
     // launch groups: the split evaluations of the push in groups of SG, then the ordinary ones in groups of G
     for (size_t g0 = first; g0 < first + count;) {
         const bool in_split = g0 < first + n_split;
@@ -1039,7 +1059,7 @@ int eval_push(qsv_t* h, size_t first, size_t count, const double* values) {
             ~Advance() { g0 += gc; }
         } advance{g0, gc};
         QSV_HIP(h, stamp(h, b.pass_events, true));
-        rc = run_group(h, b.circs, g0, gc, mode);
+        rc = run_group(h, b.circs, g0, gc, group_mode);
         if (!rc) QSV_HIP(h, stamp(h, b.pass_events, false));
         if (rc) return rc;
         if (!h->diagonal) {
@@ -1058,7 +1078,7 @@ int eval_push(qsv_t* h, size_t first, size_t count, const double* values) {
             QSV_HIP(h, stamp(h, b.exp_events, false));
         }
     }
-    if (h->diagonal) {
+    if (h->diagonal && !direct) {
         // This push's evaluations are reduced on the push's own stream, straight into the pinned result buffer: no
         // cross-stream join in front of one final reduction (the join alone cost 15-30 us at the end of every call).
         QSV_HIP(h, stamp(h, b.exp_events, true));
