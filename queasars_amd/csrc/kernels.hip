@@ -576,7 +576,8 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, FIRST>::waves_per_si
 
     constexpr bool synth = FIRST;  // the launcher picks FIRST = (pass_index == 0 && mode & kModeSynthFirst)
     const bool last = a.pass_index + 1 == n_passes;
-    const bool do_store = !last || (a.mode & kModeFinalStore) || side;
+    const bool do_probs = last && (a.mode & kModeFinalProbs) && !side;
+    const bool do_store = (!last || (a.mode & kModeFinalStore) || side) && !do_probs;
     const bool do_diag = last && (a.mode & kModeFinalDiag) && !side;
     // the compact table of this state slot lives in its own buffer: pass 1 may already be storing the state while
     // other workgroups of the same launch still read the table
@@ -945,10 +946,21 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, FIRST>::waves_per_si
             QSV_STAMP(10);
         }
 
-        if (active && (do_store || do_diag)) {
+        if (active && (do_store || do_diag || do_probs)) {
             if (!wide || cstore) {
                 unsigned char* tile = reinterpret_cast<unsigned char*>(cstore ? wt0 + (uint64_t(tile0 + j * tile_step) << k) : st0 + base);
                 const unsigned char* dtile = reinterpret_cast<const unsigned char*>(diag + base);
+                if (do_probs) {
+                    // the sampler only wants the probabilities: written here, the state is never stored or read again
+                    unsigned char* ptile = reinterpret_cast<unsigned char*>(partials + uint64_t(ev.state_slot) * a.state_stride + base);
+                    uint32_t ob = sgv << 3;
+#pragma unroll
+                    for (int i = 0; i < NR; ++i) {
+                        if (i) ob ^= gsr[__builtin_ctz(i)] << 3;
+                        const double re = double(amp[gray_index(i)].re), im = double(amp[gray_index(i)].im);
+                        *reinterpret_cast<double*>(ptile + ob) = re * re + im * im;
+                    }
+                }
                 if (do_store) {
                     uint32_t ob = sgv << ASH;
 #pragma unroll

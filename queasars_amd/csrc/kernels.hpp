@@ -44,6 +44,8 @@ enum PassMode : uint32_t {
     kModeFinalDiag = 4u,   // the last pass reduces sum_i |a_i|^2 D[i] into `partials`
     kModeDirectResult = 32u, // every evaluation of the launch is ONE workgroup (gridDim.x = 1, one tile): the fused last pass
                              // adds its waves' sums itself (fixed order) and writes result_out[out_index]; no partials
+    kModeFinalProbs = 64u,   // the last pass writes |a_i|^2 (fp64) to `partials` used as [state_slot][2^n] (the sampler's input)
+                             // instead of the state (n <= 28)
     kModeStreaming = 16u,    // the states do not fit the Infinity Cache: non-temporal state loads and stores
     kModeFusedPrepare = 8u,  // (pass 0 only) every workgroup first does prepare_kernel's work for its evaluation, reading
                              // the descriptor from host_evals (PassArgs below); no prepare launch ran for these evaluations

@@ -212,6 +212,8 @@ struct qsv_handle {
     uint32_t* h_stage = nullptr;  // pinned staging buffer for plan uploads
     size_t h_stage_words = 0;
     double* h_out = nullptr;  // pinned
+    void* h_samples = nullptr;  // pinned: sampled states (and their operator values) of one qsv_sample_batch call
+    size_t h_samples_bytes = 0;
     size_t h_out_count = 0;
 
     // streaming evaluation (qsv_eval_begin / push / end)
@@ -879,7 +881,9 @@ int run_group(qsv_t* h, const std::vector<Circuit*>& circs, size_t first, size_t
     }
     a.evals = batch_evals(h) + first + n_split;
     const bool direct = mode & kModeDirectResult;  // (eval_push decides, for the whole push)
-    if (direct) {
+    const bool fused = direct || (mode & kModeFusedPrepare);  // (... or the sampler path, for one-tile registers)
+    if (mode & kModeFinalProbs) a.partials = static_cast<double*>(h->d_scratch.ptr);  // [slot][2^n] probabilities
+    if (fused) {
         a.mode |= kModeFusedPrepare;
         a.host_evals = static_cast<const EvalDesc*>(h->h_batch) + first + n_split;
         a.evals_out = static_cast<EvalDesc*>(h->d_batch.ptr) + first + n_split;
@@ -895,7 +899,7 @@ int run_group(qsv_t* h, const std::vector<Circuit*>& circs, size_t first, size_t
         const int kind = (p == 0 && (mode & kModeSynthFirst)) ? 0 : 1;  // which instantiation of the kernel runs
         if (h->stamping) QSV_HIP(h, stamp(h, h->batch.launch_events[kind], true));
         QSV_HIP(h, launch_pass(h->dtype, h->geo.r, h->cfg.xmode, grid, h->geo.threads_launch,
-                               std::max(h->geo.lds_bytes, direct ? kFusedPrepareLdsBytes : size_t(0)), ws(h), a));
+                               std::max(h->geo.lds_bytes, fused ? kFusedPrepareLdsBytes : size_t(0)), ws(h), a));
         if (h->stamping) QSV_HIP(h, stamp(h, h->batch.launch_events[kind], false));
         h->prof.n_pass_launches += 1;
         h->prof.n_state_passes += n_plain;
@@ -1310,6 +1314,7 @@ void qsv_destroy(qsv_t* h) {
     if (h->h_batch) (void)hipHostFree(h->h_batch);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
     if (h->h_out) (void)hipHostFree(h->h_out);
+    if (h->h_samples) (void)hipHostFree(h->h_samples);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -1767,28 +1772,42 @@ static int sample_batch_locked(qsv_t* h, const std::vector<Circuit*>& circs, con
     const uint64_t dim = uint64_t(1) << h->n;
     const size_t G = size_t(h->group);
     const size_t probs_bytes = G * dim * 8, sums_bytes = G * size_t(sample_chunk_count(dim)) * 8;
-    const size_t states_off = ((probs_bytes + sums_bytes + 63) / 64) * 64;
-    const size_t values_off = states_off + n_evals * size_t(shots) * 8;
-    if ((rc = ensure(h, h->d_scratch, values_off + (out_values ? n_evals * size_t(shots) * 8 : 0)))) return rc;
+    if ((rc = ensure(h, h->d_scratch, probs_bytes + sums_bytes))) return rc;
     if ((rc = ensure(h, h->d_partials, std::max<size_t>(1, n_evals) * partials_per_state(h) * sizeof(double)))) return rc;
+    // samples (and their operator values) are written by the kernel straight into pinned host memory: no copy operations
+    const size_t out_bytes = n_evals * size_t(shots) * 8;
+    if (h->h_samples_bytes < 2 * out_bytes) {
+        if (h->h_samples) {
+            QSV_HIP(h, sync_streams(h));
+            QSV_HIP(h, hipHostFree(h->h_samples));
+            h->h_samples = nullptr;
+            h->h_samples_bytes = 0;
+        }
+        QSV_HIP(h, hipHostMalloc(&h->h_samples, 4 * out_bytes, hipHostMallocDefault));
+        h->h_samples_bytes = 4 * out_bytes;
+    }
     double* probs = static_cast<double*>(h->d_scratch.ptr);
     double* sums = probs + G * dim;
-    uint64_t* d_states = reinterpret_cast<uint64_t*>(static_cast<char*>(h->d_scratch.ptr) + states_off);
-    double* d_values = out_values ? reinterpret_cast<double*>(static_cast<char*>(h->d_scratch.ptr) + values_off) : nullptr;
-    rc = batch_ship(h, 0, n_evals, packed.data());
+    uint64_t* d_states = static_cast<uint64_t*>(h->h_samples);
+    double* d_values = out_values ? reinterpret_cast<double*>(static_cast<char*>(h->h_samples) + out_bytes) : nullptr;
+    // one-tile registers: the pass kernel prepares its evaluation itself; n <= 28: its last pass writes the
+    // probabilities, not the state
+    const bool fuse = h->geo.blocks_per_state == 1;
+    const bool probs_in_pass = h->n <= 28;
+    rc = batch_ship(h, 0, n_evals, packed.data(), fuse ? n_evals : 0);
+    const uint32_t mode = kModeSynthFirst | (probs_in_pass ? kModeFinalProbs : kModeFinalStore) | (fuse ? kModeFusedPrepare : 0u);
     for (size_t g0 = 0; !rc && g0 < n_evals; g0 += G) {
         const size_t gc = std::min(G, n_evals - g0);
-        if ((rc = run_group(h, circs, g0, gc, kModeSynthFirst | kModeFinalStore))) break;
-        QSV_HIP(h, launch_probabilities(h->dtype, h->d_states.ptr, dim, int(gc), probs, h->stream));
+        if ((rc = run_group(h, circs, g0, gc, mode))) break;
+        if (!probs_in_pass) QSV_HIP(h, launch_probabilities(h->dtype, h->d_states.ptr, dim, int(gc), probs, h->stream));
         QSV_HIP(h, launch_sample(probs, dim, int(gc), sums, shots, seed, uint32_t(g0),
                                  static_cast<const double*>(h->d_diag.ptr), d_states, d_values, h->stream));
     }
     h->batch.circs.clear();
     if (rc) return rc;
-    QSV_HIP(h, hipMemcpyAsync(out_states, d_states, n_evals * size_t(shots) * 8, hipMemcpyDeviceToHost, h->stream));
-    if (out_values)
-        QSV_HIP(h, hipMemcpyAsync(out_values, d_values, n_evals * size_t(shots) * 8, hipMemcpyDeviceToHost, h->stream));
     QSV_HIP(h, hipStreamSynchronize(h->stream));
+    std::memcpy(out_states, d_states, out_bytes);
+    if (out_values) std::memcpy(out_values, d_values, out_bytes);
     return QSV_OK;
 }
 
