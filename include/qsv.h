@@ -190,6 +190,17 @@ int qsv_sample(qsv_t* h, int circuit_id, const double* params, int n_params, int
 int qsv_sample_batch(qsv_t* h, int n_evals, const int* circuit_ids, const int64_t* param_offsets, const double* params,
                      int shots, uint64_t seed, uint64_t* out_states, double* out_values /* may be NULL */);
 
+/*
+ * Sampling and the CVaR in one call: out_cvar[i] = CVaR_alpha of the operator's values on evaluation i's `shots` samples
+ * (the samples qsv_sample_batch draws for the same seed), i.e. the mean of the lowest alpha * shots sample values with
+ * the boundary sample weighted fractionally -- what get_expectation_with_operator / _get_expectation compute from the
+ * measured distribution (reference: queasars/circuit_evaluation/expectation_calculation.py:14-69; alpha = 1: the plain
+ * mean).  Needs a diagonal operator on the handle, 0 < alpha <= 1 and shots <= 4096; the samples are sorted on the
+ * device and never cross PCIe.
+ */
+int qsv_sample_cvar_batch(qsv_t* h, int n_evals, const int* circuit_ids, const int64_t* param_offsets, const double* params,
+                          int shots, uint64_t seed, double alpha, double* out_cvar);
+
 /* ---- measurement support ----------------------------------------------------------------------- */
 
 int qsv_set_profiling(qsv_t* h, int enabled);

@@ -426,6 +426,37 @@ class StatevectorDevice:
         )
         return states, values
 
+    #: most samples per evaluation the device-side CVaR sorts (csrc/kernels.hpp kCvarMaxShots)
+    MAX_CVAR_SHOTS = 4096
+
+    def sample_cvar_batch(
+        self, circuits: Sequence[CircuitIR], parameter_values: Sequence[Sequence[float]], shots: int, seed: int, alpha: float
+    ) -> list[float]:
+        """CVaR_alpha of the (diagonal) operator over ``shots`` samples per (circuit, parameter vector) pair, sampled,
+        valued and sorted on the device (``qsv_sample_cvar_batch``): the same samples :meth:`sample_batch` draws for
+        ``seed``, but only one number per pair comes back."""
+        n = len(circuits)
+        if len(parameter_values) != n:
+            raise ValueError("circuits and parameter_values must have the same length")
+        if n == 0:
+            return []
+        ids, need = self._batch_metadata(circuits)
+        counts = np.fromiter(map(len, parameter_values), dtype=np.int64, count=n)
+        if (counts < need).any():
+            i = int(np.argmax(counts < need))
+            raise ValueError(f"circuit {i} needs {int(need[i])} parameter values, got {int(counts[i])}")
+        offsets = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(counts, out=offsets[1:])
+        flat = _pack_slice(parameter_values, 0, n, int(offsets[-1])) if offsets[-1] else np.zeros(1)
+        out = np.empty(n, dtype=np.float64)
+        self._check(
+            self._lib.qsv_sample_cvar_batch(
+                self._handle, n, _lib.as_ptr(ids), _lib.as_ptr(offsets), _lib.as_ptr(flat), int(shots),
+                C.c_uint64(seed & (2**64 - 1)), float(alpha), _lib.as_ptr(out),
+            )
+        )
+        return out.tolist()
+
     # -- measurement support ----------------------------------------------------------------------
     def set_profiling(self, enabled: bool) -> None:
         self._check(self._lib.qsv_set_profiling(self._handle, 1 if enabled else 0))
@@ -659,15 +690,16 @@ class OperatorSamplerCircuitEvaluator(BaseCircuitEvaluator):
         return self._device
 
     def evaluate_circuits(self, circuits: list[CircuitIR], parameter_values: list[list[float]]) -> list[float]:
-        """Samples every circuit on the device and gathers each sample's operator value from the device-resident
-        diagonal table, so the host only sorts ``shots`` numbers per circuit for the CVaR."""
+        """Samples every circuit on the device, gathers each sample's operator value from the device-resident diagonal
+        table and takes the CVaR there as well (up to 4096 shots; beyond that the host sorts the values)."""
         pairs = [(self._composed.get(c), p) for c, p in zip(circuits, parameter_values) if c is not None and p is not None]
+        seed = int(self._rng.integers(0, 2**63 - 1))
         with self._device.operator_lock:
             if self._device._operator is not self._operator:
                 self._device.set_operator(self._operator)
-            _, values = self._device.sample_batch(
-                [c for c, _ in pairs], [p for _, p in pairs], self._shots, int(self._rng.integers(0, 2**63 - 1)), with_values=True
-            )
+            if self._shots <= StatevectorDevice.MAX_CVAR_SHOTS:
+                return self._device.sample_cvar_batch([c for c, _ in pairs], [p for _, p in pairs], self._shots, seed, self._alpha)
+            _, values = self._device.sample_batch([c for c, _ in pairs], [p for _, p in pairs], self._shots, seed, with_values=True)
         return _cvar_of_sample_matrix(values, self._alpha)
 
     @property

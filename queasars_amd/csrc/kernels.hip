@@ -1669,6 +1669,61 @@ hipError_t launch_sample(const double* probs, uint64_t dim, int n_slots, double*
 
 uint32_t sample_chunk_count(uint64_t dim) { return uint32_t((dim + kSampleChunk - 1) / kSampleChunk); }
 
+// CVaR of one evaluation's sample values per workgroup (expectation_calculation.py:27-40 restated for equally weighted
+// samples): sort ascending, take probability mass alpha from the low end.
+__global__ void __launch_bounds__(256) cvar_kernel(const double* __restrict__ values, int shots, int padded, double alpha,
+                                                   double* __restrict__ out) {
+    extern __shared__ double sorted[];
+    const double* v = values + size_t(blockIdx.x) * size_t(shots);
+    for (int i = threadIdx.x; i < padded; i += blockDim.x) sorted[i] = i < shots ? v[i] : __builtin_huge_val();
+    __syncthreads();
+    for (int k = 2; k <= padded; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < padded; i += blockDim.x) {
+                const int partner = i ^ j;
+                if (partner > i) {
+                    const bool ascending = (i & k) == 0;
+                    const double a = sorted[i], b = sorted[partner];
+                    if ((a > b) == ascending) {
+                        sorted[i] = b;
+                        sorted[partner] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    // mass alpha * shots from the low end: `whole` samples entirely, the next one with the remaining fraction
+    const double mass = alpha * double(shots);
+    int whole = int(floor(mass + 1e-12));
+    if (whole > shots) whole = shots;
+    // fixed-order sum: every thread adds its strided share, then a tree over the threads (in place of `sorted`'s tail)
+    double part = 0.0;
+    for (int i = threadIdx.x; i < whole; i += blockDim.x) part += sorted[i];
+    const double boundary = whole < shots ? sorted[whole] : 0.0;
+    __syncthreads();
+    double* tree = sorted;  // (values no longer needed)
+    tree[threadIdx.x] = part;
+    __syncthreads();
+    for (int s = blockDim.x >> 1; s > 0; s >>= 1) {
+        if (int(threadIdx.x) < s) tree[threadIdx.x] += tree[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        double total = tree[0];
+        if (whole < shots && mass - double(whole) > 1e-12) total += (mass - double(whole)) * boundary;
+        out[blockIdx.x] = total / mass;
+    }
+}
+
+hipError_t launch_cvar(const double* values, int n_evals, int shots, double alpha, double* out, hipStream_t stream) {
+    if (shots < 1 || shots > kCvarMaxShots || !(alpha > 0.0) || alpha > 1.0) return hipErrorInvalidValue;
+    int padded = 256;  // (at least one value per thread: the reduction tree reuses the buffer)
+    while (padded < shots) padded <<= 1;
+    hipLaunchKernelGGL(cvar_kernel, dim3(n_evals), dim3(256), size_t(padded) * sizeof(double), stream, values, shots, padded,
+                       alpha, out);
+    return hipGetLastError();
+}
+
 static unsigned stream_blocks(uint64_t dim) {
     const uint64_t want = (dim + 255) / 256;
     return unsigned(want < 4096 ? want : 4096);

@@ -156,6 +156,11 @@ hipError_t launch_sample(const double* probs, uint64_t dim, int n_slots, double*
                          hipStream_t stream);
 uint32_t sample_chunk_count(uint64_t dim);
 
+// out[first_eval + e] = CVaR_alpha of values[e * shots .. (e + 1) * shots) for e < n_evals (shots <= kCvarMaxShots):
+// bitonic sort in LDS, fixed-order sum of the lowest alpha * shots values (the boundary value weighted fractionally).
+constexpr int kCvarMaxShots = 4096;
+hipError_t launch_cvar(const double* values, int n_evals, int shots, double alpha, double* out, hipStream_t stream);
+
 hipError_t launch_probabilities(int dtype, const void* state, uint64_t dim, int n_slots, double* probs,
                                 hipStream_t stream);
 hipError_t launch_state_to_f64(int dtype, const void* state, uint64_t dim, double* out_re_im, hipStream_t stream);

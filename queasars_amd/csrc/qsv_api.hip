@@ -1748,12 +1748,13 @@ int qsv_probabilities(qsv_t* h, int circuit_id, const double* params, int n_para
 
 // Sampler branch for a whole batch: run the circuits group by group, turn each resident state into probabilities,
 // draw `shots` samples per evaluation on the device and (for a diagonal operator) gather each sample's value D[state].
+// out_cvar != null: the samples and their values stay on the device, only CVaR_alpha per evaluation comes back.
 static int sample_batch_locked(qsv_t* h, const std::vector<Circuit*>& circs, const int64_t* param_offsets,
                                const double* params, int shots, uint64_t seed, uint64_t* out_states,
-                               double* out_values) {
+                               double* out_values, double alpha = 1.0, double* out_cvar = nullptr) {
     const size_t n_evals = circs.size();
     if (n_evals == 0 || shots == 0) return QSV_OK;
-    if (out_values && !(h->has_diag_part && h->diagonal))
+    if ((out_values || out_cvar) && !(h->has_diag_part && h->diagonal))
         return fail(h, QSV_E_STATE, "sample values need a diagonal operator (call qsv_set_operator with I/Z terms only)");
     std::vector<int64_t> np(n_evals);
     std::vector<double> packed;
@@ -1772,11 +1773,13 @@ static int sample_batch_locked(qsv_t* h, const std::vector<Circuit*>& circs, con
     const uint64_t dim = uint64_t(1) << h->n;
     const size_t G = size_t(h->group);
     const size_t probs_bytes = G * dim * 8, sums_bytes = G * size_t(sample_chunk_count(dim)) * 8;
-    if ((rc = ensure(h, h->d_scratch, probs_bytes + sums_bytes))) return rc;
-    if ((rc = ensure(h, h->d_partials, std::max<size_t>(1, n_evals) * partials_per_state(h) * sizeof(double)))) return rc;
-    // samples (and their operator values) are written by the kernel straight into pinned host memory: no copy operations
     const size_t out_bytes = n_evals * size_t(shots) * 8;
-    if (h->h_samples_bytes < 2 * out_bytes) {
+    const size_t dev_samples_off = ((probs_bytes + sums_bytes + 63) / 64) * 64;
+    if ((rc = ensure(h, h->d_scratch, dev_samples_off + (out_cvar ? 2 * out_bytes : 0)))) return rc;
+    if ((rc = ensure(h, h->d_partials, std::max<size_t>(1, n_evals) * partials_per_state(h) * sizeof(double)))) return rc;
+    if (out_cvar && (rc = ensure_host_out(h, n_evals))) return rc;
+    // samples (and their operator values) are written by the kernel straight into pinned host memory: no copy operations
+    if (!out_cvar && h->h_samples_bytes < 2 * out_bytes) {
         if (h->h_samples) {
             QSV_HIP(h, sync_streams(h));
             QSV_HIP(h, hipHostFree(h->h_samples));
@@ -1790,6 +1793,10 @@ static int sample_batch_locked(qsv_t* h, const std::vector<Circuit*>& circs, con
     double* sums = probs + G * dim;
     uint64_t* d_states = static_cast<uint64_t*>(h->h_samples);
     double* d_values = out_values ? reinterpret_cast<double*>(static_cast<char*>(h->h_samples) + out_bytes) : nullptr;
+    if (out_cvar) {  // (device scratch behind the probabilities and chunk sums)
+        d_states = reinterpret_cast<uint64_t*>(static_cast<char*>(h->d_scratch.ptr) + dev_samples_off);
+        d_values = reinterpret_cast<double*>(static_cast<char*>(h->d_scratch.ptr) + dev_samples_off + out_bytes);
+    }
     // one-tile registers: the pass kernel prepares its evaluation itself; n <= 28: its last pass writes the
     // probabilities, not the state
     const bool fuse = h->geo.blocks_per_state == 1;
@@ -1802,10 +1809,16 @@ static int sample_batch_locked(qsv_t* h, const std::vector<Circuit*>& circs, con
         if (!probs_in_pass) QSV_HIP(h, launch_probabilities(h->dtype, h->d_states.ptr, dim, int(gc), probs, h->stream));
         QSV_HIP(h, launch_sample(probs, dim, int(gc), sums, shots, seed, uint32_t(g0),
                                  static_cast<const double*>(h->d_diag.ptr), d_states, d_values, h->stream));
+        if (out_cvar)
+            QSV_HIP(h, launch_cvar(d_values + g0 * size_t(shots), int(gc), shots, alpha, h->h_out + g0, h->stream));
     }
     h->batch.circs.clear();
     if (rc) return rc;
     QSV_HIP(h, hipStreamSynchronize(h->stream));
+    if (out_cvar) {
+        std::memcpy(out_cvar, h->h_out, n_evals * sizeof(double));
+        return QSV_OK;
+    }
     std::memcpy(out_states, d_states, out_bytes);
     if (out_values) std::memcpy(out_values, d_values, out_bytes);
     return QSV_OK;
@@ -1826,6 +1839,25 @@ int qsv_sample_batch(qsv_t* h, int n_evals, const int* circuit_ids, const int64_
     }
     static const double dummy = 0.0;
     return sample_batch_locked(h, circs, param_offsets, params ? params : &dummy, shots, seed, out_states, out_values);
+}
+
+int qsv_sample_cvar_batch(qsv_t* h, int n_evals, const int* circuit_ids, const int64_t* param_offsets, const double* params,
+                          int shots, uint64_t seed, double alpha, double* out_cvar) {
+    if (!h) return QSV_E_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    if (n_evals < 0 || shots < 1 || (n_evals > 0 && (!circuit_ids || !param_offsets || !out_cvar)))
+        return fail(h, QSV_E_ARG, "bad arguments");
+    if (!(alpha > 0.0) || alpha > 1.0) return fail(h, QSV_E_ARG, "alpha must be in (0, 1]");
+    if (shots > kCvarMaxShots) return fail(h, QSV_E_ARG, "the device-side CVaR sorts at most 4096 samples per evaluation");
+    QSV_HIP(h, hipSetDevice(h->device));
+    std::vector<Circuit*> circs(size_t(n_evals), nullptr);
+    for (int i = 0; i < n_evals; ++i) {
+        auto it = h->circuits.find(circuit_ids[i]);
+        if (it == h->circuits.end()) return fail(h, QSV_E_ARG, "unknown circuit id " + std::to_string(circuit_ids[i]));
+        circs[size_t(i)] = &it->second;
+    }
+    static const double dummy = 0.0;
+    return sample_batch_locked(h, circs, param_offsets, params ? params : &dummy, shots, seed, nullptr, nullptr, alpha, out_cvar);
 }
 
 int qsv_sample(qsv_t* h, int circuit_id, const double* params, int n_params, int shots, uint64_t seed,

@@ -609,3 +609,22 @@ def test_prepare_without_lds_staging(n):
     got = OperatorCircuitEvaluator(op).evaluate_circuits([c, c], [params, params[::-1]])
     ref = [helpers.oracle_expectation(c, p, op) for p in (params, params[::-1])]
     assert np.abs(np.asarray(got) - np.asarray(ref)).max() < EXP_TOL
+
+
+@pytest.mark.parametrize("shots,alpha", [(512, 0.5), (500, 0.3), (1000, 1.0), (4096, 0.05), (37, 0.25)])
+def test_cvar_on_the_device_equals_the_host_cvar_of_the_same_samples(shots, alpha):
+    """qsv_sample_cvar_batch sorts the sample values on the device; the same seed through qsv_sample_batch gives the
+    samples, whose CVaR the host computes the reference's way (expectation_calculation.py:27-40 for equal weights)."""
+    from queasars_amd.circuit_evaluation.circuit_evaluation import _cvar_of_sample_matrix
+
+    n = 11
+    _, circuits, params = helpers.population_circuits(n, 3, 7, seed=21)
+    op = helpers.random_ising_operator(n, seed=8)
+    dev = StatevectorDevice(n)
+    dev.set_operator(op)
+    got = dev.sample_cvar_batch(circuits, params, shots, 99, alpha)
+    _, values = dev.sample_batch(circuits, params, shots, 99, with_values=True)
+    want = _cvar_of_sample_matrix(values, alpha)
+    assert np.abs(np.asarray(got) - np.asarray(want)).max() < 1e-12 * max(1.0, float(np.abs(values).max()))
+    with pytest.raises(ValueError):
+        dev.sample_cvar_batch(circuits, params, 5000, 1, 0.5)
