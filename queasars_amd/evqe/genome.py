@@ -27,6 +27,7 @@ from __future__ import annotations
 import math
 from dataclasses import dataclass
 from enum import Enum
+from functools import cached_property
 from random import Random
 from typing import Iterable, Optional, Sequence
 
@@ -123,11 +124,13 @@ class EVQECircuitLayer:
         if not self.is_valid():
             raise EVQECircuitLayerException("The created layer is invalid!")
 
-    @property
+    # (layers and individuals are immutable: what is derived from their fields is computed once -- the solver asks for a
+    # layer's parameter count tens of thousands of times per search, which was a quarter of a search's host time)
+    @cached_property
     def n_parameters(self) -> int:
         return sum(g.n_parameters() for g in self.gates)
 
-    @property
+    @cached_property
     def n_controlled_gates(self) -> int:
         return sum(1 for g in self.gates if g.kind is EVQEGateType.CONTROLLED_ROTATION)
 
@@ -226,7 +229,7 @@ class EVQEIndividual:
             return False
         return len(self.parameter_values) == sum(layer.n_parameters for layer in self.layers)
 
-    @property
+    @cached_property
     def layer_parameter_indices(self) -> dict[int, tuple[int, ...]]:
         out, start = {}, 0
         for i, layer in enumerate(self.layers):
