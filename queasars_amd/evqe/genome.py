@@ -27,7 +27,7 @@ from __future__ import annotations
 import math
 from dataclasses import dataclass
 from enum import Enum
-from functools import cached_property
+from functools import cached_property, lru_cache
 from random import Random
 from typing import Iterable, Optional, Sequence
 
@@ -103,11 +103,23 @@ class EVQEIndividualException(Exception):
 
 def parameter_names(layer_id: int, gates: Sequence[EVQEGate]) -> list[str]:
     """Names in genome order: gate by gate (qubit order), theta, phi, lambda."""
+    return list(_parameter_names(layer_id, tuple(gates)))
+
+
+@lru_cache(maxsize=8192)
+def _parameter_names(layer_id: int, gates: tuple) -> tuple:
+    # (the same few layers are lowered again and again during a search: formatting their names was a tenth of its time)
     names = []
     for gate in gates:
         if gate.n_parameters():
             names.extend(f"layer{layer_id}_q{gate.qubit_index}_{a}" for a in _ANGLE_NAMES)
-    return names
+    return tuple(names)
+
+
+@lru_cache(maxsize=8192)
+def _layer_parameter_rank(layer_id: int, gates: tuple) -> dict:
+    """name -> position among the layer's own name-sorted parameters (read only: shared between callers)."""
+    return sorted_parameter_rank(_parameter_names(layer_id, gates))
 
 
 def sorted_parameter_rank(names: Iterable[str]) -> dict[str, int]:
@@ -338,16 +350,16 @@ class EVQEIndividual:
         chosen = {layer_id % len(self.layers) for layer_id in parameterized_layers}
         free_names: list[str] = []
         for i in sorted(chosen):
-            free_names.extend(parameter_names(i, self.layers[i].gates))
+            free_names.extend(_parameter_names(i, self.layers[i].gates))
         free_rank = sorted_parameter_rank(free_names)
         circuit = CircuitIR(self.n_qubits)
         for i, layer in enumerate(self.layers):
-            names = parameter_names(i, layer.gates)
+            names = _parameter_names(i, layer.gates)
             if i in chosen:
                 angle_of = {name: ParamRef(free_rank[name]) for name in names}
             else:
                 values = self.get_layer_parameter_values(i)
-                rank = sorted_parameter_rank(names)
+                rank = _layer_parameter_rank(i, layer.gates)
                 angle_of = {name: float(values[rank[name]]) for name in names}
             layer.lower(circuit, i, angle_of)
         return circuit
