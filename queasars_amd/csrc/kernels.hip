@@ -1618,22 +1618,27 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
     return x ^ (x >> 31);
 }
 
+// the uniform number in [0, 1) of one shot of one evaluation: a stream per evaluation, a counter per shot
+__device__ __forceinline__ double shot_uniform(uint64_t seed, uint32_t eval, uint32_t shot) {
+    const uint64_t stream = splitmix64(seed + 0xD1B54A32D192ED03ull * (uint64_t(eval) + 1));
+    const uint64_t bits = splitmix64(stream ^ splitmix64(uint64_t(shot) + 1));
+    return double(bits >> 11) * (1.0 / 9007199254740992.0);
+}
+
 // blockIdx.y = slot; slot s samples with stream seed splitmix64(seed + stream_of[s]) and writes shots of
 // evaluation out_index[s]; when `diag` is given each sample's diagonal value D[state] is gathered too.
 __global__ void __launch_bounds__(256) sample_kernel(const double* __restrict__ probs_all, uint64_t dim,
                                                      const double* __restrict__ scanned_all, uint32_t n_chunks,
                                                      int shots, uint64_t seed, uint32_t first_eval,
                                                      const double* __restrict__ diag, uint64_t* __restrict__ out,
-                                                     double* __restrict__ out_values) {
+                                                     double* __restrict__ out_values, const EvalDesc* __restrict__ evals) {
     const int shot = blockIdx.x * blockDim.x + threadIdx.x;
     if (shot >= shots) return;
-    const uint32_t slot = blockIdx.y, eval = first_eval + slot;
+    const uint32_t slot = blockIdx.y, eval = evals ? evals[slot].out_index : first_eval + slot;
     const double* __restrict__ probs = probs_all + uint64_t(slot) * dim;
     const double* __restrict__ scanned = scanned_all + size_t(slot) * n_chunks;
     const double total = scanned[n_chunks - 1];
-    const uint64_t stream = splitmix64(seed + 0xD1B54A32D192ED03ull * (uint64_t(eval) + 1));
-    const uint64_t bits = splitmix64(stream ^ splitmix64(uint64_t(shot) + 1));
-    const double u = double(bits >> 11) * (1.0 / 9007199254740992.0) * total;  // [0, total)
+    const double u = shot_uniform(seed, eval, uint32_t(shot)) * total;  // [0, total)
     // first chunk whose inclusive prefix exceeds u
     uint32_t lo = 0, hi = n_chunks - 1;
     while (lo < hi) {
@@ -1657,13 +1662,13 @@ __global__ void __launch_bounds__(256) sample_kernel(const double* __restrict__ 
 
 hipError_t launch_sample(const double* probs, uint64_t dim, int n_slots, double* chunk_sums, int shots, uint64_t seed,
                          uint32_t first_eval, const double* diag, uint64_t* out, double* out_values,
-                         hipStream_t stream) {
+                         hipStream_t stream, const EvalDesc* evals) {
     const uint32_t n_chunks = uint32_t((dim + kSampleChunk - 1) / kSampleChunk);
     const uint32_t sum_blocks = (n_chunks + 3) / 4 < 4096 ? (n_chunks + 3) / 4 : 4096;
     hipLaunchKernelGGL(chunk_sums_kernel, dim3(sum_blocks, n_slots), dim3(256), 0, stream, probs, dim, chunk_sums, n_chunks);
     hipLaunchKernelGGL(scan_sums_kernel, dim3(n_slots), dim3(256), 0, stream, chunk_sums, n_chunks);
     hipLaunchKernelGGL(sample_kernel, dim3((shots + 255) / 256, n_slots), dim3(256), 0, stream, probs, dim, chunk_sums,
-                       n_chunks, shots, seed, first_eval, diag, out, out_values);
+                       n_chunks, shots, seed, first_eval, diag, out, out_values, evals);
     return hipGetLastError();
 }
 
@@ -1721,6 +1726,413 @@ hipError_t launch_cvar(const double* values, int n_evals, int shots, double alph
     while (padded < shots) padded <<= 1;
     hipLaunchKernelGGL(cvar_kernel, dim3(n_evals), dim3(256), size_t(padded) * sizeof(double), stream, values, shots, padded,
                        alpha, out);
+    return hipGetLastError();
+}
+
+// ---- sampling split evaluations (kernels.hpp: launch_split_tables / launch_split_sample) ---------------------------
+// Scratch of one evaluation: running sums of the marginal of x (2^(k+2) doubles: a side has at most k + 2 qubits), then
+// the Gram table T[pi][y1] (pi < J^2, y1 < 2^(|Y| - 6); J 2^|Y| <= 2^(k+2) bounds it by 2^(k-1) doubles).
+// T's rows: pi = j < J: G_jj; then for every pair j < j' two rows, 2 Re G_jj' and -2 Im G_jj', with
+// G_jj'[y1] = sum over the block's y of Y_j[y] conj(Y_j'[y]) -- so that the probability of (x, block y1) is
+//     sum_j T[j] |X_j|^2 + sum_{j<j'} T[a] Re(X_j conj X_j') + T[b] Im(X_j conj X_j')        (split_quad).
+constexpr uint32_t kSplitSampleBlockBits = 6;
+constexpr int kSplitSampleShotsPerBlock = 32;
+
+size_t split_sample_slot_doubles(int tile_bits) {
+    const size_t table = std::max<size_t>(64, size_t(1) << (tile_bits > 1 ? tile_bits - 1 : 0));
+    return (size_t(1) << (tile_bits + 2)) + table;
+}
+
+// v of the lane `shift` places down its row of 16 lanes / of lane 15 of the previous row / of lane 31 (DPP; 0.0 for a
+// lane that has no such source or whose row is masked out)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+// inclusive sums over the lanes of a wave, fixed tree, no LDS traffic: four doubling steps inside the rows of 16, then
+// the row totals
+__device__ __forceinline__ double wave_inclusive(double v) {
+    v += dpp_f64<0x111, 0xf>(v);  // row_shr:1
+    v += dpp_f64<0x112, 0xf>(v);  // row_shr:2
+    v += dpp_f64<0x114, 0xf>(v);  // row_shr:4
+    v += dpp_f64<0x118, 0xf>(v);  // row_shr:8
+    v += dpp_f64<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+    v += dpp_f64<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
+__device__ __forceinline__ double read_lane(double v, uint32_t lane) {  // lane: uniform
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), int(lane)),
+                            __builtin_amdgcn_readlane(__double2loint(v), int(lane)));
+}
+
+// Which entry of a J x J Hermitian form lane pi < J^2 stands for (the rows of T above): part 0 = the diagonal entry ja,
+// part 1 / 2 = the real / imaginary part of pair (ja, jb), ja < jb.
+template <int J>
+__device__ __forceinline__ void split_entry_of(uint32_t pi, uint32_t* ja_out, uint32_t* jb_out, uint32_t* part_out) {
+    uint32_t ja = pi, jb = pi, part = 0;
+    if (pi >= uint32_t(J)) {
+        uint32_t o = (pi - J) >> 1;
+        part = 1 + ((pi - J) & 1u);
+        ja = 0;
+        while (o >= uint32_t(J) - 1 - ja) {
+            o -= uint32_t(J) - 1 - ja;
+            ++ja;
+        }
+        jb = ja + 1 + o;
+    }
+    *ja_out = ja;
+    *jb_out = jb;
+    *part_out = part;
+}
+// ... and the value that goes with it for the vector X: |X_ja|^2, Re(X_ja conj X_jb), Im(X_ja conj X_jb)
+__device__ __forceinline__ double split_entry_value(uint32_t part, double ar, double ai, double br, double bi) {
+    return part == 2 ? fma(ai, br, -ar * bi) : fma(ar, br, ai * bi);
+}
+
+// sum_pi T[pi][col] w_pi, lane pi holding w_pi: the uniform factor of every term comes out of its lane as a scalar
+// (v_readlane), so the form costs J^2 loads and J^2 fused multiply-adds per lane and no registers for X or w
+template <int J>
+__device__ __forceinline__ double split_quad_table(const double* __restrict__ T, uint32_t stride, uint32_t col, double w_of_lane) {
+    double t = 0.0;
+#pragma unroll
+    for (uint32_t pi = 0; pi < uint32_t(J * J); ++pi) t = fma(T[pi * stride + col], read_lane(w_of_lane, pi), t);
+    return t;
+}
+// the same form with the table entries uniform (lane pi holds M_pi) and the vector per lane
+template <int J>
+__device__ __forceinline__ double split_quad_vector(double m_of_lane, const double (&xr)[J], const double (&xi)[J]) {
+    double t = 0.0;
+#pragma unroll
+    for (int j = 0; j < J; ++j) t = fma(read_lane(m_of_lane, uint32_t(j)), fma(xr[j], xr[j], xi[j] * xi[j]), t);
+    uint32_t row = J;
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+        for (int jp = j + 1; jp < J; ++jp) {
+            t = fma(read_lane(m_of_lane, row), fma(xr[j], xr[jp], xi[j] * xi[jp]), t);
+            t = fma(read_lane(m_of_lane, row + 1), fma(xi[j], xr[jp], -xr[j] * xi[jp]), t);
+            row += 2;
+        }
+    return t;
+}
+
+template <typename real, int J>
+__device__ void split_tables_body(const cx<real>* __restrict__ X, const cx<real>* __restrict__ Y, uint32_t bits_x, uint32_t bits_y,
+                                  double* __restrict__ cum, double* __restrict__ T, cx<real>* stage_all, double* lds) {
+    constexpr uint32_t NQ = J * J;  // rows of T
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6), n_waves = blockDim.x >> 6;
+    const uint32_t ly2 = bits_y < kSplitSampleBlockBits ? bits_y : kSplitSampleBlockBits;
+    const uint32_t ny2 = 1u << ly2, ny1 = 1u << (bits_y - ly2);
+    // Gram blocks.  A wave takes a block of 64 y: its J rows of Y go to the wave's own LDS region (coalesced loads); lane
+    // (sub, pi) adds row pi's products over the sub-th run of J^2 values of y, the runs are added across lanes.
+    cx<real>* stage = stage_all + size_t(wave) * J * 64;
+    const uint32_t pi = lane % NQ, sub = lane / NQ;
+    uint32_t ja, jb, part;
+    split_entry_of<J>(pi, &ja, &jb, &part);
+    double m_sum = 0.0;
+    for (uint32_t y1 = wave; y1 < ny1; y1 += n_waves) {
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            cx<real> v{real(0), real(0)};
+            if (lane < ny2) v = Y[(size_t(j) << bits_y) + size_t(y1) * ny2 + lane];
+            stage[j * 64 + int(lane)] = v;
+        }
+        double acc = 0.0;
+#pragma unroll 4
+        for (uint32_t i = 0; i < NQ; ++i) {
+            const uint32_t y2 = sub * NQ + i;
+            const cx<real> a = stage[ja * 64 + y2], b = stage[jb * 64 + y2];
+            acc += split_entry_value(part, double(a.re), double(a.im), double(b.re), double(b.im));
+        }
+        for (uint32_t off = NQ; off < 64; off <<= 1) acc += __shfl_xor(acc, int(off));
+        acc = part == 0 ? acc : part == 1 ? 2.0 * acc : -2.0 * acc;
+        if (lane < NQ) T[pi * ny1 + y1] = acc;
+        m_sum += acc;
+    }
+    // their sum over the blocks, waves in order: the Gram matrix of the whole side
+    double* M = lds;             // [NQ]
+    double* per_wave = lds + 64;  // [n_waves][NQ]
+    if (lane < NQ) per_wave[wave * NQ + pi] = m_sum;
+    __syncthreads();
+    if (tid < NQ) {
+        double m = 0.0;
+        for (uint32_t w = 0; w < n_waves; ++w) m += per_wave[w * NQ + tid];
+        M[tid] = m;
+    }
+    __syncthreads();
+    const double m_of_lane = M[pi];
+    // marginal of x and its running sums: a contiguous run of x per thread, then the threads' totals
+    const uint32_t nx = 1u << bits_x, per = (nx + blockDim.x - 1) / blockDim.x;
+    const uint32_t lo = min(nx, tid * per), hi = min(nx, lo + per);
+    double mine = 0.0;
+    // (every lane makes every trip, a lane without an x with a stand-in: the form reads its uniform factors out of lanes,
+    // and a lane that sits out a divergent loop need not hold its value any more)
+    for (uint32_t i = 0; i < per; ++i) {
+        const bool valid = lo + i < hi;
+        const uint32_t x = valid ? lo + i : 0u;
+        double xr[J], xi[J];
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const cx<real> v = X[(size_t(j) << bits_x) + x];
+            xr[j] = double(v.re);
+            xi[j] = double(v.im);
+        }
+        double p = split_quad_vector<J>(m_of_lane, xr, xi);
+        p = valid && p > 0.0 ? p : 0.0;  // (a quadratic form of a Gram matrix: negative only by rounding)
+        if (valid) cum[x] = p;
+        mine += p;
+    }
+    const double inc = wave_inclusive(mine);
+    double* wave_total = lds + 64 + 4 * 64;  // [n_waves]
+    if (lane == 63) wave_total[wave] = inc;
+    __syncthreads();
+    double run = inc - mine;
+    for (uint32_t w = 0; w < wave; ++w) run += wave_total[w];
+    for (uint32_t x = lo; x < hi; ++x) {
+        run += cum[x];
+        cum[x] = run;
+    }
+}
+
+template <typename real>
+__global__ void __launch_bounds__(256, 2) split_tables_kernel(const uint32_t* __restrict__ plan_arena, const EvalDesc* __restrict__ evals,
+                                                              const cx<real>* __restrict__ sides, uint64_t side_stride,
+                                                              double* __restrict__ scratch, uint32_t slot_doubles, uint32_t cum_doubles) {
+    __shared__ double lds[64 + 4 * 64 + 4];
+    __shared__ cx<real> stage[4 * 8 * 64];
+    const EvalDesc ev = evals[blockIdx.x];
+    if (!(ev.flags & kEvalSide)) return;
+    const uint32_t* sp = plan_arena + ev.split_base;
+    const uint32_t n_keys = sp[0], bits_x = sp[1], bits_y = sp[2];
+    const bool swap = sp[3] & 1u;
+    const cx<real>* ta = sides + uint64_t(ev.state_slot) * side_stride;
+    const cx<real>* X = ta + (swap ? side_stride >> 1 : 0);
+    const cx<real>* Y = ta + (swap ? 0 : side_stride >> 1);
+    double* cum = scratch + size_t(blockIdx.x) * slot_doubles;
+    double* T = cum + cum_doubles;
+    if (n_keys == 0)
+        split_tables_body<real, 1>(X, Y, bits_x, bits_y, cum, T, stage, lds);
+    else if (n_keys == 1)
+        split_tables_body<real, 2>(X, Y, bits_x, bits_y, cum, T, stage, lds);
+    else if (n_keys == 2)
+        split_tables_body<real, 4>(X, Y, bits_x, bits_y, cum, T, stage, lds);
+    else
+        split_tables_body<real, 8>(X, Y, bits_x, bits_y, cum, T, stage, lds);
+}
+
+// One inverse-CDF step over the lanes of a wave: the first lane of positive weight whose running sum exceeds r, and what
+// is left of r inside that lane's weight.  Rounding may leave no such lane (the caller then takes the last lane of
+// positive weight).
+struct LanePick {
+    bool crossed;
+    uint32_t lane;
+    double rest;
+};
+__device__ __forceinline__ LanePick select_lane(double weight, double inclusive, double r, uint64_t positive) {
+    const uint64_t crossed = __ballot(inclusive > r) & positive;
+    LanePick p{crossed != 0, 0u, 0.0};
+    if (crossed) {
+        p.lane = uint32_t(__builtin_ctzll(crossed));
+        const double left = r - read_lane(inclusive - weight, p.lane);
+        p.rest = left > 0.0 ? left : 0.0;
+    }
+    return p;
+}
+
+__device__ __forceinline__ uint32_t deposit_bits(uint32_t v, uint32_t mask) {
+    uint32_t out = 0;
+    while (mask) {
+        const uint32_t low = mask & (0u - mask);
+        if (v & 1u) out |= low;
+        v >>= 1;
+        mask ^= low;
+    }
+    return out;
+}
+
+// |psi(x, y)|^2 for this lane's y; lane j < J holds X_j[x] (re, im)
+template <typename real, int J>
+__device__ __forceinline__ double split_probability(const cx<real>* __restrict__ Y, uint32_t bits_y, uint32_t y, double x_re_of_lane,
+                                                    double x_im_of_lane) {
+    double pr = 0.0, pi = 0.0;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const cx<real> v = Y[(size_t(j) << bits_y) + y];
+        const double yr = double(v.re), yi = double(v.im);
+        const double xr = read_lane(x_re_of_lane, uint32_t(j)), xi = read_lane(x_im_of_lane, uint32_t(j));
+        pr = fma(xr, yr, fma(-xi, yi, pr));
+        pi = fma(xr, yi, fma(xi, yr, pi));
+    }
+    return fma(pr, pr, pi * pi);
+}
+
+// One wave per shot, three inverse-CDF levels: x (running sums of its marginal, 64 candidates per step), the block y1
+// of 64 values of y (quadratic forms of the block's Gram matrix, a candidate per lane), y inside the block (the
+// amplitudes themselves, a value of y per lane).  The levels above the last work with sums that carry rounding errors;
+// the last one only ever selects a lane whose amplitude is not zero, and when rounding has led to a block without any
+// (probability ~1e-16) the blocks are walked until one has: a state of probability zero is never drawn.
+// What is uniform over the wave (the J values of X at the shot's x, the J^2 products of the quadratic form) lives in
+// ONE register, entry pi in lane pi, and is read out as scalars where it is used.
+template <typename real, int J>
+__device__ void split_sample_body(const cx<real>* __restrict__ X, const cx<real>* __restrict__ Y, uint32_t bits_x, uint32_t bits_y,
+                                  uint32_t mask_x, uint32_t mask_y, const double* __restrict__ cum, const double* __restrict__ Tg,
+                                  double* T, int shots, uint64_t seed, uint32_t eval, const double* __restrict__ diag,
+                                  uint64_t* __restrict__ out, double* __restrict__ out_values) {
+    constexpr int SPB = kSplitSampleShotsPerBlock;
+    constexpr uint32_t NQ = J * J;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t ly2 = bits_y < kSplitSampleBlockBits ? bits_y : kSplitSampleBlockBits;
+    const uint32_t ny2 = 1u << ly2, ny1 = 1u << (bits_y - ly2);
+    const uint32_t nx = 1u << bits_x;
+    if (ny1 > 1) {  // (uniform: the workgroup's evaluation)
+        for (uint32_t i = tid; i < NQ * ny1; i += blockDim.x) T[i] = Tg[i];
+        __syncthreads();
+    }
+    uint32_t ja, jb, part;
+    split_entry_of<J>(lane % NQ, &ja, &jb, &part);
+    const double total = cum[nx - 1];
+    const double below_total = __longlong_as_double(__double_as_longlong(total) - 1);
+    const int shot0 = int(blockIdx.x) * SPB;
+    const uint32_t n_waves = blockDim.x >> 6;
+    const uint32_t my_y2 = lane < ny2 ? lane : 0u;
+    for (uint32_t s = wave; s < uint32_t(SPB) && shot0 + int(s) < shots; s += n_waves) {
+        double r = shot_uniform(seed, eval, uint32_t(shot0) + s) * total;
+        if (!(r < total)) r = below_total;  // (so that every step below finds a running sum above r)
+        // x: six bits per step, lane c looks at the last entry of the c-th part of what is left
+        uint32_t x = 0;
+        for (uint32_t left = bits_x; left > 0;) {
+            const uint32_t step = left < 6u ? left : 6u;
+            left -= step;
+            const uint32_t c = lane < (1u << step) ? lane : (1u << step) - 1u;
+            const double v = cum[((((x << step) | c) + 1u) << left) - 1u];
+            const uint64_t crossed = __ballot(v > r && lane < (1u << step));
+            x = (x << step) | (crossed ? uint32_t(__builtin_ctzll(crossed)) : (1u << step) - 1u);
+        }
+        x = __builtin_amdgcn_readfirstlane(x);
+        {
+            const double before = x ? cum[x - 1] : 0.0;
+            r = r > before ? r - before : 0.0;
+        }
+        cx<real> xa = X[(size_t(ja) << bits_x) + x], xb = X[(size_t(jb) << bits_x) + x];
+        // the block of y
+        uint32_t y1 = 0;
+        if (ny1 > 1) {
+            const double w = split_entry_value(part, double(xa.re), double(xa.im), double(xb.re), double(xb.im));
+            bool found = false;
+            uint32_t last_positive = 0;
+            double carry = 0.0, rest = __builtin_huge_val();
+            for (uint32_t base = 0; base < ny1; base += 64) {
+                const uint32_t cand = base + lane;
+                double t = split_quad_table<J>(T, ny1, cand < ny1 ? cand : ny1 - 1u, w);
+                t = cand < ny1 && t > 0.0 ? t : 0.0;
+                const double inc = wave_inclusive(t);
+                const uint64_t positive = __ballot(t > 0.0);
+                if (!found) {
+                    const LanePick p = select_lane(t, inc, r - carry, positive);
+                    if (p.crossed) {
+                        found = true;
+                        y1 = base + p.lane;
+                        rest = p.rest;
+                    }
+                }
+                if (positive) last_positive = base + 63u - uint32_t(__builtin_clzll(positive));
+                carry += read_lane(inc, 63u);
+            }
+            if (!found) y1 = last_positive;  // (rest = +inf: its last value of y)
+            r = rest;
+        }
+        y1 = __builtin_amdgcn_readfirstlane(y1);
+        // y inside the block
+        double q = split_probability<real, J>(Y, bits_y, y1 * ny2 + my_y2, double(xa.re), double(xa.im));
+        q = lane < ny2 ? q : 0.0;
+        uint64_t positive = __ballot(q > 0.0);
+        uint32_t y2;
+        if (positive) {
+            const double inc = wave_inclusive(q);
+            const LanePick p = select_lane(q, inc, r, positive);
+            y2 = p.crossed ? p.lane : 63u - uint32_t(__builtin_clzll(positive));
+        } else {
+            // rounding has led to a block in which every amplitude is zero: walk on, block by block
+            for (uint32_t tries = 0; !positive && tries < nx * ny1; ++tries) {
+                if (++y1 == ny1) {
+                    y1 = 0;
+                    x = (x + 1u) & (nx - 1u);
+                    xa = X[(size_t(ja) << bits_x) + x];
+                }
+                q = split_probability<real, J>(Y, bits_y, y1 * ny2 + my_y2, double(xa.re), double(xa.im));
+                positive = __ballot(q > 0.0 && lane < ny2);
+            }
+            y2 = positive ? uint32_t(__builtin_ctzll(positive)) : 0u;
+        }
+        if (lane == 0) {
+            const uint32_t index = deposit_bits(x, mask_x) | deposit_bits(y1 * ny2 + y2, mask_y);
+            const size_t o = size_t(eval) * size_t(shots) + size_t(shot0) + s;
+            out[o] = index;
+            if (out_values) out_values[o] = diag[index];
+        }
+    }
+}
+
+template <typename real>
+__global__ void __launch_bounds__(256, 8) split_sample_kernel(const uint32_t* __restrict__ plan_arena, const EvalDesc* __restrict__ evals,
+                                                              const cx<real>* __restrict__ sides, uint64_t side_stride,
+                                                              const double* __restrict__ scratch, uint32_t slot_doubles,
+                                                              uint32_t cum_doubles, int shots, uint64_t seed,
+                                                              const double* __restrict__ diag, uint64_t* __restrict__ out,
+                                                              double* __restrict__ out_values) {
+    extern __shared__ __align__(16) double split_lds[];
+    const EvalDesc ev = evals[blockIdx.y];
+    if (!(ev.flags & kEvalSide)) return;
+    const uint32_t* sp = plan_arena + ev.split_base;
+    const uint32_t n_keys = sp[0], bits_x = sp[1], bits_y = sp[2];
+    const bool swap = sp[3] & 1u;
+    const uint32_t mask_x = sp[kSplitMaskX], mask_y = sp[kSplitMaskY];
+    const cx<real>* ta = sides + uint64_t(ev.state_slot) * side_stride;
+    const cx<real>* X = ta + (swap ? side_stride >> 1 : 0);
+    const cx<real>* Y = ta + (swap ? 0 : side_stride >> 1);
+    const double* cum = scratch + size_t(blockIdx.y) * slot_doubles;
+    const double* T = cum + cum_doubles;
+    if (n_keys == 0)
+        split_sample_body<real, 1>(X, Y, bits_x, bits_y, mask_x, mask_y, cum, T, split_lds, shots, seed, ev.out_index, diag, out, out_values);
+    else if (n_keys == 1)
+        split_sample_body<real, 2>(X, Y, bits_x, bits_y, mask_x, mask_y, cum, T, split_lds, shots, seed, ev.out_index, diag, out, out_values);
+    else if (n_keys == 2)
+        split_sample_body<real, 4>(X, Y, bits_x, bits_y, mask_x, mask_y, cum, T, split_lds, shots, seed, ev.out_index, diag, out, out_values);
+    else
+        split_sample_body<real, 8>(X, Y, bits_x, bits_y, mask_x, mask_y, cum, T, split_lds, shots, seed, ev.out_index, diag, out, out_values);
+}
+
+hipError_t launch_split_tables(int dtype, int tile_bits, unsigned n_evals, double* scratch, hipStream_t stream, const PassArgs& a) {
+    if (n_evals == 0) return hipSuccess;
+    const uint32_t slot = uint32_t(split_sample_slot_doubles(tile_bits)), cum = 1u << (tile_bits + 2);
+    if (dtype == 0)
+        hipLaunchKernelGGL(split_tables_kernel<double>, dim3(n_evals), dim3(256), 0, stream, a.plan, a.evals,
+                           static_cast<const cx<double>*>(a.wtab), a.wtab_stride, scratch, slot, cum);
+    else
+        hipLaunchKernelGGL(split_tables_kernel<float>, dim3(n_evals), dim3(256), 0, stream, a.plan, a.evals,
+                           static_cast<const cx<float>*>(a.wtab), a.wtab_stride, scratch, slot, cum);
+    return hipGetLastError();
+}
+
+hipError_t launch_split_sample(int dtype, int tile_bits, unsigned n_evals, const double* scratch, int shots, uint64_t seed,
+                               const double* diag, uint64_t* out, double* out_values, hipStream_t stream, const PassArgs& a,
+                               uint32_t table_doubles) {
+    if (n_evals == 0 || shots <= 0) return hipSuccess;
+    const uint32_t slot = uint32_t(split_sample_slot_doubles(tile_bits)), cum = 1u << (tile_bits + 2);
+    // LDS: the Gram table of the workgroup's evaluation (the caller may know that the launch's tables are smaller
+    // than the bound: more workgroups per CU)
+    const size_t lds = size_t(table_doubles && table_doubles < slot - cum ? table_doubles : slot - cum) * sizeof(double);
+    const dim3 grid(unsigned((shots + kSplitSampleShotsPerBlock - 1) / kSplitSampleShotsPerBlock), n_evals);
+    if (dtype == 0)
+        hipLaunchKernelGGL(split_sample_kernel<double>, grid, dim3(256), lds, stream, a.plan, a.evals,
+                           static_cast<const cx<double>*>(a.wtab), a.wtab_stride, scratch, slot, cum, shots, seed, diag, out, out_values);
+    else
+        hipLaunchKernelGGL(split_sample_kernel<float>, grid, dim3(256), lds, stream, a.plan, a.evals,
+                           static_cast<const cx<float>*>(a.wtab), a.wtab_stride, scratch, slot, cum, shots, seed, diag, out, out_values);
     return hipGetLastError();
 }
 

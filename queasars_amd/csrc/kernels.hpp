@@ -31,10 +31,11 @@ constexpr uint32_t kEvalSide = 1u, kEvalSideB = 2u, kEvalNull = 4u;
 //       side with fewer of them)
 //   [4 .. 9)    thread's own bit b (X's bits first, then Y's): its bit in the table index of the side it belongs to
 //   [9 .. 14)   ... and its value in the full index (1 << position)
+//   [14] the qubits of side X as a mask of the full index  [15] of side Y (the split sampler deposits table indices there)
 //   [16 .. 144)  lane l -> (x piece, y piece) of index bits 0 .. 5 = l
 //   [144 .. 160) wave w -> pieces of the wave-index bits
 //   [160 .. 416) chunk & 127 -> pieces of the low seven chunk bits      [416 .. 672) chunk >> 7 -> pieces of the rest
-constexpr uint32_t kSplitLoopCols = 4, kSplitLoopPos = 9, kSplitLaneTable = 16, kSplitWaveTable = 144,
+constexpr uint32_t kSplitLoopCols = 4, kSplitLoopPos = 9, kSplitMaskX = 14, kSplitMaskY = 15, kSplitLaneTable = 16, kSplitWaveTable = 144,
                    kSplitChunkLow = 160, kSplitChunkHigh = 416, kSplitBlockWords = 672;
 constexpr int kSplitLoopBits = 5, kSplitMaxLoopX = 2;
 
@@ -47,6 +48,7 @@ enum PassMode : uint32_t {
     kModeFinalProbs = 64u,   // the last pass writes |a_i|^2 (fp64) to `partials` used as [state_slot][2^n] (the sampler's input)
                              // instead of the state (n <= 28)
     kModeStreaming = 16u,    // the states do not fit the Infinity Cache: non-temporal state loads and stores
+    kModeSidesOnly = 128u,   // split evaluations: run the two virtual circuits, no contraction (the split sampler follows)
     kModeFusedPrepare = 8u,  // (pass 0 only) every workgroup first does prepare_kernel's work for its evaluation, reading
                              // the descriptor from host_evals (PassArgs below); no prepare launch ran for these evaluations
 };
@@ -151,10 +153,27 @@ hipError_t launch_pauli_combine(const double* partials, uint32_t per_slot, const
 // For each of n_slots probability vectors (slot s at probs + s * dim, need not be normalised) draw `shots` basis
 // states; evaluation (first_eval + s) gets its own random stream and writes out[(first_eval + s) * shots ..].
 // chunk_sums: scratch of n_slots * sample_chunk_count(dim) doubles.  With diag != null, out_values receives D[state].
+// evals != null: slot s belongs to evaluation evals[s].out_index instead (a batch that put its split evaluations first).
 hipError_t launch_sample(const double* probs, uint64_t dim, int n_slots, double* chunk_sums, int shots, uint64_t seed,
                          uint32_t first_eval, const double* diag, uint64_t* out, double* out_values,
-                         hipStream_t stream);
+                         hipStream_t stream, const EvalDesc* evals = nullptr);
 uint32_t sample_chunk_count(uint64_t dim);
+
+// Sampling a split evaluation (split.hpp) WITHOUT forming its 2^n probabilities.  With psi(x, y) = sum_j X_j[x] Y_j[y]
+// the probability of (x, y) summed over any set S of y values is a quadratic form in the J values X_j[x] whose matrix
+// is the Gram matrix of the Y_j restricted to S.  So: Gram matrices of Y per block of 64 consecutive y (y1 = y >> 6),
+// their sum -> the marginal of x and its running sums (launch_split_tables, one workgroup per evaluation); then per shot
+// x by binary search, y1 by its quadratic forms (one candidate per lane), the last six bits of y by the amplitudes of
+// that block themselves (launch_split_sample, one wave per shot).  Work per evaluation 2^|X| J^2 + 2^|Y| J^2 / 2 + shots
+// * (J^2 + 64 J), against 2^n for the probabilities; the samples come in a different order of the index space than
+// launch_sample's (x-major), so the same seed gives different -- equally distributed -- samples.
+// PassArgs: plan, evals (device descriptors of the group, side A region), wtab / wtab_stride (side tables).
+// scratch: n_evals * split_sample_slot_doubles(tile_bits) doubles.
+size_t split_sample_slot_doubles(int tile_bits);
+hipError_t launch_split_tables(int dtype, int tile_bits, unsigned n_evals, double* scratch, hipStream_t stream, const PassArgs& args);
+hipError_t launch_split_sample(int dtype, int tile_bits, unsigned n_evals, const double* scratch, int shots, uint64_t seed,
+                               const double* diag, uint64_t* out, double* out_values, hipStream_t stream, const PassArgs& args,
+                               uint32_t table_doubles = 0);  // (the largest Gram table of the launch, 0 = not known)
 
 // out[first_eval + e] = CVaR_alpha of values[e * shots .. (e + 1) * shots) for e < n_evals (shots <= kCvarMaxShots):
 // bitonic sort in LDS, fixed-order sum of the lowest alpha * shots values (the boundary value weighted fractionally).

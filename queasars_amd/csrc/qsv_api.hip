@@ -154,6 +154,7 @@ struct qsv_handle {
     hipEvent_t ev_join = nullptr;
     int n_streams = 2;           // streams a batch cycles over (QSV_STREAMS, 1 .. 4)
     bool split_enabled = true;   // weakly entangled circuits run as two virtual circuits + a contraction (split.hpp)
+    bool split_sampling = true;  // ... and are sampled from their two side tables (kernels.hpp: launch_split_sample)
     uint32_t stream_mode = 0;    // kModeStreaming when a state is larger than the Infinity Cache (256 MiB), else 0
     mutable std::mutex mu;
     std::atomic<std::thread::id> batch_owner{};  // thread that holds `mu` between qsv_eval_begin and qsv_eval_end
@@ -434,6 +435,8 @@ int build_circuit(qsv_t* h, int n_ops, const qsv_op* ops, int n_params, bool fol
                     blk[1] = uint32_t(sc.n_side[sx]);
                     blk[2] = uint32_t(sc.n_side[1 - sx]);
                     blk[3] = (swap_xy ? 1u : 0u) | uint32_t(loop_x) << 8;
+                    blk[kSplitMaskX] = uint32_t(sc.mask[sx]);
+                    blk[kSplitMaskY] = uint32_t(sc.mask[1 - sx]);
                     {
                         int at = 0;
                         for (int which = 0; which < 2; ++which)
@@ -867,7 +870,7 @@ int run_group(qsv_t* h, const std::vector<Circuit*>& circs, size_t first, size_t
         a.mats_out = static_cast<double*>(h->d_mats.ptr);
         for (int p = 0; p < side_passes; ++p) {
             a.pass_index = uint32_t(p);
-            a.mode = (p == 0 ? (mode | kModeFusedPrepare) : mode) | h->stream_mode;
+            a.mode = ((p == 0 ? (mode | kModeFusedPrepare) : mode) & ~uint32_t(kModeSidesOnly)) | h->stream_mode;
             const int kind = p == 0 ? 0 : 1;
             if (h->stamping) QSV_HIP(h, stamp(h, h->batch.launch_events[kind], true));
             QSV_HIP(h, launch_pass(h->dtype, h->geo.r, h->cfg.xmode, dim3(side_tiles, unsigned(n_split), 2),
@@ -925,7 +928,7 @@ int run_group(qsv_t* h, const std::vector<Circuit*>& circs, size_t first, size_t
             if (size_t(p) < st.pass_pairs.size()) h->prof.kernel_flops[kind] += 24.0 * st.pass_pairs[size_t(p)];
         }
     }
-    if (any_split) {
+    if (any_split && !(mode & kModeSidesOnly)) {
         // the contraction of the split evaluations
         a.evals = batch_evals(h) + first;
         if (h->stamping) QSV_HIP(h, stamp(h, h->batch.launch_events[2], true));
@@ -983,6 +986,32 @@ int eval_begin(qsv_t* h, const std::vector<Circuit*>& circs, const std::vector<i
     return QSV_OK;
 }
 
+// Descriptors [first, first + count) of the current batch: split evaluations first, the others behind them (results,
+// partial sums and slots go by the descriptor's fields, not by its position), so that the side circuits, the ordinary
+// passes and the contraction are each launched over the evaluations they concern -- a workgroup that only finds out that
+// it has nothing to do still costs its dispatch, and a mixed launch was mostly such workgroups.  Among the split ones
+// those with more keys first: their workgroups of the contraction take longest and should not be the tail of the
+// launch.  Returns the number of split evaluations; batch.eval_at maps positions back to evaluations.
+size_t order_split_first(qsv_t* h, size_t first, size_t count) {
+    qsv_handle::Batch& b = h->batch;
+    if (!b.split_any) return 0;
+    EvalDesc* hd = static_cast<EvalDesc*>(h->h_batch);
+    const size_t P = b.circs.size();
+    std::vector<EvalDesc> tmp(hd + first, hd + first + count), tmp2(hd + P + first, hd + P + first + count);
+    size_t at = first, n_split = 0;
+    for (int cls = kMaxSplitKeys; cls >= -1; --cls)
+        for (size_t j = 0; j < count; ++j) {
+            const int mine = b.split[first + j] ? b.circs[first + j]->split.n_keys : -1;
+            if (mine != cls) continue;
+            hd[at] = tmp[j];
+            hd[P + at] = tmp2[j];
+            b.eval_at[at] = uint32_t(first + j);
+            ++at;
+            if (cls >= 0) ++n_split;
+        }
+    return n_split;
+}
+
 int eval_push(qsv_t* h, size_t first, size_t count, const double* values) {
     qsv_handle::Batch& b = h->batch;
     if (first != b.pushed) return fail(h, QSV_E_STATE, "evaluations must be pushed in order");
@@ -1002,27 +1031,7 @@ int eval_push(qsv_t* h, size_t first, size_t count, const double* values) {
     EvalDesc* hd = static_cast<EvalDesc*>(h->h_batch);  // pinned; prepare_kernel reads it after this point
     const size_t ways = size_t(std::max(1, b.ways)), lane = ways > 1 ? size_t(b.n_pushes) % ways : 0;
     const size_t P = b.circs.size();
-    size_t n_split = 0;
-    if (b.split_any) {
-        // descriptors of the push: split evaluations first, the others behind them (results, partial sums and slots go
-        // by the descriptor's fields, not by its position), so that the side circuits, the ordinary passes and the
-        // contraction are each launched over the evaluations they concern -- a workgroup that only finds out that it
-        // has nothing to do still costs its dispatch, and a mixed launch was mostly such workgroups
-        std::vector<EvalDesc> tmp(hd + first, hd + first + count), tmp2(hd + P + first, hd + P + first + count);
-        // (... and among the split ones those with more keys first: their workgroups of the contraction take longest and
-        // should not be the tail of the launch)
-        size_t at = first;
-        for (int cls = kMaxSplitKeys; cls >= -1; --cls)
-            for (size_t j = 0; j < count; ++j) {
-                const int mine = b.split[first + j] ? b.circs[first + j]->split.n_keys : -1;
-                if (mine != cls) continue;
-                hd[at] = tmp[j];
-                hd[P + at] = tmp2[j];
-                b.eval_at[at] = uint32_t(first + j);
-                ++at;
-                if (cls >= 0) ++n_split;
-            }
-    }
+    const size_t n_split = order_split_first(h, first, count);
     // Slots.  Ordinary evaluations: G states are resident together; on one stream the slot of an evaluation is its
     // position mod G and the stream orders every reuse; with several streams each push takes its stream's share of the
     // slots.  (The expectation kernels of the general-operator path index states by position in the launch group.)
@@ -1268,6 +1277,7 @@ int qsv_create(int n_qubits, int dtype, int device, const qsv_plan_config* cfg, 
     if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
     h->own_stream = true;
     if (const char* env = getenv("QSV_SPLIT")) h->split_enabled = atoi(env) != 0;
+    if (const char* env = getenv("QSV_SPLIT_SAMPLE")) h->split_sampling = atoi(env) != 0;
     h->stream_mode = state_bytes > (size_t(256) << 20) ? uint32_t(kModeStreaming) : 0u;
     if (const char* env = getenv("QSV_STREAMING")) h->stream_mode = atoi(env) ? uint32_t(kModeStreaming) : 0u;
     if (const char* env = getenv("QSV_STREAMS")) h->n_streams = std::max(1, std::min(4, atoi(env)));
@@ -1768,13 +1778,27 @@ static int sample_batch_locked(qsv_t* h, const std::vector<Circuit*>& circs, con
     for (size_t i = 0, cur = 0; i < n_evals; cur += size_t(np[i]), ++i)
         if (np[i]) std::memcpy(packed.data() + cur, params + param_offsets[i], size_t(np[i]) * sizeof(double));
     h->prof = qsv_profile{};
-    int rc = batch_layout(h, circs, np);
+    // circuits that have a split form are sampled from their two side tables: no state, no 2^n probabilities
+    int rc = batch_layout(h, circs, np, h->split_sampling);
     if (rc) return rc;
+    const size_t n_split = order_split_first(h, 0, n_evals), n_plain = n_evals - n_split;
     const uint64_t dim = uint64_t(1) << h->n;
-    const size_t G = size_t(h->group);
-    const size_t probs_bytes = G * dim * 8, sums_bytes = G * size_t(sample_chunk_count(dim)) * 8;
+    const size_t G = size_t(h->group), SG = size_t(std::max(1, h->side_slots));
+    {
+        EvalDesc* hd = static_cast<EvalDesc*>(h->h_batch);
+        for (size_t j = 0; j < n_evals; ++j) {
+            const uint32_t slot = uint32_t(j < n_split ? j % SG : (j - n_split) % G);
+            hd[j].state_slot = slot;
+            if (h->batch.split_any) hd[n_evals + j].state_slot = slot;
+        }
+    }
+    // device scratch: probabilities and chunk sums of a group of ordinary evaluations | tables of a group of split
+    // ones | (device-side CVaR) the samples
+    const size_t probs_bytes = n_plain ? G * dim * 8 : 0, sums_bytes = n_plain ? G * size_t(sample_chunk_count(dim)) * 8 : 0;
+    const size_t split_off = ((probs_bytes + sums_bytes + 63) / 64) * 64;
+    const size_t split_bytes = n_split ? std::min(SG, n_split) * split_sample_slot_doubles(h->geo.k) * 8 : 0;
     const size_t out_bytes = n_evals * size_t(shots) * 8;
-    const size_t dev_samples_off = ((probs_bytes + sums_bytes + 63) / 64) * 64;
+    const size_t dev_samples_off = ((split_off + split_bytes + 63) / 64) * 64;
     if ((rc = ensure(h, h->d_scratch, dev_samples_off + (out_cvar ? 2 * out_bytes : 0)))) return rc;
     if ((rc = ensure(h, h->d_partials, std::max<size_t>(1, n_evals) * partials_per_state(h) * sizeof(double)))) return rc;
     if (out_cvar && (rc = ensure_host_out(h, n_evals))) return rc;
@@ -1790,28 +1814,48 @@ static int sample_batch_locked(qsv_t* h, const std::vector<Circuit*>& circs, con
         h->h_samples_bytes = 4 * out_bytes;
     }
     double* probs = static_cast<double*>(h->d_scratch.ptr);
-    double* sums = probs + G * dim;
+    double* sums = probs + (n_plain ? G * dim : 0);
+    double* split_scratch = reinterpret_cast<double*>(static_cast<char*>(h->d_scratch.ptr) + split_off);
     uint64_t* d_states = static_cast<uint64_t*>(h->h_samples);
     double* d_values = out_values ? reinterpret_cast<double*>(static_cast<char*>(h->h_samples) + out_bytes) : nullptr;
     if (out_cvar) {  // (device scratch behind the probabilities and chunk sums)
         d_states = reinterpret_cast<uint64_t*>(static_cast<char*>(h->d_scratch.ptr) + dev_samples_off);
         d_values = reinterpret_cast<double*>(static_cast<char*>(h->d_scratch.ptr) + dev_samples_off + out_bytes);
     }
+    const double* diag = d_values ? static_cast<const double*>(h->d_diag.ptr) : nullptr;
     // one-tile registers: the pass kernel prepares its evaluation itself; n <= 28: its last pass writes the
     // probabilities, not the state
     const bool fuse = h->geo.blocks_per_state == 1;
     const bool probs_in_pass = h->n <= 28;
-    rc = batch_ship(h, 0, n_evals, packed.data(), fuse ? n_evals : 0);
+    rc = batch_ship(h, 0, n_evals, packed.data(), fuse ? n_evals : n_split);
+    // the split evaluations (they lead the descriptors), a group of side-table slots at a time
+    for (size_t g0 = 0; !rc && g0 < n_split; g0 += SG) {
+        const size_t gc = std::min(SG, n_split - g0);
+        if ((rc = run_group(h, circs, g0, gc, kModeSynthFirst | kModeFinalStore | kModeSidesOnly))) break;
+        PassArgs a{};
+        a.plan = static_cast<const uint32_t*>(h->d_arena.ptr);
+        a.evals = batch_evals(h) + g0;
+        a.wtab = h->d_side.ptr;
+        a.wtab_stride = h->side_stride;
+        QSV_HIP(h, launch_split_tables(h->dtype, h->geo.k, unsigned(gc), split_scratch, h->stream, a));
+        uint32_t table_doubles = 64;  // the largest Gram table of the group (whichever side the contraction calls Y)
+        for (size_t i = 0; i < gc; ++i) {
+            const SplitInfo& sp = circs[h->batch.eval_at[g0 + i]]->split;
+            for (int side = 0; side < 2; ++side)
+                table_doubles = std::max(table_doubles, uint32_t(1) << (2 * sp.n_keys + std::max(0, sp.n_virtual[side] - sp.n_keys - 6)));
+        }
+        QSV_HIP(h, launch_split_sample(h->dtype, h->geo.k, unsigned(gc), split_scratch, shots, seed, diag, d_states, d_values,
+                                       h->stream, a, table_doubles));
+    }
     const uint32_t mode = kModeSynthFirst | (probs_in_pass ? kModeFinalProbs : kModeFinalStore) | (fuse ? kModeFusedPrepare : 0u);
-    for (size_t g0 = 0; !rc && g0 < n_evals; g0 += G) {
+    for (size_t g0 = n_split; !rc && g0 < n_evals; g0 += G) {
         const size_t gc = std::min(G, n_evals - g0);
         if ((rc = run_group(h, circs, g0, gc, mode))) break;
         if (!probs_in_pass) QSV_HIP(h, launch_probabilities(h->dtype, h->d_states.ptr, dim, int(gc), probs, h->stream));
-        QSV_HIP(h, launch_sample(probs, dim, int(gc), sums, shots, seed, uint32_t(g0),
-                                 static_cast<const double*>(h->d_diag.ptr), d_states, d_values, h->stream));
-        if (out_cvar)
-            QSV_HIP(h, launch_cvar(d_values + g0 * size_t(shots), int(gc), shots, alpha, h->h_out + g0, h->stream));
+        QSV_HIP(h, launch_sample(probs, dim, int(gc), sums, shots, seed, uint32_t(g0), diag, d_states, d_values, h->stream,
+                                 n_split ? batch_evals(h) + g0 : nullptr));
     }
+    if (!rc && out_cvar) QSV_HIP(h, launch_cvar(d_values, int(n_evals), shots, alpha, h->h_out, h->stream));
     h->batch.circs.clear();
     if (rc) return rc;
     QSV_HIP(h, hipStreamSynchronize(h->stream));

@@ -563,7 +563,7 @@ def test_split_fp32_and_general_operators():
 
 def test_split_circuits_get_their_ordinary_plan_on_first_need():
     """A circuit registered in split form has no multi-pass plan until something needs its state: the read-out and the
-    sampler build it then (several at once on the worker threads), and the split evaluation still works afterwards."""
+    old sampler build it then (several at once on the worker threads), and the split evaluation still works afterwards."""
     n = 16
     _, circuits, params = helpers.population_circuits(n, 4, 8, seed=11)
     op = helpers.random_ising_operator(n, seed=2)
@@ -574,8 +574,13 @@ def test_split_circuits_get_their_ordinary_plan_on_first_need():
     assert np.abs(np.asarray(before) - np.asarray(ref)).max() < EXP_TOL
     state = dev.statevector(circuits[0], params[0])
     assert np.abs(state - helpers.oracle_state(circuits[0], params[0])).max() < 1e-12
-    states, _ = dev.sample_batch(circuits, params, shots=64, seed=5)  # the other seven plans in one go
+    states, _ = dev.sample_batch(circuits, params, shots=64, seed=5)  # (split sampler: needs no plan)
     assert np.asarray(states).shape == (8, 64)
+    old = _sampler_device(n, False)
+    old.set_operator(op)
+    old.expectation_values(circuits, params)  # (registers the circuits in split form)
+    states_old, _ = old.sample_batch(circuits, params, shots=64, seed=5)  # the eight plans in one go
+    assert np.asarray(states_old).shape == (8, 64)
     probs = np.abs(helpers.oracle_state(circuits[3], params[3])) ** 2
     assert all(probs[int(s)] > 0 for s in np.asarray(states)[3])
     assert ev.evaluate_circuits(circuits, params) == before
@@ -628,3 +633,118 @@ def test_cvar_on_the_device_equals_the_host_cvar_of_the_same_samples(shots, alph
     assert np.abs(np.asarray(got) - np.asarray(want)).max() < 1e-12 * max(1.0, float(np.abs(values).max()))
     with pytest.raises(ValueError):
         dev.sample_cvar_batch(circuits, params, 5000, 1, 0.5)
+
+
+# ---- (l) sampling split circuits from their side tables (kernels.hpp: launch_split_sample) ------------------------------
+
+
+def _sampler_device(n, split_sample, **kwargs):
+    """A device that samples split circuits from their side tables (or, off, from the 2^n probabilities as everybody else)."""
+    import os
+
+    old = os.environ.get("QSV_SPLIT_SAMPLE")
+    os.environ["QSV_SPLIT_SAMPLE"] = "1" if split_sample else "0"
+    try:
+        return StatevectorDevice(n, **kwargs)
+    finally:
+        if old is None:
+            del os.environ["QSV_SPLIT_SAMPLE"]
+        else:
+            os.environ["QSV_SPLIT_SAMPLE"] = old
+
+
+def _one_circuit_per_key_count(n, layers, count, seed, tile=12):
+    _, circuits, params = helpers.population_circuits(n, layers, count, seed=seed)
+    chosen = {}
+    for c, p in zip(circuits, params):
+        k = _split_keys(c, tile)
+        if k < 0:
+            k = _split_keys(c, min(tile + 2, n - 1))
+        if k >= 0:  # (unsplittable circuits are the old sampler's, tested elsewhere)
+            chosen.setdefault(k, (c, p))
+    return chosen
+
+
+@pytest.mark.parametrize("n,layers,seed", [(14, 5, 54), (16, 6, 56), (17, 4, 3)])
+def test_split_sampler_follows_the_exact_distribution(n, layers, seed):
+    """Per basis state: counts of 400 000 shots within 6.5 sigma of shots * p (p = |oracle amplitude|^2) and a chi-square
+    over the states expected at least five times, Poisson bounds for the rarer ones, for one circuit of every number of
+    keys the population offers; no state of probability zero is ever drawn; values are D[state]; the draw is a
+    function of the seed."""
+    chosen = _one_circuit_per_key_count(n, layers, 48, seed)
+    assert len(chosen) >= 2 and max(chosen) >= 1, sorted(chosen)
+    op = helpers.random_ising_operator(n, seed=n)
+    dev = _sampler_device(n, True)
+    dev.set_operator(op)
+    circuits = [c for c, _ in chosen.values()]
+    params = [p for _, p in chosen.values()]
+    shots = 400_000
+    states, values = dev.sample_batch(circuits, params, shots, seed=17, with_values=True)
+    again, _ = dev.sample_batch(circuits, params, shots, seed=17)
+    other, _ = dev.sample_batch(circuits, params, shots, seed=18)
+    assert np.array_equal(states, again) and not np.array_equal(states, other)
+    index = np.arange(1 << n, dtype=np.uint64)
+    table = np.zeros(1 << n)
+    for z, c in zip(op.z_mask, op.coeffs):  # D[i] = sum_k c_k (-1)^popcount(i & z_k)
+        parity = index & z
+        for shift in (32, 16, 8, 4, 2, 1):
+            parity ^= parity >> np.uint64(shift)
+        table += np.where(parity & np.uint64(1), -c.real, c.real)
+    for i, (c, p) in enumerate(zip(circuits, params)):
+        probs = np.abs(helpers.oracle_state(c, p)) ** 2
+        counts = np.bincount(states[i].astype(np.int64), minlength=1 << n)
+        assert counts[probs == 0.0].sum() == 0
+        mean = shots * probs
+        big = mean >= 5.0
+        z = (counts[big] - mean[big]) / np.sqrt(mean[big] * (1.0 - probs[big]))
+        assert np.abs(z).max() < 6.5, (n, i)
+        dof = int(big.sum())
+        assert abs(float((z * z).sum()) / dof - 1.0) < 6.0 * np.sqrt(2.0 / dof), (n, i)  # chi-square over those bins
+        # rare states: Poisson tails per bin, and their total count
+        assert (counts[~big] <= mean[~big] + 6.5 * np.sqrt(mean[~big]) + 8.0).all(), (n, i)
+        rare = float(mean[~big].sum())
+        assert abs(float(counts[~big].sum()) - rare) <= 6.0 * np.sqrt(rare) + 1.0, (n, i)
+        assert np.abs(values[i] - table[states[i].astype(np.int64)]).max() < 1e-12 * float(np.abs(op.coeffs).sum())
+
+
+def test_split_sampler_in_a_mixed_batch_and_against_the_old_sampler():
+    """n = 20: split circuits and deep (unsplittable) ones in one call -- every evaluation's sample mean of D is within
+    6 sigma of ITS exact expectation (the results are ordered by input index), with the split sampler and with the old
+    one; the device-side CVaR equals the host's CVaR of the same samples."""
+    from queasars_amd.circuit_evaluation.circuit_evaluation import _cvar_of_sample_matrix
+
+    n, shots = 20, 4096
+    _, shallow, ps = helpers.population_circuits(n, 4, 20, seed=7)
+    _, deep, pd = helpers.population_circuits(n, 9, 3, seed=8)
+    circuits = deep[:2] + shallow + deep[2:]
+    params = pd[:2] + ps + pd[2:]
+    op = helpers.random_ising_operator(n, seed=3)
+    exact = np.asarray(OperatorCircuitEvaluator(op).evaluate_circuits(circuits, params))
+    for split_sample in (True, False):
+        dev = _sampler_device(n, split_sample)
+        dev.set_operator(op)
+        _, values = dev.sample_batch(circuits, params, shots, seed=5, with_values=True)
+        mean = values.mean(axis=1)
+        sigma = values.std(axis=1) / np.sqrt(shots) + 1e-12
+        assert (np.abs(mean - exact) <= 6.0 * sigma).all(), (split_sample, np.abs(mean - exact) / sigma)
+        got = dev.sample_cvar_batch(circuits, params, shots, 5, 0.25)
+        want = _cvar_of_sample_matrix(values, 0.25)
+        assert np.abs(np.asarray(got) - np.asarray(want)).max() < 1e-12 * max(1.0, float(np.abs(values).max()))
+
+
+@pytest.mark.parametrize("n,dtype,count", [(18, "fp32", 8), (24, "fp64", 6), (28, "fp64", 2)])
+def test_split_sampler_on_large_registers(n, dtype, count):
+    """Sample means against the exact expectation where the 2^n probabilities are large (n = 24: 128 MiB, n = 28: 2 GiB
+    per evaluation): the split sampler touches 2^(n/2)-sized tables only; fp32 side tables at n = 18."""
+    shots = 4096
+    _, circuits, params = helpers.population_circuits(n, 3 if n == 28 else 4, count, seed=n)
+    tile = 13 if (dtype == "fp32" or n > 20) else 12
+    assert any(_split_keys(c, tile) >= 0 or _split_keys(c, min(tile + 2, n - 1)) >= 0 for c in circuits)
+    op = helpers.random_ising_operator(n, seed=1)
+    exact = np.asarray(OperatorCircuitEvaluator(op, dtype=dtype).evaluate_circuits(circuits, params))
+    dev = _sampler_device(n, True, dtype=dtype)
+    dev.set_operator(op)
+    _, values = dev.sample_batch(circuits, params, shots, seed=11, with_values=True)
+    mean = values.mean(axis=1)
+    sigma = values.std(axis=1) / np.sqrt(shots) + 1e-9
+    assert (np.abs(mean - exact) <= 6.0 * sigma + (1e-3 if dtype == "fp32" else 0.0)).all(), np.abs(mean - exact) / sigma
