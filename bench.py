@@ -17,6 +17,7 @@ Rank 0 prints ONE JSON line.  Beside the contract's fields it carries
                     profiled steps AFTER the timed region), and ``microbench``: single-gate sweeps at n = 24 and 26
   config3           BASELINE.json configs[2] at this N: n = 24, P = 256 in total (strong scaling), per-rank times
   cold_structure_evals_per_s / threaded_b1_evals_per_s   the reference's real calling patterns (N = 1 only)
+  sampler_branch    the same population through the sampler evaluator (1024 shots, CVaR 0.5; N = 1 only)
   cpu_baseline      the plain-C oracle on the host cores, the NumPy oracle, and Qiskit Aer when importable (N = 1 only)
 """
 
@@ -261,6 +262,24 @@ def cold_and_threaded(operator, n_steps: int = 7):
     return cold, threaded, noop
 
 
+def sampler_block(operator, circuits, params, shots: int = 1024, alpha: float = 0.5, reps: int = 20):
+    """The reference's sampler branch (OperatorSamplerCircuitEvaluator, circuit_evaluation.py:147-157) on the same
+    population: `shots` samples per circuit drawn, valued and reduced to CVaR_alpha on the device."""
+    from queasars_amd.circuit_evaluation import OperatorSamplerCircuitEvaluator
+
+    evaluator = OperatorSamplerCircuitEvaluator(shots, operator, alpha=alpha, seed=1)
+    for _ in range(3):
+        evaluator.evaluate_circuits(circuits, params)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        evaluator.evaluate_circuits(circuits, params)
+    rate = len(circuits) * reps / (time.perf_counter() - t0)
+    evaluator.statevector_device.close()
+    return {"value": rate, "unit": "circuit-evals/sec", "shots": shots, "alpha": alpha,
+            "note": "same population and operator as the headline, through the sampler evaluator (device-side sampling, "
+                    "operator values and CVaR); wall clock of whole calls"}
+
+
 def config3_block(world: int, rank: int, local_rank: int, steps: int = 8):
     """BASELINE.json configs[2] as north_star states it: n = 24, L = 4, P = 256 IN TOTAL (strong scaling: at N = 8 rank r
     takes [32r, 32r+32), at N = 1 the one GPU evaluates all 256), 300-term Ising operator of default_rng(2024), through
@@ -475,6 +494,7 @@ def main() -> None:
             result["cold_structure_evals_per_s"] = cold
             result["threaded_b1_evals_per_s"] = threaded
             result["threaded_b1_noop_tasks_per_s"] = noop
+            result["sampler_branch"] = sampler_block(operator, circuits, params)
             result["calling_pattern_note"] = (
                 "cold: every step evaluates 64 circuit structures the device has never seen (plan building + upload "
                 "inside the timed region); threaded: 64 host threads, one circuit per call (the reference's selection "

@@ -176,6 +176,9 @@ int qsv_probabilities(qsv_t* h, int circuit_id, const double* params, int n_para
 /*
  * Draw `shots` basis states from the circuit's output distribution on the device (seeded inverse-CDF sampling).
  * Replaces `sampler.run(pubs, shots)` + `get_counts()` in measure_quasi_distributions (circuit_evaluation.py:50-59).
+ * The draw is a function of (seed, circuit, parameters) on a given handle configuration; a circuit that has a split form
+ * is sampled from its two side tables (no 2^n probabilities are formed), which walks the index space in another order
+ * than the probabilities-based sampler: same distribution, different samples for the same seed.
  */
 int qsv_sample(qsv_t* h, int circuit_id, const double* params, int n_params, int shots, uint64_t seed,
                uint64_t* out_states);

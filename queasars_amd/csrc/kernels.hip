@@ -1676,7 +1676,7 @@ uint32_t sample_chunk_count(uint64_t dim) { return uint32_t((dim + kSampleChunk 
 
 // CVaR of one evaluation's sample values per workgroup (expectation_calculation.py:27-40 restated for equally weighted
 // samples): sort ascending, take probability mass alpha from the low end.
-__global__ void __launch_bounds__(256) cvar_kernel(const double* __restrict__ values, int shots, int padded, double alpha,
+__global__ void __launch_bounds__(1024) cvar_kernel(const double* __restrict__ values, int shots, int padded, double alpha,
                                                    double* __restrict__ out) {
     extern __shared__ double sorted[];
     const double* v = values + size_t(blockIdx.x) * size_t(shots);
@@ -1724,7 +1724,10 @@ hipError_t launch_cvar(const double* values, int n_evals, int shots, double alph
     if (shots < 1 || shots > kCvarMaxShots || !(alpha > 0.0) || alpha > 1.0) return hipErrorInvalidValue;
     int padded = 256;  // (at least one value per thread: the reduction tree reuses the buffer)
     while (padded < shots) padded <<= 1;
-    hipLaunchKernelGGL(cvar_kernel, dim3(n_evals), dim3(256), size_t(padded) * sizeof(double), stream, values, shots, padded,
+    // a thread per value up to 1024 (measured at 1024 shots: 30 us per launch with 256 threads -- the sort is a chain of
+    // 55 barrier-separated steps, and four values per thread and step made each of them longer)
+    const int threads = padded < 1024 ? padded : 1024;
+    hipLaunchKernelGGL(cvar_kernel, dim3(n_evals), dim3(threads), size_t(padded) * sizeof(double), stream, values, shots, padded,
                        alpha, out);
     return hipGetLastError();
 }
@@ -1820,53 +1823,88 @@ __device__ __forceinline__ double split_quad_vector(double m_of_lane, const doub
     return t;
 }
 
+// Gram blocks of one evaluation (blockIdx.y), spread over the waves of gridDim.x workgroups.  A wave takes a block of 64
+// y: its J rows of Y go to the wave's own LDS region (coalesced loads; y-major with one entry of padding per y, so that
+// neither the writes nor the reads below collide on banks); lane (sub, pi) adds row pi's products over the sub-th run
+// of J^2 values of y, the runs are added across lanes.
 template <typename real, int J>
-__device__ void split_tables_body(const cx<real>* __restrict__ X, const cx<real>* __restrict__ Y, uint32_t bits_x, uint32_t bits_y,
-                                  double* __restrict__ cum, double* __restrict__ T, cx<real>* stage_all, double* lds) {
+__device__ void split_gram_body(const cx<real>* __restrict__ Y, uint32_t bits_y, double* __restrict__ T, cx<real>* stage_all) {
     constexpr uint32_t NQ = J * J;  // rows of T
+    constexpr uint32_t PITCH = J + 1;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6), n_waves = blockDim.x >> 6;
     const uint32_t ly2 = bits_y < kSplitSampleBlockBits ? bits_y : kSplitSampleBlockBits;
     const uint32_t ny2 = 1u << ly2, ny1 = 1u << (bits_y - ly2);
-    // Gram blocks.  A wave takes a block of 64 y: its J rows of Y go to the wave's own LDS region (coalesced loads); lane
-    // (sub, pi) adds row pi's products over the sub-th run of J^2 values of y, the runs are added across lanes.
-    cx<real>* stage = stage_all + size_t(wave) * J * 64;
+    cx<real>* stage = stage_all + size_t(wave) * PITCH * 64;
     const uint32_t pi = lane % NQ, sub = lane / NQ;
     uint32_t ja, jb, part;
     split_entry_of<J>(pi, &ja, &jb, &part);
-    double m_sum = 0.0;
-    for (uint32_t y1 = wave; y1 < ny1; y1 += n_waves) {
+    for (uint32_t y1 = blockIdx.x * n_waves + wave; y1 < ny1; y1 += gridDim.x * n_waves) {
 #pragma unroll
         for (int j = 0; j < J; ++j) {
             cx<real> v{real(0), real(0)};
             if (lane < ny2) v = Y[(size_t(j) << bits_y) + size_t(y1) * ny2 + lane];
-            stage[j * 64 + int(lane)] = v;
+            stage[lane * PITCH + uint32_t(j)] = v;
         }
         double acc = 0.0;
 #pragma unroll 4
         for (uint32_t i = 0; i < NQ; ++i) {
             const uint32_t y2 = sub * NQ + i;
-            const cx<real> a = stage[ja * 64 + y2], b = stage[jb * 64 + y2];
+            const cx<real> a = stage[y2 * PITCH + ja], b = stage[y2 * PITCH + jb];
             acc += split_entry_value(part, double(a.re), double(a.im), double(b.re), double(b.im));
         }
         for (uint32_t off = NQ; off < 64; off <<= 1) acc += __shfl_xor(acc, int(off));
         acc = part == 0 ? acc : part == 1 ? 2.0 * acc : -2.0 * acc;
         if (lane < NQ) T[pi * ny1 + y1] = acc;
-        m_sum += acc;
     }
-    // their sum over the blocks, waves in order: the Gram matrix of the whole side
-    double* M = lds;             // [NQ]
-    double* per_wave = lds + 64;  // [n_waves][NQ]
-    if (lane < NQ) per_wave[wave * NQ + pi] = m_sum;
-    __syncthreads();
-    if (tid < NQ) {
+}
+
+constexpr unsigned kSplitGramParts = 4;  // workgroups per evaluation
+
+template <typename real>
+__global__ void __launch_bounds__(256, 2) split_gram_kernel(const uint32_t* __restrict__ plan_arena, const EvalDesc* __restrict__ evals,
+                                                            const cx<real>* __restrict__ sides, uint64_t side_stride,
+                                                            double* __restrict__ scratch, uint32_t slot_doubles, uint32_t cum_doubles) {
+    __shared__ cx<real> stage[4 * 9 * 64];
+    const EvalDesc ev = evals[blockIdx.y];
+    if (!(ev.flags & kEvalSide)) return;
+    const uint32_t* sp = plan_arena + ev.split_base;
+    const uint32_t n_keys = sp[0], bits_y = sp[2];
+    const bool swap = sp[3] & 1u;
+    const cx<real>* Y = sides + uint64_t(ev.state_slot) * side_stride + (swap ? 0 : side_stride >> 1);
+    double* T = scratch + size_t(blockIdx.y) * slot_doubles + cum_doubles;
+    if (n_keys == 0)
+        split_gram_body<real, 1>(Y, bits_y, T, stage);
+    else if (n_keys == 1)
+        split_gram_body<real, 2>(Y, bits_y, T, stage);
+    else if (n_keys == 2)
+        split_gram_body<real, 4>(Y, bits_y, T, stage);
+    else
+        split_gram_body<real, 8>(Y, bits_y, T, stage);
+}
+
+// The marginal of x and its running sums, one workgroup per evaluation: the Gram matrix of the whole of Y (the sum of
+// the blocks, in a fixed order), its quadratic form for every x, an inclusive scan.
+template <typename real, int J>
+__device__ void split_marginal_body(const cx<real>* __restrict__ X, uint32_t bits_x, uint32_t bits_y, double* __restrict__ cum,
+                                    const double* __restrict__ T, double* lds) {
+    constexpr uint32_t NQ = J * J;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6), n_threads = blockDim.x;
+    const uint32_t ly2 = bits_y < kSplitSampleBlockBits ? bits_y : kSplitSampleBlockBits;
+    const uint32_t ny1 = 1u << (bits_y - ly2);
+    // thread (piece, pi) adds its piece of row pi, then the pieces in order
+    const uint32_t pi = tid % NQ, piece = tid / NQ, n_pieces = n_threads / NQ;
+    double* partial = lds;  // [n_threads]
+    {
+        const uint32_t per = (ny1 + n_pieces - 1) / n_pieces;
+        const uint32_t lo = min(ny1, piece * per), hi = min(ny1, lo + per);
         double m = 0.0;
-        for (uint32_t w = 0; w < n_waves; ++w) m += per_wave[w * NQ + tid];
-        M[tid] = m;
+        for (uint32_t y1 = lo; y1 < hi; ++y1) m += T[pi * ny1 + y1];
+        partial[tid] = m;
     }
     __syncthreads();
-    const double m_of_lane = M[pi];
-    // marginal of x and its running sums: a contiguous run of x per thread, then the threads' totals
-    const uint32_t nx = 1u << bits_x, per = (nx + blockDim.x - 1) / blockDim.x;
+    double m_of_lane = 0.0;
+    for (uint32_t q = 0; q < n_pieces; ++q) m_of_lane += partial[q * NQ + (lane % NQ)];
+    const uint32_t nx = 1u << bits_x, per = (nx + n_threads - 1) / n_threads;
     const uint32_t lo = min(nx, tid * per), hi = min(nx, lo + per);
     double mine = 0.0;
     // (every lane makes every trip, a lane without an x with a stand-in: the form reads its uniform factors out of lanes,
@@ -1887,7 +1925,8 @@ __device__ void split_tables_body(const cx<real>* __restrict__ X, const cx<real>
         mine += p;
     }
     const double inc = wave_inclusive(mine);
-    double* wave_total = lds + 64 + 4 * 64;  // [n_waves]
+    __syncthreads();  // (partial[] is reused)
+    double* wave_total = lds;  // [n_waves]
     if (lane == 63) wave_total[wave] = inc;
     __syncthreads();
     double run = inc - mine;
@@ -1899,29 +1938,26 @@ __device__ void split_tables_body(const cx<real>* __restrict__ X, const cx<real>
 }
 
 template <typename real>
-__global__ void __launch_bounds__(256, 2) split_tables_kernel(const uint32_t* __restrict__ plan_arena, const EvalDesc* __restrict__ evals,
-                                                              const cx<real>* __restrict__ sides, uint64_t side_stride,
-                                                              double* __restrict__ scratch, uint32_t slot_doubles, uint32_t cum_doubles) {
-    __shared__ double lds[64 + 4 * 64 + 4];
-    __shared__ cx<real> stage[4 * 8 * 64];
+__global__ void __launch_bounds__(256, 2) split_marginal_kernel(const uint32_t* __restrict__ plan_arena, const EvalDesc* __restrict__ evals,
+                                                                const cx<real>* __restrict__ sides, uint64_t side_stride,
+                                                                double* __restrict__ scratch, uint32_t slot_doubles, uint32_t cum_doubles) {
+    __shared__ double lds[256];
     const EvalDesc ev = evals[blockIdx.x];
     if (!(ev.flags & kEvalSide)) return;
     const uint32_t* sp = plan_arena + ev.split_base;
     const uint32_t n_keys = sp[0], bits_x = sp[1], bits_y = sp[2];
     const bool swap = sp[3] & 1u;
-    const cx<real>* ta = sides + uint64_t(ev.state_slot) * side_stride;
-    const cx<real>* X = ta + (swap ? side_stride >> 1 : 0);
-    const cx<real>* Y = ta + (swap ? 0 : side_stride >> 1);
+    const cx<real>* X = sides + uint64_t(ev.state_slot) * side_stride + (swap ? side_stride >> 1 : 0);
     double* cum = scratch + size_t(blockIdx.x) * slot_doubles;
-    double* T = cum + cum_doubles;
+    const double* T = cum + cum_doubles;
     if (n_keys == 0)
-        split_tables_body<real, 1>(X, Y, bits_x, bits_y, cum, T, stage, lds);
+        split_marginal_body<real, 1>(X, bits_x, bits_y, cum, T, lds);
     else if (n_keys == 1)
-        split_tables_body<real, 2>(X, Y, bits_x, bits_y, cum, T, stage, lds);
+        split_marginal_body<real, 2>(X, bits_x, bits_y, cum, T, lds);
     else if (n_keys == 2)
-        split_tables_body<real, 4>(X, Y, bits_x, bits_y, cum, T, stage, lds);
+        split_marginal_body<real, 4>(X, bits_x, bits_y, cum, T, lds);
     else
-        split_tables_body<real, 8>(X, Y, bits_x, bits_y, cum, T, stage, lds);
+        split_marginal_body<real, 8>(X, bits_x, bits_y, cum, T, lds);
 }
 
 // One inverse-CDF step over the lanes of a wave: the first lane of positive weight whose running sum exceeds r, and what
@@ -1999,24 +2035,33 @@ __device__ void split_sample_body(const cx<real>* __restrict__ X, const cx<real>
     const int shot0 = int(blockIdx.x) * SPB;
     const uint32_t n_waves = blockDim.x >> 6;
     const uint32_t my_y2 = lane < ny2 ? lane : 0u;
+    // (the first step of the search for x looks at the same entries for every shot)
+    const uint32_t step0 = bits_x < 6u ? bits_x : 6u;
+    const double top = cum[(((lane < (1u << step0) ? lane : (1u << step0) - 1u) + 1u) << (bits_x - step0)) - 1u];
     for (uint32_t s = wave; s < uint32_t(SPB) && shot0 + int(s) < shots; s += n_waves) {
         double r = shot_uniform(seed, eval, uint32_t(shot0) + s) * total;
         if (!(r < total)) r = below_total;  // (so that every step below finds a running sum above r)
-        // x: six bits per step, lane c looks at the last entry of the c-th part of what is left
-        uint32_t x = 0;
-        for (uint32_t left = bits_x; left > 0;) {
+        // x: six bits per step, lane c looks at the last entry of the c-th part of what is left; the sum in front of
+        // the chosen part is the neighbour's entry (or what the step before left in front)
+        double before = 0.0;
+        uint32_t x;
+        {
+            const uint64_t crossed = __ballot(top > r && lane < (1u << step0));
+            x = crossed ? uint32_t(__builtin_ctzll(crossed)) : (1u << step0) - 1u;
+            if (x) before = read_lane(top, x - 1u);
+        }
+        for (uint32_t left = bits_x - step0; left > 0;) {
             const uint32_t step = left < 6u ? left : 6u;
             left -= step;
             const uint32_t c = lane < (1u << step) ? lane : (1u << step) - 1u;
             const double v = cum[((((x << step) | c) + 1u) << left) - 1u];
             const uint64_t crossed = __ballot(v > r && lane < (1u << step));
-            x = (x << step) | (crossed ? uint32_t(__builtin_ctzll(crossed)) : (1u << step) - 1u);
+            const uint32_t pick = crossed ? uint32_t(__builtin_ctzll(crossed)) : (1u << step) - 1u;
+            if (pick) before = read_lane(v, pick - 1u);
+            x = (x << step) | pick;
         }
         x = __builtin_amdgcn_readfirstlane(x);
-        {
-            const double before = x ? cum[x - 1] : 0.0;
-            r = r > before ? r - before : 0.0;
-        }
+        r = r > before ? r - before : 0.0;
         cx<real> xa = X[(size_t(ja) << bits_x) + x], xb = X[(size_t(jb) << bits_x) + x];
         // the block of y
         uint32_t y1 = 0;
@@ -2109,12 +2154,18 @@ __global__ void __launch_bounds__(256, 8) split_sample_kernel(const uint32_t* __
 hipError_t launch_split_tables(int dtype, int tile_bits, unsigned n_evals, double* scratch, hipStream_t stream, const PassArgs& a) {
     if (n_evals == 0) return hipSuccess;
     const uint32_t slot = uint32_t(split_sample_slot_doubles(tile_bits)), cum = 1u << (tile_bits + 2);
-    if (dtype == 0)
-        hipLaunchKernelGGL(split_tables_kernel<double>, dim3(n_evals), dim3(256), 0, stream, a.plan, a.evals,
+    const dim3 gram_grid(kSplitGramParts, n_evals);
+    if (dtype == 0) {
+        hipLaunchKernelGGL(split_gram_kernel<double>, gram_grid, dim3(256), 0, stream, a.plan, a.evals,
                            static_cast<const cx<double>*>(a.wtab), a.wtab_stride, scratch, slot, cum);
-    else
-        hipLaunchKernelGGL(split_tables_kernel<float>, dim3(n_evals), dim3(256), 0, stream, a.plan, a.evals,
+        hipLaunchKernelGGL(split_marginal_kernel<double>, dim3(n_evals), dim3(256), 0, stream, a.plan, a.evals,
+                           static_cast<const cx<double>*>(a.wtab), a.wtab_stride, scratch, slot, cum);
+    } else {
+        hipLaunchKernelGGL(split_gram_kernel<float>, gram_grid, dim3(256), 0, stream, a.plan, a.evals,
                            static_cast<const cx<float>*>(a.wtab), a.wtab_stride, scratch, slot, cum);
+        hipLaunchKernelGGL(split_marginal_kernel<float>, dim3(n_evals), dim3(256), 0, stream, a.plan, a.evals,
+                           static_cast<const cx<float>*>(a.wtab), a.wtab_stride, scratch, slot, cum);
+    }
     return hipGetLastError();
 }
 
