@@ -1425,18 +1425,20 @@ __device__ __forceinline__ double block_sum_256(double v, double* red) {
 }
 
 __global__ void __launch_bounds__(256) reduce_partials_kernel(const double* __restrict__ partials, uint32_t blocks,
-                                                              double* __restrict__ out) {
+                                                              double* __restrict__ out, const EvalDesc* __restrict__ evals) {
     __shared__ double red[4];
-    const double* p = partials + size_t(blockIdx.x) * blocks;
+    const uint32_t e = evals ? evals[blockIdx.x].out_index : blockIdx.x;
+    const double* p = partials + size_t(e) * blocks;
     double acc = 0.0;
     for (uint32_t i = threadIdx.x; i < blocks; i += 256) acc += p[i];
     const double total = block_sum_256(acc, red);
-    if (threadIdx.x == 0) out[blockIdx.x] = total;
+    if (threadIdx.x == 0) out[e] = total;
 }
 
 hipError_t launch_reduce_partials(const double* partials, uint32_t blocks, int n_evals, double* out,
-                                  hipStream_t stream) {
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(n_evals), dim3(256), 0, stream, partials, blocks, out);
+                                  hipStream_t stream, const EvalDesc* evals) {
+    if (n_evals <= 0) return hipSuccess;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(n_evals), dim3(256), 0, stream, partials, blocks, out, evals);
     return hipGetLastError();
 }
 
@@ -2184,6 +2186,215 @@ hipError_t launch_split_sample(int dtype, int tile_bits, unsigned n_evals, const
     else
         hipLaunchKernelGGL(split_sample_kernel<float>, grid, dim3(256), lds, stream, a.plan, a.evals,
                            static_cast<const cx<float>*>(a.wtab), a.wtab_stride, scratch, slot, cum, shots, seed, diag, out, out_values);
+    return hipGetLastError();
+}
+
+// ---- split evaluations under a quadratic diagonal operator (kernels.hpp: launch_factor) -----------------------------
+// Weighted Gram matrices of one side: entry pi of  sum_x w(x) X(x) X(x)^dagger  for the weights w = 1, D(x, 0) and the
+// bits of x.  Lanes as in split_gram_body: (run, pi); a wave takes blocks of 64 table entries (its rows staged in LDS
+// together with the block's 64 values of D; the next block's rows are already on their way while this one is added up).
+constexpr uint32_t kFactorWeights = 18;  // 1, D, and up to 16 bits
+constexpr uint32_t kFactorPitch = 65;    // doubles per row of a Gram table in LDS (64 entries + one: rows on different banks)
+
+// out (LDS, [weight][64]) may overlap other waves' staging regions: it is written after a workgroup barrier.
+template <typename real, int J>
+__device__ void factor_side_body(const cx<real>* __restrict__ tab, uint32_t bits, uint32_t mask, const double* __restrict__ diag,
+                                 uint32_t first_block, uint32_t block_step, cx<real>* stage, double* dstage, double* out) {
+    constexpr uint32_t NQ = J * J;
+    constexpr uint32_t LQ = J == 1 ? 0 : J == 2 ? 2 : J == 4 ? 4 : 6;  // log2(NQ)
+    constexpr uint32_t PITCH = J + 1;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t pi = lane % NQ, sub = lane / NQ;
+    uint32_t ja, jb, part;
+    split_entry_of<J>(pi, &ja, &jb, &part);
+    const uint32_t n_local = bits < 6u ? 1u << bits : 64u, n_blocks = bits < 6u ? 1u : 1u << (bits - 6u);
+    double acc_one = 0.0, acc_d = 0.0, acc_low[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, acc_high[10];
+#pragma unroll
+    for (int q = 0; q < 10; ++q) acc_high[q] = 0.0;
+    cx<real> rows[J];
+    double d_next = 0.0;
+    auto fetch = [&](uint32_t blk) {
+        const bool live = lane < n_local && blk < n_blocks;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            rows[j] = cx<real>{real(0), real(0)};
+            if (live) rows[j] = tab[(size_t(j) << bits) + size_t(blk) * 64 + lane];
+        }
+        d_next = live ? diag[deposit_bits(blk * 64u + lane, mask)] : 0.0;
+    };
+    fetch(first_block);
+    for (uint32_t blk = first_block; blk < n_blocks; blk += block_step) {
+#pragma unroll
+        for (int j = 0; j < J; ++j) stage[lane * PITCH + uint32_t(j)] = rows[j];
+        dstage[lane] = d_next;
+        fetch(blk + block_step);
+        double s_one = 0.0, s_d = 0.0;
+#pragma unroll
+        for (uint32_t i = 0; i < NQ; ++i) {
+            const uint32_t xl = sub * NQ + i;
+            const cx<real> a = stage[xl * PITCH + ja], b = stage[xl * PITCH + jb];
+            const double p = split_entry_value(part, double(a.re), double(a.im), double(b.re), double(b.im));
+            s_one += p;
+            s_d = fma(dstage[xl], p, s_d);
+#pragma unroll
+            for (uint32_t q = 0; q < LQ; ++q)  // (bits of i: known when the loop is unrolled)
+                if (i >> q & 1u) acc_low[q] += p;
+        }
+#pragma unroll
+        for (uint32_t q = LQ; q < 6; ++q)  // (bits of the run number: the same for the whole run)
+            acc_low[q] += (sub >> (q - LQ) & 1u) ? s_one : 0.0;
+        acc_one += s_one;
+        acc_d += s_d;
+#pragma unroll
+        for (int q = 0; q < 10; ++q)  // (bits 6 and up are the block number's)
+            if (blk >> q & 1u) acc_high[q] += s_one;
+    }
+    // the runs of one entry, added across lanes; the lanes of the first run write
+    auto across = [&](double v) {
+        for (uint32_t off = NQ; off < 64; off <<= 1) v += __shfl_xor(v, int(off));
+        return v;
+    };
+    acc_one = across(acc_one);
+    acc_d = across(acc_d);
+#pragma unroll
+    for (int q = 0; q < 6; ++q) acc_low[q] = across(acc_low[q]);
+#pragma unroll
+    for (int q = 0; q < 10; ++q) acc_high[q] = across(acc_high[q]);
+    __syncthreads();  // (every wave of the workgroup is here: nobody reads a staging region any more)
+    if (lane < NQ) {
+        out[0 * 64 + pi] = acc_one;
+        out[1 * 64 + pi] = acc_d;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) out[(2 + q) * 64 + pi] = acc_low[q];
+#pragma unroll
+        for (int q = 0; q < 10; ++q) out[(8 + q) * 64 + pi] = acc_high[q];
+    }
+}
+
+// sum_{j'j} A[j'j] B[j'j] for two Hermitian matrices in the entry representation (split_entry_of): the diagonal entries,
+// and for every pair twice the real part of the product
+__device__ __forceinline__ double factor_pairing(const double* a, const double* b, uint32_t n_keys) {
+    const uint32_t J = 1u << n_keys, NQ = J * J;
+    double t = 0.0;
+    for (uint32_t j = 0; j < J; ++j) t = fma(a[j], b[j], t);
+    for (uint32_t e = J; e < NQ; e += 2) t += 2.0 * fma(a[e], b[e], -a[e + 1] * b[e + 1]);
+    return t;
+}
+
+// Two launches.  factor_moments_kernel: kFactorParts workgroups of four waves per evaluation, the even ones on side X,
+// the odd ones on side Y; wave (slice, w) takes blocks 4 slice + w, + 16, ..; a workgroup's four partial matrices are added
+// in LDS (wave order) and leave as ONE partial per weight and entry.  factor_combine_kernel: one workgroup per evaluation
+// adds the slices' partials in order, then one thread per pair (a, b) of qubits across the cut -- and three for the
+// separable parts -- forms its term, and the terms are added in a fixed order.
+constexpr unsigned kFactorParts = 8;
+constexpr uint32_t kFactorSlices = kFactorParts / 2;
+
+template <typename real>
+__global__ void __launch_bounds__(256, 2) factor_moments_kernel(const uint32_t* __restrict__ plan_arena, const EvalDesc* __restrict__ evals,
+                                                                const cx<real>* __restrict__ sides, uint64_t side_stride,
+                                                                const double* __restrict__ diag, double* __restrict__ scratch) {
+    constexpr uint32_t kWaves = 4;
+    // the waves' staging regions (9 x 64 amplitudes each) and, afterwards, their partial matrices (18 x 64 doubles each)
+    __shared__ __align__(16) unsigned char raw[kWaves * kFactorWeights * 64 * sizeof(double)];
+    static_assert(sizeof(raw) >= kWaves * 9 * 64 * sizeof(cx<real>), "staging regions");
+    __shared__ double dstage[kWaves * 64];
+    const EvalDesc ev = evals[blockIdx.y];
+    if (!(ev.flags & kEvalSide)) return;
+    const uint32_t* sp = plan_arena + ev.split_base;
+    const uint32_t n_keys = sp[0], NQ = 1u << (2 * n_keys);
+    const bool swap = sp[3] & 1u;
+    const uint32_t side = blockIdx.x & 1u, slice = blockIdx.x >> 1;
+    const uint32_t bits = sp[1 + side], mask = sp[kSplitMaskX + side];
+    const uint32_t tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const cx<real>* ta = sides + uint64_t(ev.state_slot) * side_stride;
+    const cx<real>* tab = ta + ((side == 0) == swap ? side_stride >> 1 : 0);  // X is side B's half when swapped
+    cx<real>* stage = reinterpret_cast<cx<real>*>(raw) + size_t(wave) * 9 * 64;
+    double* partial = reinterpret_cast<double*>(raw);  // [wave][weight][64]
+    double* out = partial + size_t(wave) * kFactorWeights * 64;
+    const uint32_t first = slice * kWaves + wave, step = kFactorSlices * kWaves;
+    if (n_keys == 0)
+        factor_side_body<real, 1>(tab, bits, mask, diag, first, step, stage, dstage + wave * 64, out);
+    else if (n_keys == 1)
+        factor_side_body<real, 2>(tab, bits, mask, diag, first, step, stage, dstage + wave * 64, out);
+    else if (n_keys == 2)
+        factor_side_body<real, 4>(tab, bits, mask, diag, first, step, stage, dstage + wave * 64, out);
+    else
+        factor_side_body<real, 8>(tab, bits, mask, diag, first, step, stage, dstage + wave * 64, out);
+    __syncthreads();
+    double* mine = scratch + size_t(ev.state_slot) * factor_slot_doubles() +
+                   (size_t(side) * kFactorSlices + slice) * kFactorWeights * 64;
+    for (uint32_t idx = tid; idx < (2u + bits) * NQ; idx += blockDim.x) {
+        const uint32_t w = idx / NQ, pi = idx % NQ;
+        double v = 0.0;
+        for (uint32_t g = 0; g < kWaves; ++g) v += partial[size_t(g) * kFactorWeights * 64 + w * 64 + pi];
+        mine[w * 64 + pi] = v;
+    }
+}
+
+__global__ void __launch_bounds__(256) factor_combine_kernel(const uint32_t* __restrict__ plan_arena, const EvalDesc* __restrict__ evals,
+                                                             const double* __restrict__ scratch, const double* __restrict__ quad,
+                                                             uint32_t n_qubits, const double* __restrict__ diag,
+                                                             double* __restrict__ result_out) {
+    __shared__ double gram[2][kFactorWeights * kFactorPitch];
+    __shared__ double red[4];
+    const EvalDesc ev = evals[blockIdx.x];
+    if (!(ev.flags & kEvalSide)) return;
+    const uint32_t* sp = plan_arena + ev.split_base;
+    const uint32_t n_keys = sp[0], NQ = 1u << (2 * n_keys);
+    const uint32_t bits[2] = {sp[1], sp[2]}, mask[2] = {sp[kSplitMaskX], sp[kSplitMaskY]};
+    const double* mine = scratch + size_t(ev.state_slot) * factor_slot_doubles();
+    const uint32_t tid = threadIdx.x;
+    // (the coupling of this thread's pair of qubits: its load goes out together with the partials')
+    const uint32_t bx = bits[0], by = bits[1];
+    double coupling = 0.0;
+    uint32_t a = 0, b = 0;
+    if (tid < bx * by) {
+        a = tid / by;
+        b = tid % by;
+        uint32_t qa = 0, qb = 0;  // the a-th qubit of side X, the b-th of side Y
+        for (uint32_t m = mask[0], k = 0; m; m &= m - 1, ++k)
+            if (k == a) qa = uint32_t(__builtin_ctz(m));
+        for (uint32_t m = mask[1], k = 0; m; m &= m - 1, ++k)
+            if (k == b) qb = uint32_t(__builtin_ctz(m));
+        coupling = quad[qa * n_qubits + qb];
+    }
+    const double d00 = diag[0];
+    for (uint32_t side = 0; side < 2; ++side)
+        for (uint32_t idx = tid; idx < (2u + bits[side]) * NQ; idx += blockDim.x) {
+            const uint32_t w = idx / NQ, pi = idx % NQ;
+            double v = 0.0;
+#pragma unroll
+            for (uint32_t g = 0; g < kFactorSlices; ++g) v += mine[(size_t(side) * kFactorSlices + g) * kFactorWeights * 64 + w * 64 + pi];
+            gram[side][w * kFactorPitch + pi] = v;
+        }
+    __syncthreads();
+    double v = 0.0;
+    if (tid < bx * by) {
+        if (coupling != 0.0)
+            v = 4.0 * coupling * factor_pairing(gram[0] + (2 + a) * kFactorPitch, gram[1] + (2 + b) * kFactorPitch, n_keys);
+    } else if (tid == bx * by) {
+        v = factor_pairing(gram[0] + kFactorPitch, gram[1], n_keys);  // D(x, 0)
+    } else if (tid == bx * by + 1) {
+        v = factor_pairing(gram[0], gram[1] + kFactorPitch, n_keys);  // D(0, y)
+    } else if (tid == bx * by + 2) {
+        v = -d00 * factor_pairing(gram[0], gram[1], n_keys);          // - D(0, 0) <psi|psi>
+    }
+    const double total = block_sum_256(v, red);
+    if (tid == 0) result_out[ev.out_index] = total;
+}
+
+hipError_t launch_factor(int dtype, unsigned n_evals, double* scratch, const double* quad, int n_qubits, hipStream_t stream,
+                         const PassArgs& a) {
+    if (n_evals == 0) return hipSuccess;
+    const dim3 grid(kFactorParts, n_evals);
+    if (dtype == 0)
+        hipLaunchKernelGGL(factor_moments_kernel<double>, grid, dim3(256), 0, stream, a.plan, a.evals,
+                           static_cast<const cx<double>*>(a.wtab), a.wtab_stride, a.diag, scratch);
+    else
+        hipLaunchKernelGGL(factor_moments_kernel<float>, grid, dim3(256), 0, stream, a.plan, a.evals,
+                           static_cast<const cx<float>*>(a.wtab), a.wtab_stride, a.diag, scratch);
+    hipLaunchKernelGGL(factor_combine_kernel, dim3(n_evals), dim3(256), 0, stream, a.plan, a.evals, scratch, quad, uint32_t(n_qubits),
+                       a.diag, a.result_out);
     return hipGetLastError();
 }
 

@@ -121,6 +121,23 @@ hipError_t launch_prepare(const uint32_t* plan, const EvalDesc* host_evals, Eval
 // n_chunks workgroups per evaluation (n_chunks * threads * 32 = 2^n), n_evals evaluations.
 hipError_t launch_contract(int dtype, unsigned n_chunks, unsigned n_evals, int threads, hipStream_t stream, const PassArgs& args);
 
+// Split evaluations under a QUADRATIC diagonal operator (every term has at most two Z factors: Ising / QUBO operators,
+// which is what the reference's problem encoders produce): <psi|D|psi> from the two side tables alone, no sweep over
+// the 2^n indices.  With b_q = (1 - z_q) / 2 the bit of qubit q,
+//     D(x, y) = D(x, 0) + D(0, y) - D(0, 0) + 4 sum_{a in X, b in Y} J_ab b_a(x) b_b(y)
+// and for psi = sum_j X_j (x) Y_j every product term factorises: <psi| f(x) g(y) |psi> = sum_{j'j} F[j'j] G[j'j] with the
+// weighted Gram matrices F[j'j] = sum_x conj(X_j'[x]) f(x) X_j[x] (J x J, Hermitian).  Two launches: the Gram matrices
+// of both sides for the weights 1, D(., 0) and the |side| bits (factor_moments_kernel: eight workgroups per evaluation,
+// fixed assignment of blocks of 64 table entries to waves, partial sums added in a fixed order), then their combination
+// (factor_combine_kernel: one workgroup per evaluation, writes result_out[out_index]).  Work per evaluation about
+// (|X| / 2 + 6) 2^|X| J^2 per side.
+// quad: n x n doubles, quad[a * n + b] = J_ab (symmetric, zero diagonal).  PassArgs: plan, evals (device descriptors,
+// side A region), wtab / wtab_stride (side tables), diag, result_out.  scratch: factor_slot_doubles() per side-table slot
+// (indexed by the descriptors' state_slot).
+constexpr size_t factor_slot_doubles() { return size_t(2) * 4 * 18 * 64; }
+hipError_t launch_factor(int dtype, unsigned n_evals, double* scratch, const double* quad, int n_qubits, hipStream_t stream,
+                         const PassArgs& args);
+
 // dtype: 0 = fp64, 1 = fp32.  r = register bits (1..4).  xmode = LDS exchange mode (see kernels.hip).
 // Returns hipSuccess or the launch error.
 hipError_t launch_pass(int dtype, int r, int xmode, dim3 grid, int threads, size_t lds_bytes, hipStream_t stream,
@@ -131,8 +148,9 @@ hipError_t launch_diag_table(int n_qubits, int n_terms, const uint64_t* z_mask, 
                              hipStream_t stream);
 
 // out[e] = sum_b partials[e * blocks + b]   (fixed-order tree: bitwise reproducible)
+// evals != null: the n_evals evaluations are evals[i].out_index (partials and out are then indexed by that number)
 hipError_t launch_reduce_partials(const double* partials, uint32_t blocks, int n_evals, double* out,
-                                  hipStream_t stream);
+                                  hipStream_t stream, const EvalDesc* evals = nullptr);
 
 // Off-diagonal Pauli terms grouped by x mask (see kernels.hip).
 struct PauliGroup {

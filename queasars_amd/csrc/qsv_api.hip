@@ -155,6 +155,11 @@ struct qsv_handle {
     int n_streams = 2;           // streams a batch cycles over (QSV_STREAMS, 1 .. 4)
     bool split_enabled = true;   // weakly entangled circuits run as two virtual circuits + a contraction (split.hpp)
     bool split_sampling = true;  // ... and are sampled from their two side tables (kernels.hpp: launch_split_sample)
+    bool factor_enabled = true;  // ... and, under a quadratic diagonal operator, need no sweep over the 2^n indices at all
+                                 // (kernels.hpp: launch_factor)
+    bool quadratic = false;      // the operator is diagonal and every term has at most two Z factors
+    DeviceBuffer d_quad;         // its couplings as an n x n matrix
+    DeviceBuffer d_factor;       // launch_factor's partial Gram matrices, one region per side-table slot
     uint32_t stream_mode = 0;    // kModeStreaming when a state is larger than the Infinity Cache (256 MiB), else 0
     mutable std::mutex mu;
     std::atomic<std::thread::id> batch_owner{};  // thread that holds `mu` between qsv_eval_begin and qsv_eval_end
@@ -809,6 +814,9 @@ hipError_t stamp(qsv_t* h, std::vector<std::pair<hipEvent_t, hipEvent_t>>& list,
     return hipEventRecord(list.back().second, ws(h));
 }
 
+// Split evaluations need no contraction sweep under a quadratic diagonal operator (kernels.hpp: launch_factor).
+bool factor_path(const qsv_t* h) { return h->factor_enabled && h->diagonal && h->quadratic && h->d_quad.ptr != nullptr && h->d_factor.ptr != nullptr; }
+
 // Run the gate passes of evaluations [first, first+count) of the current batch (one launch group).
 int run_group(qsv_t* h, const std::vector<Circuit*>& circs, size_t first, size_t count, uint32_t mode) {
     const qsv_handle::Batch& b = h->batch;
@@ -928,7 +936,35 @@ int run_group(qsv_t* h, const std::vector<Circuit*>& circs, size_t first, size_t
             if (size_t(p) < st.pass_pairs.size()) h->prof.kernel_flops[kind] += 24.0 * st.pass_pairs[size_t(p)];
         }
     }
-    if (any_split && !(mode & kModeSidesOnly)) {
+    if (any_split && !(mode & kModeSidesOnly) && factor_path(h)) {
+        // quadratic operator: the expectation value from the two side tables alone, written straight to the result buffer
+        a.evals = batch_evals(h) + first;
+        a.result_out = h->h_out;
+        if (h->stamping) QSV_HIP(h, stamp(h, h->batch.launch_events[2], true));
+        QSV_HIP(h, launch_factor(h->dtype, unsigned(n_split), static_cast<double*>(h->d_factor.ptr),
+                                 static_cast<const double*>(h->d_quad.ptr), h->n, ws(h), a));
+        if (h->stamping) QSV_HIP(h, stamp(h, h->batch.launch_events[2], false));
+        h->prof.kernel_launches[2] += 2;
+        for (size_t i = 0; i < n_split; ++i) {
+            const SplitInfo& sp = circs[eval_of(first + i)]->split;
+            // what the two kernels read per state: the side tables and one value of D per table row
+            uint64_t moved = 0;
+            double flops = 0.0;
+            for (int s = 0; s < 2; ++s) {
+                const int side_bits = sp.n_virtual[s] - sp.n_keys;
+                moved += (uint64_t(1) << sp.n_virtual[s]) * h->amp_bytes + (uint64_t(8) << side_bits);
+                flops += double(uint64_t(1) << side_bits) * double(1u << (2 * sp.n_keys)) * (side_bits / 2.0 + 5.0) * 2.0;
+                h->prof.kernel_states[0] += 1;
+                if (!sp.stats[s].pass_pairs.empty()) h->prof.kernel_flops[0] += 24.0 * sp.stats[s].pass_pairs[0];
+            }
+            h->prof.state_bytes += moved;
+            h->prof.kernel_bytes[2] += moved;
+            h->prof.moved_bytes += moved;
+            h->prof.kernel_moved_bytes[2] += moved;
+            h->prof.kernel_states[2] += 1;
+            h->prof.kernel_flops[2] += flops;
+        }
+    } else if (any_split && !(mode & kModeSidesOnly)) {
         // the contraction of the split evaluations
         a.evals = batch_evals(h) + first;
         if (h->stamping) QSV_HIP(h, stamp(h, h->batch.launch_events[2], true));
@@ -1095,8 +1131,12 @@ int eval_push(qsv_t* h, size_t first, size_t count, const double* values) {
         // This push's evaluations are reduced on the push's own stream, straight into the pinned result buffer: no
         // cross-stream join in front of one final reduction (the join alone cost 15-30 us at the end of every call).
         QSV_HIP(h, stamp(h, b.exp_events, true));
-        QSV_HIP(h, launch_reduce_partials(static_cast<const double*>(h->d_partials.ptr) + first * size_t(partials_per_state(h)),
-                                          partials_per_state(h), int(count), h->h_out + first, ws(h)));
+        if (n_split > 0 && factor_path(h))  // (the split evaluations' results are already there: the others, by descriptor)
+            QSV_HIP(h, launch_reduce_partials(static_cast<const double*>(h->d_partials.ptr), partials_per_state(h),
+                                              int(count - n_split), h->h_out, ws(h), batch_evals(h) + first + n_split));
+        else
+            QSV_HIP(h, launch_reduce_partials(static_cast<const double*>(h->d_partials.ptr) + first * size_t(partials_per_state(h)),
+                                              partials_per_state(h), int(count), h->h_out + first, ws(h)));
         QSV_HIP(h, stamp(h, b.exp_events, false));
     }
     b.pushed = first + count;
@@ -1278,6 +1318,7 @@ int qsv_create(int n_qubits, int dtype, int device, const qsv_plan_config* cfg, 
     h->own_stream = true;
     if (const char* env = getenv("QSV_SPLIT")) h->split_enabled = atoi(env) != 0;
     if (const char* env = getenv("QSV_SPLIT_SAMPLE")) h->split_sampling = atoi(env) != 0;
+    if (const char* env = getenv("QSV_FACTOR")) h->factor_enabled = atoi(env) != 0;
     h->stream_mode = state_bytes > (size_t(256) << 20) ? uint32_t(kModeStreaming) : 0u;
     if (const char* env = getenv("QSV_STREAMING")) h->stream_mode = atoi(env) ? uint32_t(kModeStreaming) : 0u;
     if (const char* env = getenv("QSV_STREAMS")) h->n_streams = std::max(1, std::min(4, atoi(env)));
@@ -1301,6 +1342,11 @@ int qsv_create(int n_qubits, int dtype, int device, const qsv_plan_config* cfg, 
         if ((e = hipMalloc(&h->d_side.ptr, size_t(h->side_stride) * h->amp_bytes * size_t(h->side_slots))) != hipSuccess)
             return bail(e, "hipMalloc(side tables)");
         h->d_side.bytes = size_t(h->side_stride) * h->amp_bytes * size_t(h->side_slots);
+        if (h->factor_enabled) {
+            const size_t bytes = factor_slot_doubles() * sizeof(double) * size_t(h->side_slots);
+            if ((e = hipMalloc(&h->d_factor.ptr, bytes)) != hipSuccess) return bail(e, "hipMalloc(partial Gram matrices)");
+            h->d_factor.bytes = bytes;
+        }
     }
     if ((e = configure_pass_kernels(dtype, geo.r, pc.xmode, geo.lds_bytes)) != hipSuccess) return bail(e, "hipFuncSetAttribute");
     *out = h;
@@ -1319,7 +1365,7 @@ void qsv_destroy(qsv_t* h) {
     }
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     for (DeviceBuffer* b : {&h->d_z, &h->d_cre, &h->d_diag, &h->d_term_partials, &h->d_groups, &h->d_term_odd, &h->d_arena,
-                            &h->d_states, &h->d_wtab, &h->d_side, &h->d_batch, &h->d_mats, &h->d_partials, &h->d_out, &h->d_scratch})
+                            &h->d_states, &h->d_wtab, &h->d_side, &h->d_factor, &h->d_quad, &h->d_batch, &h->d_mats, &h->d_partials, &h->d_out, &h->d_scratch})
         if (b->ptr) (void)hipFree(b->ptr);
     if (h->h_batch) (void)hipHostFree(h->h_batch);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
@@ -1428,6 +1474,27 @@ int qsv_set_operator(qsv_t* h, int n_terms, const uint64_t* x_mask, const uint64
         h->pauli_nb = int(std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(want, 1024), n_pairs / 256 + 1)));
         if ((rc = ensure(h, h->d_term_partials, size_t(h->group) * groups.size() * size_t(h->pauli_nb) * 8))) return rc;
         QSV_HIP(h, hipStreamSynchronize(h->stream));
+    }
+    // quadratic diagonal operators: the couplings as a dense matrix (split evaluations then factorise, launch_factor)
+    h->quadratic = false;
+    if (all_diag) {
+        bool quadratic = true;
+        std::vector<double> quad(size_t(h->n) * size_t(h->n), 0.0);
+        for (size_t k = 0; k < diag_z.size() && quadratic; ++k) {
+            const int weight = __builtin_popcountll(diag_z[k]);
+            if (weight > 2) quadratic = false;
+            if (weight == 2) {
+                const int a = __builtin_ctzll(diag_z[k]), b = 63 - __builtin_clzll(diag_z[k]);
+                quad[size_t(a) * size_t(h->n) + size_t(b)] += diag_c[k];
+                quad[size_t(b) * size_t(h->n) + size_t(a)] += diag_c[k];
+            }
+        }
+        if (quadratic) {
+            if ((rc = ensure(h, h->d_quad, quad.size() * sizeof(double)))) return rc;
+            QSV_HIP(h, hipMemcpyAsync(h->d_quad.ptr, quad.data(), quad.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+            QSV_HIP(h, hipStreamSynchronize(h->stream));
+            h->quadratic = true;
+        }
     }
     h->n_terms = n_terms;
     h->diagonal = all_diag;
