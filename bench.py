@@ -53,6 +53,9 @@ def kernel_names(n_qubits: int):
     return (f"qsv::pass_kernel<double, {r}, 2, true> (pass 0: synthesises a product state, writes only; for a split "
             "evaluation the two small virtual circuits, one workgroup each)",
             f"qsv::pass_kernel<double, {r}, 2, false> (later passes; the last one fuses the diagonal expectation and only reads)",
+            "qsv::factor_moments_kernel<double> + qsv::factor_combine_kernel, timed as one (split evaluations under a "
+            "quadratic diagonal operator: weighted Gram matrices of the two side tables, combined per evaluation; nothing of "
+            "size 2^n is read)" if os.environ.get("QSV_FACTOR", "1") != "0" else
             "qsv::contract_kernel<double> (split evaluations: forms psi[i] from the two side tables on the fly and reduces "
             "sum_i D[i] |psi[i]|^2; reads D once per state)")
 
@@ -451,7 +454,14 @@ def main() -> None:
                 "note": "top-level fields describe the kernel with the most GPU time.  Gate-pass kernels: achieved = "
                 "algorithmic state bytes per launch (16 * 2^n per state and direction the pass has to move: pass 0 "
                 "synthesises and only writes, a last pass with the fused diagonal expectation only reads, passes in "
-                "between do both; SURVEY 8(d)) / mean launch time.  Contraction kernel (weakly entangled circuits run as "
+                "between do both; SURVEY 8(d)) / mean launch time; for the virtual circuits of a split evaluation (weakly "
+                "entangled circuits run as two small circuits of about n / 2 qubits, csrc/split.hpp) the states they write, "
+                "2 * 16 * 2^(n/2 + keys) bytes per evaluation -- those launches are a chain of latencies (parameters over "
+                "PCIe, one gate pass in LDS), nowhere near a roof, and under a quadratic diagonal operator (Ising / QUBO) "
+                "the expectation value follows from weighted Gram matrices of the two small states, so NO kernel of the "
+                "step sweeps 2^n amplitudes any more: the HBM roofline of the gate-pass kernel proper is roofline.microbench "
+                "(single-gate sweeps) and the deep-circuit rows of DESIGN.md.  Contraction kernel (split evaluations under "
+                "other diagonal operators: "
                 "two small virtual circuits + one sweep, csrc/split.hpp): algorithmic bytes = what the sweep reads per "
                 "state, 8 * 2^n of the diagonal table + the two side tables; the table is shared by the evaluations of a "
                 "launch and each part of it is handled by one XCD, so it is read from memory once per launch and "

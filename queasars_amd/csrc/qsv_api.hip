@@ -889,6 +889,15 @@ int run_group(qsv_t* h, const std::vector<Circuit*>& circs, size_t first, size_t
             h->prof.kernel_launches[kind] += 1;
         }
         a.mode = mode | h->stream_mode;
+        // what the side circuits move: they synthesise their input and write their final states
+        for (size_t i = 0; i < n_split; ++i) {
+            const SplitInfo& sp = circs[eval_of(first + i)]->split;
+            const uint64_t bytes = ((uint64_t(1) << sp.n_virtual[0]) + (uint64_t(1) << sp.n_virtual[1])) * h->amp_bytes;
+            h->prof.state_bytes += bytes;
+            h->prof.moved_bytes += bytes;
+            h->prof.kernel_bytes[0] += bytes;
+            h->prof.kernel_moved_bytes[0] += bytes;
+        }
     }
     a.evals = batch_evals(h) + first + n_split;
     const bool direct = mode & kModeDirectResult;  // (eval_push decides, for the whole push)
@@ -944,7 +953,7 @@ int run_group(qsv_t* h, const std::vector<Circuit*>& circs, size_t first, size_t
         QSV_HIP(h, launch_factor(h->dtype, unsigned(n_split), static_cast<double*>(h->d_factor.ptr),
                                  static_cast<const double*>(h->d_quad.ptr), h->n, ws(h), a));
         if (h->stamping) QSV_HIP(h, stamp(h, h->batch.launch_events[2], false));
-        h->prof.kernel_launches[2] += 2;
+        h->prof.kernel_launches[2] += 1;  // (the pair of launches, timed as one)
         for (size_t i = 0; i < n_split; ++i) {
             const SplitInfo& sp = circs[eval_of(first + i)]->split;
             // what the two kernels read per state: the side tables and one value of D per table row

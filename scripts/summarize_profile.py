@@ -26,7 +26,7 @@ for path in glob.glob(f"{root}/pmc_*/**/*counter_collection.csv", recursive=True
         for r in csv.DictReader(f):
             acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for kern, counters in acc.items():
-    if not any(k in kern for k in ("pass_kernel", "contract_kernel", "reduce", "prepare")):
+    if not any(k in kern for k in ("pass_kernel", "contract_kernel", "factor_", "reduce", "prepare")):
         continue
     print(kern)
     for cname, vals in sorted(counters.items()):
@@ -39,12 +39,12 @@ stats = {}
 for path in glob.glob(f"{root}/trace/**/*kernel_stats.csv", recursive=True):
     with open(path) as f:
         for r in csv.DictReader(f):
-            if "pass_kernel" in r["Name"] or "contract_kernel" in r["Name"]:
+            if "pass_kernel" in r["Name"] or "contract_kernel" in r["Name"] or "factor_" in r["Name"]:
                 stats[r["Name"]] = (int(r["Calls"]), float(r["TotalDurationNs"]))
 if stats:
     calls = sum(c for c, _ in stats.values())
     total = sum(t for _, t in stats.values())
-    print("\n== pass_kernel (both instantiations) + contract_kernel ==")
+    print("\n== pass_kernel (both instantiations) + contract_kernel / factor kernels ==")
     print(f"calls={calls} total_ns={total:.0f} avg_ns={total / calls:.0f}")
 
 # HBM traffic per launch and per instantiation of the gate-pass kernel, corrected as MI355X_MICROARCH.md (HBM section)
@@ -52,12 +52,19 @@ if stats:
 # bench.py reads this file (profiles/traffic.json) for roofline.traffic.
 kernels = {}
 for kern, counters in acc.items():
-    if "pass_kernel" not in kern and "contract_kernel" not in kern:
+    if "pass_kernel" not in kern and "contract_kernel" not in kern and "factor_" not in kern:
         continue
-    kind = "2" if "contract_kernel" in kern else ("0" if ", true>" in kern else "1")
+    kind = "2" if ("contract_kernel" in kern or "factor_" in kern) else ("0" if ", true>" in kern else "1")
     fetch, write = counters.get("FETCH_SIZE", []), counters.get("WRITE_SIZE", [])
     if fetch and write:
         f_mean, w_mean = sum(fetch) / len(fetch), sum(write) / len(write)
+        if kind in kernels:  # (the two factor kernels run as a pair, which bench.py times as one: their means add)
+            k = kernels[kind]
+            k["kernel"] += " + " + kern
+            k["FETCH_SIZE_KiB_mean"] += f_mean
+            k["WRITE_SIZE_KiB_mean"] += w_mean
+            k["hbm_bytes_per_launch"] += (2.0 * f_mean + w_mean) * 1024.0
+            continue
         kernels[kind] = {
             "kernel": kern,
             "FETCH_SIZE_KiB_mean": f_mean,

@@ -748,3 +748,66 @@ def test_split_sampler_on_large_registers(n, dtype, count):
     mean = values.mean(axis=1)
     sigma = values.std(axis=1) / np.sqrt(shots) + 1e-9
     assert (np.abs(mean - exact) <= 6.0 * sigma + (1e-3 if dtype == "fp32" else 0.0)).all(), np.abs(mean - exact) / sigma
+
+
+# ---- (m) split evaluations under a quadratic diagonal operator: no sweep over the 2^n indices (kernels.hpp: launch_factor) ---
+
+
+def _factor_device(n, factor, **kwargs):
+    """A device whose split evaluations use the factorised expectation (or, off, the contraction kernel)."""
+    import os
+
+    old = os.environ.get("QSV_FACTOR")
+    os.environ["QSV_FACTOR"] = "1" if factor else "0"
+    try:
+        return StatevectorDevice(n, **kwargs)
+    finally:
+        if old is None:
+            del os.environ["QSV_FACTOR"]
+        else:
+            os.environ["QSV_FACTOR"] = old
+
+
+def _diagonal_operator(n, seed, kind):
+    """quadratic: Ising terms, a constant, a repeated pair; fields: single-Z terms and a constant only;
+    cubic: the Ising terms plus Z strings of weight 3 and 4 (not quadratic: the contraction kernel's case)."""
+    rng = np.random.default_rng(seed)
+    terms = [("", [], 0.75)]
+    for i in range(n):
+        terms.append(("Z", [i], float(rng.normal())))
+    if kind != "fields":
+        for i in range(n):
+            for j in range(i + 1, n):
+                if rng.random() < 0.6:
+                    terms.append(("ZZ", [i, j], float(rng.normal())))
+        terms.append(("ZZ", [0, n - 1], 0.5))  # (a pair that is there already, most likely: couplings add up)
+        terms.append(("ZZ", [n - 1, 0], -0.25))
+    if kind == "cubic":
+        terms.append(("ZZZ", [0, n // 2, n - 1], 0.9))
+        terms.append(("ZZZZ", [1, 2, n // 2 + 1, n - 2], -0.6))
+    return PauliOperator.from_sparse_list(terms, n)
+
+
+@pytest.mark.parametrize("n,layers,count", [(14, 5, 24), (17, 4, 24), (20, 4, 48), (22, 5, 16), (25, 3, 6)])
+def test_factorised_expectation_agrees_with_the_contraction_and_the_pass_path(n, layers, count):
+    """Quadratic diagonal operators (with a constant, single-Z terms, repeated pairs; or no couplings at all): the
+    factorised expectation, the contraction kernel and the ordinary multi-pass path agree within 1e-10; an operator with
+    terms of weight three and four is not quadratic and still agrees (it takes the contraction kernel either way)."""
+    _, circuits, params = helpers.population_circuits(n, layers, count, seed=70 + n)
+    tile = 12 if n < 21 else 13
+    keys = [max(_split_keys(c, tile), _split_keys(c, min(tile + 2, n - 1))) for c in circuits]
+    assert max(keys) >= (1 if n < 25 else 0), keys  # (n = 25: sides of 12 and 13 qubits, the largest tables)
+    for kind in ("quadratic", "fields", "cubic"):
+        op = _diagonal_operator(n, seed=n, kind=kind)
+        factor = OperatorCircuitEvaluator(op, statevector_device=_factor_device(n, True)).evaluate_circuits(circuits, params)
+        contract = OperatorCircuitEvaluator(op, statevector_device=_factor_device(n, False)).evaluate_circuits(circuits, params)
+        scale = max(1.0, float(np.abs(op.coeffs).sum()) / 50.0)
+        assert np.abs(np.asarray(factor) - np.asarray(contract)).max() < EXP_TOL * scale, kind
+        if kind == "cubic":
+            assert factor == contract  # (the same kernels ran)
+        if n <= 22:
+            plain = OperatorCircuitEvaluator(op, statevector_device=_split_device(n, False)).evaluate_circuits(circuits, params)
+            assert np.abs(np.asarray(factor) - np.asarray(plain)).max() < EXP_TOL * scale, kind
+        if n <= 14:
+            for i in (0, count - 1):
+                assert abs(factor[i] - helpers.oracle_expectation(circuits[i], params[i], op)) < EXP_TOL * scale
