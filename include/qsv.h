@@ -160,6 +160,18 @@ int qsv_eval_coalesced(qsv_t* h, int circuit_id, const double* params, int n_par
 int qsv_eval_begin(qsv_t* h, int n_evals, const int* circuit_ids, const int64_t* param_counts);
 int qsv_eval_push(qsv_t* h, int first, int count, const double* values);
 int qsv_eval_end(qsv_t* h, double* out_expectations);
+/*
+ * Results into DEVICE memory (n_evals doubles, this handle's GPU), for a caller that feeds them to something on the
+ * device -- the fitness all-gather of a population sharded over several GPUs (one process per GPU; the reference hands
+ * every individual to a worker of its own, evolutionary_algorithm/selection.py:75-85).  Call between qsv_eval_begin and
+ * the first push.  qsv_eval_end(h, NULL) then returns WITHOUT waiting: the results are complete once the work
+ * enqueued so far on the handle's stream (qsv_set_stream) is, so whatever the caller enqueues on that stream next sees
+ * them, and one synchronisation at the end of ITS chain replaces the library's.  With a non-NULL pointer qsv_eval_end
+ * waits and also copies the results to the host.  The next call on the handle waits for an unfinished batch first.
+ */
+int qsv_eval_set_output(qsv_t* h, double* device_out);
+/* How many pushes the open batch is best delivered in (1 or 2): measurement-backed advice, any number works. */
+int qsv_eval_suggested_pushes(const qsv_t* h);
 /* Launch-group size of the handle (evaluations whose states are resident at the same time). */
 int qsv_group_size(const qsv_t* h);
 

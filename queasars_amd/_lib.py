@@ -81,6 +81,8 @@ SIGNATURES = {
     "qsv_eval_begin": (C.c_int, [_P, C.c_int, _P, _P]),
     "qsv_eval_push": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "qsv_eval_end": (C.c_int, [_P, _P]),
+    "qsv_eval_set_output": (C.c_int, [_P, _P]),
+    "qsv_eval_suggested_pushes": (C.c_int, [_P]),
     "qsv_group_size": (C.c_int, [_P]),
     "qsv_eval_batch": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P]),
     "qsv_statevector": (C.c_int, [_P, C.c_int, _P, C.c_int, _P]),

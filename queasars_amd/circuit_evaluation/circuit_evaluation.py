@@ -83,6 +83,9 @@ def _load_pyhelp():
                 lib.qsv_py_expectation_values.restype = C.c_int
                 lib.qsv_py_expectation_values.argtypes = [C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_void_p, C.py_object,
                                                           C.c_void_p, C.c_void_p]
+                lib.qsv_py_expectation_values_device.restype = C.c_int
+                lib.qsv_py_expectation_values_device.argtypes = [C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_void_p, C.py_object,
+                                                                 C.c_void_p, C.c_void_p]
                 _pyhelp = lib
         except OSError:
             _pyhelp = False
@@ -297,6 +300,38 @@ class StatevectorDevice:
         need = np.fromiter((c.num_parameters for c in circuits), dtype=np.int64, count=n)
         self._last_batch = ((CircuitIR.edits_of_registered, *map(id, circuits)), list(circuits), ids, need)
         return ids, need
+
+    def expectation_values_to_device(
+        self, circuits: Sequence[CircuitIR], parameter_values: Sequence[Sequence[float]], device_pointer: int
+    ) -> None:
+        """:meth:`expectation_values` with the results left in DEVICE memory (``len(circuits)`` doubles at
+        ``device_pointer``, this handle's GPU) and WITHOUT waiting for them (``qsv_eval_set_output``): they are complete
+        once the work enqueued so far on the handle's stream (:meth:`set_stream`) is.  For a caller that runs something on
+        that stream right behind -- the fitness all-gather of a sharded population (``queasars_amd.distributed``)."""
+        n = len(circuits)
+        if len(parameter_values) != n:
+            raise ValueError("circuits and parameter_values must have the same length")
+        if n == 0:
+            return
+        ids, need = self._batch_metadata(circuits)
+        counts = np.fromiter(map(len, parameter_values), dtype=np.int64, count=n)
+        if (counts < need).any():
+            i = int(np.argmax(counts < need))
+            raise ValueError(f"circuit {i} needs {int(need[i])} parameter values, got {int(counts[i])}")
+        helper = _load_pyhelp()
+        scratch = np.empty(int(counts.sum()) + 1, dtype=np.float64)
+        if helper is not None:
+            self._check(helper.qsv_py_expectation_values_device(self._handle, n, ids.ctypes.data, counts.ctypes.data,
+                                                                parameter_values, scratch.ctypes.data, C.c_void_p(device_pointer)))
+            return
+        lib, handle = self._lib, self._handle
+        self._check(lib.qsv_eval_begin(handle, n, _lib.as_ptr(ids), _lib.as_ptr(counts)))
+        rc = lib.qsv_eval_set_output(handle, C.c_void_p(device_pointer))
+        if rc == _lib.QSV_OK:
+            packed = _pack_slice(parameter_values, 0, n, int(counts.sum()))
+            rc = lib.qsv_eval_push(handle, 0, n, _lib.as_ptr(packed))
+        rc_end = lib.qsv_eval_end(handle, None)
+        self._check(rc if rc != _lib.QSV_OK else rc_end)
 
     def expectation_values(self, circuits: Sequence[CircuitIR], parameter_values: Sequence[Sequence[float]]) -> np.ndarray:
         """Exact ``real(<psi_i|H|psi_i>)`` for every (circuit, parameter vector) pair, in input order.
@@ -590,6 +625,20 @@ class OperatorCircuitEvaluator(BaseCircuitEvaluator):
         if self._precision > 0:
             values = values + self._rng.normal(0.0, self._precision, size=values.shape)
         return values.tolist()
+
+    def evaluate_circuits_to_device(self, circuits: list[CircuitIR], parameter_values: list[list[float]], device_pointer: int) -> bool:
+        """:meth:`evaluate_circuits` with the values left in device memory and without waiting for them
+        (:meth:`StatevectorDevice.expectation_values_to_device`).  Only the exact estimator without missing entries can do
+        that; returns False -- nothing was started -- otherwise."""
+        if self._precision > 0 or None in circuits or None in parameter_values:
+            return False
+        if self._initial_state_circuit is not None:
+            circuits = [self._with_initial_state(c) for c in circuits]
+        with self._device.operator_lock:
+            if self._device._operator is not self._operator:
+                self._device.set_operator(self._operator)
+            self._device.expectation_values_to_device(circuits, parameter_values, device_pointer)
+        return True
 
     @property
     def n_qubits(self) -> int:

@@ -50,26 +50,33 @@ Py_ssize_t qsv_pack_vectors(PyObject* vectors, Py_ssize_t first, Py_ssize_t coun
 }
 
 /* The whole of StatevectorDevice.expectation_values after its argument checks, in one call: lay the batch out, pack and
- * push it in two halves (one per HIP stream of the library; a population that does not fit a launch group goes in
- * group-sized pushes), wait for the results.  The GIL is released while the call waits for the handle and for the GPU.
+ * push it in as many parts as the library suggests (two halves, one per HIP stream, when there is GPU work to overlap the
+ * packing with; one push for a chain of short launches), wait for the results.  The GIL is released while the call waits for the handle and for the GPU.
  * In Python the same sequence costs five ctypes calls and a dozen NumPy temporaries per population: about 90 us of a
  * 345 us step on the benchmark workload.
  * Returns the library's status (0 or QSV_E_*); -100 with a Python exception set when a parameter vector is malformed.
  * `values` is scratch for sum(counts) doubles. */
-int qsv_py_expectation_values(qsv_t* h, Py_ssize_t n, const int* ids, const int64_t* counts, PyObject* vectors,
-                              double* values, double* out) {
+static int expectation_values(qsv_t* h, Py_ssize_t n, const int* ids, const int64_t* counts, PyObject* vectors,
+                              double* values, double* out, double* device_out) {
     int rc;
     Py_BEGIN_ALLOW_THREADS
     rc = qsv_eval_begin(h, (int)n, ids, counts);
     Py_END_ALLOW_THREADS
     if (rc) return rc;
+    if (device_out && (rc = qsv_eval_set_output(h, device_out))) {
+        (void)qsv_eval_end(h, out);
+        return rc;
+    }
     const Py_ssize_t group = qsv_group_size(h) > 0 ? qsv_group_size(h) : 1;
     /* (QSV_PUSHES = p: p pushes per population instead of two, for measurements) */
-    static int pushes = 0;
-    if (pushes == 0) {
+    static int env_pushes = -1;
+    if (env_pushes < 0) {
         const char* env = getenv("QSV_PUSHES");
-        pushes = env && atoi(env) > 0 ? atoi(env) : 2;
+        env_pushes = env && atoi(env) > 0 ? atoi(env) : 0;
     }
+    int pushes = env_pushes > 0 ? env_pushes : qsv_eval_suggested_pushes(h);
+    if (pushes < 1) pushes = 2;
+    if (device_out && env_pushes == 0) pushes = 1;  /* (a batch that does not wait runs on one stream: one push) */
     /* (a push may hold more evaluations than a launch group: the library cuts it into groups itself, and split
      * evaluations -- which need no resident state -- run in much larger groups than `group`) */
     Py_ssize_t step = (n + pushes - 1) / pushes > 8 ? (n + pushes - 1) / pushes : 8;
@@ -96,4 +103,16 @@ int qsv_py_expectation_values(qsv_t* h, Py_ssize_t n, const int* ids, const int6
     if (py_error) return -100;
     if (failed) return rc;
     return rc_end;
+}
+
+int qsv_py_expectation_values(qsv_t* h, Py_ssize_t n, const int* ids, const int64_t* counts, PyObject* vectors,
+                              double* values, double* out) {
+    return expectation_values(h, n, ids, counts, vectors, values, out, NULL);
+}
+
+/* The same with the results left in device memory and no wait (qsv_eval_set_output): for the sharded population, whose
+ * fitness all-gather runs on the same stream right behind. */
+int qsv_py_expectation_values_device(qsv_t* h, Py_ssize_t n, const int* ids, const int64_t* counts, PyObject* vectors,
+                                     double* values, void* device_out) {
+    return expectation_values(h, n, ids, counts, vectors, values, NULL, (double*)device_out);
 }

@@ -1,0 +1,37 @@
+"""One rank's step of the sharded evaluation on ONE GPU (nccl group of one rank): evaluation alone, evaluation + the
+fitness all-gather path as evaluate_population_sharded runs it for world > 1."""
+import os, sys, time
+from pathlib import Path
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+import torch
+import torch.distributed as dist
+from queasars_amd import distributed as qd
+from queasars_amd import workloads as helpers
+from queasars_amd.circuit_evaluation import OperatorCircuitEvaluator
+
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29534")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1)
+n, P = 20, 64
+_, circuits, params = helpers.population_circuits(n, 4, P, seed=0)
+ev = OperatorCircuitEvaluator(helpers.random_ising_operator(n, seed=3))
+dev = torch.device("cuda", 0)
+
+def timed(fn, reps=300):
+    for _ in range(30):
+        fn()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out = fn()
+    return (time.perf_counter() - t0) / reps * 1e6, out
+
+t_eval, want = timed(lambda: ev.evaluate_circuits(circuits, params))
+t_both, got = timed(lambda: qd._gather(ev.evaluate_circuits(circuits, params), P, 1, 0, None, dev))
+assert list(got) == list(want)
+print(f"evaluation {t_eval:.1f} us; evaluation + gather path {t_both:.1f} us")
+if hasattr(qd, "evaluate_block_and_gather"):
+    t_fused, got2 = timed(lambda: qd.evaluate_block_and_gather(ev, circuits, params, P, 1, 0, None, dev))
+    assert list(got2) == list(want), (got2[:3], want[:3])
+    print(f"device-resident results + gather {t_fused:.1f} us")
+dist.destroy_process_group()

@@ -811,3 +811,74 @@ def test_factorised_expectation_agrees_with_the_contraction_and_the_pass_path(n,
         if n <= 14:
             for i in (0, count - 1):
                 assert abs(factor[i] - helpers.oracle_expectation(circuits[i], params[i], op)) < EXP_TOL * scale
+
+
+# ---- (n) results left on the device, and the chained all-gather of the sharded population ---------------------------------
+
+
+def test_results_into_device_memory_without_waiting():
+    """qsv_eval_set_output: the batch's results land in the caller's device buffer, qsv_eval_end(NULL) does not wait; they
+    equal the waiting call's bit for bit (split and ordinary evaluations, diagonal and general operators), a waiting end
+    with a device output also returns them on the host, and a call that follows an unfinished batch waits for it."""
+    import torch
+
+    n = 18
+    _, shallow, ps = helpers.population_circuits(n, 4, 12, seed=3)
+    _, deep, pd = helpers.population_circuits(n, 9, 3, seed=4)
+    circuits, params = deep[:1] + shallow + deep[1:], pd[:1] + ps + pd[1:]
+    for op in (helpers.random_ising_operator(n, seed=5), helpers.random_pauli_operator(n, 10, seed=6)):
+        ev = OperatorCircuitEvaluator(op)
+        dev = ev.statevector_device
+        want = ev.evaluate_circuits(circuits, params)
+        buf = torch.full((len(circuits),), float("nan"), dtype=torch.float64, device="cuda")
+        for _ in range(3):  # (back to back: every call has to wait for the one before)
+            assert ev.evaluate_circuits_to_device(circuits, params, buf.data_ptr())
+        torch.cuda.synchronize()
+        assert buf.cpu().tolist() == want
+        assert ev.evaluate_circuits(circuits[::-1], params[::-1]) == want[::-1]  # right behind an unfinished batch
+        # the streaming entry points by hand, with a waiting end
+        lib, handle = dev._lib, dev._handle
+        ids, _ = dev._batch_metadata(circuits)
+        counts = np.asarray([len(p) for p in params], dtype=np.int64)
+        packed = np.concatenate([np.asarray(p, dtype=np.float64) for p in params])
+        buf.fill_(float("nan"))
+        out = np.zeros(len(circuits))
+        assert lib.qsv_eval_begin(handle, len(circuits), _lib.as_ptr(ids), _lib.as_ptr(counts)) == 0
+        assert lib.qsv_eval_suggested_pushes(handle) in (1, 2)
+        assert lib.qsv_eval_set_output(handle, C.c_void_p(buf.data_ptr())) == 0
+        assert lib.qsv_eval_push(handle, 0, len(circuits), _lib.as_ptr(packed)) == 0
+        assert lib.qsv_eval_set_output(handle, None) != 0  # (too late: after the first push)
+        assert lib.qsv_eval_end(handle, _lib.as_ptr(out)) == 0
+        assert out.tolist() == want and buf.cpu().tolist() == want
+    # noisy estimators cannot leave their values on the device
+    noisy = OperatorCircuitEvaluator(helpers.random_ising_operator(n, seed=5), estimator_precision=0.1)
+    assert not noisy.evaluate_circuits_to_device(circuits, params, buf.data_ptr())
+
+
+def test_chained_all_gather_of_a_sharded_population():
+    """evaluate_population_sharded over an RCCL group (of one rank: the box has one GPU) takes the chained path --
+    evaluation into the collective's send buffer, all-gather and copy back on one stream -- and returns what the
+    evaluator returns; QSV_GATHER_CHAIN=0 takes the staged path."""
+    import os
+
+    import torch
+    import torch.distributed as dist
+
+    from queasars_amd import distributed as qd
+
+    n = 16
+    _, circuits, params = helpers.population_circuits(n, 4, 24, seed=9)
+    ev = OperatorCircuitEvaluator(helpers.random_ising_operator(n, seed=1))
+    want = ev.evaluate_circuits(circuits, params)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29641")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        device = torch.device("cuda", 0)
+        for _ in range(2):
+            assert qd.evaluate_block_and_gather(ev, circuits, params, len(circuits), 1, 0, None, device) == want
+        assert qd._gather(want, len(circuits), 1, 0, None, device) == want
+        assert ev.evaluate_circuits(circuits, params) == want  # (the evaluator keeps working on the chain's stream)
+    finally:
+        dist.destroy_process_group()
