@@ -81,6 +81,11 @@ def evaluate_block_and_gather(evaluator, circuits: Sequence, parameter_values: S
     dist.all_gather_into_tensor(recv, send, group=group)
     recv_host.copy_(recv, non_blocking=True)
     stream.synchronize()
+    return _unpack(recv_host, n, world, width)
+
+
+def _unpack(recv_host, n: int, world: int, width: int) -> list[float]:
+    """The gathered slots (one of ``width`` values per rank, the unused tail NaN) as one list ordered by population index."""
     table = recv_host.numpy().reshape(world, width)
     if n == world * width:
         return table.ravel().tolist()
@@ -128,14 +133,7 @@ def _gather(local: Sequence[float], n: int, world: int, rank: int, group, device
     recv_host.copy_(recv, non_blocking=True)
     if recv.is_cuda:
         torch.cuda.current_stream(recv.device).synchronize()
-    table = recv_host.numpy().reshape(world, width)
-    if n == world * width:
-        return table.ravel().tolist()
-    out: list[float] = []
-    for r in range(world):
-        rlo, rhi = shard_bounds(n, world, r)
-        out.extend(table[r, : rhi - rlo].tolist())
-    return out
+    return _unpack(recv_host, n, world, width)
 
 
 _BUFFERS: dict = {}
