@@ -299,33 +299,28 @@ def config3_block(world: int, rank: int, local_rank: int, steps: int = 8):
     evaluator = OperatorCircuitEvaluator(operator, device=local_rank)
     lo, hi = shard_bounds(total, world, rank)
 
-    class Timed:  # this rank's own block, timed inside the sharded call: what the imbalance is computed from
-        own_s = 0.0
-
-        def evaluate_circuits(self, cs, ps):
-            t1 = time.perf_counter()
-            out = evaluator.evaluate_circuits(cs, ps)
-            Timed.own_s += time.perf_counter() - t1
-            return out
-
-    timed = Timed()
     for _ in range(3):  # warm-up: plans, buffers, clocks
-        evaluate_population_sharded(timed, circuits, params)
-    Timed.own_s = 0.0
+        evaluate_population_sharded(evaluator, circuits, params)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
-        values = evaluate_population_sharded(timed, circuits, params)
+        values = evaluate_population_sharded(evaluator, circuits, params)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    # this rank's own block alone, after the timed region: what the imbalance is computed from
+    own_c, own_p = circuits[lo:hi], params[lo:hi]
+    t1 = time.perf_counter()
+    for _ in range(steps):
+        evaluator.evaluate_circuits(own_c, own_p)
+    own_s = (time.perf_counter() - t1) / steps
     assert len(values) == total and all(np.isfinite(values))
-    per_rank = [Timed.own_s / steps]
+    per_rank = [own_s]
     if world > 1:
-        t = torch.tensor([elapsed, Timed.own_s / steps], dtype=torch.float64,
+        t = torch.tensor([elapsed, own_s], dtype=torch.float64,
                          device="cuda" if dist.get_backend() == "nccl" else "cpu")
         gathered = [torch.empty_like(t) for _ in range(world)]
         dist.all_gather(gathered, t)

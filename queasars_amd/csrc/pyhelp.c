@@ -76,7 +76,7 @@ static int expectation_values(qsv_t* h, Py_ssize_t n, const int* ids, const int6
     }
     int pushes = env_pushes > 0 ? env_pushes : qsv_eval_suggested_pushes(h);
     if (pushes < 1) pushes = 2;
-    if (device_out && env_pushes == 0) pushes = 1;  /* (a batch that does not wait runs on one stream: one push) */
+    if (device_out && env_pushes == 0 && n <= 96) pushes = 1;  /* (a batch that does not wait runs on one stream) */
     /* (a push may hold more evaluations than a launch group: the library cuts it into groups itself, and split
      * evaluations -- which need no resident state -- run in much larger groups than `group`) */
     Py_ssize_t step = (n + pushes - 1) / pushes > 8 ? (n + pushes - 1) / pushes : 8;

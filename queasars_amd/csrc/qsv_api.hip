@@ -1737,7 +1737,9 @@ int qsv_eval_suggested_pushes(const qsv_t* h) {
     const qsv_handle::Batch& b = h->batch;
     bool all_split = b.split_any;
     for (size_t i = 0; all_split && i < b.split.size(); ++i) all_split = b.split[i] != 0;
-    return all_split && factor_path(h) ? 1 : 2;
+    // (... up to about a launch group of the side circuits: 256 evaluations at 24 qubits take 0.29 ms in two pushes,
+    // 0.42 ms in one)
+    return all_split && factor_path(h) && b.split.size() <= 96 ? 1 : 2;
 }
 
 int qsv_eval_set_output(qsv_t* h, double* device_out) {
