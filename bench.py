@@ -76,8 +76,7 @@ def cpu_baseline(circuits, params, operator, budget_s: float = 12.0):
 
     orc = helpers.load_c_oracle()
     # the GPU box hands one job a 16-core share of the host: do not oversubscribe it
-    share = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    orc.lib.qsvo_set_threads(max(1, min(share, 16)))
+    orc.lib.qsvo_set_threads(helpers.host_cpu_share(16))
     cores = int(orc.lib.qsvo_max_threads())
     table = orc.diagonal_table(operator)  # once per operator, like qsv_set_operator on the GPU side: not timed
     scratch = np.zeros(2 << circuits[0].n_qubits, dtype=np.float64)

@@ -2398,6 +2398,140 @@ hipError_t launch_factor(int dtype, unsigned n_evals, double* scratch, const dou
     return hipGetLastError();
 }
 
+// ---- split evaluations under a general Pauli operator (kernels.hpp: launch_factor_terms) ----------------------------
+__device__ __forceinline__ uint32_t extract_bits(uint32_t v, uint32_t mask) {  // the bits of v under mask, packed
+    uint32_t out = 0, pos = 0;
+    while (mask) {
+        const uint32_t low = mask & (0u - mask);
+        if (v & low) out |= 1u << pos;
+        ++pos;
+        mask ^= low;
+    }
+    return out;
+}
+
+// M[j'][j] = sum_u conj(T_j'[u ^ f]) (-1)^popcount(u & z) T_j[u] for one side table; lane (run, j', j) adds its run of
+// every block of 64 values of u (the block and its partner block u ^ f staged in the wave's LDS region), the runs are
+// added across lanes: every lane of the first run ends up with its entry (re, im).
+template <typename real, int J>
+__device__ __forceinline__ void factor_term_side(const cx<real>* __restrict__ tab, uint32_t bits, uint32_t f, uint32_t z,
+                                                 cx<real>* stage, double* out_re, double* out_im) {
+    constexpr uint32_t NQ = J * J;
+    constexpr uint32_t PITCH = J + 1;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t pi = lane % NQ, sub = lane / NQ;
+    const uint32_t jr = pi / J, jc = pi % J;  // row j' (conjugated), column j
+    const uint32_t n_local = bits < 6u ? 1u << bits : 64u, n_blocks = bits < 6u ? 1u : 1u << (bits - 6u);
+    const uint32_t f_low = f & 63u, f_high = f >> 6, z_low = z & 63u, z_high = z >> 6;
+    cx<real>* here = stage;
+    cx<real>* there = stage + 64 * PITCH;
+    double acc_re = 0.0, acc_im = 0.0;
+    for (uint32_t blk = 0; blk < n_blocks; ++blk) {
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            cx<real> v{real(0), real(0)}, w{real(0), real(0)};
+            if (lane < n_local) {
+                v = tab[(size_t(j) << bits) + size_t(blk) * 64 + lane];
+                w = tab[(size_t(j) << bits) + size_t(blk ^ f_high) * 64 + lane];
+            }
+            here[lane * PITCH + uint32_t(j)] = v;
+            there[lane * PITCH + uint32_t(j)] = w;
+        }
+        const uint32_t block_sign = uint32_t(__builtin_popcount(blk & z_high)) & 1u;
+        double s_re = 0.0, s_im = 0.0;
+#pragma unroll 4
+        for (uint32_t i = 0; i < NQ; ++i) {
+            const uint32_t ul = sub * NQ + i;
+            const cx<real> a = there[(ul ^ f_low) * PITCH + jr], b = here[ul * PITCH + jc];
+            const double ar = double(a.re), ai = double(a.im), br = double(b.re), bi = double(b.im);
+            // conj(a) b, with the sign of this u
+            const double pr = fma(ar, br, ai * bi), pim = fma(ar, bi, -ai * br);
+            const bool minus = (uint32_t(__builtin_popcount(ul & z_low)) & 1u) != 0;
+            s_re += minus ? -pr : pr;
+            s_im += minus ? -pim : pim;
+        }
+        acc_re += block_sign ? -s_re : s_re;
+        acc_im += block_sign ? -s_im : s_im;
+    }
+    for (uint32_t off = NQ; off < 64; off <<= 1) {
+        acc_re += __shfl_xor(acc_re, int(off));
+        acc_im += __shfl_xor(acc_im, int(off));
+    }
+    *out_re = acc_re;
+    *out_im = acc_im;
+}
+
+template <typename real, int J>
+__device__ double factor_terms_body(const cx<real>* __restrict__ X, const cx<real>* __restrict__ Y, const uint32_t (&bits)[2],
+                                    const uint32_t (&mask)[2], const FactorTerm* __restrict__ terms, uint32_t n_terms,
+                                    uint32_t first, uint32_t step, cx<real>* stage) {
+    constexpr uint32_t NQ = J * J;
+    const uint32_t lane = threadIdx.x & 63u;
+    double total = 0.0;
+    for (uint32_t k = first; k < n_terms; k += step) {
+        const FactorTerm t = terms[k];
+        const uint32_t fx = extract_bits(t.x, mask[0]), zx = extract_bits(t.z, mask[0]);
+        const uint32_t fy = extract_bits(t.x, mask[1]), zy = extract_bits(t.z, mask[1]);
+        double ar, ai, br, bi;
+        factor_term_side<real, J>(X, bits[0], fx, zx, stage, &ar, &ai);
+        factor_term_side<real, J>(Y, bits[1], fy, zy, stage, &br, &bi);
+        // sum over the entries of A[j'j] B[j'j] (complex), then the power of i of the string's Y factors
+        double sr = lane < NQ ? fma(ar, br, -ai * bi) : 0.0, si = lane < NQ ? fma(ar, bi, ai * br) : 0.0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            sr += __shfl_xor(sr, off);
+            si += __shfl_xor(si, off);
+        }
+        const uint32_t ny = uint32_t(__builtin_popcount(t.x & t.z)) & 3u;
+        const double value = ny == 0 ? sr : ny == 1 ? -si : ny == 2 ? -sr : si;  // Re(i^ny (sr + i si))
+        total = fma(t.coeff, value, total);
+    }
+    return total;
+}
+
+template <typename real>
+__global__ void __launch_bounds__(256, 2) factor_terms_kernel(const uint32_t* __restrict__ plan_arena, const EvalDesc* __restrict__ evals,
+                                                              const cx<real>* __restrict__ sides, uint64_t side_stride,
+                                                              const FactorTerm* __restrict__ terms, uint32_t n_terms,
+                                                              double* __restrict__ partials) {
+    __shared__ cx<real> stage_all[4 * 2 * 9 * 64];
+    const EvalDesc ev = evals[blockIdx.y];
+    if (!(ev.flags & kEvalSide)) return;
+    const uint32_t* sp = plan_arena + ev.split_base;
+    const uint32_t n_keys = sp[0];
+    const bool swap = sp[3] & 1u;
+    const uint32_t bits[2] = {sp[1], sp[2]}, mask[2] = {sp[kSplitMaskX], sp[kSplitMaskY]};
+    const cx<real>* ta = sides + uint64_t(ev.state_slot) * side_stride;
+    const cx<real>* X = ta + (swap ? side_stride >> 1 : 0);
+    const cx<real>* Y = ta + (swap ? 0 : side_stride >> 1);
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n_waves = blockDim.x >> 6;
+    const uint32_t gw = blockIdx.x * n_waves + wave, step = gridDim.x * n_waves;
+    cx<real>* stage = stage_all + size_t(wave) * 2 * 9 * 64;
+    double total;
+    if (n_keys == 0)
+        total = factor_terms_body<real, 1>(X, Y, bits, mask, terms, n_terms, gw, step, stage);
+    else if (n_keys == 1)
+        total = factor_terms_body<real, 2>(X, Y, bits, mask, terms, n_terms, gw, step, stage);
+    else if (n_keys == 2)
+        total = factor_terms_body<real, 4>(X, Y, bits, mask, terms, n_terms, gw, step, stage);
+    else
+        total = factor_terms_body<real, 8>(X, Y, bits, mask, terms, n_terms, gw, step, stage);
+    if ((threadIdx.x & 63u) == 0) partials[size_t(ev.out_index) * step + gw] = total;
+}
+
+hipError_t launch_factor_terms(int dtype, unsigned n_evals, const FactorTerm* terms, uint32_t n_terms, double* partials,
+                               hipStream_t stream, const PassArgs& a) {
+    if (n_evals == 0) return hipSuccess;
+    const dim3 grid(kFactorTermWaves / 4, n_evals);
+    if (dtype == 0)
+        hipLaunchKernelGGL(factor_terms_kernel<double>, grid, dim3(256), 0, stream, a.plan, a.evals,
+                           static_cast<const cx<double>*>(a.wtab), a.wtab_stride, terms, n_terms, partials);
+    else
+        hipLaunchKernelGGL(factor_terms_kernel<float>, grid, dim3(256), 0, stream, a.plan, a.evals,
+                           static_cast<const cx<float>*>(a.wtab), a.wtab_stride, terms, n_terms, partials);
+    return hipGetLastError();
+}
+
 static unsigned stream_blocks(uint64_t dim) {
     const uint64_t want = (dim + 255) / 256;
     return unsigned(want < 4096 ? want : 4096);

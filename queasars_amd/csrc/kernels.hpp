@@ -138,6 +138,22 @@ constexpr size_t factor_slot_doubles() { return size_t(2) * 4 * 18 * 64; }
 hipError_t launch_factor(int dtype, unsigned n_evals, double* scratch, const double* quad, int n_qubits, hipStream_t stream,
                          const PassArgs& args);
 
+// Split evaluations under ANY Pauli operator: for psi = sum_j X_j (x) Y_j and a Pauli string P = P_X (x) P_Y
+//     <psi|P|psi> = sum_{j'j} <X_j'|P_X|X_j> <Y_j'|P_Y|Y_j>
+// -- two J x J matrices per term, each a sum over ONE side table (a Pauli string maps index u to u ^ f with a sign
+// (-1)^popcount(u & z) and a global power of i).  factor_terms_kernel: a wave per term (terms dealt out over
+// kFactorTermWaves waves per evaluation), both matrices, their pairing, times the coefficient; the waves' sums leave as
+// partial sums, [out_index][kFactorTermWaves], for reduce_partials_kernel.  Work per evaluation and term
+// (2^|X| + 2^|Y|) J^2 -- against a sweep over 2^n amplitudes per group of terms.
+struct FactorTerm {
+    uint32_t x, z;  // masks of the full index
+    double coeff;   // real part of the coefficient (the expectation of a Pauli string is real)
+};
+constexpr uint32_t kFactorTermWaves = 64;
+// PassArgs: plan, evals (device descriptors, side A region), wtab / wtab_stride (side tables).
+hipError_t launch_factor_terms(int dtype, unsigned n_evals, const FactorTerm* terms, uint32_t n_terms, double* partials,
+                               hipStream_t stream, const PassArgs& args);
+
 // dtype: 0 = fp64, 1 = fp32.  r = register bits (1..4).  xmode = LDS exchange mode (see kernels.hip).
 // Returns hipSuccess or the launch error.
 hipError_t launch_pass(int dtype, int r, int xmode, dim3 grid, int threads, size_t lds_bytes, hipStream_t stream,

@@ -159,6 +159,9 @@ struct qsv_handle {
                                  // (kernels.hpp: launch_factor)
     bool quadratic = false;      // the operator is diagonal and every term has at most two Z factors
     DeviceBuffer d_quad;         // its couplings as an n x n matrix
+    DeviceBuffer d_fterms;       // a general operator's terms as a plain list (kernels.hpp: launch_factor_terms)
+    uint32_t n_fterms = 0;
+    DeviceBuffer d_fpart;        // ... and that kernel's partial sums
     DeviceBuffer d_factor;       // launch_factor's partial Gram matrices, one region per side-table slot
     uint32_t stream_mode = 0;    // kModeStreaming when a state is larger than the Infinity Cache (256 MiB), else 0
     mutable std::mutex mu;
@@ -378,9 +381,9 @@ int build_circuit(qsv_t* h, int n_ops, const qsv_op* ops, int n_params, bool fol
     try {
         PlanConfig pc = h->cfg;
         pc.fold = pc.fold && fold;
-        // (not under a general operator: every evaluation then needs the state, i.e. the ordinary plan; a circuit registered
-        // now and evaluated under a diagonal operator later simply takes the ordinary path)
-        const bool state_needed = h->n_terms > 0 && !h->diagonal;
+        // (with QSV_FACTOR=0 not under a general operator: every evaluation then needs the state, i.e. the ordinary plan; a
+        // circuit registered now and evaluated under a diagonal operator later simply takes the ordinary path)
+        const bool state_needed = h->n_terms > 0 && !h->diagonal && !h->factor_enabled;
         if (h->split_enabled && !state_needed && pc.fold && h->n > h->geo.k && h->n <= 28) {  // (28: the contraction's 32-bit byte offsets into D)
             // a virtual circuit may be up to two qubits larger than a tile (it then takes the pass kernel two passes over
             // four tiles: nothing next to the 2^n indices of the contraction)
@@ -824,6 +827,9 @@ hipError_t stamp(qsv_t* h, std::vector<std::pair<hipEvent_t, hipEvent_t>>& list,
 // Split evaluations need no contraction sweep under a quadratic diagonal operator (kernels.hpp: launch_factor).
 bool factor_path(const qsv_t* h) { return h->factor_enabled && h->diagonal && h->quadratic && h->d_quad.ptr != nullptr && h->d_factor.ptr != nullptr; }
 
+// ... and none under a general operator (kernels.hpp: launch_factor_terms).
+bool factor_terms_path(const qsv_t* h) { return h->factor_enabled && !h->diagonal && h->n_fterms > 0 && h->d_side.ptr != nullptr; }
+
 // Run the gate passes of evaluations [first, first+count) of the current batch (one launch group).
 int run_group(qsv_t* h, const std::vector<Circuit*>& circs, size_t first, size_t count, uint32_t mode) {
     const qsv_handle::Batch& b = h->batch;
@@ -980,6 +986,27 @@ int run_group(qsv_t* h, const std::vector<Circuit*>& circs, size_t first, size_t
             h->prof.kernel_states[2] += 1;
             h->prof.kernel_flops[2] += flops;
         }
+    } else if (any_split && !(mode & kModeSidesOnly) && !h->diagonal) {
+        // general operator: every term's two small matrices from the side tables, summed per evaluation into d_out
+        a.evals = batch_evals(h) + first;
+        if (h->stamping) QSV_HIP(h, stamp(h, h->batch.launch_events[2], true));
+        QSV_HIP(h, launch_factor_terms(h->dtype, unsigned(n_split), static_cast<const FactorTerm*>(h->d_fterms.ptr), h->n_fterms,
+                                       static_cast<double*>(h->d_fpart.ptr), ws(h), a));
+        QSV_HIP(h, launch_reduce_partials(static_cast<const double*>(h->d_fpart.ptr), kFactorTermWaves, int(n_split),
+                                          static_cast<double*>(h->d_out.ptr), ws(h), batch_evals(h) + first));
+        if (h->stamping) QSV_HIP(h, stamp(h, h->batch.launch_events[2], false));
+        h->prof.kernel_launches[2] += 1;
+        for (size_t i = 0; i < n_split; ++i) {
+            const SplitInfo& sp = circs[eval_of(first + i)]->split;
+            for (int s = 0; s < 2; ++s) {
+                const uint64_t bytes = (uint64_t(1) << sp.n_virtual[s]) * h->amp_bytes * uint64_t(h->n_fterms);
+                h->prof.kernel_bytes[2] += bytes;
+                h->prof.kernel_moved_bytes[2] += bytes;
+                h->prof.kernel_flops[2] += 8.0 * double(uint64_t(1) << sp.n_virtual[s]) * double(1u << sp.n_keys) * double(h->n_fterms);
+                h->prof.kernel_states[0] += 1;
+            }
+            h->prof.kernel_states[2] += 1;
+        }
     } else if (any_split && !(mode & kModeSidesOnly)) {
         // the contraction of the split evaluations
         a.evals = batch_evals(h) + first;
@@ -1021,7 +1048,10 @@ int eval_begin(qsv_t* h, const std::vector<Circuit*>& circs, const std::vector<i
         QSV_HIP(h, hipEventCreate(&h->batch.ev1));
         QSV_HIP(h, hipEventRecord(h->batch.ev0, h->stream));
     }
-    if ((rc = batch_layout(h, circs, n_params, h->diagonal))) return rc;
+    if ((rc = batch_layout(h, circs, n_params, h->diagonal || factor_terms_path(h)))) return rc;
+    if (factor_terms_path(h) && h->batch.split_any &&
+        (rc = ensure(h, h->d_fpart, std::max<size_t>(1, n_evals) * kFactorTermWaves * sizeof(double))))
+        return rc;
     qsv_handle::Batch& b = h->batch;
     // Two streams: consecutive pushes alternate between them, so that kernels of different pushes share the chip
     // (+15 % on the benchmark population).  Each stream owns one half of the state slots (eval_push assigns them),
@@ -1127,7 +1157,7 @@ int eval_push(qsv_t* h, size_t first, size_t count, const double* values) {
         rc = run_group(h, b.circs, g0, gc, group_mode);
         if (!rc) QSV_HIP(h, stamp(h, b.pass_events, false));
         if (rc) return rc;
-        if (!h->diagonal) {
+        if (!h->diagonal && !in_split) {
             QSV_HIP(h, stamp(h, b.exp_events, true));
             QSV_HIP(h, launch_pauli_groups(h->dtype, h->d_states.ptr, uint64_t(1) << h->n, h->n, int(gc), h->n_groups,
                                            static_cast<const PauliGroup*>(h->d_groups.ptr),
@@ -1402,7 +1432,7 @@ void qsv_destroy(qsv_t* h) {
     }
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     for (DeviceBuffer* b : {&h->d_z, &h->d_cre, &h->d_diag, &h->d_term_partials, &h->d_groups, &h->d_term_odd, &h->d_arena,
-                            &h->d_states, &h->d_wtab, &h->d_side, &h->d_factor, &h->d_quad, &h->d_batch, &h->d_mats, &h->d_partials, &h->d_out, &h->d_scratch})
+                            &h->d_states, &h->d_wtab, &h->d_side, &h->d_factor, &h->d_quad, &h->d_fterms, &h->d_fpart, &h->d_batch, &h->d_mats, &h->d_partials, &h->d_out, &h->d_scratch})
         if (b->ptr) (void)hipFree(b->ptr);
     if (h->h_batch) (void)hipHostFree(h->h_batch);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
@@ -1532,6 +1562,16 @@ int qsv_set_operator(qsv_t* h, int n_terms, const uint64_t* x_mask, const uint64
             QSV_HIP(h, hipStreamSynchronize(h->stream));
             h->quadratic = true;
         }
+    }
+    // general operators: the terms as a plain list (split evaluations then need no state either, launch_factor_terms)
+    h->n_fterms = 0;
+    if (!all_diag && h->n <= 32) {
+        std::vector<FactorTerm> list(size_t(n_terms), FactorTerm{0, 0, 0.0});
+        for (int k = 0; k < n_terms; ++k) list[size_t(k)] = FactorTerm{uint32_t(x_mask[k]), uint32_t(z_mask[k]), coeff_re[k]};
+        if ((rc = ensure(h, h->d_fterms, list.size() * sizeof(FactorTerm)))) return rc;
+        QSV_HIP(h, hipMemcpyAsync(h->d_fterms.ptr, list.data(), list.size() * sizeof(FactorTerm), hipMemcpyHostToDevice, h->stream));
+        QSV_HIP(h, hipStreamSynchronize(h->stream));
+        h->n_fterms = uint32_t(n_terms);
     }
     h->n_terms = n_terms;
     h->diagonal = all_diag;

@@ -96,9 +96,28 @@ class COracle:
         )
 
 
+def host_cpu_share(limit: int = 16) -> int:
+    """CPUs this process may really use: its affinity mask, the cgroup's quota, at most ``limit``.  (A GPU box shows all
+    256 hardware threads of its host but grants a 16-CPU quota: OpenMP's default of one thread per visible CPU made an
+    oracle evaluation 30 times slower there.)"""
+    import os
+
+    share = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            share = min(share, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(share, limit))
+
+
 def load_c_oracle() -> COracle:
     so_path = ROOT / "oracle" / "libqsv_oracle.so"
     src = ROOT / "oracle" / "qsv_oracle.c"
     if not so_path.exists() or so_path.stat().st_mtime < src.stat().st_mtime:
         subprocess.run(["make", "-C", str(ROOT / "oracle")], check=True, capture_output=True)
-    return COracle(C.CDLL(str(so_path)))
+    oracle = COracle(C.CDLL(str(so_path)))
+    oracle.lib.qsvo_set_threads(host_cpu_share())
+    return oracle

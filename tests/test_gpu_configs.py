@@ -547,8 +547,8 @@ def test_split_results_do_not_depend_on_the_batch(c_oracle):
 
 
 def test_split_fp32_and_general_operators():
-    """fp32 tables through the contraction kernel (within the fp32 bound of the fp64 value); a general operator never
-    takes the split path (it needs the state) and still agrees."""
+    """fp32 tables through the split path (within the fp32 bound of the fp64 value); a general operator on split circuits
+    (the term kernel) against the same device with splitting off."""
     n = 18
     _, circuits, params = helpers.population_circuits(n, 4, 16, seed=5)
     op = helpers.random_ising_operator(n, seed=9)
@@ -882,3 +882,31 @@ def test_chained_all_gather_of_a_sharded_population():
         assert ev.evaluate_circuits(circuits, params) == want  # (the evaluator keeps working on the chain's stream)
     finally:
         dist.destroy_process_group()
+
+
+# ---- (o) split evaluations under a general Pauli operator: two small matrices per term (kernels.hpp: launch_factor_terms) ----
+
+
+@pytest.mark.parametrize("n,layers,count,n_terms", [(14, 5, 16, 40), (17, 4, 16, 60), (20, 4, 24, 30), (24, 3, 4, 25)])
+def test_general_operators_on_split_circuits(n, layers, count, n_terms):
+    """Random Pauli strings over {I, X, Y, Z} (diagonal strings among them): the term kernel on the two side tables against
+    the ordinary path (state + grouped expectation, QSV_FACTOR=0) within 1e-10, and against the NumPy oracle at n = 14;
+    circuits that cannot be split ride along in the same batch."""
+    _, circuits, params = helpers.population_circuits(n, layers, count, seed=90 + n)
+    _, deep, pd = helpers.population_circuits(n, 9, 2, seed=91 + n) if n <= 20 else (None, [], [])
+    circuits, params = deep[:1] + circuits + deep[1:], pd[:1] + params + pd[1:]
+    tile = 12 if n < 21 else 13
+    keys = [max(_split_keys(c, tile), _split_keys(c, min(tile + 2, n - 1))) for c in circuits]
+    assert max(keys) >= 1 or n >= 24, keys
+    op = helpers.random_pauli_operator(n, n_terms, seed=n)
+    factor = OperatorCircuitEvaluator(op, statevector_device=_factor_device(n, True)).evaluate_circuits(circuits, params)
+    plain = OperatorCircuitEvaluator(op, statevector_device=_factor_device(n, False)).evaluate_circuits(circuits, params)
+    scale = max(1.0, float(np.abs(op.coeffs).sum()) / 20.0)
+    assert np.abs(np.asarray(factor) - np.asarray(plain)).max() < EXP_TOL * scale
+    if n <= 14:
+        for i in (0, 1, len(circuits) - 1):
+            assert abs(factor[i] - helpers.oracle_expectation(circuits[i], params[i], op)) < EXP_TOL * scale
+    # fp32 side tables, within the fp32 bound
+    if n == 17:
+        got32 = OperatorCircuitEvaluator(op, dtype="fp32", statevector_device=_factor_device(n, True, dtype="fp32")).evaluate_circuits(circuits, params)
+        assert np.abs(np.asarray(got32) - np.asarray(plain)).max() < FP32_REL * float(np.abs(op.coeffs).sum())
