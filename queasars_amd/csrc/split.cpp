@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <array>
 #include <cstdlib>
+#include <functional>
 
 namespace qsv {
 
@@ -77,10 +78,11 @@ SplitCircuits find_split(int n, const std::vector<GateIn>& all_gates, const std:
     // two bins (subset sum over the component sizes, as balanced as the size limit allows).
     uint64_t side_a = 0;
     bool found = false;
-    auto try_without = [&](int r0, int r1, int r2) {
+    std::vector<int> without;  // the keys removed in this trial, ascending
+    auto try_without = [&]() {
         UnionFind uf(n);
         for (int j = 0; j < nk; ++j) {
-            if (j == r0 || j == r1 || j == r2) continue;
+            if (std::find(without.begin(), without.end(), j) != without.end()) continue;
             for (int t : keys[size_t(j)].targets) uf.join(keys[size_t(j)].control, t);
         }
         // components in order of their lowest qubit
@@ -101,7 +103,7 @@ SplitCircuits find_split(int n, const std::vector<GateIn>& all_gates, const std:
             size[size_t(c)] += 1;
             members[size_t(c)] |= uint64_t(1) << q;
         }
-        const int removed = (r0 >= 0) + (r1 >= 0) + (r2 >= 0);
+        const int removed = int(without.size());
         const int lo = n - max_side + removed, hi = max_side - removed;  // admissible |A|
         if (lo > hi) return false;
         // subset sums: choice[s] = set of components (bit mask) with total size s, component 0 always in A
@@ -124,13 +126,20 @@ SplitCircuits find_split(int n, const std::vector<GateIn>& all_gates, const std:
             if (choice[size_t(best)] >> c & 1u) side_a |= members[c];
         return true;
     };
-    found = try_without(-1, -1, -1);
-    for (int r0 = 0; !found && max_keys >= 1 && r0 < nk; ++r0) found = try_without(r0, -1, -1);
-    for (int r0 = 0; !found && max_keys >= 2 && r0 < nk; ++r0)
-        for (int r1 = r0 + 1; !found && r1 < nk; ++r1) found = try_without(r0, r1, -1);
-    for (int r0 = 0; !found && max_keys >= 3 && r0 < nk; ++r0)
-        for (int r1 = r0 + 1; !found && r1 < nk; ++r1)
-            for (int r2 = r1 + 1; !found && r2 < nk; ++r2) found = try_without(r0, r1, r2);
+    // (sets of 0, 1, 2, .. keys, each size in lexicographic order: the first hit has the fewest keys)
+    std::function<bool(int, int)> choose = [&](int start, int left) {
+        if (left == 0) return try_without();
+        for (int r = start; r + left <= nk; ++r) {
+            without.push_back(r);
+            if (choose(r + 1, left - 1)) return true;
+            without.pop_back();
+        }
+        return false;
+    };
+    for (int size = 0; !found && size <= max_keys && size <= nk; ++size) {
+        without.clear();
+        found = choose(0, size);
+    }
     if (!found) return out;
 
     // ---- the keys this partition really cuts ----------------------------------------------------------------------

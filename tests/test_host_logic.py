@@ -270,7 +270,6 @@ class TestProcessLocalRegistrations:
         """weakref finalizers may run inside any allocation, also while this thread holds the handle between
         qsv_eval_begin and qsv_eval_end: they must not call into the library."""
         import gc
-        import weakref
 
         from queasars_amd.circuit_evaluation.circuit_evaluation import StatevectorDevice
 
@@ -282,12 +281,13 @@ class TestProcessLocalRegistrations:
                 return 0
 
         dev = object.__new__(StatevectorDevice)  # no GPU here: only the bookkeeping is exercised
-        dev._dead, dev._handle, dev._lib = [], 1, FakeLib()
+        dev._dead, dev._watched, dev._handle, dev._lib = [], {}, 1, FakeLib()
         c = CircuitIR(2).u(0.1, 0.2, 0.3, 0)
-        weakref.finalize(c, StatevectorDevice._release, weakref.ref(dev), 17)
+        dev._watch(c, 17)
+        assert list(dev._watched) == [17]
         del c
         gc.collect()
-        assert dev._dead == [17] and FakeLib.destroyed == []
+        assert dev._dead == [17] and dev._watched == {} and FakeLib.destroyed == []
         dev._reap()
         assert dev._dead == [] and FakeLib.destroyed == [17]
         dev._handle = None  # keep __del__ from calling qsv_destroy on the fake
