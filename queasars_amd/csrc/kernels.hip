@@ -1735,18 +1735,20 @@ hipError_t launch_cvar(const double* values, int n_evals, int shots, double alph
 }
 
 // ---- sampling split evaluations (kernels.hpp: launch_split_tables / launch_split_sample) ---------------------------
-// Scratch of one evaluation: running sums of the marginal of x (2^(k+2) doubles: a side has at most k + 2 qubits), then
-// the Gram table T[pi][y1] (pi < J^2, y1 < 2^(|Y| - 6); J 2^|Y| <= 2^(k+2) bounds it by 2^(k-1) doubles).
+// Scratch of one evaluation: running sums of the marginal of x (one per value of x), then the Gram table T[pi][y1]
+// (pi < J^2, y1 < 2^(|Y| - 6)).
 // T's rows: pi = j < J: G_jj; then for every pair j < j' two rows, 2 Re G_jj' and -2 Im G_jj', with
 // G_jj'[y1] = sum over the block's y of Y_j[y] conj(Y_j'[y]) -- so that the probability of (x, block y1) is
 //     sum_j T[j] |X_j|^2 + sum_{j<j'} T[a] Re(X_j conj X_j') + T[b] Im(X_j conj X_j')        (split_quad).
 constexpr uint32_t kSplitSampleBlockBits = 6;
 constexpr int kSplitSampleShotsPerBlock = 32;
 
-size_t split_sample_slot_doubles(int tile_bits) {
-    const size_t table = std::max<size_t>(64, size_t(1) << (tile_bits > 1 ? tile_bits - 1 : 0));
-    return (size_t(1) << (tile_bits + 2)) + table;
+size_t split_sample_slot_doubles(int side_bits) {
+    // running sums: one per value of x; Gram table: J^2 2^(|Y| - 6) <= J 2^(side_bits - 6) <= 2^(side_bits - 3)
+    const size_t table = std::max<size_t>(64, size_t(1) << (side_bits > 3 ? side_bits - 3 : 0));
+    return (size_t(1) << side_bits) + table;
 }
+constexpr uint32_t kSplitSampleLdsDoubles = 6144;  // the Gram table is staged in LDS up to this size, read from L2 beyond
 
 // v of the lane `shift` places down its row of 16 lanes / of lane 15 of the previous row / of lane 31 (DPP; 0.0 for a
 // lane that has no such source or whose row is masked out)
@@ -2018,17 +2020,19 @@ __device__ __forceinline__ double split_probability(const cx<real>* __restrict__
 template <typename real, int J>
 __device__ void split_sample_body(const cx<real>* __restrict__ X, const cx<real>* __restrict__ Y, uint32_t bits_x, uint32_t bits_y,
                                   uint32_t mask_x, uint32_t mask_y, const double* __restrict__ cum, const double* __restrict__ Tg,
-                                  double* T, int shots, uint64_t seed, uint32_t eval, const double* __restrict__ diag,
-                                  uint64_t* __restrict__ out, double* __restrict__ out_values) {
+                                  double* lds_table, uint32_t lds_doubles, int shots, uint64_t seed, uint32_t eval,
+                                  const double* __restrict__ diag, uint64_t* __restrict__ out, double* __restrict__ out_values) {
     constexpr int SPB = kSplitSampleShotsPerBlock;
     constexpr uint32_t NQ = J * J;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t ly2 = bits_y < kSplitSampleBlockBits ? bits_y : kSplitSampleBlockBits;
     const uint32_t ny2 = 1u << ly2, ny1 = 1u << (bits_y - ly2);
     const uint32_t nx = 1u << bits_x;
-    if (ny1 > 1) {  // (uniform: the workgroup's evaluation)
-        for (uint32_t i = tid; i < NQ * ny1; i += blockDim.x) T[i] = Tg[i];
+    const double* T = Tg;  // (a table too large for the LDS share is read where it is: L2)
+    if (ny1 > 1 && NQ * ny1 <= lds_doubles) {  // (uniform: the workgroup's evaluation)
+        for (uint32_t i = tid; i < NQ * ny1; i += blockDim.x) lds_table[i] = Tg[i];
         __syncthreads();
+        T = lds_table;
     }
     uint32_t ja, jb, part;
     split_entry_of<J>(lane % NQ, &ja, &jb, &part);
@@ -2128,7 +2132,7 @@ template <typename real>
 __global__ void __launch_bounds__(256, 8) split_sample_kernel(const uint32_t* __restrict__ plan_arena, const EvalDesc* __restrict__ evals,
                                                               const cx<real>* __restrict__ sides, uint64_t side_stride,
                                                               const double* __restrict__ scratch, uint32_t slot_doubles,
-                                                              uint32_t cum_doubles, int shots, uint64_t seed,
+                                                              uint32_t cum_doubles, uint32_t lds_doubles, int shots, uint64_t seed,
                                                               const double* __restrict__ diag, uint64_t* __restrict__ out,
                                                               double* __restrict__ out_values) {
     extern __shared__ __align__(16) double split_lds[];
@@ -2144,18 +2148,18 @@ __global__ void __launch_bounds__(256, 8) split_sample_kernel(const uint32_t* __
     const double* cum = scratch + size_t(blockIdx.y) * slot_doubles;
     const double* T = cum + cum_doubles;
     if (n_keys == 0)
-        split_sample_body<real, 1>(X, Y, bits_x, bits_y, mask_x, mask_y, cum, T, split_lds, shots, seed, ev.out_index, diag, out, out_values);
+        split_sample_body<real, 1>(X, Y, bits_x, bits_y, mask_x, mask_y, cum, T, split_lds, lds_doubles, shots, seed, ev.out_index, diag, out, out_values);
     else if (n_keys == 1)
-        split_sample_body<real, 2>(X, Y, bits_x, bits_y, mask_x, mask_y, cum, T, split_lds, shots, seed, ev.out_index, diag, out, out_values);
+        split_sample_body<real, 2>(X, Y, bits_x, bits_y, mask_x, mask_y, cum, T, split_lds, lds_doubles, shots, seed, ev.out_index, diag, out, out_values);
     else if (n_keys == 2)
-        split_sample_body<real, 4>(X, Y, bits_x, bits_y, mask_x, mask_y, cum, T, split_lds, shots, seed, ev.out_index, diag, out, out_values);
+        split_sample_body<real, 4>(X, Y, bits_x, bits_y, mask_x, mask_y, cum, T, split_lds, lds_doubles, shots, seed, ev.out_index, diag, out, out_values);
     else
-        split_sample_body<real, 8>(X, Y, bits_x, bits_y, mask_x, mask_y, cum, T, split_lds, shots, seed, ev.out_index, diag, out, out_values);
+        split_sample_body<real, 8>(X, Y, bits_x, bits_y, mask_x, mask_y, cum, T, split_lds, lds_doubles, shots, seed, ev.out_index, diag, out, out_values);
 }
 
-hipError_t launch_split_tables(int dtype, int tile_bits, unsigned n_evals, double* scratch, hipStream_t stream, const PassArgs& a) {
+hipError_t launch_split_tables(int dtype, int side_bits, unsigned n_evals, double* scratch, hipStream_t stream, const PassArgs& a) {
     if (n_evals == 0) return hipSuccess;
-    const uint32_t slot = uint32_t(split_sample_slot_doubles(tile_bits)), cum = 1u << (tile_bits + 2);
+    const uint32_t slot = uint32_t(split_sample_slot_doubles(side_bits)), cum = 1u << side_bits;
     const dim3 gram_grid(kSplitGramParts, n_evals);
     if (dtype == 0) {
         hipLaunchKernelGGL(split_gram_kernel<double>, gram_grid, dim3(256), 0, stream, a.plan, a.evals,
@@ -2171,21 +2175,22 @@ hipError_t launch_split_tables(int dtype, int tile_bits, unsigned n_evals, doubl
     return hipGetLastError();
 }
 
-hipError_t launch_split_sample(int dtype, int tile_bits, unsigned n_evals, const double* scratch, int shots, uint64_t seed,
+hipError_t launch_split_sample(int dtype, int side_bits, unsigned n_evals, const double* scratch, int shots, uint64_t seed,
                                const double* diag, uint64_t* out, double* out_values, hipStream_t stream, const PassArgs& a,
                                uint32_t table_doubles) {
     if (n_evals == 0 || shots <= 0) return hipSuccess;
-    const uint32_t slot = uint32_t(split_sample_slot_doubles(tile_bits)), cum = 1u << (tile_bits + 2);
+    const uint32_t slot = uint32_t(split_sample_slot_doubles(side_bits)), cum = 1u << side_bits;
     // LDS: the Gram table of the workgroup's evaluation (the caller may know that the launch's tables are smaller
-    // than the bound: more workgroups per CU)
-    const size_t lds = size_t(table_doubles && table_doubles < slot - cum ? table_doubles : slot - cum) * sizeof(double);
+    // than the bound: more workgroups per CU); a table beyond kSplitSampleLdsDoubles stays in memory
+    const uint32_t lds_doubles = std::min(kSplitSampleLdsDoubles, table_doubles ? std::min(table_doubles, slot - cum) : slot - cum);
+    const size_t lds = size_t(lds_doubles) * sizeof(double);
     const dim3 grid(unsigned((shots + kSplitSampleShotsPerBlock - 1) / kSplitSampleShotsPerBlock), n_evals);
     if (dtype == 0)
         hipLaunchKernelGGL(split_sample_kernel<double>, grid, dim3(256), lds, stream, a.plan, a.evals,
-                           static_cast<const cx<double>*>(a.wtab), a.wtab_stride, scratch, slot, cum, shots, seed, diag, out, out_values);
+                           static_cast<const cx<double>*>(a.wtab), a.wtab_stride, scratch, slot, cum, lds_doubles, shots, seed, diag, out, out_values);
     else
         hipLaunchKernelGGL(split_sample_kernel<float>, grid, dim3(256), lds, stream, a.plan, a.evals,
-                           static_cast<const cx<float>*>(a.wtab), a.wtab_stride, scratch, slot, cum, shots, seed, diag, out, out_values);
+                           static_cast<const cx<float>*>(a.wtab), a.wtab_stride, scratch, slot, cum, lds_doubles, shots, seed, diag, out, out_values);
     return hipGetLastError();
 }
 

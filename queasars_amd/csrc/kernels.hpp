@@ -22,6 +22,11 @@ struct EvalDesc {
 // its own (region 0), side B in a second region of the descriptor array, which holds kEvalNull entries for everybody
 // else.  A side's pass kernel stores its final state in the side's half of the evaluation's compact-table slot.
 constexpr uint32_t kEvalSide = 1u, kEvalSideB = 2u, kEvalNull = 4u;
+// A virtual circuit (a side's own qubits + one per key) may be this many qubits larger than a tile: it then takes the pass
+// kernel a few passes over up to 16 tiles -- nothing next to what a split evaluation saves.  (With + 2 only, populations of
+// 26 and 28 qubits mostly found no split form: 21 k and 2 k evaluations per second against 550 k at 24 qubits.)
+constexpr int kSideExtraBits = 4;
+constexpr int kSideMaxOwnBits = 16;  // ... and a side's own qubits (launch_factor keeps one weight per bit)
 // split block (what the contraction kernel needs to know about one split circuit).  The roles of the index bits do not
 // depend on the circuit: bits 0 .. 5 are the lanes, the next W the wave index inside a workgroup (W = log2(threads / 64)),
 // the next kSplitLoopBits a thread's own bits (it walks their 32 combinations itself), the rest the chunk number.  Per
@@ -202,10 +207,10 @@ uint32_t sample_chunk_count(uint64_t dim);
 // * (J^2 + 64 J), against 2^n for the probabilities; the samples come in a different order of the index space than
 // launch_sample's (x-major), so the same seed gives different -- equally distributed -- samples.
 // PassArgs: plan, evals (device descriptors of the group, side A region), wtab / wtab_stride (side tables).
-// scratch: n_evals * split_sample_slot_doubles(tile_bits) doubles.
-size_t split_sample_slot_doubles(int tile_bits);
-hipError_t launch_split_tables(int dtype, int tile_bits, unsigned n_evals, double* scratch, hipStream_t stream, const PassArgs& args);
-hipError_t launch_split_sample(int dtype, int tile_bits, unsigned n_evals, const double* scratch, int shots, uint64_t seed,
+// scratch: n_evals * split_sample_slot_doubles(side_bits) doubles, side_bits = the most qubits a virtual circuit may have.
+size_t split_sample_slot_doubles(int side_bits);
+hipError_t launch_split_tables(int dtype, int side_bits, unsigned n_evals, double* scratch, hipStream_t stream, const PassArgs& args);
+hipError_t launch_split_sample(int dtype, int side_bits, unsigned n_evals, const double* scratch, int shots, uint64_t seed,
                                const double* diag, uint64_t* out, double* out_values, hipStream_t stream, const PassArgs& args,
                                uint32_t table_doubles = 0);  // (the largest Gram table of the launch, 0 = not known)
 

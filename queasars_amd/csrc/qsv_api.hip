@@ -385,11 +385,13 @@ int build_circuit(qsv_t* h, int n_ops, const qsv_op* ops, int n_params, bool fol
         // circuit registered now and evaluated under a diagonal operator later simply takes the ordinary path)
         const bool state_needed = h->n_terms > 0 && !h->diagonal && !h->factor_enabled;
         if (h->split_enabled && !state_needed && pc.fold && h->n > h->geo.k && h->n <= 28) {  // (28: the contraction's 32-bit byte offsets into D)
-            // a virtual circuit may be up to two qubits larger than a tile (it then takes the pass kernel two passes over
-            // four tiles: nothing next to the 2^n indices of the contraction)
+            // a virtual circuit may be a few qubits larger than a tile (it then takes the pass kernel a few passes over up
+            // to sixteen tiles: nothing next to the 2^n indices of the contraction)
             // ... but one tile each is what to look for first: no second pass, one workgroup per virtual circuit
             SplitCircuits sc = find_split(h->n, gates, angles, h->geo.k);
             if (!sc.ok) sc = find_split(h->n, gates, angles, std::min(h->geo.k + 2, h->n - 1));
+            if (!sc.ok) sc = find_split(h->n, gates, angles, std::min(h->geo.k + kSideExtraBits, h->n - 1));
+            if (sc.ok && std::max(sc.n_side[0], sc.n_side[1]) > kSideMaxOwnBits) sc.ok = false;
             if (sc.ok) {
                 SplitInfo& sp = out->split;
                 std::vector<uint32_t>& w = out->plan.words;
@@ -1403,8 +1405,8 @@ int qsv_create(int n_qubits, int dtype, int device, const qsv_plan_config* cfg, 
         return bail(e, "hipMalloc(compact tables)");
     h->d_wtab.bytes = size_t(h->wtab_stride) * h->amp_bytes * size_t(group);
     if (h->split_enabled && n_qubits > geo.k && n_qubits <= 28) {
-        // side tables of split evaluations: two virtual circuits of at most tile + 2 qubits per slot
-        h->side_stride = uint64_t(2) << (geo.k + 2);
+        // side tables of split evaluations: two virtual circuits of at most tile + kSideExtraBits qubits per slot
+        h->side_stride = uint64_t(2) << (geo.k + kSideExtraBits);
         h->side_slots = 128;
         if ((e = hipMalloc(&h->d_side.ptr, size_t(h->side_stride) * h->amp_bytes * size_t(h->side_slots))) != hipSuccess)
             return bail(e, "hipMalloc(side tables)");
@@ -1964,7 +1966,7 @@ static int sample_batch_locked(qsv_t* h, const std::vector<Circuit*>& circs, con
     // ones | (device-side CVaR) the samples
     const size_t probs_bytes = n_plain ? G * dim * 8 : 0, sums_bytes = n_plain ? G * size_t(sample_chunk_count(dim)) * 8 : 0;
     const size_t split_off = ((probs_bytes + sums_bytes + 63) / 64) * 64;
-    const size_t split_bytes = n_split ? std::min(SG, n_split) * split_sample_slot_doubles(h->geo.k) * 8 : 0;
+    const size_t split_bytes = n_split ? std::min(SG, n_split) * split_sample_slot_doubles(h->geo.k + kSideExtraBits) * 8 : 0;
     const size_t out_bytes = n_evals * size_t(shots) * 8;
     const size_t dev_samples_off = ((split_off + split_bytes + 63) / 64) * 64;
     if ((rc = ensure(h, h->d_scratch, dev_samples_off + (out_cvar ? 2 * out_bytes : 0)))) return rc;
@@ -2005,14 +2007,14 @@ static int sample_batch_locked(qsv_t* h, const std::vector<Circuit*>& circs, con
         a.evals = batch_evals(h) + g0;
         a.wtab = h->d_side.ptr;
         a.wtab_stride = h->side_stride;
-        QSV_HIP(h, launch_split_tables(h->dtype, h->geo.k, unsigned(gc), split_scratch, h->stream, a));
+        QSV_HIP(h, launch_split_tables(h->dtype, h->geo.k + kSideExtraBits, unsigned(gc), split_scratch, h->stream, a));
         uint32_t table_doubles = 64;  // the largest Gram table of the group (whichever side the contraction calls Y)
         for (size_t i = 0; i < gc; ++i) {
             const SplitInfo& sp = circs[h->batch.eval_at[g0 + i]]->split;
             for (int side = 0; side < 2; ++side)
                 table_doubles = std::max(table_doubles, uint32_t(1) << (2 * sp.n_keys + std::max(0, sp.n_virtual[side] - sp.n_keys - 6)));
         }
-        QSV_HIP(h, launch_split_sample(h->dtype, h->geo.k, unsigned(gc), split_scratch, shots, seed, diag, d_states, d_values,
+        QSV_HIP(h, launch_split_sample(h->dtype, h->geo.k + kSideExtraBits, unsigned(gc), split_scratch, shots, seed, diag, d_states, d_values,
                                        h->stream, a, table_doubles));
     }
     const uint32_t mode = kModeSynthFirst | (probs_in_pass ? kModeFinalProbs : kModeFinalStore) | (fuse ? kModeFusedPrepare : 0u);

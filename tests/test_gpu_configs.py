@@ -498,6 +498,17 @@ def _split_device(n, split, **kwargs):
             os.environ["QSV_SPLIT"] = old
 
 
+def _keys_like_the_library(circuit, n):
+    """Number of keys of the split form the library finds (it tries virtual circuits of at most a tile, then a tile + 2 and
+    + 4 qubits), -1 if there is none."""
+    tile = 12 if n < 21 else 13
+    for extra in (0, 2, 4):
+        k = _split_keys(circuit, min(tile + extra, n - 1))
+        if k >= 0:
+            return k
+    return -1
+
+
 def _split_keys(circuit, max_side):
     ops = circuit.packed()
     cap = 4 * len(ops) + 64
@@ -514,9 +525,7 @@ def test_split_evaluations_agree_with_the_pass_path(n, layers, count):
     a tile, and for circuits that cannot be split at all (deeper ones), mixed in one batch."""
     _, circuits, params = helpers.population_circuits(n, layers, count, seed=40 + n)
     op = helpers.random_ising_operator(n, seed=n)
-    tile = 12 if n < 21 else 13
-    keys = [_split_keys(c, tile) for c in circuits]
-    keys = [k if k >= 0 else _split_keys(c, min(tile + 2, n - 1)) for k, c in zip(keys, circuits)]
+    keys = [_keys_like_the_library(c, n) for c in circuits]
     assert max(keys) >= 1 and min(keys) <= 0, keys  # the population exercises keys, and key-less or unsplit circuits
     split = OperatorCircuitEvaluator(op, statevector_device=_split_device(n, True)).evaluate_circuits(circuits, params)
     plain = OperatorCircuitEvaluator(op, statevector_device=_split_device(n, False)).evaluate_circuits(circuits, params)
@@ -533,7 +542,7 @@ def test_split_results_do_not_depend_on_the_batch(c_oracle):
     n = 20
     _, shallow, ps = helpers.population_circuits(n, 4, 12, seed=7)
     _, deep, pd = helpers.population_circuits(n, 9, 3, seed=8)
-    assert all(_split_keys(c, 12) < 0 and _split_keys(c, 14) < 0 for c in deep)
+    assert all(_keys_like_the_library(c, n) < 0 for c in deep)
     op = helpers.random_ising_operator(n, seed=3)
     ev = OperatorCircuitEvaluator(op)
     alone = [ev.evaluate_circuits([c], [p])[0] for c, p in zip(shallow, ps)]
@@ -657,9 +666,7 @@ def _one_circuit_per_key_count(n, layers, count, seed, tile=12):
     _, circuits, params = helpers.population_circuits(n, layers, count, seed=seed)
     chosen = {}
     for c, p in zip(circuits, params):
-        k = _split_keys(c, tile)
-        if k < 0:
-            k = _split_keys(c, min(tile + 2, n - 1))
+        k = _keys_like_the_library(c, n)
         if k >= 0:  # (unsplittable circuits are the old sampler's, tested elsewhere)
             chosen.setdefault(k, (c, p))
     return chosen
@@ -738,8 +745,7 @@ def test_split_sampler_on_large_registers(n, dtype, count):
     per evaluation): the split sampler touches 2^(n/2)-sized tables only; fp32 side tables at n = 18."""
     shots = 4096
     _, circuits, params = helpers.population_circuits(n, 3 if n == 28 else 4, count, seed=n)
-    tile = 13 if (dtype == "fp32" or n > 20) else 12
-    assert any(_split_keys(c, tile) >= 0 or _split_keys(c, min(tile + 2, n - 1)) >= 0 for c in circuits)
+    assert any(_keys_like_the_library(c, n) >= 0 for c in circuits)
     op = helpers.random_ising_operator(n, seed=1)
     exact = np.asarray(OperatorCircuitEvaluator(op, dtype=dtype).evaluate_circuits(circuits, params))
     dev = _sampler_device(n, True, dtype=dtype)
@@ -794,8 +800,7 @@ def test_factorised_expectation_agrees_with_the_contraction_and_the_pass_path(n,
     factorised expectation, the contraction kernel and the ordinary multi-pass path agree within 1e-10; an operator with
     terms of weight three and four is not quadratic and still agrees (it takes the contraction kernel either way)."""
     _, circuits, params = helpers.population_circuits(n, layers, count, seed=70 + n)
-    tile = 12 if n < 21 else 13
-    keys = [max(_split_keys(c, tile), _split_keys(c, min(tile + 2, n - 1))) for c in circuits]
+    keys = [_keys_like_the_library(c, n) for c in circuits]
     assert max(keys) >= (1 if n < 25 else 0), keys  # (n = 25: sides of 12 and 13 qubits, the largest tables)
     for kind in ("quadratic", "fields", "cubic"):
         op = _diagonal_operator(n, seed=n, kind=kind)
@@ -895,8 +900,7 @@ def test_general_operators_on_split_circuits(n, layers, count, n_terms):
     _, circuits, params = helpers.population_circuits(n, layers, count, seed=90 + n)
     _, deep, pd = helpers.population_circuits(n, 9, 2, seed=91 + n) if n <= 20 else (None, [], [])
     circuits, params = deep[:1] + circuits + deep[1:], pd[:1] + params + pd[1:]
-    tile = 12 if n < 21 else 13
-    keys = [max(_split_keys(c, tile), _split_keys(c, min(tile + 2, n - 1))) for c in circuits]
+    keys = [_keys_like_the_library(c, n) for c in circuits]
     assert max(keys) >= 1 or n >= 24, keys
     op = helpers.random_pauli_operator(n, n_terms, seed=n)
     factor = OperatorCircuitEvaluator(op, statevector_device=_factor_device(n, True)).evaluate_circuits(circuits, params)
@@ -910,3 +914,33 @@ def test_general_operators_on_split_circuits(n, layers, count, n_terms):
     if n == 17:
         got32 = OperatorCircuitEvaluator(op, dtype="fp32", statevector_device=_factor_device(n, True, dtype="fp32")).evaluate_circuits(circuits, params)
         assert np.abs(np.asarray(got32) - np.asarray(plain)).max() < FP32_REL * float(np.abs(op.coeffs).sum())
+
+
+# ---- (p) registers of 26 and 28 qubits: virtual circuits of up to a tile + 4 qubits ------------------------------------
+
+
+@pytest.mark.parametrize("n,count", [(26, 12), (28, 8)])
+def test_split_evaluations_on_the_largest_registers(n, count):
+    """At 26 and 28 qubits a split form needs virtual circuits larger than a tile + 2 qubits (13 + 13 or 14 + 14 own
+    qubits plus keys): such circuits take the pass kernel several passes over up to 16 tiles.  Factorised expectation =
+    contraction kernel (1e-10) for the whole population; the ordinary multi-pass path (a 1 / 4 GiB state per evaluation)
+    for two of its circuits; sample means of the split sampler within 6 sigma."""
+    _, circuits, params = helpers.population_circuits(n, 4, count, seed=n)
+    keys = [_keys_like_the_library(c, n) for c in circuits]
+    assert sum(k >= 0 for k in keys) >= count // 2 and max(keys) >= 1, keys
+    op = helpers.random_ising_operator(n, seed=2)
+    factor_dev = _factor_device(n, True)
+    factor = OperatorCircuitEvaluator(op, statevector_device=factor_dev).evaluate_circuits(circuits, params)
+    contract = OperatorCircuitEvaluator(op, statevector_device=_factor_device(n, False)).evaluate_circuits(circuits, params)
+    scale = max(1.0, float(np.abs(op.coeffs).sum()) / 50.0)
+    assert np.abs(np.asarray(factor) - np.asarray(contract)).max() < EXP_TOL * scale
+    some = [i for i, k in enumerate(keys) if k >= 0][:2]
+    plain = OperatorCircuitEvaluator(op, statevector_device=_split_device(n, False)).evaluate_circuits(
+        [circuits[i] for i in some], [params[i] for i in some])
+    assert np.abs(np.asarray(plain) - np.asarray([factor[i] for i in some])).max() < EXP_TOL * scale
+    shots = 4096
+    split_only = [i for i, k in enumerate(keys) if k >= 0]
+    _, values = factor_dev.sample_batch([circuits[i] for i in split_only], [params[i] for i in split_only], shots, seed=3, with_values=True)
+    exact = np.asarray([factor[i] for i in split_only])
+    sigma = values.std(axis=1) / np.sqrt(shots) + 1e-9
+    assert (np.abs(values.mean(axis=1) - exact) <= 6.0 * sigma).all()
