@@ -1,4 +1,4 @@
-// Register splitting: evaluate a weakly entangled circuit as two small circuits and one contraction.
+// Register splitting: evaluate a weakly entangled circuit as two small circuits and a combination of their final states.
 //
 // EVQE individuals are shallow (a few layers of one gate per qubit), so their controlled rotations often leave the
 // register in two halves A and B that interact through very few cu3 gates.  Every such CROSS gate (control c on one
@@ -11,10 +11,16 @@
 // where a_kappa / b_kappa are the final states of two VIRTUAL circuits on |A| + K and |B| + K qubits: the side's own
 // gates, plus one extra qubit per key that starts as (1, 1) and is never targeted.  On the target side the cross gate
 // becomes cu3(key -> target); on the control side the key's first use becomes the projector P_kappa(c), written as
-// [X(c) if key] P0(c) [X(c) if key].  Both virtual circuits are small (at most two qubits more than a tile), so the
-// ordinary pass kernel runs each in one to four workgroups, and one streaming kernel (contract_kernel) forms psi on the
-// fly and reduces <psi|D|psi> -- the only sweep over 2^n indices, with 4 * 2^K + 3 fp64 operations per amplitude instead
-// of a pass of gates.
+// [X(c) if key] P0(c) [X(c) if key].  Both virtual circuits are small (at most a few qubits more than a tile), so the
+// ordinary pass kernel runs each in one to sixteen workgroups.  What is left is the expectation value of
+// psi = sum_kappa a_kappa (x) b_kappa:
+//   * under a diagonal operator whose terms have at most two Z factors (Ising / QUBO), from weighted Gram matrices of the
+//     two small states alone (kernels.hpp: launch_factor) -- nothing of size 2^n is touched;
+//   * under any other diagonal operator, one streaming kernel (contract_kernel) forms psi on the fly and reduces
+//     <psi|D|psi> -- the only sweep over 2^n indices, with 4 * 2^K + 3 fp64 operations per amplitude instead of a pass of
+//     gates;
+//   * under a general Pauli operator, two small matrices per term (launch_factor_terms);
+//   * and samples of |psi|^2 are drawn from the two states directly (launch_split_sample).
 //
 // This generalises the compact first pass (plan.hpp): there only pass 0 worked on a table of tiles, here every gate
 // does.  A circuit that has no such partition (deeper, well entangled circuits) keeps the ordinary multi-pass plan.
