@@ -388,9 +388,9 @@ int build_circuit(qsv_t* h, int n_ops, const qsv_op* ops, int n_params, bool fol
             // a virtual circuit may be a few qubits larger than a tile (it then takes the pass kernel a few passes over up
             // to sixteen tiles: nothing next to the 2^n indices of the contraction)
             // ... but one tile each is what to look for first: no second pass, one workgroup per virtual circuit
-            SplitCircuits sc = find_split(h->n, gates, angles, h->geo.k);
-            if (!sc.ok) sc = find_split(h->n, gates, angles, std::min(h->geo.k + 2, h->n - 1));
-            if (!sc.ok) sc = find_split(h->n, gates, angles, std::min(h->geo.k + kSideExtraBits, h->n - 1));
+            SplitCircuits sc = find_split(h->n, gates, angles,
+                                          std::vector<int>{h->geo.k, std::min(h->geo.k + 2, h->n - 1),
+                                                           std::min(h->geo.k + kSideExtraBits, h->n - 1)});
             if (sc.ok && std::max(sc.n_side[0], sc.n_side[1]) > kSideMaxOwnBits) sc.ok = false;
             if (sc.ok) {
                 SplitInfo& sp = out->split;

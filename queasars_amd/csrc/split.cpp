@@ -34,8 +34,19 @@ struct UnionFind {
 
 SplitCircuits find_split(int n, const std::vector<GateIn>& all_gates, const std::vector<AngleSource>& op_angles,
                          int max_side, int max_keys) {
-    SplitCircuits out;
-    if (n > 60 || n <= max_side || 2 * max_side < n) return out;
+    return find_split(n, all_gates, op_angles, std::vector<int>{max_side}, max_keys);
+}
+
+SplitCircuits find_split(int n, const std::vector<GateIn>& all_gates, const std::vector<AngleSource>& op_angles,
+                         const std::vector<int>& max_sides, int max_keys) {
+    // which of the size limits can apply at all
+    std::vector<char> open_stage(max_sides.size(), 0);
+    bool any_open = false;
+    for (size_t s = 0; s < max_sides.size(); ++s) {
+        open_stage[s] = !(n > 60 || n <= max_sides[s] || 2 * max_sides[s] < n);
+        any_open |= open_stage[s] != 0;
+    }
+    if (!any_open) return SplitCircuits{};
 
     // ---- which gates act at all, and the keys -------------------------------------------------------------------
     // (the drop rule of build_plan: a cu3 whose control nobody has targeted yet acts on |0> and is the identity)
@@ -76,7 +87,13 @@ SplitCircuits find_split(int n, const std::vector<GateIn>& all_gates, const std:
     // ---- partition: the fewest cut keys such that both virtual circuits fit a tile --------------------------------
     // Remove a set R of keys (|R| = 0, 1, 2, ..), take the connected components of what is left and pack them into
     // two bins (subset sum over the component sizes, as balanced as the size limit allows).
-    uint64_t side_a = 0;
+    // One enumeration serves every size limit: a trial's components are packed under each limit that has no partition
+    // yet, and the enumeration stops at the first partition for the FIRST (smallest) limit -- the same partition per
+    // limit as one search per limit would find, at a third of the cost for a circuit that has none.
+    std::vector<uint64_t> side_of_stage(max_sides.size(), 0);
+    std::vector<char> hit(max_sides.size(), 0);
+    size_t first_open = 0;
+    while (!open_stage[first_open]) ++first_open;
     bool found = false;
     std::vector<int> without;  // the keys removed in this trial, ascending
     auto try_without = [&]() {
@@ -104,8 +121,6 @@ SplitCircuits find_split(int n, const std::vector<GateIn>& all_gates, const std:
             members[size_t(c)] |= uint64_t(1) << q;
         }
         const int removed = int(without.size());
-        const int lo = n - max_side + removed, hi = max_side - removed;  // admissible |A|
-        if (lo > hi) return false;
         // subset sums: choice[s] = set of components (bit mask) with total size s, component 0 always in A
         std::vector<uint64_t> choice(size_t(n) + 1, 0);
         std::vector<char> reach(size_t(n) + 1, 0);
@@ -117,19 +132,103 @@ SplitCircuits find_split(int n, const std::vector<GateIn>& all_gates, const std:
                     reach[size_t(s + size[c])] = 1;
                     choice[size_t(s + size[c])] = choice[size_t(s)] | uint64_t(1) << c;
                 }
-        int best = -1;
-        for (int s = lo; s <= hi; ++s)
-            if (reach[size_t(s)] && (best < 0 || std::abs(2 * s - n) < std::abs(2 * best - n))) best = s;
-        if (best < 0) return false;
-        side_a = 0;
-        for (size_t c = 0; c < size.size(); ++c)
-            if (choice[size_t(best)] >> c & 1u) side_a |= members[c];
-        return true;
+        for (size_t stage = 0; stage < max_sides.size(); ++stage) {
+            if (!open_stage[stage] || hit[stage]) continue;
+            const int lo = n - max_sides[stage] + removed, hi = max_sides[stage] - removed;  // admissible |A|
+            int best = -1;
+            for (int s = lo; s <= hi; ++s)
+                if (s >= 0 && s <= n && reach[size_t(s)] && (best < 0 || std::abs(2 * s - n) < std::abs(2 * best - n))) best = s;
+            if (best < 0) continue;
+            uint64_t side_a = 0;
+            for (size_t c = 0; c < size.size(); ++c)
+                if (choice[size_t(best)] >> c & 1u) side_a |= members[c];
+            side_of_stage[stage] = side_a;
+            hit[stage] = 1;
+        }
+        return hit[first_open] != 0;
     };
-    // (sets of 0, 1, 2, .. keys, each size in lexicographic order: the first hit has the fewest keys)
+    // Sets of 0, 1, 2, .. keys, each size in lexicographic order: the first hit has the fewest keys.  The LAST key of a
+    // set is only worth trying if its removal splits a component of what the others leave (an articulation point of the
+    // qubit / key incidence graph): otherwise the components are those of the smaller set, which has already failed under
+    // looser size bounds.  That filter is exact and turns the C(keys, 3) trials of a deep circuit (10 - 40 ms per
+    // registration at eight to twelve layers, all in vain) into C(keys, 2) linear-time sweeps with hardly a trial.
+    std::vector<std::vector<int>> keys_of_qubit(static_cast<size_t>(n));
+    for (int j = 0; j < nk; ++j) {
+        keys_of_qubit[size_t(keys[size_t(j)].control)].push_back(j);
+        for (int t : keys[size_t(j)].targets) keys_of_qubit[size_t(t)].push_back(j);
+    }
+    const int n_nodes = n + nk;  // qubits, then keys
+    std::vector<int> disc(static_cast<size_t>(n_nodes)), low(static_cast<size_t>(n_nodes)), parent(static_cast<size_t>(n_nodes));
+    std::vector<int> next_edge(static_cast<size_t>(n_nodes)), stack;
+    std::vector<char> removed(static_cast<size_t>(nk), 0), articulation(static_cast<size_t>(nk), 0);
+    auto neighbour = [&](int u, int i) -> int {  // i-th neighbour of node u, -1 past the end
+        if (u < n) return i < int(keys_of_qubit[size_t(u)].size()) ? n + keys_of_qubit[size_t(u)][size_t(i)] : -1;
+        const Key& k = keys[size_t(u - n)];
+        if (i == 0) return k.control;
+        return i <= int(k.targets.size()) ? k.targets[size_t(i - 1)] : -1;
+    };
+    // keys (not removed) whose removal disconnects their component, ascending
+    auto splitting_keys = [&](std::vector<int>& result) {
+        result.clear();
+        std::fill(disc.begin(), disc.end(), -1);
+        std::fill(articulation.begin(), articulation.end(), 0);
+        int clock = 0;
+        for (int root = 0; root < n; ++root) {
+            if (disc[size_t(root)] >= 0) continue;
+            int root_children = 0;
+            disc[size_t(root)] = low[size_t(root)] = clock++;
+            parent[size_t(root)] = -1;
+            next_edge[size_t(root)] = 0;
+            stack.assign(1, root);
+            while (!stack.empty()) {
+                const int u = stack.back();
+                const int v = neighbour(u, next_edge[size_t(u)]++);
+                if (v < 0) {
+                    stack.pop_back();
+                    const int p = parent[size_t(u)];
+                    if (p >= 0) {
+                        low[size_t(p)] = std::min(low[size_t(p)], low[size_t(u)]);
+                        if (p != root && p >= n && low[size_t(u)] >= disc[size_t(p)]) articulation[size_t(p - n)] = 1;
+                        if (p == root) ++root_children;
+                    }
+                    continue;
+                }
+                if (v >= n && removed[size_t(v - n)]) continue;
+                if (disc[size_t(v)] < 0) {
+                    disc[size_t(v)] = low[size_t(v)] = clock++;
+                    parent[size_t(v)] = u;
+                    next_edge[size_t(v)] = 0;
+                    stack.push_back(v);
+                } else if (v != parent[size_t(u)]) {
+                    low[size_t(u)] = std::min(low[size_t(u)], disc[size_t(v)]);
+                }
+            }
+            (void)root_children;  // (roots are qubits: only key nodes are asked about)
+        }
+        for (int j = 0; j < nk; ++j)
+            if (articulation[size_t(j)]) result.push_back(j);
+    };
+    std::vector<int> last_candidates;
+    // (a bound on the sweeps, for circuits with very many keys: C(70, 2) sweeps are 8 ms, and such circuits never split)
+    constexpr int kMaxSweeps = 2000;
+    int sweeps = 0;
     std::function<bool(int, int)> choose = [&](int start, int left) {
         if (left == 0) return try_without();
-        for (int r = start; r + left <= nk; ++r) {
+        if (left == 1) {
+            if (++sweeps > kMaxSweeps) return false;
+            for (int r : without) removed[size_t(r)] = 1;
+            splitting_keys(last_candidates);
+            for (int r : without) removed[size_t(r)] = 0;
+            const std::vector<int> candidates = last_candidates;
+            for (int r : candidates) {
+                if (r < start) continue;
+                without.push_back(r);
+                if (try_without()) return true;
+                without.pop_back();
+            }
+            return false;
+        }
+        for (int r = start; r + left <= nk && sweeps <= kMaxSweeps; ++r) {
             without.push_back(r);
             if (choose(r + 1, left - 1)) return true;
             without.pop_back();
@@ -140,7 +239,12 @@ SplitCircuits find_split(int n, const std::vector<GateIn>& all_gates, const std:
         without.clear();
         found = choose(0, size);
     }
-    if (!found) return out;
+    (void)found;
+    for (size_t stage = 0; stage < max_sides.size(); ++stage) {
+    if (!hit[stage]) continue;
+    const uint64_t side_a = side_of_stage[stage];
+    const int max_side = max_sides[stage];
+    SplitCircuits out;
 
     // ---- the keys this partition really cuts ----------------------------------------------------------------------
     auto side_of = [&](int q) { return int(!(side_a >> q & 1u)); };  // 0 = A, 1 = B
@@ -154,7 +258,7 @@ SplitCircuits find_split(int n, const std::vector<GateIn>& all_gates, const std:
     out.mask[0] = side_a;
     out.mask[1] = ~side_a & ((uint64_t(1) << n) - 1);
     for (int s = 0; s < 2; ++s) out.n_side[s] = __builtin_popcountll(out.mask[s]);
-    if (n_cut > max_keys || out.n_side[0] + n_cut > max_side || out.n_side[1] + n_cut > max_side) return out;
+    if (n_cut > max_keys || out.n_side[0] + n_cut > max_side || out.n_side[1] + n_cut > max_side) continue;
     out.n_keys = n_cut;
 
     // ---- the two virtual circuits -------------------------------------------------------------------------------------
@@ -217,6 +321,8 @@ SplitCircuits find_split(int n, const std::vector<GateIn>& all_gates, const std:
     }
     out.ok = true;
     return out;
+    }
+    return SplitCircuits{};
 }
 
 }  // namespace qsv

@@ -53,5 +53,9 @@ struct SplitCircuits {
 // max_side: most qubits a virtual circuit may have.  Deterministic.
 SplitCircuits find_split(int n_qubits, const std::vector<GateIn>& gates, const std::vector<AngleSource>& op_angles,
                          int max_side, int max_keys = kMaxSplitKeys);
+// Several size limits in order of preference (smaller virtual circuits first): the result of the first limit that has a
+// partition, found in ONE enumeration of key sets.
+SplitCircuits find_split(int n_qubits, const std::vector<GateIn>& gates, const std::vector<AngleSource>& op_angles,
+                         const std::vector<int>& max_sides, int max_keys = kMaxSplitKeys);
 
 }  // namespace qsv
