@@ -122,3 +122,42 @@ def test_no_split_when_the_register_is_well_entangled_or_fits_a_tile():
             ring.u(0.1 * q, 0.2, 0.3, q)
     assert describe(ring, 6) is None
     assert describe(ring, 10) is None  # n <= max_side: the whole register is one tile anyway
+
+
+def _keys_of(circuit: CircuitIR):
+    """The splitter's keys restated: a key is one control qubit between two gates that target it; a cu3 whose control
+    nobody has targeted yet is the identity.  Returns [(control, {targets})]."""
+    touched, epoch, keys = set(), {}, {}
+    for op in circuit.packed():
+        kind, target, control = int(op["kind"]), int(op["target"]), int(op["control"])
+        if kind == 0:
+            continue
+        if kind == 2:
+            if control not in touched:
+                continue
+            keys.setdefault((control, epoch.get(control, 0)), set()).add(target)
+        touched.add(target)
+        epoch[target] = epoch.get(target, 0) + 1
+    return [(c, ts) for (c, _), ts in keys.items()]
+
+
+@pytest.mark.parametrize("n,layers,max_side", [(8, 3, 5), (9, 4, 6), (10, 4, 6), (10, 5, 7), (11, 3, 6)])
+def test_the_partition_cuts_as_few_keys_as_any(n, layers, max_side):
+    """Against brute force over all 2^(n-1) bipartitions: the splitter's number of keys is the minimum over the partitions
+    whose virtual circuits fit the size limit, and it reports no split form exactly when there is none with at most three
+    keys (the pruned search -- articulation points, one enumeration for several limits -- is exact)."""
+    population = EVQEPopulation.random_population(n, layers, 40, True, 300 + n + layers)
+    outcomes = set()
+    for individual in population.individuals:
+        circuit = individual.get_parameterized_quantum_circuit()
+        keys = _keys_of(circuit)
+        best = None
+        for a_mask in range(1, 1 << (n - 1)):  # qubit n - 1 always on side B: every bipartition once
+            cut = sum(1 for c, ts in keys if any(((a_mask >> c) & 1) != ((a_mask >> t) & 1) for t in ts))
+            size_a = bin(a_mask).count("1")
+            if cut <= 3 and size_a + cut <= max_side and n - size_a + cut <= max_side and (best is None or cut < best):
+                best = cut
+        got = describe(circuit, max_side)
+        assert (got[0] if got is not None else None) == best, (keys, got and got[:2], best)
+        outcomes.add(best)
+    assert len(outcomes) >= 2, outcomes  # (the populations exercise several outcomes)
