@@ -157,6 +157,7 @@ class StatevectorDevice:
         self._group = max(1, int(self._lib.qsv_group_size(self._handle)))
         self._push_groups = 1  # launch groups per qsv_eval_push
         self._last_batch = None  # (identities, circuits, ids, parameter counts) of the previous expectation_values call
+        self._last_total = 0
         self._push_evals = int(os.environ.get("QSV_PUSH_EVALS", "0"))  # measurement knob: evaluations per push
         self._push_plan = [int(x) for x in os.environ.get("QSV_PUSH_PLAN", "").split(",") if x]  # ... or explicit sizes
         self._operator: Optional[PauliOperator] = None
@@ -308,6 +309,7 @@ class StatevectorDevice:
         ids = np.fromiter((self.circuit_id(c) for c in circuits), dtype=np.int32, count=n)
         need = np.fromiter((c.num_parameters for c in circuits), dtype=np.int64, count=n)
         self._last_batch = ((CircuitIR.edits_of_registered, *map(id, circuits)), list(circuits), ids, need)
+        self._last_total = int(need.sum())  # parameter values the batch takes
         return ids, need
 
     def expectation_values_to_device(
@@ -323,16 +325,16 @@ class StatevectorDevice:
         if n == 0:
             return
         ids, need = self._batch_metadata(circuits)
+        helper = _load_pyhelp()
+        if helper is not None:
+            scratch = np.empty(self._last_total + 1, dtype=np.float64)
+            self._check(helper.qsv_py_expectation_values_device(self._handle, n, ids.ctypes.data, need.ctypes.data,
+                                                                parameter_values, scratch.ctypes.data, C.c_void_p(device_pointer)))
+            return
         counts = np.fromiter(map(len, parameter_values), dtype=np.int64, count=n)
         if (counts < need).any():
             i = int(np.argmax(counts < need))
             raise ValueError(f"circuit {i} needs {int(need[i])} parameter values, got {int(counts[i])}")
-        helper = _load_pyhelp()
-        scratch = np.empty(int(counts.sum()) + 1, dtype=np.float64)
-        if helper is not None:
-            self._check(helper.qsv_py_expectation_values_device(self._handle, n, ids.ctypes.data, counts.ctypes.data,
-                                                                parameter_values, scratch.ctypes.data, C.c_void_p(device_pointer)))
-            return
         lib, handle = self._lib, self._handle
         self._check(lib.qsv_eval_begin(handle, n, _lib.as_ptr(ids), _lib.as_ptr(counts)))
         rc = lib.qsv_eval_set_output(handle, C.c_void_p(device_pointer))
@@ -354,20 +356,21 @@ class StatevectorDevice:
         if n == 0:
             return np.zeros(0, dtype=np.float64)
         ids, need = self._batch_metadata(circuits)
-        counts = np.fromiter(map(len, parameter_values), dtype=np.int64, count=n)
-        if (counts < need).any():
-            i = int(np.argmax(counts < need))
-            raise ValueError(f"circuit {i} needs {int(need[i])} parameter values, got {int(counts[i])}")
         out = np.empty(n, dtype=np.float64)
         lib, handle = self._lib, self._handle
         helper = None if (self._push_evals or self._push_plan or os.environ.get("QSV_LIBRARY")) else _load_pyhelp()
         if helper is not None:
-            # the whole begin / pack / push / end sequence in one call of the CPython-API helper (csrc/pyhelp.c)
-            scratch = np.empty(int(counts.sum()) + 1, dtype=np.float64)
-            rc = helper.qsv_py_expectation_values(handle, n, ids.ctypes.data, counts.ctypes.data, parameter_values,
+            # the whole begin / pack / push / end sequence in one call of the CPython-API helper (csrc/pyhelp.c), which
+            # takes the first need[i] values of vector i and complains about a shorter one itself
+            scratch = np.empty(self._last_total + 1, dtype=np.float64)
+            rc = helper.qsv_py_expectation_values(handle, n, ids.ctypes.data, need.ctypes.data, parameter_values,
                                                   scratch.ctypes.data, out.ctypes.data)
             self._check(rc)
             return out
+        counts = np.fromiter(map(len, parameter_values), dtype=np.int64, count=n)
+        if (counts < need).any():
+            i = int(np.argmax(counts < need))
+            raise ValueError(f"circuit {i} needs {int(need[i])} parameter values, got {int(counts[i])}")
         self._check(lib.qsv_eval_begin(handle, n, _lib.as_ptr(ids), _lib.as_ptr(counts)))
         rc = _lib.QSV_OK
         try:

@@ -49,13 +49,55 @@ Py_ssize_t qsv_pack_vectors(PyObject* vectors, Py_ssize_t first, Py_ssize_t coun
     return n;
 }
 
+/* out[0 .. n) = the first take[i] values of vectors[i] for i = first .. first + count - 1, back to back (a vector may be
+ * longer than its circuit needs; a shorter one raises ValueError).  Returns n, or -1 with a Python exception set. */
+static Py_ssize_t pack_exact(PyObject* vectors, Py_ssize_t first, Py_ssize_t count, const int64_t* take, double* out) {
+    PyObject* outer = PySequence_Fast(vectors, "parameter_values must be a sequence of sequences");
+    if (!outer) return -1;
+    Py_ssize_t n = 0;
+    if (first < 0 || count < 0 || first + count > PySequence_Fast_GET_SIZE(outer)) {
+        PyErr_SetString(PyExc_IndexError, "slice of parameter vectors out of range");
+        Py_DECREF(outer);
+        return -1;
+    }
+    for (Py_ssize_t i = first; i < first + count; ++i) {
+        PyObject* inner = PySequence_Fast(PySequence_Fast_GET_ITEM(outer, i), "a parameter vector must be a sequence of numbers");
+        if (!inner) {
+            Py_DECREF(outer);
+            return -1;
+        }
+        const Py_ssize_t m = PySequence_Fast_GET_SIZE(inner), want = (Py_ssize_t)take[i];
+        if (m < want) {
+            PyErr_Format(PyExc_ValueError, "circuit %zd needs %zd parameter values, got %zd", i, want, m);
+            Py_DECREF(inner);
+            Py_DECREF(outer);
+            return -1;
+        }
+        PyObject** items = PySequence_Fast_ITEMS(inner);
+        for (Py_ssize_t j = 0; j < want; ++j) {
+            PyObject* v = items[j];
+            double d = PyFloat_CheckExact(v) ? PyFloat_AS_DOUBLE(v) : PyFloat_AsDouble(v);
+            if (d == -1.0 && PyErr_Occurred()) {
+                Py_DECREF(inner);
+                Py_DECREF(outer);
+                return -1;
+            }
+            out[n++] = d;
+        }
+        Py_DECREF(inner);
+    }
+    Py_DECREF(outer);
+    return n;
+}
+
 /* The whole of StatevectorDevice.expectation_values after its argument checks, in one call: lay the batch out, pack and
  * push it in as many parts as the library suggests (two halves, one per HIP stream, when there is GPU work to overlap the
  * packing with; one push for a chain of short launches), wait for the results.  The GIL is released while the call waits for the handle and for the GPU.
  * In Python the same sequence costs five ctypes calls and a dozen NumPy temporaries per population: about 90 us of a
  * 345 us step on the benchmark workload.
  * Returns the library's status (0 or QSV_E_*); -100 with a Python exception set when a parameter vector is malformed.
- * `values` is scratch for sum(counts) doubles. */
+ * counts[i] = the number of parameters circuit i needs: that many values are taken from the front of vector i (a shorter
+ * vector raises ValueError).  `values` is scratch for sum(counts) doubles. */
 static int expectation_values(qsv_t* h, Py_ssize_t n, const int* ids, const int64_t* counts, PyObject* vectors,
                               double* values, double* out, double* device_out) {
     int rc;
@@ -87,7 +129,7 @@ static int expectation_values(qsv_t* h, Py_ssize_t n, const int* ids, const int6
         const Py_ssize_t count = first + step <= n ? step : n - first;
         Py_ssize_t total = 0;
         for (Py_ssize_t i = first; i < first + count; ++i) total += (Py_ssize_t)counts[i];
-        if (total > 0 && qsv_pack_vectors(vectors, first, count, values + offset, total) != total) {
+        if (pack_exact(vectors, first, count, counts, values + offset) != total) {
             if (!PyErr_Occurred()) PyErr_SetString(PyExc_ValueError, "parameter vectors changed length while they were being packed");
             failed = py_error = 1;
             break;
