@@ -150,6 +150,8 @@ struct qsv_handle {
     // Second stream for the streaming evaluation: consecutive pushes alternate between the two, so that the
     // compute-bound first pass of one push runs beside the memory-bound later passes of the other.
     std::vector<hipStream_t> side_streams;  // (own, non-blocking); pushes cycle over `stream` and these
+    int aux_stream = -1;  // index in side_streams of the stream that is never a push's lane: in a batch that mixes split and
+                          // ordinary evaluations the ordinary ones run there, beside the split ones (eval_push)
     hipStream_t work = nullptr;  // stream of the push being issued (null: `stream`)
     hipEvent_t ev_join = nullptr;
     int n_streams = 2;           // streams a batch cycles over (QSV_STREAMS, 1 .. 4)
@@ -244,6 +246,8 @@ struct qsv_handle {
         std::vector<uint32_t> eval_at;  // descriptor position -> evaluation (a push puts its split evaluations first)
         int ways = 1;           // streams this batch cycles over
         unsigned used_mask = 0; // side streams (bit i = side_streams[i]) with work of this batch in flight
+        bool aux_plain = false; // the batch's ordinary evaluations run on the auxiliary stream (eval_begin)
+        size_t aux_count = 0;   // ... how many of them have been pushed (their state slots cycle over the whole group)
         size_t n_pushes = 0;
     } batch;
     std::unique_lock<std::mutex> batch_lock;  // held from begin to end
@@ -1064,7 +1068,15 @@ int eval_begin(qsv_t* h, const std::vector<Circuit*>& circs, const std::vector<i
     // each other.
     b.ways = 1;
     if (h->diagonal && n_evals >= 2)
-        b.ways = std::max(1, std::min({h->n_streams, int(h->side_streams.size()) + 1, h->group}));
+        b.ways = std::max(1, std::min({h->n_streams, int(h->side_streams.size()), h->group}));  // (lanes: not the auxiliary stream)
+    // A batch that mixes split evaluations (three short launches, no state) with ordinary ones (passes over resident
+    // states): the ordinary ones go to the auxiliary stream, every push's, so that the two kinds run side by side instead
+    // of one after the other (n = 14, 64 four-layer circuits of which a third has no split form: 114 -> see DESIGN.md).
+    // Only where the split ones leave no partial sums for the push's common reduction (quadratic operator).
+    b.aux_plain = false;
+    if (h->diagonal && b.split_any && factor_path(h) && h->aux_stream >= 0 && h->geo.blocks_per_state > 1)
+        for (size_t i = 0; i < n_evals && !b.aux_plain; ++i) b.aux_plain = b.split[i] == 0;
+    b.aux_count = 0;
     b.used_mask = 0;
     b.n_pushes = 0;
     return QSV_OK;
@@ -1133,17 +1145,28 @@ int eval_push(qsv_t* h, size_t first, size_t count, const double* values) {
         hd[first + j].state_slot = slot;
         hd[P + first + j].state_slot = slot;
     }
+    hipStream_t const lane_stream = h->work;  // (null: the handle's own)
+    hipStream_t const plain_stream = b.aux_plain ? h->side_streams[size_t(h->aux_stream)] : lane_stream;
+    if (b.aux_plain && n_split < count) b.used_mask |= 1u << h->aux_stream;
     for (size_t j = n_split; j < count; ++j) {
-        const uint32_t slot = uint32_t(lane * G + (j - n_split) % G);
+        // (on the auxiliary stream every ordinary evaluation of the batch: one stream orders every reuse of a slot)
+        const uint32_t slot = b.aux_plain ? uint32_t((b.aux_count + (j - n_split)) % size_t(h->group))
+                                          : uint32_t(lane * G + (j - n_split) % G);
         hd[first + j].state_slot = slot;
         if (b.split_any) hd[P + first + j].state_slot = slot;
+    }
+    if (b.aux_plain) {
+        b.aux_count += count - n_split;
+        G = size_t(h->group);
     }
     b.n_pushes += 1;
     const uint32_t mode = kModeSynthFirst | (h->diagonal ? kModeFinalDiag : kModeFinalStore) |
                           (h->has_diag_part ? kModeFinalDiag : 0u);
     bool direct = single_workgroup_path(h, mode);
     for (size_t j = 0; direct && j < count; ++j) direct = b.circs[first + j]->plan.stats.n_passes == 1;
+    h->work = plain_stream;  // (the preparation launch concerns the ordinary evaluations only)
     int rc = batch_ship(h, first, count, values, direct ? count : n_split);
+    h->work = lane_stream;
     if (rc) return rc;
     const uint32_t group_mode = mode | (direct ? uint32_t(kModeDirectResult) : 0u);
     // launch groups: the split evaluations of the push in groups of SG, then the ordinary ones in groups of G
@@ -1155,6 +1178,7 @@ int eval_push(qsv_t* h, size_t first, size_t count, const double* values) {
             size_t gc;
             ~Advance() { g0 += gc; }
         } advance{g0, gc};
+        h->work = in_split ? lane_stream : plain_stream;
         QSV_HIP(h, stamp(h, b.pass_events, true));
         rc = run_group(h, b.circs, g0, gc, group_mode);
         if (!rc) QSV_HIP(h, stamp(h, b.pass_events, false));
@@ -1179,6 +1203,7 @@ int eval_push(qsv_t* h, size_t first, size_t count, const double* values) {
         // This push's evaluations are reduced on the push's own stream, straight into the pinned result buffer: no
         // cross-stream join in front of one final reduction (the join alone cost 15-30 us at the end of every call).
         QSV_HIP(h, stamp(h, b.exp_events, true));
+        h->work = n_split > 0 && factor_path(h) ? plain_stream : lane_stream;
         if (n_split > 0 && factor_path(h))  // (the split evaluations' results are already there: the others, by descriptor)
             QSV_HIP(h, launch_reduce_partials(static_cast<const double*>(h->d_partials.ptr), partials_per_state(h),
                                               int(count - n_split), h->out_target ? h->out_target : h->h_out, ws(h),
@@ -1391,11 +1416,12 @@ int qsv_create(int n_qubits, int dtype, int device, const qsv_plan_config* cfg, 
     h->stream_mode = state_bytes > (size_t(256) << 20) ? uint32_t(kModeStreaming) : 0u;
     if (const char* env = getenv("QSV_STREAMING")) h->stream_mode = atoi(env) ? uint32_t(kModeStreaming) : 0u;
     if (const char* env = getenv("QSV_STREAMS")) h->n_streams = std::max(1, std::min(4, atoi(env)));
-    for (int i = 1; i < std::max(2, h->n_streams); ++i) {
+    for (int i = 1; i < std::max(2, h->n_streams) + 1; ++i) {  // (the lanes' streams, then the auxiliary one)
         hipStream_t st = nullptr;
         if ((e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
         h->side_streams.push_back(st);
     }
+    h->aux_stream = int(h->side_streams.size()) - 1;
     if ((e = hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
     if ((e = hipMalloc(&h->d_states.ptr, state_bytes * size_t(group))) != hipSuccess) return bail(e, "hipMalloc(states)");
     h->d_states.bytes = state_bytes * size_t(group);
@@ -1781,7 +1807,8 @@ int qsv_eval_suggested_pushes(const qsv_t* h) {
     for (size_t i = 0; all_split && i < b.split.size(); ++i) all_split = b.split[i] != 0;
     // (... up to about a launch group of the side circuits: 256 evaluations at 24 qubits take 0.29 ms in two pushes,
     // 0.42 ms in one)
-    return all_split && factor_path(h) && b.split.size() <= 96 ? 1 : 2;
+    // (a mixed batch whose ordinary evaluations run beside the split ones on the auxiliary stream likewise)
+    return ((all_split && factor_path(h)) || b.aux_plain) && b.split.size() <= 96 ? 1 : 2;
 }
 
 int qsv_eval_set_output(qsv_t* h, double* device_out) {
