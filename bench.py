@@ -24,6 +24,7 @@ Rank 0 prints ONE JSON line.  Beside the contract's fields it carries
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import os
 import sys
@@ -307,12 +308,16 @@ def config3_block(world: int, rank: int, local_rank: int, steps: int = 8):
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
+    marks = []
     for _ in range(steps):
         values = evaluate_population_sharded(evaluator, circuits, params)
+        marks.append(time.perf_counter())
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    if os.environ.get("QSV_BENCH_VERBOSE"):
+        print("config 3 step times (us):", [round((b - a) * 1e6) for a, b in zip([t0] + marks[:-1], marks)], file=sys.stderr)
     # this rank's own block alone, after the timed region: what the imbalance is computed from
     own_c, own_p = circuits[lo:hi], params[lo:hi]
     t1 = time.perf_counter()
@@ -342,8 +347,8 @@ def config3_block(world: int, rank: int, local_rank: int, steps: int = 8):
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)  # (200 steps of 85 us: a timed region of 17 ms; 20 steps made it 1.7 ms, a tenth of which one host hiccup takes)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="only the headline measurement (profiling runs)")
     args = ap.parse_args()
@@ -381,6 +386,12 @@ def main() -> None:
     operator = ising_operator(N_QUBITS, 2020)
     evaluator = OperatorCircuitEvaluator(operator, device=local_rank)
     device = evaluator.statevector_device
+
+    # The populations, circuits and plans built so far are long-lived: out of the garbage collector's way (what a
+    # long-running service does after start-up), so that a full collection inside a timed region of a few milliseconds
+    # does not walk them.
+    gc.collect()
+    gc.freeze()
 
     def step():
         # the product's sharding function: this rank's block on its GPU, then one all-gather of the fitness values

@@ -150,8 +150,12 @@ struct qsv_handle {
     // Second stream for the streaming evaluation: consecutive pushes alternate between the two, so that the
     // compute-bound first pass of one push runs beside the memory-bound later passes of the other.
     std::vector<hipStream_t> side_streams;  // (own, non-blocking); pushes cycle over `stream` and these
+    int n_lane_streams = 0;  // the first so many of side_streams are lanes of pushes
     int aux_stream = -1;  // index in side_streams of the stream that is never a push's lane: in a batch that mixes split and
-                          // ordinary evaluations the ordinary ones run there, beside the split ones (eval_push)
+                          // ordinary evaluations the ordinary ones run there, beside the split ones (eval_push).  Created
+                          // when a batch first needs it: a process has few hardware queues (four by default), and streams
+                          // beyond them share queues -- with two handles alive, a third stream per handle made the two
+                          // pushes of a 256-evaluation step run one after the other (262 -> 358 us).
     hipStream_t work = nullptr;  // stream of the push being issued (null: `stream`)
     hipEvent_t ev_join = nullptr;
     int n_streams = 2;           // streams a batch cycles over (QSV_STREAMS, 1 .. 4)
@@ -1068,14 +1072,23 @@ int eval_begin(qsv_t* h, const std::vector<Circuit*>& circs, const std::vector<i
     // each other.
     b.ways = 1;
     if (h->diagonal && n_evals >= 2)
-        b.ways = std::max(1, std::min({h->n_streams, int(h->side_streams.size()), h->group}));  // (lanes: not the auxiliary stream)
+        b.ways = std::max(1, std::min({h->n_streams, h->n_lane_streams + 1, h->group}));  // (lanes: not the auxiliary stream)
     // A batch that mixes split evaluations (three short launches, no state) with ordinary ones (passes over resident
     // states): the ordinary ones go to the auxiliary stream, every push's, so that the two kinds run side by side instead
     // of one after the other (n = 14, 64 four-layer circuits of which a third has no split form: 114 -> see DESIGN.md).
     // Only where the split ones leave no partial sums for the push's common reduction (quadratic operator).
     b.aux_plain = false;
-    if (h->diagonal && b.split_any && factor_path(h) && h->aux_stream >= 0 && h->geo.blocks_per_state > 1)
+    if (h->diagonal && b.split_any && factor_path(h) && h->geo.blocks_per_state > 1)
         for (size_t i = 0; i < n_evals && !b.aux_plain; ++i) b.aux_plain = b.split[i] == 0;
+    if (b.aux_plain && h->aux_stream < 0) {
+        hipStream_t st = nullptr;
+        QSV_HIP(h, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        h->side_streams.push_back(st);
+        h->aux_stream = int(h->side_streams.size()) - 1;
+        // (the plans of this batch were uploaded on the handle's stream before this stream existed)
+        QSV_HIP(h, hipEventRecord(h->ev_join, h->stream));
+        QSV_HIP(h, hipStreamWaitEvent(st, h->ev_join, 0));
+    }
     b.aux_count = 0;
     b.used_mask = 0;
     b.n_pushes = 0;
@@ -1416,12 +1429,12 @@ int qsv_create(int n_qubits, int dtype, int device, const qsv_plan_config* cfg, 
     h->stream_mode = state_bytes > (size_t(256) << 20) ? uint32_t(kModeStreaming) : 0u;
     if (const char* env = getenv("QSV_STREAMING")) h->stream_mode = atoi(env) ? uint32_t(kModeStreaming) : 0u;
     if (const char* env = getenv("QSV_STREAMS")) h->n_streams = std::max(1, std::min(4, atoi(env)));
-    for (int i = 1; i < std::max(2, h->n_streams) + 1; ++i) {  // (the lanes' streams, then the auxiliary one)
+    for (int i = 1; i < std::max(2, h->n_streams); ++i) {  // (the lanes' streams; the auxiliary one on first need)
         hipStream_t st = nullptr;
         if ((e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
         h->side_streams.push_back(st);
     }
-    h->aux_stream = int(h->side_streams.size()) - 1;
+    h->n_lane_streams = int(h->side_streams.size());
     if ((e = hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
     if ((e = hipMalloc(&h->d_states.ptr, state_bytes * size_t(group))) != hipSuccess) return bail(e, "hipMalloc(states)");
     h->d_states.bytes = state_bytes * size_t(group);
