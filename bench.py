@@ -283,6 +283,17 @@ def sampler_block(operator, circuits, params, shots: int = 1024, alpha: float = 
                     "operator values and CVaR); wall clock of whole calls"}
 
 
+def agreed_count(mine: int, world: int, comm_device: str, limit: int = 5000) -> int:
+    """A loop count every rank uses: rank 0's (loops whose steps are collectives must not end at different iterations on
+    different ranks -- a time-based exit per rank is a deadlock waiting for two clocks to disagree)."""
+    mine = max(0, min(int(mine), limit))
+    if world <= 1:
+        return mine
+    t = torch.tensor([mine], dtype=torch.int64, device=comm_device)
+    dist.broadcast(t, src=0)
+    return int(t.item())
+
+
 def config3_block(world: int, rank: int, local_rank: int, steps: int = 8):
     """BASELINE.json configs[2] as north_star states it: n = 24, L = 4, P = 256 IN TOTAL (strong scaling: at N = 8 rank r
     takes [32r, 32r+32), at N = 1 the one GPU evaluates all 256), 300-term Ising operator of default_rng(2024), through
@@ -300,10 +311,11 @@ def config3_block(world: int, rank: int, local_rank: int, steps: int = 8):
     lo, hi = shard_bounds(total, world, rank)
 
     t_warm = time.perf_counter()  # warm-up: plans, buffers, and 0.1 s of load for the clocks (as before the headline)
-    for i in range(1000):
+    for _ in range(3):
         evaluate_population_sharded(evaluator, circuits, params)
-        if i >= 2 and time.perf_counter() - t_warm > 0.1:
-            break
+    comm_device = "cpu" if (world > 1 and dist.get_backend() != "nccl") else "cuda"
+    for _ in range(agreed_count(int(0.1 / max((time.perf_counter() - t_warm) / 3, 1e-6)), world, comm_device)):
+        evaluate_population_sharded(evaluator, circuits, params)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -408,10 +420,14 @@ def main() -> None:
     # Steady state before the clock starts: a fresh GPU needs tens of milliseconds of load before it holds its clocks
     # (measured: 20 timed steps right after 5 warm-up steps run 10 % slower than the same 20 steps after 0.25 s of
     # load), and 20 steps of this workload last 7 ms.  Untimed, the same step, reported in the output line.
-    prewarm_steps, t_pre = 0, time.perf_counter()
-    while time.perf_counter() - t_pre < PREWARM_S:
+    # (every rank must make the same number of steps -- each is a collective -- so the count is rank 0's estimate)
+    t_pre = time.perf_counter()
+    for _ in range(5):
         step()
-        prewarm_steps += 1
+    prewarm_steps = agreed_count(int(PREWARM_S / max((time.perf_counter() - t_pre) / 5, 1e-6)), world, comm_device)
+    for _ in range(prewarm_steps):
+        step()
+    prewarm_steps += 5
     # ---- timed region: exactly K steps (no profiling events inside) ---------------------------------------
     fence()
     t0 = time.perf_counter()
