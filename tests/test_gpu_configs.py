@@ -875,10 +875,13 @@ def test_chained_all_gather_of_a_sharded_population():
     _, circuits, params = helpers.population_circuits(n, 4, 24, seed=9)
     ev = OperatorCircuitEvaluator(helpers.random_ising_operator(n, seed=1))
     want = ev.evaluate_circuits(circuits, params)
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29641")
+    import socket
+
+    with socket.socket() as probe:  # (a port nobody holds: the group has one rank, nobody else needs to know it)
+        probe.bind(("127.0.0.1", 0))
+        port = probe.getsockname()[1]
     torch.cuda.set_device(0)
-    dist.init_process_group("nccl", rank=0, world_size=1)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
     try:
         device = torch.device("cuda", 0)
         for _ in range(2):
