@@ -4,7 +4,7 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
 import numpy as np
-import helpers
+from queasars_amd import workloads as helpers
 from queasars_amd.circuit_evaluation import OperatorCircuitEvaluator, StatevectorDevice
 
 
