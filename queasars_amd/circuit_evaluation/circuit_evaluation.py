@@ -120,6 +120,17 @@ def _pack_doubles(vectors: Sequence[Sequence[float]], total: int) -> np.ndarray:
     return np.frombuffer(packed, dtype=np.float64)
 
 
+def _make_gone(dead: list, watched: dict):
+    """Callback of the weak references StatevectorDevice._watch creates: queue the dead circuit's id for destruction."""
+
+    def gone(ref):
+        entry = watched.pop(id(ref), None)
+        if entry is not None:
+            dead.append(entry[1])  # no library call here: see StatevectorDevice.__init__
+
+    return gone
+
+
 class StatevectorDevice:
     """Owns one ``qsv_t`` handle: the resident state buffers, plans and operator tables of one GPU.
 
@@ -168,7 +179,8 @@ class StatevectorDevice:
         # allocation, also between qsv_eval_begin and qsv_eval_end, where a call into the library would wait for the
         # handle this very thread holds); the ids are destroyed at the start of the next call that registers circuits.
         self._dead: list[int] = []
-        self._watched: dict[int, weakref.ref] = {}  # circuit id -> weak reference to its CircuitIR (see _watch)
+        self._watched: dict[int, tuple] = {}  # id(weak reference) -> (weak reference to a CircuitIR, its circuit id)
+        self._gone = _make_gone(self._dead, self._watched)  # (holds the two containers, not the device)
         # held across "set the operator, then evaluate" by evaluators that share this device
         self.operator_lock = threading.RLock()
 
@@ -278,13 +290,8 @@ class StatevectorDevice:
         """Note the device-side plan ``cid`` for destruction once ``circuit`` is garbage collected.  (A plain weak
         reference with a callback, kept alive in a dict: ``weakref.finalize`` cost 1.4 us per circuit -- 90 us of the
         registration of a generation's 64 new structures.)"""
-        dead, watched = self._dead, self._watched
-
-        def gone(_ref, cid=cid):
-            watched.pop(cid, None)
-            dead.append(cid)  # no library call here: see __init__
-
-        watched[cid] = weakref.ref(circuit, gone)
+        ref = weakref.ref(circuit, self._gone)  # (one callback per device, not one closure per circuit)
+        self._watched[id(ref)] = (ref, cid)
 
     def _reap(self) -> None:
         """Destroy the device-side plans of circuits that were garbage collected (caller holds ``_reg_lock``)."""

@@ -281,10 +281,13 @@ class TestProcessLocalRegistrations:
                 return 0
 
         dev = object.__new__(StatevectorDevice)  # no GPU here: only the bookkeeping is exercised
+        from queasars_amd.circuit_evaluation.circuit_evaluation import _make_gone
+
         dev._dead, dev._watched, dev._handle, dev._lib = [], {}, 1, FakeLib()
+        dev._gone = _make_gone(dev._dead, dev._watched)
         c = CircuitIR(2).u(0.1, 0.2, 0.3, 0)
         dev._watch(c, 17)
-        assert list(dev._watched) == [17]
+        assert [cid for _, cid in dev._watched.values()] == [17]
         del c
         gc.collect()
         assert dev._dead == [17] and dev._watched == {} and FakeLib.destroyed == []
