@@ -441,14 +441,6 @@ int build_circuit(qsv_t* h, int n_ops, const qsv_op* ops, int n_params, bool fol
                                 coly[size_t(q)] = 1u << cy_++;
                         }
                     }
-                    auto pieces = [&](uint64_t index_bits, uint32_t* out) {  // (x piece, y piece) of a set of index bits
-                        out[0] = out[1] = 0;
-                        for (int q = 0; q < h->n; ++q)
-                            if (index_bits >> q & 1u) {
-                                out[0] |= colx[size_t(q)];
-                                out[1] |= coly[size_t(q)];
-                            }
-                    };
                     sp.off_block = uint32_t(w.size());
                     w.resize(w.size() + kSplitBlockWords, 0);
                     uint32_t* blk = w.data() + sp.off_block;
@@ -470,12 +462,20 @@ int build_circuit(qsv_t* h, int n_ops, const qsv_op* ops, int n_params, bool fol
                                 ++at;
                             }
                     }
-                    for (uint32_t l = 0; l < 64; ++l) pieces(l, blk + kSplitLaneTable + 2 * l);
-                    for (uint32_t v = 0; v < (1u << wave_bits); ++v) pieces(uint64_t(v) << 6, blk + kSplitWaveTable + 2 * v);
-                    for (uint32_t c = 0; c < 128; ++c) {
-                        pieces((uint64_t(c) << chunk0) & ((uint64_t(1) << h->n) - 1), blk + kSplitChunkLow + 2 * c);
-                        pieces((uint64_t(c) << (chunk0 + 7)) & ((uint64_t(1) << h->n) - 1), blk + kSplitChunkHigh + 2 * c);
-                    }
+                    // (entry v of a table = entry v without its lowest set bit | that bit's own pieces: one step per entry)
+                    auto fill = [&](uint32_t* table, uint32_t entries, int first_bit) {
+                        table[0] = table[1] = 0;
+                        for (uint32_t v = 1; v < entries; ++v) {
+                            const uint32_t low = v & (0u - v), rest = v ^ low;
+                            const int q = first_bit + __builtin_ctz(low);
+                            table[2 * v] = table[2 * rest] | (q < h->n ? colx[size_t(q)] : 0u);
+                            table[2 * v + 1] = table[2 * rest + 1] | (q < h->n ? coly[size_t(q)] : 0u);
+                        }
+                    };
+                    fill(blk + kSplitLaneTable, 64, 0);
+                    fill(blk + kSplitWaveTable, 1u << wave_bits, 6);
+                    fill(blk + kSplitChunkLow, 128, chunk0);
+                    fill(blk + kSplitChunkHigh, 128, chunk0 + 7);
                     sp.n_keys = sc.n_keys;
                     sp.ok = true;
                 } else {
@@ -540,7 +540,8 @@ void build_many(qsv_t* h, size_t count, const std::function<void(size_t, BuiltCi
     {
         std::lock_guard<std::mutex> lock(h->pool_mu);
         if (!h->pool) {
-            const unsigned hw = std::max(2u, std::min(16u, std::thread::hardware_concurrency()));
+            unsigned hw = std::max(2u, std::min(16u, std::thread::hardware_concurrency()));
+            if (const char* env = getenv("QSV_BUILD_THREADS")) hw = std::max(2u, std::min(64u, unsigned(atoi(env))));
             h->pool.reset(new WorkerPool(hw - 1));
         }
         pool = h->pool.get();
