@@ -2293,6 +2293,7 @@ __device__ __forceinline__ double factor_pairing(const double* a, const double* 
 // separable parts -- forms its term, and the terms are added in a fixed order.
 constexpr unsigned kFactorParts = 8;
 constexpr uint32_t kFactorSlices = kFactorParts / 2;
+static_assert(factor_slot_doubles() == size_t(2) * kFactorSlices * kFactorWeights * 64, "scratch of one evaluation");
 
 template <typename real>
 __global__ void __launch_bounds__(256, 2) factor_moments_kernel(const uint32_t* __restrict__ plan_arena, const EvalDesc* __restrict__ evals,
