@@ -1,11 +1,13 @@
 """Kernel timeline of the last step in a rocprofv3 kernel trace: start/end (us) per kernel, with stream/queue."""
 import csv, glob, sys
 root = sys.argv[1]
-f = sorted(glob.glob(f"{root}/**/*kernel_trace.csv", recursive=True))[-1]
+import os
+f = max(glob.glob(f"{root}/**/*kernel_trace.csv", recursive=True), key=os.path.getmtime)
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-# steps are separated by the reduce_partials kernel
-ends = [i for i, r in enumerate(rows) if "reduce_partials" in r["Kernel_Name"]]
+# steps end with the reduce_partials kernel, or -- split evaluations under a quadratic operator -- with factor_combine_kernel
+last = "factor_combine" if any("factor_combine" in r["Kernel_Name"] for r in rows) else "reduce_partials"
+ends = [i for i, r in enumerate(rows) if last in r["Kernel_Name"]]
 lo, hi = ends[-2] + 1, ends[-1] + 1
 t0 = int(rows[lo]["Start_Timestamp"])
 prev_end = int(rows[ends[-2]]["End_Timestamp"])
