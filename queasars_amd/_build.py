@@ -35,6 +35,12 @@ def have_hipcc() -> bool:
         return False
 
 
+def pyhelp_stale() -> bool:
+    """The helper's signatures follow csrc/pyhelp.c: an older build must not be called with the newer argument lists."""
+    src = CSRC / "pyhelp.c"
+    return not PYHELP_PATH.exists() or PYHELP_PATH.stat().st_mtime < src.stat().st_mtime
+
+
 def build_pyhelp(force: bool = False) -> "Path | None":
     """gcc csrc/pyhelp.c against this interpreter's headers; returns None when they (or gcc) are not there -- the Python
     layer then packs parameter vectors with array.fromlist."""

@@ -75,17 +75,21 @@ def _load_pyhelp():
 
         _pyhelp = False
         try:
-            path = _build.PYHELP_PATH if _build.PYHELP_PATH.exists() else _build.build_pyhelp()
+            path = _build.build_pyhelp()  # (rebuilt when csrc/pyhelp.c or libqsv.so is newer; None when it cannot be)
+            if path is None and _build.PYHELP_PATH.exists() and not _build.pyhelp_stale():
+                path = _build.PYHELP_PATH
             if path is not None:
                 lib = C.PyDLL(str(path))
                 lib.qsv_pack_vectors.restype = C.c_ssize_t
                 lib.qsv_pack_vectors.argtypes = [C.py_object, C.c_ssize_t, C.c_ssize_t, C.c_void_p, C.c_ssize_t]
                 lib.qsv_py_expectation_values.restype = C.c_int
                 lib.qsv_py_expectation_values.argtypes = [C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_void_p, C.py_object,
-                                                          C.c_void_p, C.c_void_p]
+                                                          C.c_void_p, C.c_ssize_t, C.c_void_p]
                 lib.qsv_py_expectation_values_device.restype = C.c_int
                 lib.qsv_py_expectation_values_device.argtypes = [C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_void_p, C.py_object,
-                                                                 C.c_void_p, C.c_void_p]
+                                                                 C.c_void_p, C.c_ssize_t, C.c_void_p]
+                lib.qsv_pack_exact.restype = C.c_ssize_t
+                lib.qsv_pack_exact.argtypes = [C.py_object, C.c_ssize_t, C.c_ssize_t, C.c_void_p, C.c_void_p, C.c_ssize_t]
                 _pyhelp = lib
         except OSError:
             _pyhelp = False
@@ -167,8 +171,9 @@ class StatevectorDevice:
         self._dtype = dtype
         self._group = max(1, int(self._lib.qsv_group_size(self._handle)))
         self._push_groups = 1  # launch groups per qsv_eval_push
-        self._last_batch = None  # (identities, circuits, ids, parameter counts) of the previous expectation_values call
-        self._last_total = 0
+        # (identities, circuits, ids, parameter counts, their sum) of the previous call: ONE tuple, replaced as a whole, so
+        # that a thread never pairs one call's counts with another call's total (evaluators may share a device)
+        self._last_batch = None
         self._push_evals = int(os.environ.get("QSV_PUSH_EVALS", "0"))  # measurement knob: evaluations per push
         self._push_plan = [int(x) for x in os.environ.get("QSV_PUSH_PLAN", "").split(",") if x]  # ... or explicit sizes
         self._operator: Optional[PauliOperator] = None
@@ -300,24 +305,24 @@ class StatevectorDevice:
             if self._handle:
                 self._lib.qsv_circuit_destroy(self._handle, cid)
 
-    def _batch_metadata(self, circuits: Sequence[CircuitIR]) -> tuple[np.ndarray, np.ndarray]:
-        """(circuit ids, parameter counts) of a batch.  An optimiser calls with the same circuit objects over and
+    def _batch_metadata(self, circuits: Sequence[CircuitIR]) -> tuple[np.ndarray, np.ndarray, int]:
+        """(circuit ids, parameter counts, sum of the counts) of a batch.  An optimiser calls with the same circuit objects over and
         over: both arrays are kept from the previous call, keyed by the objects' identities (the entry holds the
         circuits, so an identity cannot be recycled while it exists) and by the global edit counter."""
         n = len(circuits)
         key = (CircuitIR.edits_of_registered, *map(id, circuits))
         cached = self._last_batch
         if cached is not None and cached[0] == key:
-            return cached[2], cached[3]
+            return cached[2], cached[3], cached[4]
         if self._dead:
             with self._reg_lock:
                 self._reap()
         self._register_many([c for c in circuits if self._serial not in c._registered])
         ids = np.fromiter((self.circuit_id(c) for c in circuits), dtype=np.int32, count=n)
         need = np.fromiter((c.num_parameters for c in circuits), dtype=np.int64, count=n)
-        self._last_batch = ((CircuitIR.edits_of_registered, *map(id, circuits)), list(circuits), ids, need)
-        self._last_total = int(need.sum())  # parameter values the batch takes
-        return ids, need
+        total = int(need.sum())  # parameter values the batch takes
+        self._last_batch = ((CircuitIR.edits_of_registered, *map(id, circuits)), list(circuits), ids, need, total)
+        return ids, need, total
 
     def expectation_values_to_device(
         self, circuits: Sequence[CircuitIR], parameter_values: Sequence[Sequence[float]], device_pointer: int
@@ -331,12 +336,14 @@ class StatevectorDevice:
             raise ValueError("circuits and parameter_values must have the same length")
         if n == 0:
             return
-        ids, need = self._batch_metadata(circuits)
-        helper = _load_pyhelp()
+        ids, need, total = self._batch_metadata(circuits)
+        # (the helper is linked against the default libqsv.so: a handle of a diagnostic build, QSV_LIBRARY, is not its to touch)
+        helper = None if os.environ.get("QSV_LIBRARY") else _load_pyhelp()
         if helper is not None:
-            scratch = np.empty(self._last_total + 1, dtype=np.float64)
+            scratch = np.empty(total + 1, dtype=np.float64)
             self._check(helper.qsv_py_expectation_values_device(self._handle, n, ids.ctypes.data, need.ctypes.data,
-                                                                parameter_values, scratch.ctypes.data, C.c_void_p(device_pointer)))
+                                                                parameter_values, scratch.ctypes.data, total,
+                                                                C.c_void_p(device_pointer)))
             return
         counts = np.fromiter(map(len, parameter_values), dtype=np.int64, count=n)
         if (counts < need).any():
@@ -362,16 +369,16 @@ class StatevectorDevice:
             raise ValueError("circuits and parameter_values must have the same length")
         if n == 0:
             return np.zeros(0, dtype=np.float64)
-        ids, need = self._batch_metadata(circuits)
+        ids, need, total = self._batch_metadata(circuits)
         out = np.empty(n, dtype=np.float64)
         lib, handle = self._lib, self._handle
         helper = None if (self._push_evals or self._push_plan or os.environ.get("QSV_LIBRARY")) else _load_pyhelp()
         if helper is not None:
             # the whole begin / pack / push / end sequence in one call of the CPython-API helper (csrc/pyhelp.c), which
             # takes the first need[i] values of vector i and complains about a shorter one itself
-            scratch = np.empty(self._last_total + 1, dtype=np.float64)
+            scratch = np.empty(total + 1, dtype=np.float64)
             rc = helper.qsv_py_expectation_values(handle, n, ids.ctypes.data, need.ctypes.data, parameter_values,
-                                                  scratch.ctypes.data, out.ctypes.data)
+                                                  scratch.ctypes.data, total, out.ctypes.data)
             self._check(rc)
             return out
         counts = np.fromiter(map(len, parameter_values), dtype=np.int64, count=n)
@@ -464,7 +471,7 @@ class StatevectorDevice:
         values = np.empty((n, int(shots)), dtype=np.float64) if with_values else None
         if n == 0 or shots == 0:
             return states, values
-        ids, need = self._batch_metadata(circuits)
+        ids, need, _ = self._batch_metadata(circuits)
         counts = np.fromiter(map(len, parameter_values), dtype=np.int64, count=n)
         if (counts < need).any():
             i = int(np.argmax(counts < need))
@@ -494,7 +501,7 @@ class StatevectorDevice:
             raise ValueError("circuits and parameter_values must have the same length")
         if n == 0:
             return []
-        ids, need = self._batch_metadata(circuits)
+        ids, need, _ = self._batch_metadata(circuits)
         counts = np.fromiter(map(len, parameter_values), dtype=np.int64, count=n)
         if (counts < need).any():
             i = int(np.argmax(counts < need))
@@ -512,6 +519,12 @@ class StatevectorDevice:
         return out.tolist()
 
     # -- measurement support ----------------------------------------------------------------------
+    def set_option(self, name: str, value: int) -> None:
+        """Switches of the handle (``qsv_set_option``): "split", "factor", "split_sampling" (0 / 1), "streams" (1 .. 4).
+        A circuit keeps the form it was registered in; the cache of the previous batch is dropped."""
+        self._check(self._lib.qsv_set_option(self._handle, name.encode(), int(value)))
+        self._last_batch = None
+
     def set_profiling(self, enabled: bool) -> None:
         self._check(self._lib.qsv_set_profiling(self._handle, 1 if enabled else 0))
 

@@ -50,8 +50,10 @@ Py_ssize_t qsv_pack_vectors(PyObject* vectors, Py_ssize_t first, Py_ssize_t coun
 }
 
 /* out[0 .. n) = the first take[i] values of vectors[i] for i = first .. first + count - 1, back to back (a vector may be
- * longer than its circuit needs; a shorter one raises ValueError).  Returns n, or -1 with a Python exception set. */
-static Py_ssize_t pack_exact(PyObject* vectors, Py_ssize_t first, Py_ssize_t count, const int64_t* take, double* out) {
+ * longer than its circuit needs; a shorter one raises ValueError).  Never writes past out[capacity): a batch whose counts
+ * add up to more than the caller made room for raises ValueError.  Returns n, or -1 with a Python exception set. */
+static Py_ssize_t pack_exact(PyObject* vectors, Py_ssize_t first, Py_ssize_t count, const int64_t* take, double* out,
+                             Py_ssize_t capacity) {
     PyObject* outer = PySequence_Fast(vectors, "parameter_values must be a sequence of sequences");
     if (!outer) return -1;
     Py_ssize_t n = 0;
@@ -69,6 +71,12 @@ static Py_ssize_t pack_exact(PyObject* vectors, Py_ssize_t first, Py_ssize_t cou
         const Py_ssize_t m = PySequence_Fast_GET_SIZE(inner), want = (Py_ssize_t)take[i];
         if (m < want) {
             PyErr_Format(PyExc_ValueError, "circuit %zd needs %zd parameter values, got %zd", i, want, m);
+            Py_DECREF(inner);
+            Py_DECREF(outer);
+            return -1;
+        }
+        if (want < 0 || n + want > capacity) {
+            PyErr_SetString(PyExc_ValueError, "the batch needs more parameter values than its scratch buffer holds");
             Py_DECREF(inner);
             Py_DECREF(outer);
             return -1;
@@ -97,9 +105,15 @@ static Py_ssize_t pack_exact(PyObject* vectors, Py_ssize_t first, Py_ssize_t cou
  * 345 us step on the benchmark workload.
  * Returns the library's status (0 or QSV_E_*); -100 with a Python exception set when a parameter vector is malformed.
  * counts[i] = the number of parameters circuit i needs: that many values are taken from the front of vector i (a shorter
- * vector raises ValueError).  `values` is scratch for sum(counts) doubles. */
+ * vector raises ValueError).  `values` is scratch for `capacity` >= sum(counts) doubles. */
+/* (exported for the CPU tests of the capacity check) */
+Py_ssize_t qsv_pack_exact(PyObject* vectors, Py_ssize_t first, Py_ssize_t count, const int64_t* take, double* out,
+                          Py_ssize_t capacity) {
+    return pack_exact(vectors, first, count, take, out, capacity);
+}
+
 static int expectation_values(qsv_t* h, Py_ssize_t n, const int* ids, const int64_t* counts, PyObject* vectors,
-                              double* values, double* out, double* device_out) {
+                              double* values, Py_ssize_t capacity, double* out, double* device_out) {
     int rc;
     Py_BEGIN_ALLOW_THREADS
     rc = qsv_eval_begin(h, (int)n, ids, counts);
@@ -129,7 +143,7 @@ static int expectation_values(qsv_t* h, Py_ssize_t n, const int* ids, const int6
         const Py_ssize_t count = first + step <= n ? step : n - first;
         Py_ssize_t total = 0;
         for (Py_ssize_t i = first; i < first + count; ++i) total += (Py_ssize_t)counts[i];
-        if (pack_exact(vectors, first, count, counts, values + offset) != total) {
+        if (pack_exact(vectors, first, count, counts, values + offset, capacity - offset) != total) {
             if (!PyErr_Occurred()) PyErr_SetString(PyExc_ValueError, "parameter vectors changed length while they were being packed");
             failed = py_error = 1;
             break;
@@ -148,13 +162,13 @@ static int expectation_values(qsv_t* h, Py_ssize_t n, const int* ids, const int6
 }
 
 int qsv_py_expectation_values(qsv_t* h, Py_ssize_t n, const int* ids, const int64_t* counts, PyObject* vectors,
-                              double* values, double* out) {
-    return expectation_values(h, n, ids, counts, vectors, values, out, NULL);
+                              double* values, Py_ssize_t capacity, double* out) {
+    return expectation_values(h, n, ids, counts, vectors, values, capacity, out, NULL);
 }
 
 /* The same with the results left in device memory and no wait (qsv_eval_set_output): for the sharded population, whose
  * fitness all-gather runs on the same stream right behind. */
 int qsv_py_expectation_values_device(qsv_t* h, Py_ssize_t n, const int* ids, const int64_t* counts, PyObject* vectors,
-                                     double* values, void* device_out) {
-    return expectation_values(h, n, ids, counts, vectors, values, NULL, (double*)device_out);
+                                     double* values, Py_ssize_t capacity, void* device_out) {
+    return expectation_values(h, n, ids, counts, vectors, values, capacity, NULL, (double*)device_out);
 }

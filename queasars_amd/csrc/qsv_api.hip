@@ -1832,7 +1832,16 @@ int qsv_eval_set_output(qsv_t* h, double* device_out) {
     h->out_target = device_out;
     // every push on the handle's own stream: the caller continues on that stream (joining the other streams into it
     // cost 15 us per batch of 64 evaluations at 20 qubits; callers should push such a batch in one go)
-    if (device_out) h->batch.ways = 1;
+    if (device_out) {
+        h->batch.ways = 1;
+        // The caller may already have queued writes to the output buffer on the handle's stream (a fill of the unused
+        // tail of an uneven shard).  The batch's ordinary evaluations can run on the auxiliary stream (mixed batches,
+        // eval_begin): whatever stream of ours writes results must come after that work.
+        if (h->batch.aux_plain && h->aux_stream >= 0) {
+            QSV_HIP(h, hipEventRecord(h->ev_join, h->stream));
+            QSV_HIP(h, hipStreamWaitEvent(h->side_streams[size_t(h->aux_stream)], h->ev_join, 0));
+        }
+    }
     return QSV_OK;
 }
 
@@ -2127,6 +2136,30 @@ int qsv_sample(qsv_t* h, int circuit_id, const double* params, int n_params, int
     const int64_t offsets[2] = {0, n_params};
     static const double dummy = 0.0;
     return sample_batch_locked(h, circs, offsets, params ? params : &dummy, shots, seed, out_states, nullptr);
+}
+
+int qsv_set_option(qsv_t* h, const char* name, int value) {
+    if (!h) return QSV_E_ARG;
+    if (!name) return fail(h, QSV_E_ARG, "option name is null");
+    std::lock_guard<std::mutex> lock(h->mu);
+    const std::string key(name);
+    if (key == "split") {
+        if (value != 0 && !h->d_side.ptr && h->n > h->geo.k && h->n <= 28)
+            return fail(h, QSV_E_ARG, "this handle was created without side tables (QSV_SPLIT=0): splitting cannot be switched on");
+        h->split_enabled = value != 0;
+    } else if (key == "factor") {
+        if (value != 0 && h->split_enabled && h->d_side.ptr && !h->d_factor.ptr)
+            return fail(h, QSV_E_ARG, "this handle was created without the factorised path (QSV_FACTOR=0)");
+        h->factor_enabled = value != 0;
+    } else if (key == "split_sampling") {
+        h->split_sampling = value != 0;
+    } else if (key == "streams") {
+        if (value < 1 || value > h->n_lane_streams + 1) return fail(h, QSV_E_ARG, "streams must be between 1 and the number the handle was created with");
+        h->n_streams = value;
+    } else {
+        return fail(h, QSV_E_ARG, "unknown option '" + key + "'");
+    }
+    return QSV_OK;
 }
 
 int qsv_set_profiling(qsv_t* h, int enabled) {

@@ -50,7 +50,8 @@ def evaluate_population_sharded(evaluator, circuits: Sequence, parameter_values:
     local = evaluator.evaluate_circuits(list(circuits[lo:hi]), list(parameter_values[lo:hi])) if hi > lo else []
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
-    return _gather(local, n, world, rank, group, torch.device(device))
+    owner = id(getattr(evaluator, "statevector_device", None) or evaluator)
+    return _gather(local, n, world, rank, group, torch.device(device), owner)
 
 
 def evaluate_block_and_gather(evaluator, circuits: Sequence, parameter_values: Sequence, n: int, world: int, rank: int, group, device):
@@ -59,29 +60,61 @@ def evaluate_block_and_gather(evaluator, circuits: Sequence, parameter_values: S
     the all-gather and the copy to the host follow on the same stream.  Measured on one MI355X (nccl group of one rank,
     ``scripts/gatherstep.py``): the step with the gather costs 138 us the old way (evaluate, wait, stage, copy to the
     device, gather, copy back, wait) against 91 us for the evaluation alone.  Returns None when the evaluator cannot leave
-    its values on the device (the caller then takes the old way)."""
+    its values on the device (the caller then takes the old way).
+
+    The chain runs on a stream of its own (the one the evaluator's device launches on).  It is ordered behind whatever the
+    caller has queued on ITS current stream (one event wait), and the caller's current stream is the same after the call
+    as before it: torch work of the host application never ends up on the chain's stream.
+
+    The first chained step of an evaluator in a group is also run the staged way and the two results compared: a
+    difference (an RCCL build or a stream ordering this path was never run on) switches that evaluator back to the staged
+    path for good, with a warning, instead of handing selection wrong fitness values."""
     import torch
     import torch.distributed as dist
 
     to_device = getattr(evaluator, "evaluate_circuits_to_device", None)
     if to_device is None or device.type != "cuda":
         return None
+    state = _chain_state(evaluator, device)
+    if state is None or state.get("disabled"):
+        return None
     lo, hi = shard_bounds(n, world, rank)
     width = -(-n // world)
-    _, send, recv, recv_host = _buffers(world, width, device)
-    stream = _chain_stream(evaluator, device)
-    # The chain's stream becomes (and stays) this thread's current torch stream: the collective orders itself behind the
-    # current stream, and switching streams around every step (`with torch.cuda.stream(..)`) costs 13 us of Python.
-    if torch.cuda.current_stream(device) != stream:
+    _, send, recv, recv_host = _buffers(world, width, device, group, state["key"])
+    stream = state["stream"]
+    caller = torch.cuda.current_stream(device)
+    if caller != stream:
+        stream.wait_stream(caller)  # (the application's earlier work on its own stream comes first)
         torch.cuda.set_stream(stream)
-    if hi - lo < width:
-        send.fill_(float("nan"))
-    if hi > lo and not to_device(circuits[lo:hi], parameter_values[lo:hi], send.data_ptr()):
-        return None
-    dist.all_gather_into_tensor(recv, send, group=group)
-    recv_host.copy_(recv, non_blocking=True)
-    stream.synchronize()
-    return _unpack(recv_host, n, world, width)
+    try:
+        if hi - lo < width:
+            send.fill_(float("nan"))
+        if hi > lo and not to_device(circuits[lo:hi], parameter_values[lo:hi], send.data_ptr()):
+            return None
+        dist.all_gather_into_tensor(recv, send, group=group)
+        recv_host.copy_(recv, non_blocking=True)
+        stream.synchronize()
+    finally:
+        if caller != stream:
+            torch.cuda.set_stream(caller)
+    values = _unpack(recv_host, n, world, width)
+    verified = state["verified"]
+    if id(group) not in verified:
+        local = evaluator.evaluate_circuits(list(circuits[lo:hi]), list(parameter_values[lo:hi])) if hi > lo else []
+        staged = _gather(local, n, world, rank, group, device, state["key"])
+        same = len(staged) == len(values) and all(a == b for a, b in zip(staged, values))
+        # every rank must take the same path from now on: agree on the verdict (a collective itself, staged way)
+        flag = torch.tensor([1.0 if same else 0.0], dtype=torch.float64, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        if float(flag.item()) != 1.0:
+            import warnings
+
+            warnings.warn("queasars_amd.distributed: the chained evaluate + all-gather step disagreed with the staged one; "
+                          "using the staged path", RuntimeWarning)
+            state["disabled"] = True
+            return staged
+        verified.add(id(group))
+    return values
 
 
 def _unpack(recv_host, n: int, world: int, width: int) -> list[float]:
@@ -96,33 +129,42 @@ def _unpack(recv_host, n: int, world: int, width: int) -> list[float]:
     return out
 
 
-_CHAIN_STREAMS: dict = {}
+_CHAIN_STATE: dict = {}
 
 
-def _chain_stream(evaluator, device):
-    """The HIP stream an evaluator's device launches on, as a torch stream (created once per evaluator device and handed
-    to the library: its kernels, the collective and the copy back are then ordered by the stream alone)."""
+def _chain_state(evaluator, device):
+    """Per evaluator device: the HIP stream it launches on as a torch stream (created once and handed to the library: its
+    kernels, the collective and the copy back are then ordered by the stream alone), which groups the chained step has
+    been verified on, and the key of its buffers.  The entry goes when the device does."""
     import torch
+    import weakref
 
-    dev = evaluator.statevector_device
-    hit = _CHAIN_STREAMS.get(id(dev))
-    if hit is None or hit[0]() is not dev:
-        import weakref
+    dev = getattr(evaluator, "statevector_device", None)
+    if dev is None:
+        return None
+    hit = _CHAIN_STATE.get(id(dev))
+    if hit is None or hit["ref"]() is not dev:
+        key = id(dev)
+
+        def gone(_ref, key=key):
+            _CHAIN_STATE.pop(key, None)
+            for k in [k for k in _BUFFERS if k[-1] == key]:
+                _BUFFERS.pop(k, None)
 
         stream = torch.cuda.Stream(device=device)
         dev.set_stream(stream.cuda_stream)
-        hit = (weakref.ref(dev), stream)
-        _CHAIN_STREAMS[id(dev)] = hit
-    return hit[1]
+        hit = {"ref": weakref.ref(dev, gone), "stream": stream, "verified": set(), "disabled": False, "key": key}
+        _CHAIN_STATE[key] = hit
+    return hit
 
 
-def _gather(local: Sequence[float], n: int, world: int, rank: int, group, device) -> list[float]:
+def _gather(local: Sequence[float], n: int, world: int, rank: int, group, device, owner=None) -> list[float]:
     """All ranks' blocks of fitness values, ordered by population index (``local`` is this rank's block)."""
     import torch
     import torch.distributed as dist
 
     width = -(-n // world)  # every rank contributes a fixed-size slot so one all_gather_into_tensor suffices
-    send_host, send, recv, recv_host = _buffers(world, width, device)
+    send_host, send, recv, recv_host = _buffers(world, width, device, group, owner)
     # pinned staging buffers and device tensors are kept between calls: the collective moves a few hundred bytes and
     # is latency bound, so every allocation and every synchronous pageable copy on its path counts
     staged = send_host.numpy()
@@ -139,11 +181,15 @@ def _gather(local: Sequence[float], n: int, world: int, rank: int, group, device
 _BUFFERS: dict = {}
 
 
-def _buffers(world: int, width: int, device):
-    """(pinned send staging, device send, device receive, pinned receive staging) for one (world, width, device)."""
+def _buffers(world: int, width: int, device, group=None, owner=None):
+    """(pinned send staging, device send, device receive, pinned receive staging) for one (world, width, device, group,
+    calling thread, owner): two evaluators, groups or threads never share a send / receive buffer (``owner`` = the
+    evaluator device of a chained step; its entries are dropped when it dies)."""
+    import threading
+
     import torch
 
-    key = (world, width, str(device))
+    key = (world, width, str(device), id(group) if group is not None else 0, threading.get_ident(), owner)
     hit = _BUFFERS.get(key)
     if hit is None:
         pin = device.type == "cuda"

@@ -140,3 +140,28 @@ def test_two_rank_sharded_evaluation_on_rccl(tmp_path):
     for rank in range(world):
         got = np.load(tmp_path / f"rank{rank}.npy")
         assert np.array_equal(got, want)
+
+
+def test_gather_buffers_are_not_shared_between_evaluators_groups_or_threads():
+    """Advisor finding (round 2): the staging buffers were keyed by (world, width, device) alone, so two evaluators (or
+    two threads) with the same shard width overwrote each other's fitness values."""
+    import threading
+
+    import torch
+
+    from queasars_amd.distributed import _BUFFERS, _buffers
+
+    cpu = torch.device("cpu")
+    a = _buffers(2, 4, cpu, None, 101)
+    assert _buffers(2, 4, cpu, None, 101)[0] is a[0], "the same caller gets its buffers back"
+    b = _buffers(2, 4, cpu, None, 202)
+    assert b[0] is not a[0] and b[3] is not a[3]
+    group = object()
+    assert _buffers(2, 4, cpu, group, 101)[0] is not a[0]
+    other = []
+    t = threading.Thread(target=lambda: other.append(_buffers(2, 4, cpu, None, 101)))
+    t.start()
+    t.join()
+    assert other[0][0] is not a[0]
+    for key in [k for k in _BUFFERS if k[-1] in (101, 202)]:
+        _BUFFERS.pop(key)

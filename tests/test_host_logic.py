@@ -405,3 +405,64 @@ class TestConfiguredPrimitives:
             evaluator_for(ConfiguredEstimatorV2(object(), 0.0), bitstring_evaluator=ev)
         with pytest.raises(TypeError):
             evaluator_for(object(), operator=op)
+
+
+class TestSharedDeviceScratch:
+    """Advisor finding (round 2): the scratch buffer of a batch was sized from a field another thread could overwrite
+    between the metadata call and the allocation; the CPython-API packer then wrote past it."""
+
+    @staticmethod
+    def _bare_device():
+        import threading
+
+        from queasars_amd.circuit_evaluation.circuit_evaluation import StatevectorDevice, _make_gone
+
+        dev = object.__new__(StatevectorDevice)  # no GPU here: only the bookkeeping is exercised
+        dev._dead, dev._watched, dev._handle, dev._lib = [], {}, None, None
+        dev._gone = _make_gone(dev._dead, dev._watched)
+        dev._serial, dev._n_qubits, dev._last_batch, dev._reg_lock = ("test", 1), 3, None, threading.Lock()
+        return dev
+
+    def test_two_threads_with_batches_of_different_sizes_get_their_own_totals(self):
+        import threading
+
+        dev = self._bare_device()
+        small = [CircuitIR(3).u(ParamRef(0), 0.1, 0.2, 0) for _ in range(2)]
+        large = [CircuitIR(3).u(ParamRef(0), ParamRef(1), ParamRef(2), 1).cu3(ParamRef(3), ParamRef(4), ParamRef(5), 0, 2) for _ in range(9)]
+        for i, c in enumerate(small + large):
+            c.packed()
+            c._registered[dev._serial] = i + 1  # (as if registered: no library call is made)
+        wrong = []
+
+        def worker(batch, want):
+            for _ in range(2000):
+                ids, need, total = dev._batch_metadata(batch)
+                if total != int(need.sum()) or total != want or len(ids) != len(batch):
+                    wrong.append((total, int(need.sum()), want))
+
+        threads = [threading.Thread(target=worker, args=(small, 2)), threading.Thread(target=worker, args=(large, 54))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert wrong == []
+
+    def test_the_packer_refuses_to_write_past_its_buffer(self):
+        import ctypes as C
+
+        from queasars_amd.circuit_evaluation.circuit_evaluation import _load_pyhelp
+
+        helper = _load_pyhelp()
+        if helper is None:
+            pytest.skip("csrc/pyhelp.c was not built (no Python headers)")
+        vectors = [[0.5] * 6, [1.5] * 6, [2.5] * 6]
+        take = np.asarray([6, 4, 6], dtype=np.int64)
+        out = np.full(32, -1.0)
+        n = helper.qsv_pack_exact(vectors, 0, 3, take.ctypes.data, out.ctypes.data, 16)
+        assert n == 16 and out[:16].tolist() == [0.5] * 6 + [1.5] * 4 + [2.5] * 6 and (out[16:] == -1.0).all()
+        out[:] = -1.0
+        with pytest.raises(ValueError, match="scratch"):
+            helper.qsv_pack_exact(vectors, 0, 3, take.ctypes.data, out.ctypes.data, 15)
+        assert (out[15:] == -1.0).all(), "nothing may be written beyond the capacity"
+        with pytest.raises(ValueError, match="needs 6 parameter values, got 2"):
+            helper.qsv_pack_exact([[1.0, 2.0]], 0, 1, take.ctypes.data, out.ctypes.data, 32)
