@@ -47,7 +47,7 @@ HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s m
 FP64_PEAK_TFLOPS = 78.6     # vector fp64, half the 157.3 TFLOP/s fp32 vector rate of MI355X_MICROARCH.md (spec)
 
 
-def kernel_names(n_qubits: int):
+def kernel_names(n_qubits: int, factor: bool = True):
     """The kernels of the hot path at this size (register bits by size: qsv_api.hip resolve_config), in the order of
     qsv_profile's per-kernel arrays."""
     r = 4 if n_qubits >= 20 else 3
@@ -56,7 +56,7 @@ def kernel_names(n_qubits: int):
             f"qsv::pass_kernel<double, {r}, 2, false> (later passes; the last one fuses the diagonal expectation and only reads)",
             "qsv::factor_moments_kernel<double> + qsv::factor_combine_kernel, timed as one (split evaluations under a "
             "quadratic diagonal operator: weighted Gram matrices of the two side tables, combined per evaluation; nothing of "
-            "size 2^n is read)" if os.environ.get("QSV_FACTOR", "1") != "0" else
+            "size 2^n is read)" if (factor and os.environ.get("QSV_FACTOR", "1") != "0") else
             "qsv::contract_kernel<double> (split evaluations: forms psi[i] from the two side tables on the fly and reduces "
             "sum_i D[i] |psi[i]|^2; reads D once per state)")
 
@@ -70,7 +70,7 @@ def ising_operator(n_qubits: int, seed: int):
 # ---- CPU baselines (rank 0, N = 1 only; the oracle is the checker and the baseline, never the product) ---------------
 
 
-def cpu_baseline(circuits, params, operator, budget_s: float = 12.0):
+def cpu_baseline(circuits, params, operator, budget_s: float = 12.0, gpu_values=None):
     """Time the plain-C oracle (OpenMP, the host cores of this job) on a bounded sample of the same workload; also the
     NumPy oracle on two individuals, and Qiskit Aer's statevector estimator when it can be imported."""
     import helpers  # tests/helpers.py: the only place outside tests/ that touches oracle/, as the timed baseline
@@ -102,12 +102,14 @@ def cpu_baseline(circuits, params, operator, budget_s: float = 12.0):
     out["numpy_oracle"] = {"value": 2 / (time.perf_counter() - t0), "unit": "circuit-evals/s", "cores": 1,
                            "sample": "first 2 individuals, oracle/statevector_oracle.py (tensor-reshape formulation)",
                            "max_abs_diff_vs_c_oracle": float(np.abs(np.asarray(numpy_values) - np.asarray(values[:2])).max())}
-    out["aer"] = aer_baseline(circuits, params, operator)
+    out["aer"] = aer_baseline(circuits, params, operator, gpu_values)
     return out, values
 
 
-def aer_baseline(circuits, params, operator):
-    """SURVEY.md 8(d) "CPU baseline" item 1: Qiskit Aer's statevector estimator on the same pubs, if the host has it."""
+def aer_baseline(circuits, params, operator, gpu_values=None):
+    """SURVEY.md 8(d) "CPU baseline" item 1: Qiskit Aer's statevector estimator on the same pubs, if the host has it.
+    Where it runs it also pins parity: ``max_abs_diff_vs_aer`` = the GPU's values of the same individuals against Aer's
+    (the reference's own arithmetic, circuit_evaluation.py:210-215, at precision 0)."""
     try:
         import qiskit_aer  # noqa: F401
         from qiskit import QuantumCircuit
@@ -130,17 +132,22 @@ def aer_baseline(circuits, params, operator):
     t0 = time.perf_counter()
     result = est.run(pubs, precision=0).result()
     dt = time.perf_counter() - t0
-    return {"status": "measured", "value": len(pubs) / dt, "unit": "circuit-evals/s", "cores": os.cpu_count(),
-            "omp_num_threads": os.environ.get("OMP_NUM_THREADS"), "values": [float(np.real(r.data.evs)) for r in result]}
+    aer_values = [float(np.real(r.data.evs)) for r in result]
+    out = {"status": "measured", "value": len(pubs) / dt, "unit": "circuit-evals/s", "cores": os.cpu_count(),
+           "omp_num_threads": os.environ.get("OMP_NUM_THREADS"), "values": aer_values}
+    if gpu_values is not None:
+        out["max_abs_diff_vs_aer"] = float(np.abs(np.asarray(gpu_values[: len(aer_values)]) - np.asarray(aer_values)).max())
+    return out
 
 
 # ---- extra measurements around the headline ---------------------------------------------------------------------------
 
 
-def kernel_rooflines(device, step, profiled_steps: int, traffic: dict):
+def kernel_rooflines(device, step, profiled_steps: int, traffic: dict, n_qubits: int = None):
     """Per kernel of the hot path (the two instantiations of the gate-pass kernel, the contraction kernel): launches, mean launch time (HIP events on the stream each launch runs
     on), algorithmic bytes and flops per launch, and the fractions of the two roofs.  Measured in steps of their own,
     after the timed region: the per-launch events cost a few microseconds each."""
+    n_qubits = N_QUBITS if n_qubits is None else n_qubits
     device.set_profiling(True)
     acc = None
     for _ in range(profiled_steps):
@@ -163,7 +170,7 @@ def kernel_rooflines(device, step, profiled_steps: int, traffic: dict):
         flops = acc["kernel_flops"][kind] / launches
         measured = traffic.get("kernels", {}).get(str(kind), {}).get("hbm_bytes_per_launch")
         entry = {
-            "kernel": kernel_names(N_QUBITS)[kind],
+            "kernel": kernel_names(n_qubits)[kind],
             "launches": launches,
             "states_per_launch": acc["kernel_states"][kind] / launches,
             "avg_launch_us": avg_ms * 1e3,
@@ -283,6 +290,110 @@ def sampler_block(operator, circuits, params, shots: int = 1024, alpha: float = 
                     "operator values and CVaR); wall clock of whole calls"}
 
 
+# ---- the deep (unsplit) multi-pass path: the statevector sweep north_star names ----------------------------------------
+
+DEEP_ROWS = {
+    # name: (qubits, layers, individuals, splitting on?)   -- reference behaviour: circuit_evaluation.py:200-215
+    "deep_n20_L8": (20, 8, 64, True),
+    "deep_n24_L4_nosplit": (24, 4, 32, False),
+    "deep_n24_L8": (24, 8, 32, True),
+}
+
+
+def load_traffic(row: str) -> dict:
+    """HBM traffic per launch of a bench row from the committed profile (profiles/r03_traffic.json: separate rocprofv3
+    --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --only <row>`); not measured inside this run."""
+    for name in ("r03_traffic.json", "traffic.json"):
+        f = ROOT / "profiles" / name
+        if f.exists():
+            try:
+                data = json.loads(f.read_text())
+            except Exception:
+                continue
+            if row in data:
+                return data[row]
+            if row == "headline" and "kernels" in data:
+                return data
+    return {}
+
+
+def deep_block(local_rank: int, only: str = None, kernels_only: bool = False):
+    """Populations whose circuits the splitter cannot take (or may not: splitting switched off): every evaluation runs the
+    multi-pass plan over its 2^n state.  Per row: whole-call throughput with the library's defaults, then -- on one HIP
+    stream, so that a launch has the chip to itself -- per instantiation of the gate-pass kernel launches, mean launch
+    time (HIP events), SURVEY 8(d) bytes, what the launches really move, and the fractions of the HBM and fp64 roofs."""
+    from queasars_amd.circuit_evaluation import OperatorCircuitEvaluator
+    from queasars_amd.evqe import EVQEPopulation
+
+    rows = {}
+    for name, (n, layers, pop, split) in DEEP_ROWS.items():
+        if only is not None and name != only:
+            continue
+        population = EVQEPopulation.random_population(n, layers, pop, True, 0)
+        circuits = [ind.get_parameterized_quantum_circuit() for ind in population.individuals]
+        params = [list(ind.parameter_values) for ind in population.individuals]
+        operator = ising_operator(n, 2020 if n == 20 else 2024)
+        evaluator = OperatorCircuitEvaluator(operator, device=local_rank)
+        device = evaluator.statevector_device
+        if not split:
+            device.set_option("split", 0)
+
+        def step():
+            return evaluator.evaluate_circuits(circuits, params)
+
+        if kernels_only:  # (profiling runs: rocprofv3 then sees the one-stream launches alone)
+            device.set_option("streams", 1)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            values = step()
+        per = (time.perf_counter() - t0) / 3
+        for _ in range(int(0.15 / max(per, 1e-6))):  # clocks under load before anything is timed
+            step()
+        reps = max(3, int(0.25 / max(per, 1e-6)))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            step()
+        torch.cuda.synchronize()
+        rate = pop * reps / (time.perf_counter() - t0)
+        # how the population is evaluated: ordinary plans (passes) / split
+        device.set_profiling(True)
+        step()
+        prof = device.profile()
+        device.set_profiling(False)
+        # the kernels alone: one stream
+        device.set_option("streams", 1)
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            step()
+        torch.cuda.synchronize()
+        rate_one = pop * reps / (time.perf_counter() - t0)
+        kernels, _ = kernel_rooflines(device, step, 5, load_traffic(name), n)
+        later = next((k for k in kernels if "later passes" in k["kernel"]), None)
+        rows[name] = {
+            "workload": f"{n}-qubit EVQE population={pop}, {layers} layers, Ising operator, fp64"
+                        + ("" if split else ", register splitting switched off"),
+            "value": rate, "unit": "circuit-evals/s", "value_one_stream": rate_one,
+            "pass_launches_per_call": prof["n_pass_launches"], "state_passes_per_call": prof["n_state_passes"],
+            "split_evaluations": int(prof["kernel_states"][2]),
+            "kernels_one_stream": kernels,
+            "later_pass_frac_hbm": later["frac_hbm_algorithmic"] if later else None,
+            "later_pass_frac_fp64": later["frac_fp64"] if later else None,
+            "all_values_finite": bool(np.isfinite(values).all()),
+        }
+        evaluator.statevector_device.close()
+    rows["note"] = ("gate application over the 2^n state on real EVQE circuits (reference: circuit_evaluation.py:200-215).  "
+                    "kernels_one_stream: HIP events around every launch with the handle on ONE stream (a launch then has the "
+                    "chip to itself; with the default two streams launches overlap and stretch each other), bytes per SURVEY "
+                    "8(d): 16 * 2^n per state and direction a pass has to move; traffic_bytes_per_launch from the committed "
+                    "rocprofv3 PMC passes of `bench.py --only <row>` (profiles/r03_traffic.json), not measured in this run")
+    return rows
+
+
+
 def agreed_count(mine: int, world: int, comm_device: str, limit: int = 5000) -> int:
     """A loop count every rank uses: rank 0's (loops whose steps are collectives must not end at different iterations on
     different ranks -- a time-based exit per rank is a deadlock waiting for two clocks to disagree)."""
@@ -294,16 +405,20 @@ def agreed_count(mine: int, world: int, comm_device: str, limit: int = 5000) -> 
     return int(t.item())
 
 
-def config3_block(world: int, rank: int, local_rank: int, steps: int = 8):
+COLLECTIVE_US = 27.0  # chained all-gather + copy back on an RCCL group of ONE rank (112 us against 85)
+
+
+def config3_block(world: int, rank: int, local_rank: int, steps: int = 8, layers: int = 4):
     """BASELINE.json configs[2] as north_star states it: n = 24, L = 4, P = 256 IN TOTAL (strong scaling: at N = 8 rank r
     takes [32r, 32r+32), at N = 1 the one GPU evaluates all 256), 300-term Ising operator of default_rng(2024), through
-    the product's ``evaluate_population_sharded``."""
+    the product's ``evaluate_population_sharded``.  ``layers`` = 8: the same with eight-layer individuals, whose
+    evaluations are milliseconds of gate passes per rank (config3_deep)."""
     from queasars_amd.circuit_evaluation import OperatorCircuitEvaluator
     from queasars_amd.distributed import evaluate_population_sharded, shard_bounds
     from queasars_amd.evqe import EVQEPopulation
 
     n, total = 24, 256
-    population = EVQEPopulation.random_population(n, 4, total, True, 0)
+    population = EVQEPopulation.random_population(n, layers, total, True, 0)
     circuits = [ind.get_parameterized_quantum_circuit() for ind in population.individuals]
     params = [list(ind.parameter_values) for ind in population.individuals]
     operator = ising_operator(n, 2024)
@@ -345,10 +460,28 @@ def config3_block(world: int, rank: int, local_rank: int, steps: int = 8):
         dist.all_gather(gathered, t)
         elapsed = max(float(g[0]) for g in gathered)
         per_rank = [float(g[1]) for g in gathered]
+    # What strong scaling can give (N = 1 only): the first rank's block at 2, 4, 8 ranks timed on this GPU, plus the
+    # collective's latency as measured on a one-rank RCCL group -- skew between ranks and the ring's hops are not in it.
+    predicted = None
+    if world == 1:
+        predicted = {}
+        t_all = elapsed / steps
+        for g in (2, 4, 8):
+            blo, bhi = shard_bounds(total, g, 0)
+            bc, bp = circuits[blo:bhi], params[blo:bhi]
+            evaluator.evaluate_circuits(bc, bp)
+            t1 = time.perf_counter()
+            for _ in range(steps):
+                evaluator.evaluate_circuits(bc, bp)
+            t_block = (time.perf_counter() - t1) / steps
+            predicted[str(g)] = {"block_ms": t_block * 1e3, "speedup": t_all / (t_block + COLLECTIVE_US * 1e-6)}
+        predicted["note"] = (f"speedup at N ranks = this GPU's time for all 256 / (its time for rank 0's block of 256 / N + "
+                             f"{COLLECTIVE_US:.0f} us of collective latency, DESIGN.md section 6); a prediction, not a measurement")
     evaluator.statevector_device.close()
     return {
-        "workload": "24-qubit EVQE population = 256 in total, 4 layers, Ising 300 terms (default_rng(2024)), fp64 "
+        "workload": f"24-qubit EVQE population = 256 in total, {layers} layers, Ising 300 terms (default_rng(2024)), fp64 "
         "(BASELINE.json configs[2]); strong scaling: rank r evaluates its contiguous block, one RCCL all-gather",
+        "predicted_speedup": predicted,
         "value": total * steps / elapsed, "unit": "circuit-evals/s", "n_gpus": world, "steps": steps,
         "ms_per_step": elapsed / steps * 1e3, "scaling": "strong", "individuals_per_rank": hi - lo,
         "per_rank_ms_own_block": [round(x * 1e3, 3) for x in per_rank],
@@ -363,7 +496,15 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="only the headline measurement (profiling runs)")
+    ap.add_argument("--only", default=None, help="profiling runs: just one row of the deep block (" + ", ".join(DEEP_ROWS) + ")")
     args = ap.parse_args()
+    if args.only is not None:
+        # (rocprofv3 then sees the kernels of that row alone; N = 1)
+        if args.only not in DEEP_ROWS:
+            raise SystemExit(f"--only takes one of {list(DEEP_ROWS)}")
+        torch.cuda.set_device(0)
+        print(json.dumps({"deep": deep_block(0, args.only, kernels_only=True)}), flush=True)
+        return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -428,30 +569,38 @@ def main() -> None:
     for _ in range(prewarm_steps):
         step()
     prewarm_steps += 5
-    # ---- timed region: exactly K steps (no profiling events inside) ---------------------------------------
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        values = step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=comm_device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # ---- timed region: exactly K steps (no profiling events inside), barrier + synchronize on both sides, MAX over ranks.
+    # A window of K steps of this workload lasts K * 60-90 us: with the driver's K = 20 a single host hiccup is a tenth
+    # of it.  So the K-step window is REPEATED until at least 50 ms have been timed (every window bracketed the same way;
+    # the count is rank 0's, agreed between the ranks) and the line reports the MEDIAN window; `steps` stays K.
+    def window():
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step()
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=comm_device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, out
+
+    first, values = window()
+    n_windows = 1 + agreed_count(min(255, int(0.05 / max(first, 1e-6))), world, comm_device)
+    windows = [first]
+    for _ in range(n_windows - 1):
+        dt, values = window()
+        windows.append(dt)
+    elapsed = sorted(windows)[len(windows) // 2]
 
     # ---- after the timed region: per-kernel roofline of the same step -------------------------------------
-    traffic = {}
-    tfile = ROOT / "profiles" / "traffic.json"
-    if tfile.exists():
-        try:
-            traffic = json.loads(tfile.read_text())
-        except Exception:
-            traffic = {}
+    traffic = load_traffic("headline")
     kernels, prof = kernel_rooflines(device, step, min(args.steps, 10), traffic)
-    config3 = None
+    config3 = config3_deep = None
     if not args.no_extras:
         config3 = config3_block(world, rank, local_rank)
+        config3_deep = config3_block(world, rank, local_rank, steps=3, layers=8)
 
     if rank == 0:
         total_evals = POP_PER_GPU * world * args.steps
@@ -459,14 +608,17 @@ def main() -> None:
         roofline = None
         if dominant is not None:
             roofline = {
-                "bound": "hbm",
+                # what the counters say limits the dominant kernel ("latency/issue": neither roof is near); `peak` and
+                # `frac` below are against the HBM roof whatever the limiter, as SURVEY 8(d) asks
+                "bound": dominant["bound"],
+                "roof": "hbm",
                 "kernel": dominant["kernel"],
                 "achieved": dominant["achieved_GBps"],
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": dominant["frac_hbm_algorithmic"],
                 "traffic": dominant["traffic_bytes_per_launch"],
-                "traffic_source": traffic.get("source"),
+                "traffic_source": ("committed profile, not measured in this run: " + traffic["source"]) if traffic.get("source") else None,
                 "avg_launch_us": dominant["avg_launch_us"],
                 "algorithmic_bytes_per_launch": dominant["algorithmic_bytes_per_launch"],
                 "observed_limiter": dominant["bound"],
@@ -503,6 +655,10 @@ def main() -> None:
             "warmup": args.warmup,
             "prewarm": {"seconds": PREWARM_S, "untimed_steps": prewarm_steps,
                         "why": "GPU clocks reach steady state only after tens of ms of load; the timed K steps follow"},
+            "timed_windows": {"count": len(windows), "steps_each": args.steps, "reported": "median",
+                              "ms_min": min(windows) * 1e3, "ms_median": elapsed * 1e3, "ms_max": max(windows) * 1e3,
+                              "why": "K steps of this workload last a millisecond or two: the K-step window is repeated until "
+                                     ">= 50 ms have been timed and the median window is the one reported"},
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
@@ -522,6 +678,9 @@ def main() -> None:
         }
         if config3 is not None:
             result["config3"] = config3
+            result["config3_deep"] = config3_deep
+        if world == 1 and not args.no_extras:
+            result["deep"] = deep_block(local_rank)
         if world == 1 and not args.no_extras:
             result["roofline"]["microbench"] = microbench_block()
             cold, threaded, noop = cold_and_threaded(operator)
@@ -536,7 +695,7 @@ def main() -> None:
                 "pool.map with tasks that do nothing, i.e. the rate at which this host's CPython can hand out and collect "
                 "such calls at all")
         if world == 1 and not args.no_cpu_baseline:
-            base, ref_values = cpu_baseline(circuits, params, operator)
+            base, ref_values = cpu_baseline(circuits, params, operator, gpu_values=values)
             result["cpu_baseline"] = base
             err = float(np.abs(np.asarray(values[: len(ref_values)]) - np.asarray(ref_values)).max())
             result["max_abs_diff_vs_cpu_oracle"] = err

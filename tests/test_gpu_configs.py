@@ -843,7 +843,7 @@ def test_results_into_device_memory_without_waiting():
         assert ev.evaluate_circuits(circuits[::-1], params[::-1]) == want[::-1]  # right behind an unfinished batch
         # the streaming entry points by hand, with a waiting end
         lib, handle = dev._lib, dev._handle
-        ids, _ = dev._batch_metadata(circuits)
+        ids, _, _ = dev._batch_metadata(circuits)
         counts = np.asarray([len(p) for p in params], dtype=np.int64)
         packed = np.concatenate([np.asarray(p, dtype=np.float64) for p in params])
         buf.fill_(float("nan"))
