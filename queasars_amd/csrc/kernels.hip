@@ -237,6 +237,20 @@ static __device__ __forceinline__ unsigned long long qsv_stamp_now() {
 #define QSV_STAMP(ph)
 #endif
 
+// 16-byte (8-byte) store that leaves no dirty line in L2 (sc1: write-through); the compiler does not count it, the caller
+// waits for it with s_waitcnt vmcnt(0).
+__device__ __forceinline__ void store_through(void* p, const cx<double>& v) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 bits = {uint32_t(__double2loint(v.re)), uint32_t(__double2hiint(v.re)), uint32_t(__double2loint(v.im)),
+                        uint32_t(__double2hiint(v.im))};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(bits) : "memory");
+}
+__device__ __forceinline__ void store_through(void* p, const cx<float>& v) {
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 bits = {__float_as_uint(v.re), __float_as_uint(v.im)};
+    asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(bits) : "memory");
+}
+
 // Workgroup barrier for the LDS exchanges.  __syncthreads() carries a release fence over GLOBAL memory as well: hipcc
 // puts s_waitcnt vmcnt(0) in front of s_barrier, so every wave would sit out the full latency of the previous
 // tile's state stores at the next barrier.  Nothing a workgroup writes to global memory is read by the same launch,
@@ -258,6 +272,10 @@ struct PassScalars {
     const double* host_params;
     double* mats_out;
     double* result_out;
+    const double* quad;
+    double* factor_scratch;
+    uint32_t* factor_counters;
+    uint32_t n_full;
 };
 
 // XMODE selects how a tile is transposed through LDS:
@@ -503,6 +521,13 @@ __device__ __forceinline__ void prepare_eval(const uint32_t* __restrict__ plan, 
     QSV_PSTAMP(7);  // tile info
 }
 
+// (defined with the factor kernels below) the tail of a pass-0 launch under kModeFusedFactor
+template <typename real>
+__device__ __forceinline__ void fused_factor_tail(const uint32_t* __restrict__ plan_arena, const EvalDesc& ev,
+                                                  const cx<real>* __restrict__ slot_tables, uint64_t side_stride,
+                                                  const double* __restrict__ diag, const PassScalars& a, unsigned char* lds,
+                                                  uint32_t gram_waves);
+
 // FIRST = the pass synthesises its input (pass 0 of an evaluation from |0..0>): two instantiations, so that neither
 // carries the other's load path through register allocation.
 template <typename real, int R, int XMODE, bool FIRST>
@@ -597,6 +622,10 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, FIRST>::waves_per_si
     // states larger than the Infinity Cache are streamed: non-temporal loads and stores of the state (measured on
     // single-gate sweeps: n = 26 / 27 +3.8 %, 5.23 -> 5.43 TB/s; at n = 24, where the state fits the cache, -28 %)
     const bool streaming = (a.mode & kModeStreaming) && !cload && !cstore && !side;
+    // A side whose Gram matrices this workgroup forms itself (fused_factor_tail) stores its state WRITE-THROUGH: nobody but
+    // this workgroup reads it, and left dirty in L2 the side tables of a launch (12 MB at 64 evaluations) are written back
+    // when the kernel ends -- ten microseconds between the last workgroup and the host seeing the results.
+    const bool through = FIRST && R == 4 && side && (ev.flags & kEvalFused) && (a.mode & kModeFusedFactor);
 
     const uint32_t tg = xor_columns(pp + kPassLoadColsOffset, tid, wave);
     const uint32_t sg = xor_columns(pp + kPassStoreColsOffset, tid, wave);
@@ -970,6 +999,8 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, FIRST>::waves_per_si
                             typedef real vec2 __attribute__((ext_vector_type(2)));
                             const vec2 v = {amp[gray_index(i)].re, amp[gray_index(i)].im};
                             __builtin_nontemporal_store(v, reinterpret_cast<vec2*>(tile + ob));
+                        } else if (through) {
+                            store_through(tile + ob, amp[gray_index(i)]);
                         } else {
                             *reinterpret_cast<cxr*>(tile + ob) = amp[gray_index(i)];
                         }
@@ -1011,6 +1042,15 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, FIRST>::waves_per_si
         QSV_STAMP(11);
     }
 
+    if constexpr (FIRST && R == 4) {
+        // split evaluations whose virtual circuits are one tile and one pass each, under a quadratic operator: this side's
+        // workgroup goes straight on to its weighted Gram matrices, and the side that finishes second combines
+        if (side && (ev.flags & kEvalFused) && (a.mode & kModeFusedFactor)) {
+            // (Gram waves: by the virtual circuit's own geometry, never by the launch's block size)
+            fused_factor_tail<real>(plan_arena, ev, wt0, a.wtab_stride, diag, a, lds_raw, t >= 9 ? 8u : 4u);
+            return;
+        }
+    }
     if (do_diag) {
         // one partial sum per WAVE leaves the kernel (fixed shuffle tree, no LDS, no barrier); reduce_partials_kernel
         // adds them in a fixed order
@@ -1064,7 +1104,7 @@ static hipError_t launch_pass_t(dim3 grid, int threads, size_t lds_bytes, hipStr
     const size_t lds = lds_bytes < 256 ? 256 : lds_bytes;
     const PassScalars sc{args.state_stride, args.wtab_stride, args.pass_index, args.mode, args.tiles_per_block,
                          args.partial_chunks, args.region_stride, args.host_evals, args.evals_out, args.host_params,
-                         args.mats_out, args.result_out};
+                         args.mats_out, args.result_out, args.quad, args.factor_scratch, args.factor_counters, args.n_full};
     cx<real>* st = reinterpret_cast<cx<real>*>(args.states);
     const bool first = args.pass_index == 0 && (args.mode & kModeSynthFirst);
     if (first)
@@ -1109,7 +1149,7 @@ static hipError_t pass_dispatch(int op, int dtype, int r, int xmode, dim3 grid, 
     if (op) return hipSuccess;
     const PassScalars sc{args->state_stride, args->wtab_stride, args->pass_index, args->mode, args->tiles_per_block,
                          args->partial_chunks, args->region_stride, args->host_evals, args->evals_out, args->host_params,
-                         args->mats_out, args->result_out};
+                         args->mats_out, args->result_out, args->quad, args->factor_scratch, args->factor_counters, args->n_full};
     if (args->pass_index == 0 && (args->mode & kModeSynthFirst))
         hipLaunchKernelGGL((pass_kernel<double, QSV_PROBE_R, 2, true>), grid, dim3(threads), lds_bytes, stream, args->plan,
                            args->mats, args->evals, reinterpret_cast<cx<double>*>(args->states),
@@ -2202,8 +2242,10 @@ constexpr uint32_t kFactorWeights = 18;  // 1, D, and up to 16 bits
 constexpr uint32_t kFactorPitch = 65;    // doubles per row of a Gram table in LDS (64 entries + one: rows on different banks)
 
 // out (LDS, [weight][64]) may overlap other waves' staging regions: it is written after a workgroup barrier.
-template <typename real, int J>
-__device__ void factor_side_body(const cx<real>* __restrict__ tab, uint32_t bits, uint32_t mask, const double* __restrict__ diag,
+// AHEAD: the next block's rows are fetched while this one is added up (32 more registers at eight terms; the tail of the pass
+// kernel, which has none to spare, fetches each block when it needs it).
+template <typename real, int J, bool AHEAD = true>
+__device__ __forceinline__ void factor_side_body(const cx<real>* __restrict__ tab, uint32_t bits, uint32_t mask, const double* __restrict__ diag,
                                  uint32_t first_block, uint32_t block_step, cx<real>* stage, double* dstage, double* out) {
     constexpr uint32_t NQ = J * J;
     constexpr uint32_t LQ = J == 1 ? 0 : J == 2 ? 2 : J == 4 ? 4 : 6;  // log2(NQ)
@@ -2227,12 +2269,13 @@ __device__ void factor_side_body(const cx<real>* __restrict__ tab, uint32_t bits
         }
         d_next = live ? diag[deposit_bits(blk * 64u + lane, mask)] : 0.0;
     };
-    fetch(first_block);
+    if constexpr (AHEAD) fetch(first_block);
     for (uint32_t blk = first_block; blk < n_blocks; blk += block_step) {
+        if constexpr (!AHEAD) fetch(blk);
 #pragma unroll
         for (int j = 0; j < J; ++j) stage[lane * PITCH + uint32_t(j)] = rows[j];
         dstage[lane] = d_next;
-        fetch(blk + block_step);
+        if constexpr (AHEAD) fetch(blk + block_step);
         double s_one = 0.0, s_d = 0.0;
 #pragma unroll
         for (uint32_t i = 0; i < NQ; ++i) {
@@ -2266,7 +2309,7 @@ __device__ void factor_side_body(const cx<real>* __restrict__ tab, uint32_t bits
 #pragma unroll
     for (int q = 0; q < 10; ++q) acc_high[q] = across(acc_high[q]);
     __syncthreads();  // (every wave of the workgroup is here: nobody reads a staging region any more)
-    if (lane < NQ) {
+    if (lane < NQ && out) {  // (out = null: a wave that only keeps the others company at the barrier)
         out[0 * 64 + pi] = acc_one;
         out[1 * 64 + pi] = acc_d;
 #pragma unroll
@@ -2387,6 +2430,117 @@ __global__ void __launch_bounds__(256) factor_combine_kernel(const uint32_t* __r
     }
     const double total = block_sum_256(v, red);
     if (tid == 0) result_out[ev.out_index] = total;
+}
+
+// The two launches above as the tail of the kernel that ran the virtual circuits (pass_kernel, kModeFusedFactor): the side's
+// final state has just been stored to its half of the slot; four waves -- eight for a virtual circuit whose own tile needs
+// 512 threads; never a function of the launch's block size: the assignment of table blocks to waves, and with it the order
+// of every sum, must not depend on the batch -- form the weighted Gram matrices of this side, the workgroup leaves them in the slot's scratch, and the workgroup of an evaluation that gets there second
+// combines the two sets.  The hand-off between the two workgroups (which may sit on different XCDs, whose L2s are not
+// coherent): the Gram matrices leave by write-through (agent-scope relaxed) stores, every storing wave drains them, workgroup
+// barrier, one lane adds to the slot's counter at agent scope; the workgroup whose add returns an odd value is the second:
+// workgroup barrier, then agent-scope loads of both sets (MI355X_MICROARCH.md, hand-offs with sc1 stores and loads in place
+// of a release / acquire pair, first row: one unsharded counter, the last adder told by its add's return value).  The order in
+// which the two sides finish does not enter any sum.
+template <typename real>
+__device__ __forceinline__ void fused_factor_tail(const uint32_t* __restrict__ plan_arena, const EvalDesc& ev,
+                                                  const cx<real>* __restrict__ slot_tables, uint64_t side_stride,
+                                                  const double* __restrict__ diag, const PassScalars& a, unsigned char* lds,
+                                                  uint32_t gram_waves) {
+    constexpr uint32_t kMaxWaves = 8;
+    const uint32_t kWaves = gram_waves;
+    const uint32_t* sp = plan_arena + ev.split_base;
+    const uint32_t n_keys = sp[0], NQ = 1u << (2 * n_keys);
+    const bool swap = sp[3] & 1u, is_b = ev.flags & kEvalSideB;
+    const uint32_t xy = (is_b == swap) ? 0u : 1u;  // this side's name in the contraction's terms (X is B's half when swapped)
+    const uint32_t bits = sp[1 + xy], mask = sp[kSplitMaskX + xy];
+    const uint32_t tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const cx<real>* tab = slot_tables + (is_b ? side_stride >> 1 : 0);
+    // the side's state was stored by this workgroup: its waves' stores have to be in L2 before anybody reads them back
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    double* partial = reinterpret_cast<double*>(lds);                              // [wave][weight][64]
+    double* dstage_all = partial + size_t(kMaxWaves) * kFactorWeights * 64;        // [wave][64]
+    uint32_t* flag = reinterpret_cast<uint32_t*>(dstage_all + size_t(kMaxWaves) * 64);
+    {
+        // (waves beyond the fourth take no blocks -- first block past the end -- but join the body's barrier)
+        const uint32_t w = wave < kWaves ? wave : 0u;
+        cx<real>* stage = reinterpret_cast<cx<real>*>(lds) + size_t(w) * 9 * 64;
+        double* out = partial + size_t(w) * kFactorWeights * 64;
+        const uint32_t first = wave < kWaves ? wave : 0xffffffu, step = kWaves;
+        double* sink = wave < kWaves ? out : nullptr;
+        if (n_keys == 0)
+            factor_side_body<real, 1, false>(tab, bits, mask, diag, first, step, stage, dstage_all + w * 64, sink);
+        else if (n_keys == 1)
+            factor_side_body<real, 2, false>(tab, bits, mask, diag, first, step, stage, dstage_all + w * 64, sink);
+        else if (n_keys == 2)
+            factor_side_body<real, 4, false>(tab, bits, mask, diag, first, step, stage, dstage_all + w * 64, sink);
+        else
+            factor_side_body<real, 8, false>(tab, bits, mask, diag, first, step, stage, dstage_all + w * 64, sink);
+    }
+    __syncthreads();
+    double* slot = a.factor_scratch + size_t(ev.state_slot) * factor_slot_doubles();
+    double* mine = slot + size_t(xy) * kFactorSlices * kFactorWeights * 64;
+    // (write-through stores: the few hundred bytes the other side will read must not wait for a write-back of everything
+    // this XCD's L2 holds dirty -- the side tables of sixteen workgroups; an agent-scope release did that: 46 us per launch)
+    for (uint32_t idx = tid; idx < (2u + bits) * NQ; idx += blockDim.x) {
+        const uint32_t w = idx / NQ, pi = idx % NQ;
+        double v = 0.0;
+        for (uint32_t g = 0; g < kWaves; ++g) v += partial[size_t(g) * kFactorWeights * 64 + w * 64 + pi];
+        __hip_atomic_store(mine + w * 64 + pi, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave, before the barrier the signalling lane joins
+    __syncthreads();
+    if (tid == 0) {
+        const uint32_t before = __hip_atomic_fetch_add(a.factor_counters + ev.state_slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *flag = before & 1u;  // (the add has returned: its value is used)
+    }
+    __syncthreads();
+    if (!*flag) return;
+    // ---- the combination (factor_combine_kernel's, with one slice per side) ----
+    const uint32_t bx = sp[1], by = sp[2];
+    const uint32_t masks[2] = {sp[kSplitMaskX], sp[kSplitMaskY]};
+    double coupling = 0.0;
+    uint32_t qa_i = 0, qb_i = 0;
+    if (tid < bx * by) {
+        qa_i = tid / by;
+        qb_i = tid % by;
+        uint32_t qa = 0, qb = 0;
+        for (uint32_t m = masks[0], k = 0; m; m &= m - 1, ++k)
+            if (k == qa_i) qa = uint32_t(__builtin_ctz(m));
+        for (uint32_t m = masks[1], k = 0; m; m &= m - 1, ++k)
+            if (k == qb_i) qb = uint32_t(__builtin_ctz(m));
+        coupling = a.quad[qa * a.n_full + qb];
+    }
+    const double d00 = diag[0];
+    double* gram = reinterpret_cast<double*>(lds);  // [side][weight][kFactorPitch] (the partial matrices are no longer needed)
+    const uint32_t side_bits[2] = {bx, by};
+    for (uint32_t s2 = 0; s2 < 2; ++s2)
+        for (uint32_t idx = tid; idx < (2u + side_bits[s2]) * NQ; idx += blockDim.x) {
+            const uint32_t w = idx / NQ, pi = idx % NQ;
+            gram[size_t(s2) * kFactorWeights * kFactorPitch + w * kFactorPitch + pi] = __hip_atomic_load(
+                slot + size_t(s2) * kFactorSlices * kFactorWeights * 64 + w * 64 + pi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    __syncthreads();
+    const double* g0 = gram;
+    const double* g1 = gram + size_t(kFactorWeights) * kFactorPitch;
+    double v = 0.0;
+    if (tid < bx * by) {
+        if (coupling != 0.0) v = 4.0 * coupling * factor_pairing(g0 + (2 + qa_i) * kFactorPitch, g1 + (2 + qb_i) * kFactorPitch, n_keys);
+    } else if (tid == bx * by) {
+        v = factor_pairing(g0 + kFactorPitch, g1, n_keys);  // D(x, 0)
+    } else if (tid == bx * by + 1) {
+        v = factor_pairing(g0, g1 + kFactorPitch, n_keys);  // D(0, y)
+    } else if (tid == bx * by + 2) {
+        v = -d00 * factor_pairing(g0, g1, n_keys);          // - D(0, 0) <psi|psi>
+    }
+    // fixed-order sum over the first 256 threads (bx by + 3 <= 172 of them carry a term)
+    double* red = reinterpret_cast<double*>(flag) + 1;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if ((tid & 63u) == 0 && wave < 4) red[wave] = v;
+    __syncthreads();
+    if (tid == 0) a.result_out[ev.out_index] = red[0] + red[1] + red[2] + red[3];
 }
 
 hipError_t launch_factor(int dtype, unsigned n_evals, double* scratch, const double* quad, int n_qubits, hipStream_t stream,

@@ -22,6 +22,10 @@ struct EvalDesc {
 // its own (region 0), side B in a second region of the descriptor array, which holds kEvalNull entries for everybody
 // else.  A side's pass kernel stores its final state in the side's half of the evaluation's compact-table slot.
 constexpr uint32_t kEvalSide = 1u, kEvalSideB = 2u, kEvalNull = 4u;
+// (split evaluations) both virtual circuits are one pass: under a quadratic diagonal operator the kernel that runs them (one
+// workgroup per side, sweeping the side's tiles one after the other) also forms their weighted Gram matrices and combines
+// them (kModeFusedFactor) -- one launch per push
+constexpr uint32_t kEvalFused = 8u;
 // A virtual circuit (a side's own qubits + one per key) may be this many qubits larger than a tile: it then takes the pass
 // kernel a few passes over up to 16 tiles -- nothing next to what a split evaluation saves.  (With + 2 only, populations of
 // 26 and 28 qubits mostly found no split form: 21 k and 2 k evaluations per second against 550 k at 24 qubits.)
@@ -54,6 +58,10 @@ enum PassMode : uint32_t {
                              // instead of the state (n <= 28)
     kModeStreaming = 16u,    // the states do not fit the Infinity Cache: non-temporal state loads and stores
     kModeSidesOnly = 128u,   // split evaluations: run the two virtual circuits, no contraction (the split sampler follows)
+    kModeFusedFactor = 256u, // (pass 0 only) split evaluations flagged kEvalFused: each side's workgroup goes on to the weighted Gram
+                             // matrices of its final state (what launch_factor's first kernel computes), hands them over
+                             // through PassArgs::factor_scratch, and the side that finishes second combines them and writes
+                             // result_out[out_index] -- no further launch for these evaluations
     kModeFusedPrepare = 8u,  // (pass 0 only) every workgroup first does prepare_kernel's work for its evaluation, reading
                              // the descriptor from host_evals (PassArgs below); no prepare launch ran for these evaluations
 };
@@ -81,7 +89,15 @@ struct PassArgs {
     double* result_out;          // kModeDirectResult: one double per evaluation (pinned host memory)
     uint32_t partial_chunks;   // workgroup slots per evaluation in `partials` (>= gridDim.x; 0 means gridDim.x): launches
                                // of one batch may use different grids (pass 0 / later passes), the reducer sees one shape
+    // kModeFusedFactor: what launch_factor takes (quad: n_full x n_full couplings; scratch: factor_slot_doubles() per
+    // side-table slot) and one counter per side-table slot (zero before the handle's first launch; every evaluation adds two)
+    const double* quad;
+    double* factor_scratch;
+    uint32_t* factor_counters;
+    uint32_t n_full;
 };
+// LDS bytes the fused factor tail of a pass launch needs (up to eight waves form a side's Gram matrices)
+constexpr size_t kFusedFactorLdsBytes = 8 * (18 * 64 + 64) * sizeof(double) + 64;
 
 // Diagnostic stamps (only in a -DQSV_STAMPS build): [pass][phase] shader cycles summed over WAVES; the last phase
 // slot counts waves.  Phases: 0 setup, 1 load / synthesis, 2 xor-column setup + wait for the previous exchange's

@@ -44,6 +44,8 @@ struct SplitInfo {
     int n_virtual[2] = {0, 0};      // qubits of the virtual circuits
     uint32_t off_side[2] = {0, 0};  // word offsets of the side plans
     uint32_t off_block = 0;         // ... and of the split block (kernels.hpp)
+    int tile_bits[2] = {0, 0};      // tile of the two plans (a side's tile may be larger than the handle's, see build_circuit)
+    bool fused = false;             // both virtual circuits are one pass (kernels.hpp kEvalFused)
 };
 
 struct Circuit {
@@ -169,6 +171,7 @@ struct qsv_handle {
     uint32_t n_fterms = 0;
     DeviceBuffer d_fpart;        // ... and that kernel's partial sums
     DeviceBuffer d_factor;       // launch_factor's partial Gram matrices, one region per side-table slot
+    DeviceBuffer d_factor_count; // kModeFusedFactor: one counter per side-table slot (each fused evaluation adds two)
     uint32_t stream_mode = 0;    // kModeStreaming when a state is larger than the Infinity Cache (256 MiB), else 0
     mutable std::mutex mu;
     std::atomic<std::thread::id> batch_owner{};  // thread that holds `mu` between qsv_eval_begin and qsv_eval_end
@@ -396,9 +399,14 @@ int build_circuit(qsv_t* h, int n_ops, const qsv_op* ops, int n_params, bool fol
             // a virtual circuit may be a few qubits larger than a tile (it then takes the pass kernel a few passes over up
             // to sixteen tiles: nothing next to the 2^n indices of the contraction)
             // ... but one tile each is what to look for first: no second pass, one workgroup per virtual circuit
-            SplitCircuits sc = find_split(h->n, gates, angles,
-                                          std::vector<int>{h->geo.k, std::min(h->geo.k + 2, h->n - 1),
-                                                           std::min(h->geo.k + kSideExtraBits, h->n - 1)});
+            // (with 16 amplitudes per thread a side's tile may be one qubit larger than the handle's, below: sides that
+            // fit THAT are the second choice)
+            const int side_tile = std::max(h->geo.k, std::min(h->geo.r + 9, int(kMaxTileBits)));
+            std::vector<int> limits{h->geo.k};
+            if (side_tile > h->geo.k && side_tile < h->n) limits.push_back(side_tile);
+            limits.push_back(std::min(h->geo.k + 2, h->n - 1));
+            limits.push_back(std::min(h->geo.k + kSideExtraBits, h->n - 1));
+            SplitCircuits sc = find_split(h->n, gates, angles, limits);
             if (sc.ok && std::max(sc.n_side[0], sc.n_side[1]) > kSideMaxOwnBits) sc.ok = false;
             if (sc.ok) {
                 SplitInfo& sp = out->split;
@@ -407,7 +415,10 @@ int build_circuit(qsv_t* h, int n_ops, const qsv_op* ops, int n_params, bool fol
                 for (int s = 0; s < 2 && fits; ++s) {
                     PlanConfig side = pc;
                     sp.n_virtual[s] = sc.n_side[s] + sc.n_keys;
-                    side.tile_bits = std::min(sp.n_virtual[s], h->geo.k);
+                    // (a virtual circuit one qubit larger than the handle's tile still fits ONE workgroup when that may have
+                    // 512 threads: n = 20 keeps 12-qubit tiles of 256 threads for its states, but a three-key circuit's
+                    // 13-qubit sides then stay one tile and one pass -- and with that in the one-launch path, kEvalFused)
+                    side.tile_bits = std::min(sp.n_virtual[s], side_tile);
                     side.reg_bits = h->geo.r;
                     side.compact = false;  // (the compact-table buffer is where a side's state lives)
                     fits = side.tile_bits > side.reg_bits;
@@ -416,6 +427,7 @@ int build_circuit(qsv_t* h, int n_ops, const qsv_op* ops, int n_params, bool fol
                     sp.stats[s] = p.stats;
                     sp.t[s] = side.tile_bits - side.reg_bits;
                     sp.outer[s] = sp.n_virtual[s] - side.tile_bits;
+                    sp.tile_bits[s] = side.tile_bits;
                     sp.off_side[s] = uint32_t(w.size());
                     w.insert(w.end(), p.words.begin(), p.words.end());
                 }
@@ -478,6 +490,15 @@ int build_circuit(qsv_t* h, int n_ops, const qsv_op* ops, int n_params, bool fol
                     fill(blk + kSplitChunkHigh, 128, chunk0 + 7);
                     sp.n_keys = sc.n_keys;
                     sp.ok = true;
+                    // (the one-launch path exists in the 16-amplitudes-per-thread instantiation: its 128 registers hold the
+                    // Gram matrices' accumulators, the 80 of the 8-amplitude one do not)
+                    // (a side of several tiles is swept by its ONE workgroup, tile after tile, as long as it is one pass)
+                    sp.fused = h->geo.r == 4 && sp.stats[0].n_passes == 1 && sp.stats[1].n_passes == 1;
+                    if (const char* env = getenv("QSV_FUSED_MAX_KEYS")) sp.fused = sp.fused && sp.n_keys <= atoi(env);  // (measurements)
+                    if (getenv("QSV_SPLIT_DEBUG"))
+                        fprintf(stderr, "split: keys %d sides %d+%d virtual %d/%d tiles 2^%d/2^%d passes %d/%d fused %d\n", sp.n_keys, sc.n_side[0],
+                                sc.n_side[1], sp.n_virtual[0], sp.n_virtual[1], sp.outer[0], sp.outer[1], sp.stats[0].n_passes,
+                                sp.stats[1].n_passes, int(sp.fused));
                 } else {
                     w.resize(sp.off_side[0] ? sp.off_side[0] : w.size());
                     sp = SplitInfo{};
@@ -770,7 +791,8 @@ int batch_layout(qsv_t* h, const std::vector<Circuit*>& circs, const std::vector
             for (int s = 0; s < 2; ++s) {
                 hd[size_t(s) * n_evals + i] =
                     EvalDesc{c.plan_base + c.split.off_side[s], uint32_t(mcur), slot, uint32_t(i), uint32_t(pcur),
-                             uint32_t(n_params[i]), kEvalSide | (s ? kEvalSideB : 0u), c.plan_base + c.split.off_block};
+                             uint32_t(n_params[i]), kEvalSide | (s ? kEvalSideB : 0u) | (c.split.fused ? kEvalFused : 0u),
+                             c.plan_base + c.split.off_block};
                 mcur += mat_doubles_of(h, c, true, s);
             }
         }
@@ -879,39 +901,76 @@ int run_group(qsv_t* h, const std::vector<Circuit*>& circs, size_t first, size_t
     a.partial_chunks = chunks;
     a.region_stride = uint32_t(circs.size());
     const uint64_t sweep = (uint64_t(1) << h->n) * h->amp_bytes;
+    // of the split evaluations (they lead the group) the first n_unfused need launches of their own after the virtual
+    // circuits; the others are finished by the launch that runs theirs (kEvalFused, under a quadratic operator only)
+    size_t n_unfused = n_split;
+    const bool fuse_ok = factor_path(h) && !(mode & kModeSidesOnly) && h->d_factor_count.ptr != nullptr && !getenv("QSV_NO_FUSED_FACTOR");
+    if (fuse_ok) {
+        n_unfused = 0;
+        while (n_unfused < n_split && !circs[eval_of(first + n_unfused)]->split.fused) ++n_unfused;
+    }
     if (any_split) {
         if (n_plain > 0) return fail(h, QSV_E_STATE, "internal: a launch group mixes split and ordinary evaluations");
         a.wtab = h->d_side.ptr;  // (the side tables' own slots)
         a.wtab_stride = h->side_stride;
-        // both virtual circuits of every split evaluation (second descriptor region: z = 1): one tile and one pass each,
-        // or up to four tiles and a few passes when a virtual circuit is larger than a tile
-        int side_passes = 1;
-        unsigned side_tiles = 1;
-        for (size_t i = 0; i < n_split; ++i) {
-            const SplitInfo& sp = circs[eval_of(first + i)]->split;
-            for (int s = 0; s < 2; ++s) {
-                side_passes = std::max(side_passes, sp.stats[s].n_passes);
-                side_tiles = std::max(side_tiles, 1u << sp.outer[s]);
-            }
-        }
+        a.quad = static_cast<const double*>(h->d_quad.ptr);
+        a.factor_scratch = static_cast<double*>(h->d_factor.ptr);
+        a.factor_counters = static_cast<uint32_t*>(h->d_factor_count.ptr);
+        a.n_full = uint32_t(h->n);
+        a.result_out = h->out_target ? h->out_target : h->h_out;
         a.tiles_per_block = 1;
-        // (pass 0 prepares the virtual circuits' matrices and tables itself: no prepare launch ran for them)
-        a.host_evals = static_cast<const EvalDesc*>(h->h_batch) + first;
-        a.evals_out = static_cast<EvalDesc*>(h->d_batch.ptr) + first;
         a.host_params = reinterpret_cast<const double*>(static_cast<const char*>(h->h_batch) + h->batch.desc_bytes);
         a.mats_out = static_cast<double*>(h->d_mats.ptr);
-        for (int p = 0; p < side_passes; ++p) {
-            a.pass_index = uint32_t(p);
-            a.mode = ((p == 0 ? (mode | kModeFusedPrepare) : mode) & ~uint32_t(kModeSidesOnly)) | h->stream_mode;
-            const int kind = p == 0 ? 0 : 1;
-            if (h->stamping) QSV_HIP(h, stamp(h, h->batch.launch_events[kind], true));
-            QSV_HIP(h, launch_pass(h->dtype, h->geo.r, h->cfg.xmode, dim3(side_tiles, unsigned(n_split), 2),
-                                   h->geo.threads_launch, std::max(h->geo.lds_bytes, p == 0 ? kFusedPrepareLdsBytes : size_t(0)),
-                                   ws(h), a));
-            if (h->stamping) QSV_HIP(h, stamp(h, h->batch.launch_events[kind], false));
-            h->prof.n_pass_launches += 1;
-            h->prof.kernel_launches[kind] += 1;
-        }
+        // threads and LDS of a launch over split evaluations [lo, hi) of the group: a side's tile may be larger than the
+        // handle's (build_circuit)
+        auto shape_of = [&](size_t lo, size_t hi, int* threads, size_t* lds, int* passes, unsigned* tiles) {
+            int tile = 0, t = 0;
+            *passes = 1;
+            *tiles = 1;
+            for (size_t i = lo; i < hi; ++i) {
+                const SplitInfo& sp = circs[eval_of(first + i)]->split;
+                for (int s = 0; s < 2; ++s) {
+                    tile = std::max(tile, sp.tile_bits[s]);
+                    t = std::max(t, sp.t[s]);
+                    *passes = std::max(*passes, sp.stats[s].n_passes);
+                    *tiles = std::max(*tiles, 1u << sp.outer[s]);
+                }
+            }
+            *threads = std::max(64, 1 << t);
+            *lds = (size_t(1) << tile) * h->amp_bytes / (h->cfg.xmode == 2 ? 2 : 1);
+        };
+        auto at_least_four_waves = [](int threads) { return std::max(256, threads); };  // (the fused factor tail's Gram waves)
+        auto launch_sides = [&](size_t lo, size_t hi, uint32_t extra_mode) -> int {
+            int threads, passes;
+            size_t lds;
+            unsigned tiles;
+            shape_of(lo, hi, &threads, &lds, &passes, &tiles);
+            if (extra_mode & kModeFusedFactor) threads = at_least_four_waves(threads);
+            // (fused: ONE workgroup per side sweeps all its tiles, then goes on to the side's Gram matrices)
+            a.tiles_per_block = (extra_mode & kModeFusedFactor) ? tiles : 1u;
+            const unsigned grid_x = (extra_mode & kModeFusedFactor) ? 1u : tiles;
+            // (pass 0 prepares the virtual circuits' matrices and tables itself: no prepare launch ran for them)
+            a.evals = batch_evals(h) + first + lo;
+            a.host_evals = static_cast<const EvalDesc*>(h->h_batch) + first + lo;
+            a.evals_out = static_cast<EvalDesc*>(h->d_batch.ptr) + first + lo;
+            for (int p = 0; p < passes; ++p) {
+                a.pass_index = uint32_t(p);
+                a.mode = ((p == 0 ? (mode | kModeFusedPrepare | extra_mode) : mode) & ~uint32_t(kModeSidesOnly)) | h->stream_mode;
+                const int kind = p == 0 ? 0 : 1;
+                size_t need = lds;
+                if (p == 0) need = std::max(need, kFusedPrepareLdsBytes);
+                if (p == 0 && (extra_mode & kModeFusedFactor)) need = std::max(need, kFusedFactorLdsBytes);
+                if (h->stamping) QSV_HIP(h, stamp(h, h->batch.launch_events[kind], true));
+                QSV_HIP(h, launch_pass(h->dtype, h->geo.r, h->cfg.xmode, dim3(grid_x, unsigned(hi - lo), 2), threads, need, ws(h), a));
+                if (h->stamping) QSV_HIP(h, stamp(h, h->batch.launch_events[kind], false));
+                h->prof.n_pass_launches += 1;
+                h->prof.kernel_launches[kind] += 1;
+            }
+            return QSV_OK;
+        };
+        int rc2;
+        if (n_unfused > 0 && (rc2 = launch_sides(0, n_unfused, 0u))) return rc2;
+        if (n_split > n_unfused && (rc2 = launch_sides(n_unfused, n_split, kModeFusedFactor))) return rc2;
         a.mode = mode | h->stream_mode;
         // what the side circuits move: they synthesise their input and write their final states
         for (size_t i = 0; i < n_split; ++i) {
@@ -921,6 +980,20 @@ int run_group(qsv_t* h, const std::vector<Circuit*>& circs, size_t first, size_t
             h->prof.moved_bytes += bytes;
             h->prof.kernel_bytes[0] += bytes;
             h->prof.kernel_moved_bytes[0] += bytes;
+        }
+        // (the fused ones: what their Gram matrices read and compute is part of that launch)
+        for (size_t i = n_unfused; i < n_split; ++i) {
+            const SplitInfo& sp = circs[eval_of(first + i)]->split;
+            for (int s = 0; s < 2; ++s) {
+                const int side_bits = sp.n_virtual[s] - sp.n_keys;
+                const uint64_t moved = (uint64_t(1) << sp.n_virtual[s]) * h->amp_bytes + (uint64_t(8) << side_bits);
+                h->prof.kernel_bytes[0] += moved;
+                h->prof.kernel_moved_bytes[0] += moved;
+                h->prof.kernel_flops[0] += double(uint64_t(1) << side_bits) * double(1u << (2 * sp.n_keys)) * (side_bits / 2.0 + 5.0) * 2.0;
+                h->prof.kernel_states[0] += 1;
+                if (!sp.stats[s].pass_pairs.empty()) h->prof.kernel_flops[0] += 24.0 * sp.stats[s].pass_pairs[0];
+            }
+            h->prof.kernel_states[2] += 1;
         }
     }
     a.evals = batch_evals(h) + first + n_split;
@@ -970,15 +1043,17 @@ int run_group(qsv_t* h, const std::vector<Circuit*>& circs, size_t first, size_t
         }
     }
     if (any_split && !(mode & kModeSidesOnly) && factor_path(h)) {
+      if (n_unfused > 0) {
         // quadratic operator: the expectation value from the two side tables alone, written straight to the result buffer
         a.evals = batch_evals(h) + first;
         a.result_out = h->out_target ? h->out_target : h->h_out;
         if (h->stamping) QSV_HIP(h, stamp(h, h->batch.launch_events[2], true));
-        QSV_HIP(h, launch_factor(h->dtype, unsigned(n_split), static_cast<double*>(h->d_factor.ptr),
+        QSV_HIP(h, launch_factor(h->dtype, unsigned(n_unfused), static_cast<double*>(h->d_factor.ptr),
                                  static_cast<const double*>(h->d_quad.ptr), h->n, ws(h), a));
         if (h->stamping) QSV_HIP(h, stamp(h, h->batch.launch_events[2], false));
         h->prof.kernel_launches[2] += 1;  // (the pair of launches, timed as one)
-        for (size_t i = 0; i < n_split; ++i) {
+      }
+        for (size_t i = 0; i < n_unfused; ++i) {
             const SplitInfo& sp = circs[eval_of(first + i)]->split;
             // what the two kernels read per state: the side tables and one value of D per table row
             uint64_t moved = 0;
@@ -1109,16 +1184,27 @@ size_t order_split_first(qsv_t* h, size_t first, size_t count) {
     const size_t P = b.circs.size();
     std::vector<EvalDesc> tmp(hd + first, hd + first + count), tmp2(hd + P + first, hd + P + first + count);
     size_t at = first, n_split = 0;
-    for (int cls = kMaxSplitKeys; cls >= -1; --cls)
-        for (size_t j = 0; j < count; ++j) {
-            const int mine = b.split[first + j] ? b.circs[first + j]->split.n_keys : -1;
-            if (mine != cls) continue;
-            hd[at] = tmp[j];
-            hd[P + at] = tmp2[j];
-            b.eval_at[at] = uint32_t(first + j);
-            ++at;
-            if (cls >= 0) ++n_split;
-        }
+    // (among the split ones first those that need launches of their own after the virtual circuits -- kEvalFused ones are
+    // finished by the launch that runs theirs --, so that each kind is one contiguous range of every launch group)
+    for (int fused = 0; fused <= 1; ++fused)
+        for (int cls = kMaxSplitKeys; cls >= 0; --cls)
+            for (size_t j = 0; j < count; ++j) {
+                if (!b.split[first + j]) continue;
+                const SplitInfo& sp = b.circs[first + j]->split;
+                if (sp.n_keys != cls || int(sp.fused) != fused) continue;
+                hd[at] = tmp[j];
+                hd[P + at] = tmp2[j];
+                b.eval_at[at] = uint32_t(first + j);
+                ++at;
+                ++n_split;
+            }
+    for (size_t j = 0; j < count; ++j) {
+        if (b.split[first + j]) continue;
+        hd[at] = tmp[j];
+        hd[P + at] = tmp2[j];
+        b.eval_at[at] = uint32_t(first + j);
+        ++at;
+    }
     return n_split;
 }
 
@@ -1455,9 +1541,20 @@ int qsv_create(int n_qubits, int dtype, int device, const qsv_plan_config* cfg, 
             const size_t bytes = factor_slot_doubles() * sizeof(double) * size_t(h->side_slots);
             if ((e = hipMalloc(&h->d_factor.ptr, bytes)) != hipSuccess) return bail(e, "hipMalloc(partial Gram matrices)");
             h->d_factor.bytes = bytes;
+            const size_t cbytes = sizeof(uint32_t) * size_t(h->side_slots);
+            if ((e = hipMalloc(&h->d_factor_count.ptr, cbytes)) != hipSuccess) return bail(e, "hipMalloc(hand-off counters)");
+            h->d_factor_count.bytes = cbytes;
+            if ((e = hipMemset(h->d_factor_count.ptr, 0, cbytes)) != hipSuccess) return bail(e, "hipMemset(hand-off counters)");
         }
     }
-    if ((e = configure_pass_kernels(dtype, geo.r, pc.xmode, geo.lds_bytes)) != hipSuccess) return bail(e, "hipFuncSetAttribute");
+    {
+        // the most dynamic LDS a pass launch of this handle may ask for: the exchange plane of the largest tile (a side of a
+        // split circuit may have a tile one qubit larger than the handle's), the fused preparation, the fused factor tail
+        const int side_tile = std::max(geo.k, std::min(geo.r + 9, int(kMaxTileBits)));
+        const size_t plane = (size_t(1) << side_tile) * h->amp_bytes / (pc.xmode == 2 ? 2 : 1);
+        const size_t most = std::max({geo.lds_bytes, plane, kFusedPrepareLdsBytes, kFusedFactorLdsBytes});
+        if ((e = configure_pass_kernels(dtype, geo.r, pc.xmode, most)) != hipSuccess) return bail(e, "hipFuncSetAttribute");
+    }
     *out = h;
     return QSV_OK;
 }
@@ -1474,7 +1571,7 @@ void qsv_destroy(qsv_t* h) {
     }
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     for (DeviceBuffer* b : {&h->d_z, &h->d_cre, &h->d_diag, &h->d_term_partials, &h->d_groups, &h->d_term_odd, &h->d_arena,
-                            &h->d_states, &h->d_wtab, &h->d_side, &h->d_factor, &h->d_quad, &h->d_fterms, &h->d_fpart, &h->d_batch, &h->d_mats, &h->d_partials, &h->d_out, &h->d_scratch})
+                            &h->d_states, &h->d_wtab, &h->d_side, &h->d_factor, &h->d_factor_count, &h->d_quad, &h->d_fterms, &h->d_fpart, &h->d_batch, &h->d_mats, &h->d_partials, &h->d_out, &h->d_scratch})
         if (b->ptr) (void)hipFree(b->ptr);
     if (h->h_batch) (void)hipHostFree(h->h_batch);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
