@@ -2470,9 +2470,9 @@ __device__ __forceinline__ void fused_factor_tail(const uint32_t* __restrict__ p
         const uint32_t first = wave < kWaves ? wave : 0xffffffu, step = kWaves;
         double* sink = wave < kWaves ? out : nullptr;
         if (n_keys == 0)
-            factor_side_body<real, 1, false>(tab, bits, mask, diag, first, step, stage, dstage_all + w * 64, sink);
+            factor_side_body<real, 1, true>(tab, bits, mask, diag, first, step, stage, dstage_all + w * 64, sink);
         else if (n_keys == 1)
-            factor_side_body<real, 2, false>(tab, bits, mask, diag, first, step, stage, dstage_all + w * 64, sink);
+            factor_side_body<real, 2, true>(tab, bits, mask, diag, first, step, stage, dstage_all + w * 64, sink);
         else if (n_keys == 2)
             factor_side_body<real, 4, false>(tab, bits, mask, diag, first, step, stage, dstage_all + w * 64, sink);
         else

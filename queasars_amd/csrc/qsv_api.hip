@@ -493,7 +493,11 @@ int build_circuit(qsv_t* h, int n_ops, const qsv_op* ops, int n_params, bool fol
                     // (the one-launch path exists in the 16-amplitudes-per-thread instantiation: its 128 registers hold the
                     // Gram matrices' accumulators, the 80 of the 8-amplitude one do not)
                     // (a side of several tiles is swept by its ONE workgroup, tile after tile, as long as it is one pass)
-                    sp.fused = h->geo.r == 4 && sp.stats[0].n_passes == 1 && sp.stats[1].n_passes == 1;
+                    // A property of the circuit and the handle, never of the batch: the two routes add in different orders.
+                    // Measured (profiles/r03_fused_factor.txt): the one-launch route wins where a side's Gram matrices are a
+                    // few blocks per wave -- 20-qubit registers, every population size -- and loses from 22 qubits on, where
+                    // a side's table is 2^11 .. 2^13 rows for the four to eight waves of its one workgroup.
+                    sp.fused = h->geo.r == 4 && h->geo.k == 12 && sp.stats[0].n_passes == 1 && sp.stats[1].n_passes == 1;
                     if (const char* env = getenv("QSV_FUSED_MAX_KEYS")) sp.fused = sp.fused && sp.n_keys <= atoi(env);  // (measurements)
                     if (getenv("QSV_SPLIT_DEBUG"))
                         fprintf(stderr, "split: keys %d sides %d+%d virtual %d/%d tiles 2^%d/2^%d passes %d/%d fused %d\n", sp.n_keys, sc.n_side[0],
