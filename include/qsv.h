@@ -223,6 +223,7 @@ int qsv_sample_cvar_batch(qsv_t* h, int n_evals, const int* circuit_ids, const i
  *   "split" 0|1          weakly entangled circuits run as two virtual circuits (csrc/split.hpp); 1 needs a handle that was
  *                        created with splitting on.  Applies to circuits registered afterwards.
  *   "factor" 0|1         split evaluations use the factorised expectation kernels instead of the contraction sweep
+ *   "fused_factor" 0|1   ... inside the launch that runs their virtual circuits, where a circuit qualifies (one launch per push)
  *   "split_sampling" 0|1 split circuits are sampled from their side tables
  *   "streams" 1..4       HIP streams the pushes of a batch cycle over (at most as many as were created with the handle)
  * Returns QSV_E_ARG for an unknown name or a value out of range.

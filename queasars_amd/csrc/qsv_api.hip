@@ -165,6 +165,7 @@ struct qsv_handle {
     bool split_sampling = true;  // ... and are sampled from their two side tables (kernels.hpp: launch_split_sample)
     bool factor_enabled = true;  // ... and, under a quadratic diagonal operator, need no sweep over the 2^n indices at all
                                  // (kernels.hpp: launch_factor)
+    bool fused_factor = true;    // ... in the launch that runs the virtual circuits, where the circuit qualifies (kEvalFused)
     bool quadratic = false;      // the operator is diagonal and every term has at most two Z factors
     DeviceBuffer d_quad;         // its couplings as an n x n matrix
     DeviceBuffer d_fterms;       // a general operator's terms as a plain list (kernels.hpp: launch_factor_terms)
@@ -908,7 +909,7 @@ int run_group(qsv_t* h, const std::vector<Circuit*>& circs, size_t first, size_t
     // of the split evaluations (they lead the group) the first n_unfused need launches of their own after the virtual
     // circuits; the others are finished by the launch that runs theirs (kEvalFused, under a quadratic operator only)
     size_t n_unfused = n_split;
-    const bool fuse_ok = factor_path(h) && !(mode & kModeSidesOnly) && h->d_factor_count.ptr != nullptr && !getenv("QSV_NO_FUSED_FACTOR");
+    const bool fuse_ok = factor_path(h) && !(mode & kModeSidesOnly) && h->d_factor_count.ptr != nullptr && h->fused_factor;
     if (fuse_ok) {
         n_unfused = 0;
         while (n_unfused < n_split && !circs[eval_of(first + n_unfused)]->split.fused) ++n_unfused;
@@ -1517,6 +1518,7 @@ int qsv_create(int n_qubits, int dtype, int device, const qsv_plan_config* cfg, 
     if (const char* env = getenv("QSV_SPLIT")) h->split_enabled = atoi(env) != 0;
     if (const char* env = getenv("QSV_SPLIT_SAMPLE")) h->split_sampling = atoi(env) != 0;
     if (const char* env = getenv("QSV_FACTOR")) h->factor_enabled = atoi(env) != 0;
+    if (getenv("QSV_NO_FUSED_FACTOR")) h->fused_factor = false;
     h->stream_mode = state_bytes > (size_t(256) << 20) ? uint32_t(kModeStreaming) : 0u;
     if (const char* env = getenv("QSV_STREAMING")) h->stream_mode = atoi(env) ? uint32_t(kModeStreaming) : 0u;
     if (const char* env = getenv("QSV_STREAMS")) h->n_streams = std::max(1, std::min(4, atoi(env)));
@@ -2252,6 +2254,8 @@ int qsv_set_option(qsv_t* h, const char* name, int value) {
         if (value != 0 && h->split_enabled && h->d_side.ptr && !h->d_factor.ptr)
             return fail(h, QSV_E_ARG, "this handle was created without the factorised path (QSV_FACTOR=0)");
         h->factor_enabled = value != 0;
+    } else if (key == "fused_factor") {
+        h->fused_factor = value != 0;
     } else if (key == "split_sampling") {
         h->split_sampling = value != 0;
     } else if (key == "streams") {

@@ -555,6 +555,42 @@ def test_split_results_do_not_depend_on_the_batch(c_oracle):
     assert np.abs(np.asarray(alone[:4]) - np.asarray(ref)).max() < EXP_TOL
 
 
+def test_one_launch_route_of_split_evaluations(c_oracle):
+    """Split evaluations under a quadratic operator at n = 20: the launch that runs the two virtual circuits also forms
+    their Gram matrices and combines them (kModeFusedFactor; the two sides' workgroups hand over through global memory).
+    Same values as the three-launch route (another summation order: 1e-10), as the C oracle, in fp32 within the fp32
+    bound -- and the SAME BITS on every one of many repetitions, alone or in company, on one stream or two: a hand-off
+    that read a stale line would show as a repetition that differs."""
+    n = 20
+    _, circuits, params = helpers.population_circuits(n, 4, 64, seed=0)
+    keys = [_keys_like_the_library(c, n) for c in circuits]
+    assert max(keys) >= 2 and min(keys) == 0
+    op = helpers.random_ising_operator(n, seed=2020)
+    ev = OperatorCircuitEvaluator(op)
+    dev = ev.statevector_device
+    one = ev.evaluate_circuits(circuits, params)
+    dev.set_option("fused_factor", 0)
+    three = ev.evaluate_circuits(circuits, params)
+    dev.set_option("fused_factor", 1)
+    assert np.abs(np.asarray(one) - np.asarray(three)).max() < EXP_TOL
+    table = c_oracle.diagonal_table(op)
+    scratch = np.zeros(2 << n)
+    for i in (0, 17, 63, int(np.argmax(keys))):
+        assert abs(one[i] - c_oracle.evaluate(circuits[i], params[i], op, table, scratch)) < EXP_TOL
+    for rep in range(400):
+        assert ev.evaluate_circuits(circuits, params) == one, rep
+    assert ev.evaluate_circuits(circuits[::-1], params[::-1]) == one[::-1]
+    assert [ev.evaluate_circuits([c], [p])[0] for c, p in zip(circuits[:16], params[:16])] == one[:16]
+    # more evaluations than side-table slots of one stream (several launch groups per push), twice over
+    big_c, big_p = circuits * 5, params * 5
+    for _ in range(2):
+        assert ev.evaluate_circuits(big_c, big_p) == one * 5
+    dev.set_option("streams", 1)
+    assert ev.evaluate_circuits(circuits, params) == one
+    got32 = np.asarray(OperatorCircuitEvaluator(op, dtype="fp32").evaluate_circuits(circuits, params))
+    assert np.abs(got32 - np.asarray(one)).max() < FP32_REL * float(np.abs(op.coeffs).sum())
+
+
 def test_split_fp32_and_general_operators():
     """fp32 tables through the split path (within the fp32 bound of the fp64 value); a general operator on split circuits
     (the term kernel) against the same device with splitting off."""
