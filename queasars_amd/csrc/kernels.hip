@@ -2329,28 +2329,163 @@ __device__ __forceinline__ double factor_pairing(const double* a, const double* 
     return t;
 }
 
+constexpr unsigned kFactorParts = 8;
+constexpr uint32_t kFactorSlices = kFactorParts / 2;
+
+// ---- the same for sixteen and thirty-two product terms (four and five cut keys) ------------------------------------------
+// J^2 = 256 / 1024 entries no longer fit the lanes of a wave: here a workgroup's 256 threads each own ONE entry (of a
+// group of 256) and every wave walks ALL rows of the workgroup's blocks, which the workgroup stages in LDS together
+// (J x 64 amplitudes, x-major with one amplitude of padding per x, and the block's 64 values of D).  Grid: entry groups x
+// kFactorSlices (a slice takes blocks slice, slice + 4, ..) x the two sides, per evaluation; a slice's sums leave as
+// partial sums [side][slice][weight][entry], added in slice order by factor_combine_big_kernel.  Bound by the LDS reads
+// (two 16-byte reads per entry and row): about 1.7 us per block and workgroup.
+constexpr uint32_t kFactorBigEntries = 1024;  // J = 32
+constexpr size_t factor_big_slot_doubles_c() { return size_t(2) * kFactorSlices * kFactorWeights * kFactorBigEntries; }
+size_t factor_big_slot_doubles() { return factor_big_slot_doubles_c(); }
+
+template <typename real, int J>
+__device__ __forceinline__ void factor_moments_big_body(const EvalDesc& ev, const uint32_t* __restrict__ sp,
+                                                        const cx<real>* __restrict__ sides, uint64_t side_stride,
+                                                        const double* __restrict__ diag, double* __restrict__ scratch,
+                                                        cx<real>* stage, double* dstage) {
+    constexpr uint32_t NQ = J * J, PITCH = J + 1;
+    const bool swap = sp[3] & 1u;
+    const uint32_t side = blockIdx.x & 1u, slice = (blockIdx.x >> 1) & (kFactorSlices - 1), group = blockIdx.x >> 3;
+    if (group * 256u >= NQ) return;  // (uniform: before any barrier)
+    const uint32_t bits = sp[1 + side], mask = sp[kSplitMaskX + side];
+    const uint32_t tid = threadIdx.x;
+    const cx<real>* ta = sides + uint64_t(ev.state_slot) * side_stride;
+    const cx<real>* tab = ta + ((side == 0) == swap ? side_stride >> 1 : 0);  // X is side B's half when swapped
+    const uint32_t pi = group * 256u + tid;
+    uint32_t ja, jb, part;
+    split_entry_of<J>(pi, &ja, &jb, &part);
+    const uint32_t n_local = bits < 6u ? 1u << bits : 64u, n_blocks = bits < 6u ? 1u : 1u << (bits - 6u);
+    double acc_one = 0.0, acc_d = 0.0, acc_low[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, acc_high[10];
+#pragma unroll
+    for (int q = 0; q < 10; ++q) acc_high[q] = 0.0;
+    for (uint32_t blk = slice; blk < n_blocks; blk += kFactorSlices) {
+        __syncthreads();  // (the block before is no longer read)
+        for (uint32_t idx = tid; idx < uint32_t(J) * 64u; idx += 256u) {
+            const uint32_t j = idx >> 6, xl = idx & 63u;
+            cx<real> v{real(0), real(0)};
+            if (xl < n_local) v = tab[(size_t(j) << bits) + size_t(blk) * 64 + xl];
+            stage[xl * PITCH + j] = v;
+        }
+        if (tid < 64) dstage[tid] = tid < n_local ? diag[deposit_bits(blk * 64u + tid, mask)] : 0.0;
+        __syncthreads();
+        double s_one = 0.0, s_d = 0.0;
+#pragma unroll
+        for (uint32_t i = 0; i < 64; ++i) {
+            const cx<real> a = stage[i * PITCH + ja], b = stage[i * PITCH + jb];
+            const double p = split_entry_value(part, double(a.re), double(a.im), double(b.re), double(b.im));
+            s_one += p;
+            s_d = fma(dstage[i], p, s_d);
+#pragma unroll
+            for (uint32_t q = 0; q < 6; ++q)  // (bits of i: known when the loop is unrolled)
+                if (i >> q & 1u) acc_low[q] += p;
+        }
+        acc_one += s_one;
+        acc_d += s_d;
+#pragma unroll
+        for (int q = 0; q < 10; ++q)  // (bits 6 and up are the block number's)
+            if (blk >> q & 1u) acc_high[q] += s_one;
+    }
+    double* mine = scratch + size_t(ev.state_slot) * factor_big_slot_doubles_c() +
+                   (size_t(side) * kFactorSlices + slice) * kFactorWeights * kFactorBigEntries;
+    mine[0 * kFactorBigEntries + pi] = acc_one;
+    mine[1 * kFactorBigEntries + pi] = acc_d;
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+        if (uint32_t(q) < bits) mine[size_t(2 + q) * kFactorBigEntries + pi] = acc_low[q];
+#pragma unroll
+    for (int q = 0; q < 10; ++q)
+        if (uint32_t(6 + q) < bits) mine[size_t(8 + q) * kFactorBigEntries + pi] = acc_high[q];
+}
+
+// One workgroup per evaluation: a thread takes entries tid, tid + 256, ..; per entry the slices' partial sums in order, then
+//   sigma_e [ 4 sum_{ab} J_ab FX_{2+a}[e] FY_{2+b}[e] + FX_D[e] FY_1[e] + FX_1[e] FY_D[e] - D(0,0) FX_1[e] FY_1[e] ]
+// (sigma = 1 / 2 / -2 for a diagonal entry / the real / the imaginary part of a pair: factor_pairing entry by entry);
+// a thread's entries in ascending order, then the fixed-order block sum.
+template <int J>
+__device__ __forceinline__ void factor_combine_big_body(const EvalDesc& ev, const uint32_t* __restrict__ sp, const double* __restrict__ scratch,
+                                                        const double* __restrict__ quad, uint32_t n_qubits, const double* __restrict__ diag,
+                                                        double* __restrict__ result_out, double* coupling, double* red) {
+    constexpr uint32_t NQ = J * J;
+    const uint32_t bx = sp[1], by = sp[2];
+    const uint32_t masks[2] = {sp[kSplitMaskX], sp[kSplitMaskY]};
+    const uint32_t tid = threadIdx.x;
+    if (tid < bx * by) {
+        const uint32_t a = tid / by, b = tid % by;
+        uint32_t qa = 0, qb = 0;
+        for (uint32_t m = masks[0], k = 0; m; m &= m - 1, ++k)
+            if (k == a) qa = uint32_t(__builtin_ctz(m));
+        for (uint32_t m = masks[1], k = 0; m; m &= m - 1, ++k)
+            if (k == b) qb = uint32_t(__builtin_ctz(m));
+        coupling[a * 16 + b] = quad[qa * n_qubits + qb];
+    }
+    __syncthreads();
+    const double d00 = diag[0];
+    const double* base = scratch + size_t(ev.state_slot) * factor_big_slot_doubles_c();
+    auto gram = [&](uint32_t side, uint32_t w, uint32_t pi) {
+        double v = 0.0;
+#pragma unroll
+        for (uint32_t g = 0; g < kFactorSlices; ++g)
+            v += base[((size_t(side) * kFactorSlices + g) * kFactorWeights + w) * kFactorBigEntries + pi];
+        return v;
+    };
+    double acc = 0.0;
+    for (uint32_t pi = tid; pi < NQ; pi += 256) {
+        uint32_t ja, jb, part;
+        split_entry_of<J>(pi, &ja, &jb, &part);
+        const double sigma = part == 0 ? 1.0 : part == 1 ? 2.0 : -2.0;
+        double fy[kFactorWeights];  // (fixed trip counts: the array stays in registers)
+#pragma unroll
+        for (uint32_t w = 0; w < kFactorWeights; ++w) fy[w] = w < 2 + by ? gram(1, w, pi) : 0.0;
+        const double fx_one = gram(0, 0, pi), fx_d = gram(0, 1, pi);
+        double t = fma(fx_d, fy[0], fx_one * fy[1]) - d00 * fx_one * fy[0];
+        for (uint32_t a = 0; a < bx; ++a) {
+            const double fxa = gram(0, 2 + a, pi);
+            double row = 0.0;
+#pragma unroll
+            for (uint32_t b = 0; b < 16; ++b) row = fma(b < by ? coupling[a * 16 + b] : 0.0, fy[2 + b], row);
+            t = fma(4.0 * fxa, row, t);
+        }
+        acc = fma(sigma, t, acc);
+    }
+    const double total = block_sum_256(acc, red);
+    if (tid == 0) result_out[ev.out_index] = total;
+}
+
 // Two launches.  factor_moments_kernel: kFactorParts workgroups of four waves per evaluation, the even ones on side X,
 // the odd ones on side Y; wave (slice, w) takes blocks 4 slice + w, + 16, ..; a workgroup's four partial matrices are added
 // in LDS (wave order) and leave as ONE partial per weight and entry.  factor_combine_kernel: one workgroup per evaluation
 // adds the slices' partials in order, then one thread per pair (a, b) of qubits across the cut -- and three for the
 // separable parts -- forms its term, and the terms are added in a fixed order.
-constexpr unsigned kFactorParts = 8;
-constexpr uint32_t kFactorSlices = kFactorParts / 2;
 static_assert(factor_slot_doubles() == size_t(2) * kFactorSlices * kFactorWeights * 64, "scratch of one evaluation");
 
 template <typename real>
 __global__ void __launch_bounds__(256, 2) factor_moments_kernel(const uint32_t* __restrict__ plan_arena, const EvalDesc* __restrict__ evals,
                                                                 const cx<real>* __restrict__ sides, uint64_t side_stride,
-                                                                const double* __restrict__ diag, double* __restrict__ scratch) {
+                                                                const double* __restrict__ diag, double* __restrict__ scratch,
+                                                                double* __restrict__ scratch_big) {
     constexpr uint32_t kWaves = 4;
     // the waves' staging regions (9 x 64 amplitudes each) and, afterwards, their partial matrices (18 x 64 doubles each)
     __shared__ __align__(16) unsigned char raw[kWaves * kFactorWeights * 64 * sizeof(double)];
     static_assert(sizeof(raw) >= kWaves * 9 * 64 * sizeof(cx<real>), "staging regions");
+    static_assert(sizeof(raw) >= 64 * 33 * sizeof(cx<real>), "block of 32 product terms");
     __shared__ double dstage[kWaves * 64];
     const EvalDesc ev = evals[blockIdx.y];
     if (!(ev.flags & kEvalSide)) return;
     const uint32_t* sp = plan_arena + ev.split_base;
     const uint32_t n_keys = sp[0], NQ = 1u << (2 * n_keys);
+    if (n_keys > 3) {  // sixteen / thirty-two product terms: a thread per entry (grid: up to four entry groups)
+        if (n_keys == 4)
+            factor_moments_big_body<real, 16>(ev, sp, sides, side_stride, diag, scratch_big, reinterpret_cast<cx<real>*>(raw), dstage);
+        else
+            factor_moments_big_body<real, 32>(ev, sp, sides, side_stride, diag, scratch_big, reinterpret_cast<cx<real>*>(raw), dstage);
+        return;
+    }
+    if (blockIdx.x >= kFactorParts) return;  // (a grid widened for an evaluation of 32 terms)
     const bool swap = sp[3] & 1u;
     const uint32_t side = blockIdx.x & 1u, slice = blockIdx.x >> 1;
     const uint32_t bits = sp[1 + side], mask = sp[kSplitMaskX + side];
@@ -2381,15 +2516,23 @@ __global__ void __launch_bounds__(256, 2) factor_moments_kernel(const uint32_t* 
 }
 
 __global__ void __launch_bounds__(256) factor_combine_kernel(const uint32_t* __restrict__ plan_arena, const EvalDesc* __restrict__ evals,
-                                                             const double* __restrict__ scratch, const double* __restrict__ quad,
-                                                             uint32_t n_qubits, const double* __restrict__ diag,
-                                                             double* __restrict__ result_out) {
+                                                             const double* __restrict__ scratch, const double* __restrict__ scratch_big,
+                                                             const double* __restrict__ quad, uint32_t n_qubits,
+                                                             const double* __restrict__ diag, double* __restrict__ result_out) {
     __shared__ double gram[2][kFactorWeights * kFactorPitch];
     __shared__ double red[4];
     const EvalDesc ev = evals[blockIdx.x];
     if (!(ev.flags & kEvalSide)) return;
     const uint32_t* sp = plan_arena + ev.split_base;
     const uint32_t n_keys = sp[0], NQ = 1u << (2 * n_keys);
+    if (n_keys > 3) {
+        static_assert(sizeof(gram) >= 16 * 16 * sizeof(double), "couplings of the cut");
+        if (n_keys == 4)
+            factor_combine_big_body<16>(ev, sp, scratch_big, quad, n_qubits, diag, result_out, &gram[0][0], red);
+        else
+            factor_combine_big_body<32>(ev, sp, scratch_big, quad, n_qubits, diag, result_out, &gram[0][0], red);
+        return;
+    }
     const uint32_t bits[2] = {sp[1], sp[2]}, mask[2] = {sp[kSplitMaskX], sp[kSplitMaskY]};
     const double* mine = scratch + size_t(ev.state_slot) * factor_slot_doubles();
     const uint32_t tid = threadIdx.x;
@@ -2544,17 +2687,19 @@ __device__ __forceinline__ void fused_factor_tail(const uint32_t* __restrict__ p
 }
 
 hipError_t launch_factor(int dtype, unsigned n_evals, double* scratch, const double* quad, int n_qubits, hipStream_t stream,
-                         const PassArgs& a) {
+                         const PassArgs& a, double* scratch_big, int most_keys) {
     if (n_evals == 0) return hipSuccess;
-    const dim3 grid(kFactorParts, n_evals);
+    if (most_keys > 3 && !scratch_big) return hipErrorInvalidValue;
+    // (an evaluation of 32 product terms has four groups of 256 entries: four times the workgroups)
+    const dim3 grid(most_keys >= 5 ? 4 * kFactorParts : kFactorParts, n_evals);
     if (dtype == 0)
         hipLaunchKernelGGL(factor_moments_kernel<double>, grid, dim3(256), 0, stream, a.plan, a.evals,
-                           static_cast<const cx<double>*>(a.wtab), a.wtab_stride, a.diag, scratch);
+                           static_cast<const cx<double>*>(a.wtab), a.wtab_stride, a.diag, scratch, scratch_big);
     else
         hipLaunchKernelGGL(factor_moments_kernel<float>, grid, dim3(256), 0, stream, a.plan, a.evals,
-                           static_cast<const cx<float>*>(a.wtab), a.wtab_stride, a.diag, scratch);
-    hipLaunchKernelGGL(factor_combine_kernel, dim3(n_evals), dim3(256), 0, stream, a.plan, a.evals, scratch, quad, uint32_t(n_qubits),
-                       a.diag, a.result_out);
+                           static_cast<const cx<float>*>(a.wtab), a.wtab_stride, a.diag, scratch, scratch_big);
+    hipLaunchKernelGGL(factor_combine_kernel, dim3(n_evals), dim3(256), 0, stream, a.plan, a.evals, scratch, scratch_big, quad,
+                       uint32_t(n_qubits), a.diag, a.result_out);
     return hipGetLastError();
 }
 

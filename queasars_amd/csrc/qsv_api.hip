@@ -173,6 +173,7 @@ struct qsv_handle {
     DeviceBuffer d_fpart;        // ... and that kernel's partial sums
     DeviceBuffer d_factor;       // launch_factor's partial Gram matrices, one region per side-table slot
     DeviceBuffer d_factor_count; // kModeFusedFactor: one counter per side-table slot (each fused evaluation adds two)
+    DeviceBuffer d_factor_big;   // launch_factor_big's partial Gram matrices (four and five keys), allocated on first need
     uint32_t stream_mode = 0;    // kModeStreaming when a state is larger than the Infinity Cache (256 MiB), else 0
     mutable std::mutex mu;
     std::atomic<std::thread::id> batch_owner{};  // thread that holds `mu` between qsv_eval_begin and qsv_eval_end
@@ -256,6 +257,10 @@ struct qsv_handle {
         unsigned used_mask = 0; // side streams (bit i = side_streams[i]) with work of this batch in flight
         bool aux_plain = false; // the batch's ordinary evaluations run on the auxiliary stream (eval_begin)
         size_t aux_count = 0;   // ... how many of them have been pushed (their state slots cycle over the whole group)
+        bool aux_split = false; // the batch mixes split evaluations that one launch finishes (kEvalFused) with split ones that
+                                // need launches of their own: the latter run on the auxiliary stream, in side-table slots
+                                // only that stream uses, beside the former
+        size_t aux_split_count = 0;
         size_t n_pushes = 0;
     } batch;
     std::unique_lock<std::mutex> batch_lock;  // held from begin to end
@@ -407,7 +412,8 @@ int build_circuit(qsv_t* h, int n_ops, const qsv_op* ops, int n_params, bool fol
             if (side_tile > h->geo.k && side_tile < h->n) limits.push_back(side_tile);
             limits.push_back(std::min(h->geo.k + 2, h->n - 1));
             limits.push_back(std::min(h->geo.k + kSideExtraBits, h->n - 1));
-            SplitCircuits sc = find_split(h->n, gates, angles, limits);
+            static const int max_keys = getenv("QSV_SPLIT_MAX_KEYS") ? std::max(0, std::min(kMaxSplitKeys, atoi(getenv("QSV_SPLIT_MAX_KEYS")))) : kMaxSplitKeys;
+            SplitCircuits sc = find_split(h->n, gates, angles, limits, max_keys);
             if (sc.ok && std::max(sc.n_side[0], sc.n_side[1]) > kSideMaxOwnBits) sc.ok = false;
             if (sc.ok) {
                 SplitInfo& sp = out->split;
@@ -498,7 +504,8 @@ int build_circuit(qsv_t* h, int n_ops, const qsv_op* ops, int n_params, bool fol
                     // Measured (profiles/r03_fused_factor.txt): the one-launch route wins where a side's Gram matrices are a
                     // few blocks per wave -- 20-qubit registers, every population size -- and loses from 22 qubits on, where
                     // a side's table is 2^11 .. 2^13 rows for the four to eight waves of its one workgroup.
-                    sp.fused = h->geo.r == 4 && h->geo.k == 12 && sp.stats[0].n_passes == 1 && sp.stats[1].n_passes == 1;
+                    sp.fused = h->geo.r == 4 && h->geo.k == 12 && sp.n_keys <= 3 && sp.outer[0] == 0 && sp.outer[1] == 0 &&
+                               sp.stats[0].n_passes == 1 && sp.stats[1].n_passes == 1;
                     if (const char* env = getenv("QSV_FUSED_MAX_KEYS")) sp.fused = sp.fused && sp.n_keys <= atoi(env);  // (measurements)
                     if (getenv("QSV_SPLIT_DEBUG"))
                         fprintf(stderr, "split: keys %d sides %d+%d virtual %d/%d tiles 2^%d/2^%d passes %d/%d fused %d\n", sp.n_keys, sc.n_side[0],
@@ -711,7 +718,11 @@ size_t mat_doubles_of(const qsv_t* h, const Circuit& c, bool split, int side) {
 
 // allow_split: the caller only wants <D> of the final states (fused diagonal expectation), so a circuit that has a
 // split form (split.hpp) may run as its two virtual circuits + the contraction kernel.
-int batch_layout(qsv_t* h, const std::vector<Circuit*>& circs, const std::vector<int64_t>& n_params, bool allow_split = false) {
+// max_keys: split forms with more cut keys than the caller's kernels take (four and five keys: the factorised expectation
+// under a quadratic operator only) are not used; such a circuit runs its ordinary plan.
+int batch_layout(qsv_t* h, const std::vector<Circuit*>& circs, const std::vector<int64_t>& n_params, bool allow_split = false,
+                 int max_keys = 3) {
+    auto splits = [&](const Circuit* c) { return allow_split && c->split.ok && c->split.n_keys <= max_keys; };
     qsv_handle::Batch& b = h->batch;
     const size_t n_evals = circs.size();
     int rc;
@@ -724,7 +735,7 @@ int batch_layout(qsv_t* h, const std::vector<Circuit*>& circs, const std::vector
         // host's worker threads when there are several
         std::vector<Circuit*> missing;
         for (Circuit* c : circs)
-            if (!(allow_split && c->split.ok) && !c->has_plan && std::find(missing.begin(), missing.end(), c) == missing.end())
+            if (!splits(c) && !c->has_plan && std::find(missing.begin(), missing.end(), c) == missing.end())
                 missing.push_back(c);
         if (missing.size() >= 4) {
             std::vector<BuiltCircuit> built;
@@ -767,7 +778,7 @@ int batch_layout(qsv_t* h, const std::vector<Circuit*>& circs, const std::vector
             return fail(h, QSV_E_ARG, "circuit needs " + std::to_string(circs[i]->n_params) + " parameter values, got " +
                                           std::to_string(n_params[i]));
         total_params += size_t(n_params[i]);
-        const bool split = allow_split && circs[i]->split.ok;
+        const bool split = splits(circs[i]);
         b.split[i] = split;
         b.split_any |= split;
         total_mats += mat_doubles_of(h, *circs[i], split, 0) + (split ? mat_doubles_of(h, *circs[i], true, 1) : 0);
@@ -868,6 +879,10 @@ bool factor_path(const qsv_t* h) { return h->factor_enabled && h->diagonal && h-
 // ... and none under a general operator (kernels.hpp: launch_factor_terms).
 bool factor_terms_path(const qsv_t* h) { return h->factor_enabled && !h->diagonal && h->n_fterms > 0 && h->d_side.ptr != nullptr; }
 
+// Split evaluations flagged kEvalFused are finished by the launch that runs their virtual circuits (quadratic operator).
+bool fused_route(const qsv_t* h) { return factor_path(h) && h->d_factor_count.ptr != nullptr && h->fused_factor; }
+constexpr int kAuxSideSlots = 32;  // side-table slots set aside for the auxiliary stream in a batch with aux_split
+
 // Run the gate passes of evaluations [first, first+count) of the current batch (one launch group).
 int run_group(qsv_t* h, const std::vector<Circuit*>& circs, size_t first, size_t count, uint32_t mode) {
     const qsv_handle::Batch& b = h->batch;
@@ -909,7 +924,7 @@ int run_group(qsv_t* h, const std::vector<Circuit*>& circs, size_t first, size_t
     // of the split evaluations (they lead the group) the first n_unfused need launches of their own after the virtual
     // circuits; the others are finished by the launch that runs theirs (kEvalFused, under a quadratic operator only)
     size_t n_unfused = n_split;
-    const bool fuse_ok = factor_path(h) && !(mode & kModeSidesOnly) && h->d_factor_count.ptr != nullptr && h->fused_factor;
+    const bool fuse_ok = fused_route(h) && !(mode & kModeSidesOnly);
     if (fuse_ok) {
         n_unfused = 0;
         while (n_unfused < n_split && !circs[eval_of(first + n_unfused)]->split.fused) ++n_unfused;
@@ -1050,13 +1065,20 @@ int run_group(qsv_t* h, const std::vector<Circuit*>& circs, size_t first, size_t
     if (any_split && !(mode & kModeSidesOnly) && factor_path(h)) {
       if (n_unfused > 0) {
         // quadratic operator: the expectation value from the two side tables alone, written straight to the result buffer
+        int most_keys = 0;
+        for (size_t i = 0; i < n_unfused; ++i) most_keys = std::max(most_keys, circs[eval_of(first + i)]->split.n_keys);
+        if (most_keys > 3) {
+            int rc3 = ensure(h, h->d_factor_big, factor_big_slot_doubles() * sizeof(double) * size_t(h->side_slots));
+            if (rc3) return rc3;
+        }
         a.evals = batch_evals(h) + first;
         a.result_out = h->out_target ? h->out_target : h->h_out;
         if (h->stamping) QSV_HIP(h, stamp(h, h->batch.launch_events[2], true));
         QSV_HIP(h, launch_factor(h->dtype, unsigned(n_unfused), static_cast<double*>(h->d_factor.ptr),
-                                 static_cast<const double*>(h->d_quad.ptr), h->n, ws(h), a));
+                                 static_cast<const double*>(h->d_quad.ptr), h->n, ws(h), a, static_cast<double*>(h->d_factor_big.ptr),
+                                 most_keys));
         if (h->stamping) QSV_HIP(h, stamp(h, h->batch.launch_events[2], false));
-        h->prof.kernel_launches[2] += 1;  // (the pair of launches, timed as one)
+        h->prof.kernel_launches[2] += 1;  // (the launches of the route, timed as one)
       }
         for (size_t i = 0; i < n_unfused; ++i) {
             const SplitInfo& sp = circs[eval_of(first + i)]->split;
@@ -1139,7 +1161,7 @@ int eval_begin(qsv_t* h, const std::vector<Circuit*>& circs, const std::vector<i
         QSV_HIP(h, hipEventCreate(&h->batch.ev1));
         QSV_HIP(h, hipEventRecord(h->batch.ev0, h->stream));
     }
-    if ((rc = batch_layout(h, circs, n_params, h->diagonal || factor_terms_path(h)))) return rc;
+    if ((rc = batch_layout(h, circs, n_params, h->diagonal || factor_terms_path(h), factor_path(h) ? kMaxSplitKeys : 3))) return rc;
     if (factor_terms_path(h) && h->batch.split_any &&
         (rc = ensure(h, h->d_fpart, std::max<size_t>(1, n_evals) * kFactorTermWaves * sizeof(double))))
         return rc;
@@ -1161,7 +1183,15 @@ int eval_begin(qsv_t* h, const std::vector<Circuit*>& circs, const std::vector<i
     b.aux_plain = false;
     if (h->diagonal && b.split_any && factor_path(h) && h->geo.blocks_per_state > 1)
         for (size_t i = 0; i < n_evals && !b.aux_plain; ++i) b.aux_plain = b.split[i] == 0;
-    if (b.aux_plain && h->aux_stream < 0) {
+    b.aux_split = false;
+    if (h->diagonal && b.split_any && fused_route(h) && h->side_slots >= 4 * kAuxSideSlots) {
+        bool any_fused = false, any_other = false;
+        for (size_t i = 0; i < n_evals; ++i)
+            if (b.split[i]) (circs[i]->split.fused ? any_fused : any_other) = true;
+        b.aux_split = any_fused && any_other;
+    }
+    b.aux_split_count = 0;
+    if ((b.aux_plain || b.aux_split) && h->aux_stream < 0) {
         hipStream_t st = nullptr;
         QSV_HIP(h, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
         h->side_streams.push_back(st);
@@ -1244,15 +1274,25 @@ int eval_push(qsv_t* h, size_t first, size_t count, const double* values) {
             b.used_mask |= 1u << (lane - 1);
         }
     }
-    const size_t SG = h->side_slots > 0 ? std::max<size_t>(1, size_t(h->side_slots) / ways) : 1;
+    // (a batch with aux_split: the split evaluations that need launches of their own lead the push; they take the slots set
+    // aside for the auxiliary stream, which orders every reuse of those)
+    size_t n_aux_split = 0;
+    if (b.aux_split)
+        while (n_aux_split < n_split && !b.circs[b.eval_at[first + n_aux_split]]->split.fused) ++n_aux_split;
+    const size_t lane_slots = h->side_slots > 0 ? size_t(h->side_slots) - (b.aux_split ? size_t(kAuxSideSlots) : 0) : 0;
+    const size_t SG = lane_slots > 0 ? std::max<size_t>(1, lane_slots / ways) : 1;
     for (size_t j = 0; j < n_split; ++j) {
-        const uint32_t slot = uint32_t(lane * SG + j % SG);
+        const uint32_t slot = j < n_aux_split ? uint32_t(lane_slots + (b.aux_split_count + j) % size_t(kAuxSideSlots))
+                                              : uint32_t(lane * SG + (j - n_aux_split) % SG);
         hd[first + j].state_slot = slot;
         hd[P + first + j].state_slot = slot;
     }
+    b.aux_split_count += n_aux_split;
     hipStream_t const lane_stream = h->work;  // (null: the handle's own)
     hipStream_t const plain_stream = b.aux_plain ? h->side_streams[size_t(h->aux_stream)] : lane_stream;
     if (b.aux_plain && n_split < count) b.used_mask |= 1u << h->aux_stream;
+    hipStream_t const aux_split_stream = n_aux_split > 0 ? h->side_streams[size_t(h->aux_stream)] : lane_stream;
+    if (n_aux_split > 0) b.used_mask |= 1u << h->aux_stream;
     for (size_t j = n_split; j < count; ++j) {
         // (on the auxiliary stream every ordinary evaluation of the batch: one stream orders every reuse of a slot)
         const uint32_t slot = b.aux_plain ? uint32_t((b.aux_count + (j - n_split)) % size_t(h->group))
@@ -1277,13 +1317,16 @@ int eval_push(qsv_t* h, size_t first, size_t count, const double* values) {
     // launch groups: the split evaluations of the push in groups of SG, then the ordinary ones in groups of G
     for (size_t g0 = first; g0 < first + count;) {
         const bool in_split = g0 < first + n_split;
-        const size_t gc = in_split ? std::min(SG, first + n_split - g0) : std::min(G, first + count - g0);
+        const bool in_aux_split = g0 < first + n_aux_split;
+        const size_t gc = in_aux_split ? std::min(size_t(kAuxSideSlots), first + n_aux_split - g0)
+                          : in_split   ? std::min(SG, first + n_split - g0)
+                                       : std::min(G, first + count - g0);
         struct Advance {
             size_t& g0;
             size_t gc;
             ~Advance() { g0 += gc; }
         } advance{g0, gc};
-        h->work = in_split ? lane_stream : plain_stream;
+        h->work = in_aux_split ? aux_split_stream : in_split ? lane_stream : plain_stream;
         QSV_HIP(h, stamp(h, b.pass_events, true));
         rc = run_group(h, b.circs, g0, gc, group_mode);
         if (!rc) QSV_HIP(h, stamp(h, b.pass_events, false));
@@ -1577,7 +1620,7 @@ void qsv_destroy(qsv_t* h) {
     }
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     for (DeviceBuffer* b : {&h->d_z, &h->d_cre, &h->d_diag, &h->d_term_partials, &h->d_groups, &h->d_term_odd, &h->d_arena,
-                            &h->d_states, &h->d_wtab, &h->d_side, &h->d_factor, &h->d_factor_count, &h->d_quad, &h->d_fterms, &h->d_fpart, &h->d_batch, &h->d_mats, &h->d_partials, &h->d_out, &h->d_scratch})
+                            &h->d_states, &h->d_wtab, &h->d_side, &h->d_factor, &h->d_factor_count, &h->d_factor_big, &h->d_quad, &h->d_fterms, &h->d_fpart, &h->d_batch, &h->d_mats, &h->d_partials, &h->d_out, &h->d_scratch})
         if (b->ptr) (void)hipFree(b->ptr);
     if (h->h_batch) (void)hipHostFree(h->h_batch);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
@@ -1940,7 +1983,7 @@ int qsv_eval_set_output(qsv_t* h, double* device_out) {
         // The caller may already have queued writes to the output buffer on the handle's stream (a fill of the unused
         // tail of an uneven shard).  The batch's ordinary evaluations can run on the auxiliary stream (mixed batches,
         // eval_begin): whatever stream of ours writes results must come after that work.
-        if (h->batch.aux_plain && h->aux_stream >= 0) {
+        if ((h->batch.aux_plain || h->batch.aux_split) && h->aux_stream >= 0) {
             QSV_HIP(h, hipEventRecord(h->ev_join, h->stream));
             QSV_HIP(h, hipStreamWaitEvent(h->side_streams[size_t(h->aux_stream)], h->ev_join, 0));
         }

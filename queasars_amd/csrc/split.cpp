@@ -235,9 +235,121 @@ SplitCircuits find_split(int n, const std::vector<GateIn>& all_gates, const std:
         }
         return false;
     };
-    for (int size = 0; !found && size <= max_keys && size <= nk; ++size) {
+    // Up to three keys by enumeration (above); four and five by branch and bound over the QUBITS (below): C(keys, 4) key
+    // sets are tens of thousands of sweeps for the circuits that need them, whereas few partial assignments of a well
+    // connected register cut at most five keys.
+    for (int size = 0; !found && size <= std::min(max_keys, 3) && size <= nk; ++size) {
         without.clear();
         found = choose(0, size);
+    }
+    bool any_hit = false;
+    for (size_t stage = 0; stage < max_sides.size(); ++stage) any_hit |= hit[stage] != 0;
+    if (!any_hit && max_keys > 3 && nk > 3) {
+        // Assign the qubits that take part in keys one by one (breadth first from the busiest one, so that keys are
+        // decided early); a key is cut once it has members on both sides; a branch dies when it cuts more keys than the
+        // bound or a side no longer fits the largest limit.  Bounds 4, then 5: the first leaf found has the fewest keys
+        // beyond three.  Qubits without keys go wherever the sizes need them.  Exact up to the node budget.
+        std::vector<int> order;
+        {
+            std::vector<char> seen(size_t(n), 0);
+            std::vector<int> degree(size_t(n), 0);
+            for (int q = 0; q < n; ++q) degree[size_t(q)] = int(keys_of_qubit[size_t(q)].size());
+            for (;;) {
+                int start = -1;
+                for (int q = 0; q < n; ++q)
+                    if (!seen[size_t(q)] && degree[size_t(q)] > 0 && (start < 0 || degree[size_t(q)] > degree[size_t(start)])) start = q;
+                if (start < 0) break;
+                size_t head = order.size();
+                order.push_back(start);
+                seen[size_t(start)] = 1;
+                while (head < order.size()) {
+                    const int u = order[head++];
+                    for (int j : keys_of_qubit[size_t(u)]) {
+                        const Key& k = keys[size_t(j)];
+                        auto visit = [&](int v) {
+                            if (!seen[size_t(v)]) {
+                                seen[size_t(v)] = 1;
+                                order.push_back(v);
+                            }
+                        };
+                        visit(k.control);
+                        for (int t : k.targets) visit(t);
+                    }
+                }
+            }
+        }
+        const int n_active = int(order.size()), n_free = n - n_active;
+        int largest = 0;
+        for (size_t stage = 0; stage < max_sides.size(); ++stage)
+            if (open_stage[stage]) largest = std::max(largest, max_sides[stage]);
+        std::vector<int> side(size_t(n), -1), on_a(size_t(nk), 0), on_b(size_t(nk), 0);
+        int count[2] = {0, 0}, cut = 0;
+        long nodes = 0;
+        constexpr long kNodeBudget = 200000;
+        int bound = 0;
+        bool done = false;
+        std::function<void(int)> descend = [&](int depth) {
+            if (done || ++nodes > kNodeBudget) return;
+            if (depth == n_active) {
+                // the free qubits fill the sides up: most balanced split the sizes allow, per stage
+                for (size_t stage = 0; stage < max_sides.size(); ++stage) {
+                    if (!open_stage[stage] || hit[stage]) continue;
+                    const int room = max_sides[stage] - cut;  // own qubits a side may have
+                    if (count[0] > room || count[1] > room || n > 2 * room) continue;
+                    int to_a = std::max(0, std::min(n_free, n / 2 - count[0]));
+                    to_a = std::max(to_a, n_free - (room - count[1]));
+                    to_a = std::min(to_a, room - count[0]);
+                    uint64_t side_a = 0;
+                    int given = 0;
+                    for (int q = 0; q < n; ++q) {
+                        if (side[size_t(q)] == 0 || (side[size_t(q)] < 0 && given < to_a)) {
+                            side_a |= uint64_t(1) << q;
+                            given += side[size_t(q)] < 0;
+                        }
+                    }
+                    side_of_stage[stage] = side_a;
+                    hit[stage] = 1;
+                }
+                // (a smaller limit cannot have a partition with this many keys or more: n / 2 + keys is what a side needs)
+                bool more = false;
+                for (size_t stage = 0; stage < max_sides.size(); ++stage)
+                    more |= open_stage[stage] && !hit[stage] && 2 * (max_sides[stage] - bound) >= n;
+                done = !more;
+                return;
+            }
+            const int v = order[size_t(depth)];
+            const int first_side = (depth == 0 || count[0] <= count[1]) ? 0 : 1;
+            for (int turn = 0; turn < 2 && !done; ++turn) {
+                const int s2 = turn == 0 ? first_side : 1 - first_side;
+                if (depth == 0 && s2 == 1) break;  // (the mirror image)
+                int newly_cut = 0;
+                for (int j : keys_of_qubit[size_t(v)]) {
+                    int& mine = s2 == 0 ? on_a[size_t(j)] : on_b[size_t(j)];
+                    const int other = s2 == 0 ? on_b[size_t(j)] : on_a[size_t(j)];
+                    if (mine == 0 && other > 0) ++newly_cut;
+                    ++mine;
+                }
+                cut += newly_cut;
+                count[s2] += 1;
+                side[size_t(v)] = s2;
+                if (cut <= bound && count[0] + cut <= largest && count[1] + cut <= largest) descend(depth + 1);
+                side[size_t(v)] = -1;
+                count[s2] -= 1;
+                cut -= newly_cut;
+                for (int j : keys_of_qubit[size_t(v)]) --(s2 == 0 ? on_a[size_t(j)] : on_b[size_t(j)]);
+            }
+        };
+        // (a qubit is listed once per key it belongs to: a key that names it as control AND target cannot exist)
+        for (bound = 4; bound <= max_keys && !done; ++bound) {
+            bool possible = false;
+            for (size_t stage = 0; stage < max_sides.size(); ++stage) possible |= open_stage[stage] && 2 * (max_sides[stage] - bound) >= n;
+            if (!possible) break;
+            nodes = 0;
+            descend(0);
+            bool got = false;
+            for (size_t stage = 0; stage < max_sides.size(); ++stage) got |= hit[stage] != 0;
+            if (got) break;
+        }
     }
     (void)found;
     for (size_t stage = 0; stage < max_sides.size(); ++stage) {

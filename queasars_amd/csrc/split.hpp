@@ -39,7 +39,7 @@ constexpr int32_t kFixedProj0 = -2;  // [[1, 0], [0, 0]]
 constexpr int32_t kFixedOnes = -3;   // [[1, 0], [1, 0]]: applied to |0> it gives (1, 1)
 constexpr int32_t kFixedX = -4;      // [[0, 1], [1, 0]]
 
-constexpr int kMaxSplitKeys = 3;
+constexpr int kMaxSplitKeys = 5;  // (beyond three: 16 / 32 product terms, kernels.hpp launch_factor_big; quadratic operators only)
 
 struct SplitCircuits {
     bool ok = false;

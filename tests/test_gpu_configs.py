@@ -15,7 +15,7 @@ import pytest
 
 import helpers
 from queasars_amd import _lib
-from queasars_amd.circuit_evaluation import OperatorCircuitEvaluator, StatevectorDevice
+from queasars_amd.circuit_evaluation import OperatorCircuitEvaluator, OperatorSamplerCircuitEvaluator, StatevectorDevice
 from queasars_amd.ir import QSV_OP_DTYPE, CircuitIR, PauliOperator
 
 pytestmark = pytest.mark.gpu
@@ -526,7 +526,8 @@ def test_split_evaluations_agree_with_the_pass_path(n, layers, count):
     _, circuits, params = helpers.population_circuits(n, layers, count, seed=40 + n)
     op = helpers.random_ising_operator(n, seed=n)
     keys = [_keys_like_the_library(c, n) for c in circuits]
-    assert max(keys) >= 1 and min(keys) <= 0, keys  # the population exercises keys, and key-less or unsplit circuits
+    # the population exercises keys, and key-less or unsplit circuits (or, since four and five keys are taken, those)
+    assert max(keys) >= 1 and (min(keys) <= 0 or max(keys) >= 4), keys
     split = OperatorCircuitEvaluator(op, statevector_device=_split_device(n, True)).evaluate_circuits(circuits, params)
     plain = OperatorCircuitEvaluator(op, statevector_device=_split_device(n, False)).evaluate_circuits(circuits, params)
     assert np.abs(np.asarray(split) - np.asarray(plain)).max() < EXP_TOL
@@ -534,6 +535,44 @@ def test_split_evaluations_agree_with_the_pass_path(n, layers, count):
     for i in (0, count // 2, count - 1):
         if n <= 16:
             assert abs(split[i] - helpers.oracle_expectation(circuits[i], params[i], op)) < EXP_TOL
+
+
+@pytest.mark.parametrize("n,layers,count", [(20, 6, 32), (20, 5, 48), (24, 6, 12)])
+def test_split_evaluations_with_four_and_five_keys(n, layers, count, c_oracle):
+    """Deeper individuals split with four and five cut keys (16 / 32 product terms: launch_factor_big, quadratic operators
+    only): against the C oracle (1e-10), against the multi-pass path, bitwise the same alone as in the batch; under a
+    general operator and in the sampler branch the same circuits take their ordinary plans."""
+    _, circuits, params = helpers.population_circuits(n, layers, count, seed=0)
+    limit = 16 if n < 21 else 17
+    keys = [_split_keys(c, limit) for c in circuits]
+    assert max(keys) >= 4, keys
+    op = helpers.random_ising_operator(n, seed=2020)
+    ev = OperatorCircuitEvaluator(op)
+    got = ev.evaluate_circuits(circuits, params)
+    prof_dev = ev.statevector_device
+    prof_dev.set_profiling(True)
+    ev.evaluate_circuits(circuits, params)
+    prof = prof_dev.profile()
+    prof_dev.set_profiling(False)
+    assert prof["kernel_states"][2] >= sum(1 for k in keys if k >= 4), "the circuits with four and five keys did not run split"
+    table = c_oracle.diagonal_table(op)
+    scratch = np.zeros(2 << n)
+    big = [i for i, k in enumerate(keys) if k >= 4]
+    for i in (big[:6] if n < 24 else big[:2]) + [0]:
+        assert abs(got[i] - c_oracle.evaluate(circuits[i], params[i], op, table, scratch)) < EXP_TOL, (i, keys[i])
+    plain = OperatorCircuitEvaluator(op, statevector_device=_split_device(n, False)).evaluate_circuits(circuits, params)
+    assert np.abs(np.asarray(got) - np.asarray(plain)).max() < EXP_TOL
+    assert [ev.evaluate_circuits([circuits[i]], [params[i]])[0] for i in big[:4]] == [got[i] for i in big[:4]]
+    if n == 20 and layers == 6:
+        general = helpers.random_pauli_operator(n, 6, seed=4)
+        sub_c, sub_p = [circuits[i] for i in big[:3]], [params[i] for i in big[:3]]
+        a = OperatorCircuitEvaluator(general).evaluate_circuits(sub_c, sub_p)
+        b = OperatorCircuitEvaluator(general, statevector_device=_split_device(n, False)).evaluate_circuits(sub_c, sub_p)
+        assert np.abs(np.asarray(a) - np.asarray(b)).max() < EXP_TOL
+        sampler = OperatorSamplerCircuitEvaluator(20000, op, alpha=1.0, seed=3)
+        means = sampler.evaluate_circuits(sub_c, sub_p)
+        spread = float(np.abs(op.coeffs).sum())
+        assert np.abs(np.asarray(means) - np.asarray([got[i] for i in big[:3]])).max() < 0.05 * spread
 
 
 def test_split_results_do_not_depend_on_the_batch(c_oracle):

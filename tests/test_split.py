@@ -79,7 +79,8 @@ def check(circuit: CircuitIR, params, max_side: int):
     return k
 
 
-@pytest.mark.parametrize("n,layers,max_side", [(10, 3, 7), (12, 4, 8), (14, 4, 9), (14, 6, 9), (16, 4, 10)])
+@pytest.mark.parametrize("n,layers,max_side", [(10, 3, 7), (12, 4, 8), (14, 4, 9), (14, 6, 9), (16, 4, 10), (12, 6, 11), (14, 7, 12),
+                                               (16, 6, 13)])
 def test_virtual_circuits_reproduce_the_state(n, layers, max_side):
     population = EVQEPopulation.random_population(n, layers, 24, True, 5 + n)
     seen = []
@@ -90,6 +91,8 @@ def test_virtual_circuits_reproduce_the_state(n, layers, max_side):
     assert seen, "no circuit of the population was split"
     if layers >= 4:
         assert max(seen) >= 1, "only fully separable circuits: the key construction was not exercised"
+    if 2 * max_side >= n + 8 and layers >= 6:  # (room for four keys on both sides)
+        assert max(seen) >= 4, f"no circuit with four or five keys (16 / 32 product terms): {seen}"
 
 
 def test_keys_and_projections_by_hand():
@@ -141,11 +144,13 @@ def _keys_of(circuit: CircuitIR):
     return [(c, ts) for (c, _), ts in keys.items()]
 
 
-@pytest.mark.parametrize("n,layers,max_side", [(8, 3, 5), (9, 4, 6), (10, 4, 6), (10, 5, 7), (11, 3, 6)])
+@pytest.mark.parametrize("n,layers,max_side", [(8, 3, 5), (9, 4, 6), (10, 4, 6), (10, 5, 7), (11, 3, 6), (10, 5, 9), (11, 6, 10),
+                                               (12, 5, 10), (12, 7, 11), (13, 6, 11)])
 def test_the_partition_cuts_as_few_keys_as_any(n, layers, max_side):
     """Against brute force over all 2^(n-1) bipartitions: the splitter's number of keys is the minimum over the partitions
-    whose virtual circuits fit the size limit, and it reports no split form exactly when there is none with at most three
-    keys (the pruned search -- articulation points, one enumeration for several limits -- is exact)."""
+    whose virtual circuits fit the size limit, and it reports no split form exactly when there is none with at most five
+    keys (up to three keys: the pruned enumeration -- articulation points, one enumeration for several limits --; four and
+    five: branch and bound over the qubits; both exact)."""
     population = EVQEPopulation.random_population(n, layers, 40, True, 300 + n + layers)
     outcomes = set()
     for individual in population.individuals:
@@ -155,7 +160,7 @@ def test_the_partition_cuts_as_few_keys_as_any(n, layers, max_side):
         for a_mask in range(1, 1 << (n - 1)):  # qubit n - 1 always on side B: every bipartition once
             cut = sum(1 for c, ts in keys if any(((a_mask >> c) & 1) != ((a_mask >> t) & 1) for t in ts))
             size_a = bin(a_mask).count("1")
-            if cut <= 3 and size_a + cut <= max_side and n - size_a + cut <= max_side and (best is None or cut < best):
+            if cut <= 5 and size_a + cut <= max_side and n - size_a + cut <= max_side and (best is None or cut < best):
                 best = cut
         got = describe(circuit, max_side)
         assert (got[0] if got is not None else None) == best, (keys, got and got[:2], best)
