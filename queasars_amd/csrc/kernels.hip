@@ -555,6 +555,15 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, FIRST>::waves_per_si
         const size_t slot = size_t(blockIdx.y) + size_t(blockIdx.z) * a.region_stride;
         ev = a.host_evals[slot];
         if (ev.flags & kEvalNull) return;
+        {
+            // a launch's grid is as wide as its largest evaluation: a workgroup beyond THIS evaluation's tiles leaves before
+            // the preparation (its reads of parameters over PCIe, times the width of the grid, were most of such a launch)
+            const uint32_t* c0 = plan_arena + ev.plan_base;
+            const uint32_t* p0 = c0 + c0[kCircuitHeaderWords];
+            const uint32_t f0 = p0[2];
+            const uint32_t tiles0 = (f0 & kPassCompactStore) ? 1u << ((f0 >> 8) & 0xffu) : 1u << (c0[2] - (p0[0] & 0xffu));
+            if (blockIdx.x >= tiles0) return;
+        }
         if (threadIdx.x == 0 && blockIdx.x == 0) a.evals_out[slot] = ev;
 #ifdef QSV_STAMPS
         QSV_STAMP(0);  // descriptor

@@ -881,7 +881,7 @@ bool factor_terms_path(const qsv_t* h) { return h->factor_enabled && !h->diagona
 
 // Split evaluations flagged kEvalFused are finished by the launch that runs their virtual circuits (quadratic operator).
 bool fused_route(const qsv_t* h) { return factor_path(h) && h->d_factor_count.ptr != nullptr && h->fused_factor; }
-constexpr int kAuxSideSlots = 32;  // side-table slots set aside for the auxiliary stream in a batch with aux_split
+constexpr int kAuxSideSlots = 48;  // side-table slots set aside for the auxiliary stream in a batch with aux_split
 
 // Run the gate passes of evaluations [first, first+count) of the current batch (one launch group).
 int run_group(qsv_t* h, const std::vector<Circuit*>& circs, size_t first, size_t count, uint32_t mode) {
@@ -1184,7 +1184,7 @@ int eval_begin(qsv_t* h, const std::vector<Circuit*>& circs, const std::vector<i
     if (h->diagonal && b.split_any && factor_path(h) && h->geo.blocks_per_state > 1)
         for (size_t i = 0; i < n_evals && !b.aux_plain; ++i) b.aux_plain = b.split[i] == 0;
     b.aux_split = false;
-    if (h->diagonal && b.split_any && fused_route(h) && h->side_slots >= 4 * kAuxSideSlots) {
+    if (h->diagonal && b.split_any && fused_route(h) && h->side_slots > 2 * kAuxSideSlots) {
         bool any_fused = false, any_other = false;
         for (size_t i = 0; i < n_evals; ++i)
             if (b.split[i]) (circs[i]->split.fused ? any_fused : any_other) = true;
