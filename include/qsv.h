@@ -216,6 +216,18 @@ int qsv_sample_batch(qsv_t* h, int n_evals, const int* circuit_ids, const int64_
 int qsv_sample_cvar_batch(qsv_t* h, int n_evals, const int* circuit_ids, const int64_t* param_offsets, const double* params,
                           int shots, uint64_t seed, double alpha, double* out_cvar);
 
+/*
+ * The sampler branch without sampling noise: out_cvar[i] = CVaR_alpha of the operator's values under the EXACT distribution
+ * |amplitude|^2 of evaluation i -- the value get_expectation_with_operator / _get_expectation would return for a measured
+ * distribution that equals the exact one (reference: queasars/circuit_evaluation/expectation_calculation.py:14-32, :55-69),
+ * including the loop's stopping rule numpy.isclose(gathered, alpha) and, for states of equal value, the index order a stable
+ * sort leaves them in.  Needs a diagonal operator on the handle, 0 < alpha <= 1 and at most 28 qubits; deterministic.
+ * (For alpha = 1 this is the expectation value qsv_eval_circuits computes.)  Circuits that have a split form are read from
+ * their two side tables, the others from the probabilities their last gate pass writes.
+ */
+int qsv_exact_cvar_batch(qsv_t* h, int n_evals, const int* circuit_ids, const int64_t* param_offsets, const double* params,
+                         double alpha, double* out_cvar);
+
 /* ---- measurement support ----------------------------------------------------------------------- */
 
 /*

@@ -15,7 +15,7 @@ PKG_DIR = Path(__file__).resolve().parent
 CSRC = PKG_DIR / "csrc"
 LIB_PATH = PKG_DIR / "libqsv.so"
 PYHELP_PATH = PKG_DIR / "_qsvpyhelp.so"  # CPython-API helper of the Python layer (csrc/pyhelp.c), optional
-SOURCES = ["kernels.hip", "qsv_api.hip", "plan.cpp", "split.cpp"]
+SOURCES = ["kernels.hip", "qsv_api.hip", "plan.cpp", "split.cpp", "sort.hip"]
 HEADERS = ["kernels.hpp", "plan.hpp", "split.hpp", "gate_loop_gen.inc", "../../include/qsv.h"]
 ARCH = "gfx950"
 

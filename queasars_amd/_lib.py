@@ -90,6 +90,7 @@ SIGNATURES = {
     "qsv_sample": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_uint64, _P]),
     "qsv_sample_batch": (C.c_int, [_P, C.c_int, _P, _P, _P, C.c_int, C.c_uint64, _P, _P]),
     "qsv_sample_cvar_batch": (C.c_int, [_P, C.c_int, _P, _P, _P, C.c_int, C.c_uint64, C.c_double, _P]),
+    "qsv_exact_cvar_batch": (C.c_int, [_P, C.c_int, _P, _P, _P, C.c_double, _P]),
     "qsv_set_option": (C.c_int, [_P, C.c_char_p, C.c_int]),
     "qsv_set_profiling": (C.c_int, [_P, C.c_int]),
     "qsv_get_profile": (C.c_int, [_P, C.POINTER(QsvProfile)]),

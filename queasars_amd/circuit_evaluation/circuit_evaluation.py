@@ -518,6 +518,28 @@ class StatevectorDevice:
         )
         return out.tolist()
 
+    def exact_cvar_batch(self, circuits: Sequence[CircuitIR], parameter_values: Sequence[Sequence[float]], alpha: float) -> list[float]:
+        """CVaR_alpha of the (diagonal) operator under the EXACT output distribution of every (circuit, parameter vector)
+        pair (``qsv_exact_cvar_batch``): what the reference's accumulation loop returns for a measured distribution that
+        equals the exact one (expectation_calculation.py:14-32), stopping rule and tie order included.  Deterministic."""
+        n = len(circuits)
+        if len(parameter_values) != n:
+            raise ValueError("circuits and parameter_values must have the same length")
+        if n == 0:
+            return []
+        ids, need, _ = self._batch_metadata(circuits)
+        counts = np.fromiter(map(len, parameter_values), dtype=np.int64, count=n)
+        if (counts < need).any():
+            i = int(np.argmax(counts < need))
+            raise ValueError(f"circuit {i} needs {int(need[i])} parameter values, got {int(counts[i])}")
+        offsets = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(counts, out=offsets[1:])
+        flat = _pack_slice(parameter_values, 0, n, int(offsets[-1])) if offsets[-1] else np.zeros(1)
+        out = np.empty(n, dtype=np.float64)
+        self._check(self._lib.qsv_exact_cvar_batch(self._handle, n, _lib.as_ptr(ids), _lib.as_ptr(offsets), _lib.as_ptr(flat),
+                                                   float(alpha), _lib.as_ptr(out)))
+        return out.tolist()
+
     # -- measurement support ----------------------------------------------------------------------
     def set_option(self, name: str, value: int) -> None:
         """Switches of the handle (``qsv_set_option``): "split", "factor", "split_sampling" (0 / 1), "streams" (1 .. 4).
@@ -734,11 +756,15 @@ def _cvar_of_sample_matrix(values: np.ndarray, alpha: float) -> list[float]:
 
 
 class OperatorSamplerCircuitEvaluator(BaseCircuitEvaluator):
-    """Expectation / CVaR_alpha of a diagonal operator from ``sampler_shots`` measurements (reference [94-161])."""
+    """Expectation / CVaR_alpha of a diagonal operator from ``sampler_shots`` measurements (reference [94-161]).
+
+    ``sampler_shots=None`` (not in the reference, whose samplers always draw): the same quantity for the EXACT output
+    distribution -- no sampling noise, deterministic, the limit the sampled values scatter around -- computed on the
+    device (:meth:`StatevectorDevice.exact_cvar_batch`)."""
 
     def __init__(
         self,
-        sampler_shots: int,
+        sampler_shots: Optional[int],
         operator: PauliOperator,
         alpha: float = 1.0,
         initial_state_circuit: Optional[CircuitIR] = None,
@@ -757,7 +783,9 @@ class OperatorSamplerCircuitEvaluator(BaseCircuitEvaluator):
             raise ValueError("alpha must be in the range (0, 1]!")
         _check_initial_state(initial_state_circuit, operator.num_qubits, "the amount of qubits in the given operator")
         self._operator = operator
-        self._shots = int(sampler_shots)
+        if sampler_shots is not None and int(sampler_shots) < 1:
+            raise ValueError("sampler_shots must be a positive number of shots, or None for the exact distribution!")
+        self._shots = None if sampler_shots is None else int(sampler_shots)
         self._alpha = float(alpha)
         self._initial_state_circuit = initial_state_circuit
         self._rng = np.random.default_rng(seed)
@@ -778,6 +806,10 @@ class OperatorSamplerCircuitEvaluator(BaseCircuitEvaluator):
         with self._device.operator_lock:
             if self._device._operator is not self._operator:
                 self._device.set_operator(self._operator)
+            if self._shots is None:
+                if np.isclose(self._alpha, 1):  # (the reference takes the plain mean there: the expectation value)
+                    return self._device.expectation_values([c for c, _ in pairs], [p for _, p in pairs]).tolist()
+                return self._device.exact_cvar_batch([c for c, _ in pairs], [p for _, p in pairs], self._alpha)
             if self._shots <= StatevectorDevice.MAX_CVAR_SHOTS:
                 return self._device.sample_cvar_batch([c for c, _ in pairs], [p for _, p in pairs], self._shots, seed, self._alpha)
             _, values = self._device.sample_batch([c for c, _ in pairs], [p for _, p in pairs], self._shots, seed, with_values=True)

@@ -2846,6 +2846,252 @@ hipError_t launch_factor_terms(int dtype, unsigned n_evals, const FactorTerm* te
     return hipGetLastError();
 }
 
+// ---- exact-probability CVaR (kernels.hpp: launch_cvar_exact) -------------------------------------------------------------
+// The probability of one basis state of one evaluation: an entry of the probabilities a gate pass left, or -- a split
+// circuit -- |sum_j X_j[x(i)] Y_j[y(i)]|^2 from the two side tables.
+template <typename real>
+struct ExactSource {
+    const double* probs = nullptr;
+    const cx<real>* X = nullptr;
+    const cx<real>* Y = nullptr;
+    uint32_t bits_x = 0, bits_y = 0, mask_x = 0, mask_y = 0, terms = 0;
+    __device__ __forceinline__ double operator()(uint32_t i) const {
+        if (terms == 0) return probs[i];
+        const uint32_t x = extract_bits(i, mask_x), y = extract_bits(i, mask_y);
+        double pr = 0.0, pi = 0.0;
+        for (uint32_t j = 0; j < terms; ++j) {
+            const cx<real> a = X[(size_t(j) << bits_x) + x], b = Y[(size_t(j) << bits_y) + y];
+            const double ar = double(a.re), ai = double(a.im), br = double(b.re), bi = double(b.im);
+            pr = fma(ar, br, fma(-ai, bi, pr));
+            pi = fma(ar, bi, fma(ai, br, pi));
+        }
+        return fma(pr, pr, pi * pi);
+    }
+};
+
+template <typename real>
+__device__ __forceinline__ ExactSource<real> exact_source(const uint32_t* __restrict__ plan_arena, const EvalDesc& ev, uint32_t position,
+                                                          const double* __restrict__ probs_all, uint64_t dim,
+                                                          const cx<real>* __restrict__ sides, uint64_t side_stride) {
+    ExactSource<real> src;
+    if (ev.flags & kEvalSide) {
+        const uint32_t* sp = plan_arena + ev.split_base;
+        const bool swap = sp[3] & 1u;
+        const cx<real>* ta = sides + uint64_t(ev.state_slot) * side_stride;
+        src.X = ta + (swap ? side_stride >> 1 : 0);
+        src.Y = ta + (swap ? 0 : side_stride >> 1);
+        src.bits_x = sp[1];
+        src.bits_y = sp[2];
+        src.mask_x = sp[kSplitMaskX];
+        src.mask_y = sp[kSplitMaskY];
+        src.terms = 1u << sp[0];
+    } else {
+        src.probs = probs_all + uint64_t(ev.state_slot) * dim;  // (the group's states: slot = position in the group's buffers)
+    }
+    (void)position;
+    return src;
+}
+
+// chunk c of evaluation e: mass and mass x value of ranks [c kCvarChunk, (c + 1) kCvarChunk), every thread its strided share
+// in ascending order, then the fixed-order block sums
+template <typename real>
+__global__ void __launch_bounds__(256) cvar_exact_chunks_kernel(const uint32_t* __restrict__ plan_arena, const EvalDesc* __restrict__ evals,
+                                                                const double* __restrict__ probs_all, uint64_t dim,
+                                                                const cx<real>* __restrict__ sides, uint64_t side_stride,
+                                                                const uint32_t* __restrict__ order, const double* __restrict__ sorted,
+                                                                uint32_t n_chunks, double* __restrict__ scratch) {
+    __shared__ double red[4];
+    const EvalDesc ev = evals[blockIdx.y];
+    const ExactSource<real> src = exact_source<real>(plan_arena, ev, blockIdx.y, probs_all, dim, sides, side_stride);
+    const uint64_t base = uint64_t(blockIdx.x) * kCvarChunk;
+    double m = 0.0, w = 0.0;
+#pragma unroll 4
+    for (uint32_t k = 0; k < kCvarChunk / 256; ++k) {
+        const uint64_t pos = base + uint64_t(k) * 256 + threadIdx.x;
+        if (pos < dim) {
+            const double p = src(order[pos]);
+            m += p;
+            w = fma(p, sorted[pos], w);
+        }
+    }
+    const double mass = block_sum_256(m, red);
+    const double wsum = block_sum_256(w, red);
+    if (threadIdx.x == 0) {
+        scratch[(size_t(blockIdx.y) * 2 + 0) * n_chunks + blockIdx.x] = mass;
+        scratch[(size_t(blockIdx.y) * 2 + 1) * n_chunks + blockIdx.x] = wsum;
+    }
+}
+
+// one workgroup per evaluation: the chunk in which the gathered mass comes within numpy.isclose of alpha, the rank inside it,
+// and the accumulation up to there (see kernels.hpp for the rule being restated)
+template <typename real>
+__global__ void __launch_bounds__(256) cvar_exact_finish_kernel(const uint32_t* __restrict__ plan_arena, const EvalDesc* __restrict__ evals,
+                                                                const double* __restrict__ probs_all, uint64_t dim,
+                                                                const cx<real>* __restrict__ sides, uint64_t side_stride,
+                                                                const uint32_t* __restrict__ order, const double* __restrict__ sorted,
+                                                                uint32_t n_chunks, const double* __restrict__ scratch, double alpha,
+                                                                double* __restrict__ out) {
+    __shared__ double sh_a[256], sh_b[256];
+    __shared__ uint32_t sh_i[256];
+    __shared__ double pick[4];
+    __shared__ uint32_t pick_i[2];
+    const EvalDesc ev = evals[blockIdx.x];
+    const uint32_t t = threadIdx.x;
+    const double* mass = scratch + (size_t(blockIdx.x) * 2 + 0) * n_chunks;
+    const double* wsum = scratch + (size_t(blockIdx.x) * 2 + 1) * n_chunks;
+    const double target = alpha - (1e-8 + 1e-5 * fabs(alpha));  // isclose(gathered, alpha) with gathered <= alpha
+    // ---- which chunk ----
+    const uint32_t per = (n_chunks + 255) / 256;
+    const uint32_t lo = min(n_chunks, t * per), hi = min(n_chunks, lo + per);
+    double local = 0.0;
+    for (uint32_t c = lo; c < hi; ++c) local += mass[c];
+    sh_a[t] = local;
+    __syncthreads();
+    if (t == 0) {
+        double run = 0.0;
+        for (int i = 0; i < 256; ++i) {
+            const double v = sh_a[i];
+            sh_a[i] = run;
+            run += v;
+        }
+    }
+    __syncthreads();
+    {
+        double cum = sh_a[t], before = 0.0;
+        uint32_t found = n_chunks;
+        for (uint32_t c = lo; c < hi; ++c) {
+            const double next = cum + mass[c];
+            if (found == n_chunks && next >= target) {
+                found = c;
+                before = cum;
+            }
+            cum = next;
+        }
+        sh_i[t] = found;
+        sh_b[t] = before;
+    }
+    __syncthreads();
+    if (t == 0) {
+        uint32_t chunk = n_chunks;
+        double before = 0.0;
+        for (int i = 0; i < 256 && chunk == n_chunks; ++i)
+            if (sh_i[i] < n_chunks) {
+                chunk = sh_i[i];
+                before = sh_b[i];
+            }
+        pick_i[0] = chunk;
+        pick[0] = before;
+    }
+    __syncthreads();
+    const uint32_t chunk = pick_i[0];
+    const double mass_before = pick[0];
+    // ---- the accumulation over the chunks in front of it ----
+    double part = 0.0;
+    for (uint32_t c = lo; c < hi && c < chunk; ++c) part += wsum[c];
+    __syncthreads();
+    sh_a[t] = part;
+    __syncthreads();
+    if (t == 0) {
+        double run = 0.0;
+        for (int i = 0; i < 256; ++i) run += sh_a[i];
+        pick[1] = run;
+    }
+    __syncthreads();
+    const double sum_before = pick[1];
+    if (chunk == n_chunks) {  // (the whole distribution carries less than alpha - tolerance: everything counts)
+        if (t == 0) out[ev.out_index] = sum_before / alpha;
+        return;
+    }
+    // ---- which rank inside the chunk: thread t owns ranks t 16 .. t 16 + 15 of it ----
+    const ExactSource<real> src = exact_source<real>(plan_arena, ev, blockIdx.x, probs_all, dim, sides, side_stride);
+    constexpr uint32_t OWN = kCvarChunk / 256;
+    double p[OWN], v[OWN];
+    double lm = 0.0, lw = 0.0;
+#pragma unroll
+    for (uint32_t k = 0; k < OWN; ++k) {
+        const uint64_t pos = uint64_t(chunk) * kCvarChunk + uint64_t(t) * OWN + k;
+        p[k] = pos < dim ? src(order[pos]) : 0.0;
+        v[k] = pos < dim ? sorted[pos] : 0.0;
+        lm += p[k];
+        lw = fma(p[k], v[k], lw);
+    }
+    __syncthreads();
+    sh_a[t] = lm;
+    sh_b[t] = lw;
+    __syncthreads();
+    if (t == 0) {
+        double run = 0.0;
+        for (int i = 0; i < 256; ++i) {
+            const double x = sh_a[i];
+            sh_a[i] = run;
+            run += x;
+        }
+    }
+    __syncthreads();
+    {
+        double cum = mass_before + sh_a[t];
+        uint32_t found = OWN;
+        double inside = 0.0, last = 0.0;
+#pragma unroll
+        for (uint32_t k = 0; k < OWN; ++k) {
+            const double next = cum + p[k];
+            if (found == OWN) {
+                if (next >= target) {
+                    found = k;
+                    last = fmin(alpha - cum, p[k]) * v[k];  // the last state's mass, clipped to what is missing
+                } else {
+                    inside = fma(p[k], v[k], inside);
+                }
+            }
+            cum = next;
+        }
+        sh_i[t] = found;
+        sh_a[t] = inside;  // (this thread's ranks in front of the last one)
+        __syncthreads();
+        if (t == 0) {
+            double run = 0.0;
+            bool done = false;
+            for (int i = 0; i < 256 && !done; ++i) {
+                if (sh_i[i] < OWN) {
+                    run += sh_a[i];
+                    pick_i[1] = uint32_t(i);
+                    done = true;
+                } else {
+                    run += sh_b[i];  // a thread in front of the crossing: all of its ranks
+                }
+            }
+            pick[2] = run;
+            if (!done) pick_i[1] = 256;  // (rounding: the chunk's own sum fell short of what the chunk scan saw)
+        }
+        __syncthreads();
+        if (pick_i[1] == 256) {
+            if (t == 0) out[ev.out_index] = (sum_before + pick[2]) / alpha;
+        } else if (t == pick_i[1]) {
+            out[ev.out_index] = (sum_before + pick[2] + last) / alpha;
+        }
+    }
+}
+
+hipError_t launch_cvar_exact(int dtype, const double* probs, uint64_t dim, unsigned n_evals, const uint32_t* order,
+                             const double* sorted_values, double alpha, double* chunk_scratch, double* out, hipStream_t stream,
+                             const PassArgs& a) {
+    if (n_evals == 0) return hipSuccess;
+    if (!(alpha > 0.0) || alpha > 1.0 || dim > (uint64_t(1) << 30)) return hipErrorInvalidValue;
+    const uint32_t n_chunks = cvar_exact_chunks(dim);
+    if (dtype == 0) {
+        hipLaunchKernelGGL(cvar_exact_chunks_kernel<double>, dim3(n_chunks, n_evals), dim3(256), 0, stream, a.plan, a.evals, probs, dim,
+                           static_cast<const cx<double>*>(a.wtab), a.wtab_stride, order, sorted_values, n_chunks, chunk_scratch);
+        hipLaunchKernelGGL(cvar_exact_finish_kernel<double>, dim3(n_evals), dim3(256), 0, stream, a.plan, a.evals, probs, dim,
+                           static_cast<const cx<double>*>(a.wtab), a.wtab_stride, order, sorted_values, n_chunks, chunk_scratch, alpha, out);
+    } else {
+        hipLaunchKernelGGL(cvar_exact_chunks_kernel<float>, dim3(n_chunks, n_evals), dim3(256), 0, stream, a.plan, a.evals, probs, dim,
+                           static_cast<const cx<float>*>(a.wtab), a.wtab_stride, order, sorted_values, n_chunks, chunk_scratch);
+        hipLaunchKernelGGL(cvar_exact_finish_kernel<float>, dim3(n_evals), dim3(256), 0, stream, a.plan, a.evals, probs, dim,
+                           static_cast<const cx<float>*>(a.wtab), a.wtab_stride, order, sorted_values, n_chunks, chunk_scratch, alpha, out);
+    }
+    return hipGetLastError();
+}
+
 static unsigned stream_blocks(uint64_t dim) {
     const uint64_t want = (dim + 255) / 256;
     return unsigned(want < 4096 ? want : 4096);

@@ -239,6 +239,25 @@ hipError_t launch_split_sample(int dtype, int side_bits, unsigned n_evals, const
 constexpr int kCvarMaxShots = 4096;
 hipError_t launch_cvar(const double* values, int n_evals, int shots, double alpha, double* out, hipStream_t stream);
 
+// ---- exact-probability CVaR (the sampler branch without sampling noise) ---------------------------------------------------
+// order[j] = the basis state of rank j when the states are sorted by their value under the diagonal operator (ties in index
+// order), sorted_values[j] = that value (sort.hip, once per operator).
+hipError_t sort_states_by_value(const double* values, uint64_t dim, uint32_t* order, double* sorted_values, hipStream_t stream);
+// CVaR_alpha of the EXACT distribution |a_i|^2 over the operator's values, as the reference's accumulation loop computes it
+// from a measured distribution (queasars/circuit_evaluation/expectation_calculation.py:14-32): states in ascending order of
+// value, probability mass gathered until numpy.isclose(gathered, alpha) (rtol 1e-5, atol 1e-8), the last state's mass
+// clipped to what is missing, the sum divided by alpha.  The probabilities of evaluation e come from probs[slot e][2^n]
+// (what a gate pass with kModeFinalProbs leaves), or -- descriptors with kEvalSide -- from the two side tables of a split
+// circuit (|sum_j X_j[x(i)] Y_j[y(i)]|^2, formed per state; at most three keys).  Two launches: sums per chunk of
+// kCvarChunk ranks (mass and mass x value; fixed order), then per evaluation the chunk in which the mass is reached and
+// the rank inside it.  PassArgs: plan, evals (the group's device descriptors), wtab / wtab_stride (side tables).
+// chunk_scratch: 2 * n_evals * cvar_exact_chunks(dim) doubles.  out[evals[e].out_index] receives the result.
+constexpr uint32_t kCvarChunk = 4096;
+inline uint32_t cvar_exact_chunks(uint64_t dim) { return uint32_t((dim + kCvarChunk - 1) / kCvarChunk); }
+hipError_t launch_cvar_exact(int dtype, const double* probs, uint64_t dim, unsigned n_evals, const uint32_t* order,
+                             const double* sorted_values, double alpha, double* chunk_scratch, double* out, hipStream_t stream,
+                             const PassArgs& args);
+
 hipError_t launch_probabilities(int dtype, const void* state, uint64_t dim, int n_slots, double* probs,
                                 hipStream_t stream);
 hipError_t launch_state_to_f64(int dtype, const void* state, uint64_t dim, double* out_re_im, hipStream_t stream);

@@ -184,6 +184,8 @@ struct qsv_handle {
     bool has_diag_part = false;   // some terms are I/Z (their diagonal table exists)
     int n_groups = 0;             // x-mask groups of the off-diagonal terms
     DeviceBuffer d_z, d_cre, d_diag, d_term_partials, d_groups, d_term_odd;
+    DeviceBuffer d_order, d_sorted;  // the basis states in ascending order of the diagonal operator's value, and the values
+    bool order_valid = false;        // (sort.hip; built when the exact-probability CVaR first needs them)
     int pauli_nb = 0;
 
     // circuits
@@ -1619,7 +1621,7 @@ void qsv_destroy(qsv_t* h) {
         (void)hipStreamDestroy(st);
     }
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
-    for (DeviceBuffer* b : {&h->d_z, &h->d_cre, &h->d_diag, &h->d_term_partials, &h->d_groups, &h->d_term_odd, &h->d_arena,
+    for (DeviceBuffer* b : {&h->d_z, &h->d_cre, &h->d_diag, &h->d_order, &h->d_sorted, &h->d_term_partials, &h->d_groups, &h->d_term_odd, &h->d_arena,
                             &h->d_states, &h->d_wtab, &h->d_side, &h->d_factor, &h->d_factor_count, &h->d_factor_big, &h->d_quad, &h->d_fterms, &h->d_fpart, &h->d_batch, &h->d_mats, &h->d_partials, &h->d_out, &h->d_scratch})
         if (b->ptr) (void)hipFree(b->ptr);
     if (h->h_batch) (void)hipHostFree(h->h_batch);
@@ -1762,6 +1764,7 @@ int qsv_set_operator(qsv_t* h, int n_terms, const uint64_t* x_mask, const uint64
         h->n_fterms = uint32_t(n_terms);
     }
     h->n_terms = n_terms;
+    h->order_valid = false;
     h->diagonal = all_diag;
     h->has_diag_part = !diag_z.empty();
     h->n_groups = int(groups.size());
@@ -2234,6 +2237,83 @@ static int sample_batch_locked(qsv_t* h, const std::vector<Circuit*>& circs, con
     return QSV_OK;
 }
 
+// Exact-probability CVaR for a whole batch: the circuits group by group as in the sampler branch (split circuits as their
+// two virtual circuits, the others with the probabilities written by their last gate pass), then launch_cvar_exact.
+static int exact_cvar_locked(qsv_t* h, const std::vector<Circuit*>& circs, const int64_t* param_offsets, const double* params,
+                             double alpha, double* out_cvar) {
+    const size_t n_evals = circs.size();
+    if (n_evals == 0) return QSV_OK;
+    if (!(h->has_diag_part && h->diagonal))
+        return fail(h, QSV_E_STATE, "the exact CVaR needs a diagonal operator (call qsv_set_operator with I/Z terms only)");
+    if (h->n > 28) return fail(h, QSV_E_UNSUPPORTED, "the exact CVaR is available up to 28 qubits");
+    const uint64_t dim = uint64_t(1) << h->n;
+    int rc;
+    if (!h->order_valid) {
+        if ((rc = ensure(h, h->d_order, dim * sizeof(uint32_t))) || (rc = ensure(h, h->d_sorted, dim * sizeof(double)))) return rc;
+        QSV_HIP(h, sort_states_by_value(static_cast<const double*>(h->d_diag.ptr), dim, static_cast<uint32_t*>(h->d_order.ptr),
+                                        static_cast<double*>(h->d_sorted.ptr), h->stream));
+        h->order_valid = true;
+    }
+    std::vector<int64_t> np(n_evals);
+    std::vector<double> packed;
+    size_t total = 0;
+    for (size_t i = 0; i < n_evals; ++i) {
+        np[i] = param_offsets[i + 1] - param_offsets[i];
+        if (np[i] < 0) return fail(h, QSV_E_ARG, "param_offsets must be non-decreasing");
+        total += size_t(np[i]);
+    }
+    packed.resize(total + 1);
+    for (size_t i = 0, cur = 0; i < n_evals; cur += size_t(np[i]), ++i)
+        if (np[i]) std::memcpy(packed.data() + cur, params + param_offsets[i], size_t(np[i]) * sizeof(double));
+    h->prof = qsv_profile{};
+    if ((rc = batch_layout(h, circs, np, h->split_sampling))) return rc;
+    const size_t n_split = order_split_first(h, 0, n_evals), n_plain = n_evals - n_split;
+    const size_t G = size_t(h->group), SG = size_t(std::max(1, h->side_slots));
+    {
+        EvalDesc* hd = static_cast<EvalDesc*>(h->h_batch);
+        for (size_t j = 0; j < n_evals; ++j) {
+            const uint32_t slot = uint32_t(j < n_split ? j % SG : (j - n_split) % G);
+            hd[j].state_slot = slot;
+            if (h->batch.split_any) hd[n_evals + j].state_slot = slot;
+        }
+    }
+    const uint32_t n_chunks = cvar_exact_chunks(dim);
+    const size_t probs_bytes = n_plain ? G * dim * 8 : 0;
+    const size_t chunk_off = ((probs_bytes + 63) / 64) * 64;
+    const size_t chunk_bytes = 2 * std::max(G, std::min(SG, std::max<size_t>(1, n_split))) * size_t(n_chunks) * 8;
+    if ((rc = ensure(h, h->d_scratch, chunk_off + chunk_bytes))) return rc;
+    if ((rc = ensure(h, h->d_partials, std::max<size_t>(1, n_evals) * partials_per_state(h) * sizeof(double)))) return rc;
+    if ((rc = ensure_host_out(h, n_evals))) return rc;
+    double* probs = static_cast<double*>(h->d_scratch.ptr);
+    double* chunk_scratch = reinterpret_cast<double*>(static_cast<char*>(h->d_scratch.ptr) + chunk_off);
+    const bool fuse = h->geo.blocks_per_state == 1;
+    rc = batch_ship(h, 0, n_evals, packed.data(), fuse ? n_evals : n_split);
+    PassArgs a{};
+    a.plan = static_cast<const uint32_t*>(h->d_arena.ptr);
+    a.wtab = h->d_side.ptr;
+    a.wtab_stride = h->side_stride;
+    const uint32_t* order = static_cast<const uint32_t*>(h->d_order.ptr);
+    const double* sorted = static_cast<const double*>(h->d_sorted.ptr);
+    for (size_t g0 = 0; !rc && g0 < n_split; g0 += SG) {
+        const size_t gc = std::min(SG, n_split - g0);
+        if ((rc = run_group(h, circs, g0, gc, kModeSynthFirst | kModeFinalStore | kModeSidesOnly))) break;
+        a.evals = batch_evals(h) + g0;
+        QSV_HIP(h, launch_cvar_exact(h->dtype, probs, dim, unsigned(gc), order, sorted, alpha, chunk_scratch, h->h_out, h->stream, a));
+    }
+    const uint32_t mode = kModeSynthFirst | kModeFinalProbs | (fuse ? kModeFusedPrepare : 0u);
+    for (size_t g0 = n_split; !rc && g0 < n_evals; g0 += G) {
+        const size_t gc = std::min(G, n_evals - g0);
+        if ((rc = run_group(h, circs, g0, gc, mode))) break;
+        a.evals = batch_evals(h) + g0;
+        QSV_HIP(h, launch_cvar_exact(h->dtype, probs, dim, unsigned(gc), order, sorted, alpha, chunk_scratch, h->h_out, h->stream, a));
+    }
+    h->batch.circs.clear();
+    if (rc) return rc;
+    QSV_HIP(h, hipStreamSynchronize(h->stream));
+    std::memcpy(out_cvar, h->h_out, n_evals * sizeof(double));
+    return QSV_OK;
+}
+
 int qsv_sample_batch(qsv_t* h, int n_evals, const int* circuit_ids, const int64_t* param_offsets, const double* params,
                      int shots, uint64_t seed, uint64_t* out_states, double* out_values) {
     if (!h) return QSV_E_ARG;
@@ -2268,6 +2348,23 @@ int qsv_sample_cvar_batch(qsv_t* h, int n_evals, const int* circuit_ids, const i
     }
     static const double dummy = 0.0;
     return sample_batch_locked(h, circs, param_offsets, params ? params : &dummy, shots, seed, nullptr, nullptr, alpha, out_cvar);
+}
+
+int qsv_exact_cvar_batch(qsv_t* h, int n_evals, const int* circuit_ids, const int64_t* param_offsets, const double* params,
+                         double alpha, double* out_cvar) {
+    if (!h) return QSV_E_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    if (n_evals < 0 || (n_evals > 0 && (!circuit_ids || !param_offsets || !out_cvar))) return fail(h, QSV_E_ARG, "bad arguments");
+    if (!(alpha > 0.0) || alpha > 1.0) return fail(h, QSV_E_ARG, "alpha must be in (0, 1]");
+    QSV_HIP(h, hipSetDevice(h->device));
+    std::vector<Circuit*> circs(size_t(n_evals), nullptr);
+    for (int i = 0; i < n_evals; ++i) {
+        auto it = h->circuits.find(circuit_ids[i]);
+        if (it == h->circuits.end()) return fail(h, QSV_E_ARG, "unknown circuit id " + std::to_string(circuit_ids[i]));
+        circs[size_t(i)] = &it->second;
+    }
+    static const double dummy = 0.0;
+    return exact_cvar_locked(h, circs, param_offsets, params ? params : &dummy, alpha, out_cvar);
 }
 
 int qsv_sample(qsv_t* h, int circuit_id, const double* params, int n_params, int shots, uint64_t seed,

@@ -575,6 +575,37 @@ def test_split_evaluations_with_four_and_five_keys(n, layers, count, c_oracle):
         assert np.abs(np.asarray(means) - np.asarray([got[i] for i in big[:3]])).max() < 0.05 * spread
 
 
+@pytest.mark.parametrize("n,layers,count", [(8, 3, 6), (14, 4, 6), (20, 4, 4), (20, 7, 2), (12, 2, 4)])
+def test_exact_probability_cvar_against_the_oracle(n, layers, count, c_oracle):
+    """The sampler branch without sampling noise (``sampler_shots=None``): CVaR_alpha of the exact distribution on the device
+    against the oracle's restatement of the reference's accumulation loop (oracle.cvar_expectation, expectation_calculation.py
+    :14-32) fed with the oracle's own exact probabilities and values -- 1e-10, for alpha = 1, 0.5, 0.05 and one awkward
+    value; split circuits (side tables), unsplittable ones (probabilities of the last pass), operators with many equal
+    values (ties), one-tile registers."""
+    from oracle import statevector_oracle as so
+
+    _, circuits, params = helpers.population_circuits(n, layers, count, seed=11 + n)
+    operators = [helpers.random_ising_operator(n, seed=5 + n)]
+    if n <= 14:  # an operator with few distinct values: ties everywhere
+        operators.append(PauliOperator.from_sparse_list([("Z", [0], 1.0), ("Z", [1], 1.0), ("ZZ", [2, 3], 2.0), ("Z", [n - 1], -1.0)], n))
+    for op in operators:
+        table = c_oracle.diagonal_table(op)
+        for alpha in (1.0, 0.5, 0.05, 0.3217):
+            ev = OperatorSamplerCircuitEvaluator(None, op, alpha=alpha)
+            got = ev.evaluate_circuits(circuits, params)
+            assert got == ev.evaluate_circuits(circuits, params)  # deterministic
+            for i in range(count if n < 20 else 2):
+                probs = np.abs(c_oracle.simulate(circuits[i], params[i])) ** 2
+                if np.isclose(alpha, 1):
+                    want = float(np.dot(probs, table))
+                else:
+                    want = so.cvar_expectation(list(zip(range(1 << n), probs.tolist(), table.tolist())), alpha)
+                assert abs(got[i] - want) < EXP_TOL, (n, alpha, i, got[i], want)
+            ev.statevector_device.close()
+    with pytest.raises(ValueError):
+        OperatorSamplerCircuitEvaluator(0, operators[0])
+
+
 def test_split_results_do_not_depend_on_the_batch(c_oracle):
     """Bitwise: an evaluation's value is the same alone, in a batch of split evaluations and in a batch mixed with
     circuits that keep the ordinary plan; and it matches the C oracle at n = 20."""
