@@ -207,3 +207,32 @@ def test_population_wire_format_round_trip_and_key_names():
     plain = EVQEPopulation.random_population(4, 1, 2, False, random_seed=1)
     assert json.loads(ser.dumps(plain))["evqe_population_species_members"] is None
     assert ser.loads(ser.dumps(plain)).individuals == plain.individuals
+
+
+def test_committed_population_fixture_in_the_reference_wire_format():
+    """tests/golden/population_n6.json: a population in the JSON layout the reference writes
+    (queasars/minimum_eigensolvers/evqe/serialization.py:27-65; key names evqe_population_*, evqe_individual_*,
+    evqe_circuit_layer_*, evqe_gate_type ...) loads into the same genomes the generator made, re-encodes to the same
+    document, and its individuals evaluate (oracle) to the stored expectation values."""
+    import json
+    from pathlib import Path
+
+    import helpers
+    from queasars_amd.evqe.serialization import population_from_dict, population_to_dict
+    from queasars_amd.ir import PauliOperator
+
+    data = json.loads((Path(__file__).parent / "golden" / "population_n6.json").read_text())
+    doc = data["population"]
+    assert set(doc) == {"evqe_population_individuals", "evqe_population_species_representatives",
+                        "evqe_population_species_members", "evqe_population_species_membership"}
+    first = doc["evqe_population_individuals"][0]
+    assert set(first) == {"evqe_individual_n_qubits", "evqe_individual_layers", "evqe_individual_parameter_values"}
+    assert set(first["evqe_individual_layers"][0]) == {"evqe_circuit_layer_n_qubits", "evqe_circuit_layer_gates"}
+    population = population_from_dict(doc)
+    assert population_to_dict(population) == doc
+    same = EVQEPopulation.random_population(6, 3, 5, True, 606)
+    assert [ind.parameter_values for ind in population.individuals] == [ind.parameter_values for ind in same.individuals]
+    op = PauliOperator(data["operator"]["labels"], data["operator"]["coeffs"])
+    for ind, want in zip(population.individuals, data["expectations"]):
+        got = helpers.oracle_expectation(ind.get_parameterized_quantum_circuit(), list(ind.parameter_values), op)
+        assert abs(got - want) < 1e-12

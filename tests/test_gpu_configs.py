@@ -606,6 +606,34 @@ def test_exact_probability_cvar_against_the_oracle(n, layers, count, c_oracle):
         OperatorSamplerCircuitEvaluator(0, operators[0])
 
 
+def test_config2_exact_workload_against_the_c_oracle(c_oracle):
+    """BASELINE.json configs[1] exactly as bench.py runs it -- n = 20, P = 64, L = 4, population seed 0, 190 ZZ + 20 Z Ising
+    operator of default_rng(2020) --: all 64 individuals against the C oracle (1e-10)."""
+    n = 20
+    _, circuits, params = helpers.population_circuits(n, 4, 64, seed=0)
+    op = helpers.random_ising_operator(n, seed=2020)
+    assert len(op) == 210
+    got = np.asarray(OperatorCircuitEvaluator(op).evaluate_circuits(circuits, params))
+    table = c_oracle.diagonal_table(op)
+    scratch = np.zeros(2 << n)
+    ref = np.asarray([c_oracle.evaluate(c, p, op, table, scratch) for c, p in zip(circuits, params)])
+    assert np.abs(got - ref).max() < EXP_TOL
+
+
+def test_population_fixture_in_the_reference_wire_format_evaluates_to_its_stored_values():
+    """tests/golden/population_n6.json (the reference's JSON layout, serialization.py:27-65): load -> evaluate on the device
+    -> the stored expectation values (1e-10)."""
+    from queasars_amd.evqe.serialization import population_from_dict
+
+    data = json.loads((Path(__file__).resolve().parent / "golden" / "population_n6.json").read_text())
+    population = population_from_dict(data["population"])
+    op = PauliOperator(data["operator"]["labels"], data["operator"]["coeffs"])
+    circuits = [ind.get_parameterized_quantum_circuit() for ind in population.individuals]
+    params = [list(ind.parameter_values) for ind in population.individuals]
+    got = np.asarray(OperatorCircuitEvaluator(op).evaluate_circuits(circuits, params))
+    assert np.abs(got - np.asarray(data["expectations"])).max() < EXP_TOL
+
+
 def test_split_results_do_not_depend_on_the_batch(c_oracle):
     """Bitwise: an evaluation's value is the same alone, in a batch of split evaluations and in a batch mixed with
     circuits that keep the ordinary plan; and it matches the C oracle at n = 20."""
