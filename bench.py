@@ -267,9 +267,15 @@ def cold_and_threaded(operator, n_steps: int = 7):
         for _ in range(reps):
             list(pool.map(lambda j: j, range(POP_PER_GPU)))
         noop = POP_PER_GPU * reps / (time.perf_counter() - t0)
+        # ... and with tasks that BLOCK outside the interpreter for about as long as a merged evaluation takes (0.1 ms of
+        # sleep with the GIL released): every task then costs thread hand-overs, as the real calls do
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            list(pool.map(lambda j: time.sleep(1e-4), range(POP_PER_GPU)))
+        blocking = POP_PER_GPU * reps / (time.perf_counter() - t0)
     assert got == evaluator.evaluate_circuits(circuits, params)
     evaluator.statevector_device.close()
-    return cold, threaded, noop
+    return cold, threaded, noop, blocking
 
 
 def sampler_block(operator, circuits, params, shots: int = 1024, alpha: float = 0.5, reps: int = 20):
@@ -683,17 +689,19 @@ def main() -> None:
             result["deep"] = deep_block(local_rank)
         if world == 1 and not args.no_extras:
             result["roofline"]["microbench"] = microbench_block()
-            cold, threaded, noop = cold_and_threaded(operator)
+            cold, threaded, noop, blocking = cold_and_threaded(operator)
             result["cold_structure_evals_per_s"] = cold
             result["threaded_b1_evals_per_s"] = threaded
             result["threaded_b1_noop_tasks_per_s"] = noop
+            result["threaded_b1_blocking_tasks_per_s"] = blocking
             result["sampler_branch"] = sampler_block(operator, circuits, params)
             result["calling_pattern_note"] = (
                 "cold: every step evaluates 64 circuit structures the device has never seen (plan building + upload "
                 "inside the timed region); threaded: 64 host threads, one circuit per call (the reference's selection "
                 "operator, selection.py:75-82) through CoalescingCircuitEvaluator; threaded_b1_noop_tasks_per_s: the same "
                 "pool.map with tasks that do nothing, i.e. the rate at which this host's CPython can hand out and collect "
-                "such calls at all")
+                "such calls at all; threaded_b1_blocking_tasks_per_s: the same with tasks that sleep 0.1 ms outside the "
+                "interpreter -- what 64 threads that each BLOCK once per task can reach, whatever they wait for")
         if world == 1 and not args.no_cpu_baseline:
             base, ref_values = cpu_baseline(circuits, params, operator, gpu_values=values)
             result["cpu_baseline"] = base

@@ -96,6 +96,32 @@ def _load_pyhelp():
     return _pyhelp or None
 
 
+_pyhelp_module = None
+
+
+def _load_pyhelp_module():
+    """csrc/pyhelp.c as an extension module (its ``eval_one``: a whole single-circuit call in C, no ctypes conversion);
+    None when the helper was not built."""
+    global _pyhelp_module
+    if _pyhelp_module is None:
+        _pyhelp_module = False
+        if _load_pyhelp() is not None and not os.environ.get("QSV_LIBRARY"):
+            try:
+                import importlib.machinery
+                import importlib.util
+
+                from queasars_amd import _build
+
+                loader = importlib.machinery.ExtensionFileLoader("_qsvpyhelp", str(_build.PYHELP_PATH))
+                spec = importlib.util.spec_from_loader("_qsvpyhelp", loader)
+                module = importlib.util.module_from_spec(spec)
+                loader.exec_module(module)
+                _pyhelp_module = module
+            except (ImportError, OSError):
+                _pyhelp_module = False
+    return _pyhelp_module or None
+
+
 def _pack_slice(vectors: Sequence[Sequence[float]], first: int, last: int, total: int) -> np.ndarray:
     """The parameter vectors ``vectors[first:last]`` back to back as one float64 array of ``total`` values."""
     helper = _load_pyhelp()
@@ -428,6 +454,17 @@ class StatevectorDevice:
         """One evaluation, merged inside the library with the evaluations other threads ask for at the same time
         (``qsv_eval_coalesced``).  The call blocks in C with the GIL released, so population_size Python threads calling
         with one circuit each (the reference's selection operator) are answered from one batch."""
+        fast = _load_pyhelp_module()
+        if fast is not None:
+            # the whole call in one C function (csrc/pyhelp.c eval_one); None: the circuit is not registered here yet
+            try:
+                value = fast.eval_one(self._handle.value, self._serial, circuit, parameter_values, float(window_us))
+                if value is None:
+                    self.circuit_id(circuit)
+                    value = fast.eval_one(self._handle.value, self._serial, circuit, parameter_values, float(window_us))
+                return value
+            except RuntimeError as exc:
+                raise CircuitEvaluatorException(str(exc)) from None
         cid = circuit._registered.get(self._serial)
         if cid is None:
             cid = self.circuit_id(circuit)

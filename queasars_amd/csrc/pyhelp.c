@@ -172,3 +172,84 @@ int qsv_py_expectation_values_device(qsv_t* h, Py_ssize_t n, const int* ids, con
                                      double* values, Py_ssize_t capacity, void* device_out) {
     return expectation_values(h, n, ids, counts, vectors, values, capacity, NULL, (double*)device_out);
 }
+
+/* ---- the reference's calling pattern: one circuit per call from population_size threads ---------------------------------
+ * (queasars/minimum_eigensolvers/evqe/evolutionary_algorithm/selection.py:75-82, mutation.py:63-75).  The whole call in
+ * ONE C function, reached as a method of an extension module (no ctypes argument conversion): circuit id out of the
+ * circuit's registration table, the parameter vector onto the stack, qsv_eval_coalesced with the GIL released, a float
+ * back.  eval_one(handle, serial, circuit, vector, window_us) -> float, or None when the circuit is not registered on
+ * that device yet (the caller registers it and calls again).  ValueError for bad arguments, RuntimeError otherwise. */
+static PyObject* name_registered = NULL;
+
+static PyObject* eval_one(PyObject* self, PyObject* const* args, Py_ssize_t nargs) {
+    (void)self;
+    if (nargs != 5) {
+        PyErr_SetString(PyExc_TypeError, "eval_one(handle, serial, circuit, vector, window_us)");
+        return NULL;
+    }
+    qsv_t* h = (qsv_t*)PyLong_AsVoidPtr(args[0]);
+    if (!h) {
+        if (!PyErr_Occurred()) PyErr_SetString(PyExc_ValueError, "null handle");
+        return NULL;
+    }
+    PyObject* table = PyObject_GetAttr(args[2], name_registered);
+    if (!table) return NULL;
+    PyObject* id_obj = PyDict_Check(table) ? PyDict_GetItemWithError(table, args[1]) : NULL; /* borrowed */
+    if (!id_obj) {
+        Py_DECREF(table);
+        if (PyErr_Occurred()) return NULL;
+        Py_RETURN_NONE;
+    }
+    const long cid = PyLong_AsLong(id_obj);
+    Py_DECREF(table);
+    if (cid == -1 && PyErr_Occurred()) return NULL;
+    const double window_us = PyFloat_AsDouble(args[4]);
+    if (window_us == -1.0 && PyErr_Occurred()) return NULL;
+    PyObject* seq = PySequence_Fast(args[3], "a parameter vector must be a sequence of numbers");
+    if (!seq) return NULL;
+    const Py_ssize_t n = PySequence_Fast_GET_SIZE(seq);
+    double stack[512];
+    double* values = n <= 512 ? stack : (double*)malloc((size_t)n * sizeof(double));
+    if (!values) {
+        Py_DECREF(seq);
+        return PyErr_NoMemory();
+    }
+    PyObject** items = PySequence_Fast_ITEMS(seq);
+    for (Py_ssize_t j = 0; j < n; ++j) {
+        PyObject* v = items[j];
+        const double d = PyFloat_CheckExact(v) ? PyFloat_AS_DOUBLE(v) : PyFloat_AsDouble(v);
+        if (d == -1.0 && PyErr_Occurred()) {
+            Py_DECREF(seq);
+            if (values != stack) free(values);
+            return NULL;
+        }
+        values[j] = d;
+    }
+    Py_DECREF(seq);
+    double out = 0.0;
+    int rc;
+    Py_BEGIN_ALLOW_THREADS
+    rc = qsv_eval_coalesced(h, (int)cid, values, (int)n, window_us, &out);
+    Py_END_ALLOW_THREADS
+    if (values != stack) free(values);
+    if (rc) {
+        const char* msg = qsv_last_error(h);
+        PyErr_SetString(rc == QSV_E_ARG ? PyExc_ValueError : PyExc_RuntimeError, msg && *msg ? msg : "qsv_eval_coalesced failed");
+        return NULL;
+    }
+    return PyFloat_FromDouble(out);
+}
+
+static PyMethodDef helper_methods[] = {
+    {"eval_one", (PyCFunction)(void (*)(void))eval_one, METH_FASTCALL,
+     "eval_one(handle, serial, circuit, vector, window_us): one evaluation, merged in the library with other threads'"},
+    {NULL, NULL, 0, NULL}};
+
+static struct PyModuleDef helper_module = {PyModuleDef_HEAD_INIT, "_qsvpyhelp", "CPython-API helper of queasars_amd", -1, helper_methods,
+                                           NULL, NULL, NULL, NULL};
+
+PyMODINIT_FUNC PyInit__qsvpyhelp(void) {
+    name_registered = PyUnicode_InternFromString("_registered");
+    if (!name_registered) return NULL;
+    return PyModule_Create(&helper_module);
+}
