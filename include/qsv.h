@@ -236,6 +236,8 @@ int qsv_exact_cvar_batch(qsv_t* h, int n_evals, const int* circuit_ids, const in
  *                        created with splitting on.  Applies to circuits registered afterwards.
  *   "factor" 0|1         split evaluations use the factorised expectation kernels instead of the contraction sweep
  *   "fused_factor" 0|1   ... inside the launch that runs their virtual circuits, where a circuit qualifies (one launch per push)
+ *   "split_max_keys" 0..5 most cut keys of a split form (default 3; four and five: quadratic operators only, worth it for
+ *                        populations in which many circuits need them).  Applies to circuits registered afterwards.
  *   "split_sampling" 0|1 split circuits are sampled from their side tables
  *   "streams" 1..4       HIP streams the pushes of a batch cycle over (at most as many as were created with the handle)
  * Returns QSV_E_ARG for an unknown name or a value out of range.

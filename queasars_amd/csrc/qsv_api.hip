@@ -166,6 +166,10 @@ struct qsv_handle {
     bool factor_enabled = true;  // ... and, under a quadratic diagonal operator, need no sweep over the 2^n indices at all
                                  // (kernels.hpp: launch_factor)
     bool fused_factor = true;    // ... in the launch that runs the virtual circuits, where the circuit qualifies (kEvalFused)
+    int split_max_keys = 3;      // most cut keys of a split form: four and five (16 / 32 product terms, quadratic operators
+                                 // only) pay where MANY circuits of a batch need them -- populations of six-layer circuits:
+                                 // +50 % -- and cost latency where few do (their chain of launches is the longest of the
+                                 // step): off unless asked for (QSV_SPLIT_MAX_KEYS, qsv_set_option "split_max_keys")
     bool quadratic = false;      // the operator is diagonal and every term has at most two Z factors
     DeviceBuffer d_quad;         // its couplings as an n x n matrix
     DeviceBuffer d_fterms;       // a general operator's terms as a plain list (kernels.hpp: launch_factor_terms)
@@ -259,10 +263,7 @@ struct qsv_handle {
         unsigned used_mask = 0; // side streams (bit i = side_streams[i]) with work of this batch in flight
         bool aux_plain = false; // the batch's ordinary evaluations run on the auxiliary stream (eval_begin)
         size_t aux_count = 0;   // ... how many of them have been pushed (their state slots cycle over the whole group)
-        bool aux_split = false; // the batch mixes split evaluations that one launch finishes (kEvalFused) with split ones that
-                                // need launches of their own: the latter run on the auxiliary stream, in side-table slots
-                                // only that stream uses, beside the former
-        size_t aux_split_count = 0;
+
         size_t n_pushes = 0;
     } batch;
     std::unique_lock<std::mutex> batch_lock;  // held from begin to end
@@ -414,8 +415,7 @@ int build_circuit(qsv_t* h, int n_ops, const qsv_op* ops, int n_params, bool fol
             if (side_tile > h->geo.k && side_tile < h->n) limits.push_back(side_tile);
             limits.push_back(std::min(h->geo.k + 2, h->n - 1));
             limits.push_back(std::min(h->geo.k + kSideExtraBits, h->n - 1));
-            static const int max_keys = getenv("QSV_SPLIT_MAX_KEYS") ? std::max(0, std::min(kMaxSplitKeys, atoi(getenv("QSV_SPLIT_MAX_KEYS")))) : kMaxSplitKeys;
-            SplitCircuits sc = find_split(h->n, gates, angles, limits, max_keys);
+            SplitCircuits sc = find_split(h->n, gates, angles, limits, h->split_max_keys);
             if (sc.ok && std::max(sc.n_side[0], sc.n_side[1]) > kSideMaxOwnBits) sc.ok = false;
             if (sc.ok) {
                 SplitInfo& sp = out->split;
@@ -883,7 +883,6 @@ bool factor_terms_path(const qsv_t* h) { return h->factor_enabled && !h->diagona
 
 // Split evaluations flagged kEvalFused are finished by the launch that runs their virtual circuits (quadratic operator).
 bool fused_route(const qsv_t* h) { return factor_path(h) && h->d_factor_count.ptr != nullptr && h->fused_factor; }
-constexpr int kAuxSideSlots = 48;  // side-table slots set aside for the auxiliary stream in a batch with aux_split
 
 // Run the gate passes of evaluations [first, first+count) of the current batch (one launch group).
 int run_group(qsv_t* h, const std::vector<Circuit*>& circs, size_t first, size_t count, uint32_t mode) {
@@ -1185,15 +1184,7 @@ int eval_begin(qsv_t* h, const std::vector<Circuit*>& circs, const std::vector<i
     b.aux_plain = false;
     if (h->diagonal && b.split_any && factor_path(h) && h->geo.blocks_per_state > 1)
         for (size_t i = 0; i < n_evals && !b.aux_plain; ++i) b.aux_plain = b.split[i] == 0;
-    b.aux_split = false;
-    if (h->diagonal && b.split_any && fused_route(h) && h->side_slots > 2 * kAuxSideSlots) {
-        bool any_fused = false, any_other = false;
-        for (size_t i = 0; i < n_evals; ++i)
-            if (b.split[i]) (circs[i]->split.fused ? any_fused : any_other) = true;
-        b.aux_split = any_fused && any_other;
-    }
-    b.aux_split_count = 0;
-    if ((b.aux_plain || b.aux_split) && h->aux_stream < 0) {
+    if (b.aux_plain && h->aux_stream < 0) {
         hipStream_t st = nullptr;
         QSV_HIP(h, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
         h->side_streams.push_back(st);
@@ -1276,25 +1267,16 @@ int eval_push(qsv_t* h, size_t first, size_t count, const double* values) {
             b.used_mask |= 1u << (lane - 1);
         }
     }
-    // (a batch with aux_split: the split evaluations that need launches of their own lead the push; they take the slots set
-    // aside for the auxiliary stream, which orders every reuse of those)
-    size_t n_aux_split = 0;
-    if (b.aux_split)
-        while (n_aux_split < n_split && !b.circs[b.eval_at[first + n_aux_split]]->split.fused) ++n_aux_split;
-    const size_t lane_slots = h->side_slots > 0 ? size_t(h->side_slots) - (b.aux_split ? size_t(kAuxSideSlots) : 0) : 0;
-    const size_t SG = lane_slots > 0 ? std::max<size_t>(1, lane_slots / ways) : 1;
+    const size_t SG = h->side_slots > 0 ? std::max<size_t>(1, size_t(h->side_slots) / ways) : 1;
     for (size_t j = 0; j < n_split; ++j) {
-        const uint32_t slot = j < n_aux_split ? uint32_t(lane_slots + (b.aux_split_count + j) % size_t(kAuxSideSlots))
-                                              : uint32_t(lane * SG + (j - n_aux_split) % SG);
+        const uint32_t slot = uint32_t(lane * SG + j % SG);
         hd[first + j].state_slot = slot;
         hd[P + first + j].state_slot = slot;
     }
-    b.aux_split_count += n_aux_split;
     hipStream_t const lane_stream = h->work;  // (null: the handle's own)
     hipStream_t const plain_stream = b.aux_plain ? h->side_streams[size_t(h->aux_stream)] : lane_stream;
     if (b.aux_plain && n_split < count) b.used_mask |= 1u << h->aux_stream;
-    hipStream_t const aux_split_stream = n_aux_split > 0 ? h->side_streams[size_t(h->aux_stream)] : lane_stream;
-    if (n_aux_split > 0) b.used_mask |= 1u << h->aux_stream;
+
     for (size_t j = n_split; j < count; ++j) {
         // (on the auxiliary stream every ordinary evaluation of the batch: one stream orders every reuse of a slot)
         const uint32_t slot = b.aux_plain ? uint32_t((b.aux_count + (j - n_split)) % size_t(h->group))
@@ -1319,16 +1301,13 @@ int eval_push(qsv_t* h, size_t first, size_t count, const double* values) {
     // launch groups: the split evaluations of the push in groups of SG, then the ordinary ones in groups of G
     for (size_t g0 = first; g0 < first + count;) {
         const bool in_split = g0 < first + n_split;
-        const bool in_aux_split = g0 < first + n_aux_split;
-        const size_t gc = in_aux_split ? std::min(size_t(kAuxSideSlots), first + n_aux_split - g0)
-                          : in_split   ? std::min(SG, first + n_split - g0)
-                                       : std::min(G, first + count - g0);
+        const size_t gc = in_split ? std::min(SG, first + n_split - g0) : std::min(G, first + count - g0);
         struct Advance {
             size_t& g0;
             size_t gc;
             ~Advance() { g0 += gc; }
         } advance{g0, gc};
-        h->work = in_aux_split ? aux_split_stream : in_split ? lane_stream : plain_stream;
+        h->work = in_split ? lane_stream : plain_stream;
         QSV_HIP(h, stamp(h, b.pass_events, true));
         rc = run_group(h, b.circs, g0, gc, group_mode);
         if (!rc) QSV_HIP(h, stamp(h, b.pass_events, false));
@@ -1564,6 +1543,7 @@ int qsv_create(int n_qubits, int dtype, int device, const qsv_plan_config* cfg, 
     if (const char* env = getenv("QSV_SPLIT_SAMPLE")) h->split_sampling = atoi(env) != 0;
     if (const char* env = getenv("QSV_FACTOR")) h->factor_enabled = atoi(env) != 0;
     if (getenv("QSV_NO_FUSED_FACTOR")) h->fused_factor = false;
+    if (const char* env = getenv("QSV_SPLIT_MAX_KEYS")) h->split_max_keys = std::max(0, std::min(kMaxSplitKeys, atoi(env)));
     h->stream_mode = state_bytes > (size_t(256) << 20) ? uint32_t(kModeStreaming) : 0u;
     if (const char* env = getenv("QSV_STREAMING")) h->stream_mode = atoi(env) ? uint32_t(kModeStreaming) : 0u;
     if (const char* env = getenv("QSV_STREAMS")) h->n_streams = std::max(1, std::min(4, atoi(env)));
@@ -1986,7 +1966,7 @@ int qsv_eval_set_output(qsv_t* h, double* device_out) {
         // The caller may already have queued writes to the output buffer on the handle's stream (a fill of the unused
         // tail of an uneven shard).  The batch's ordinary evaluations can run on the auxiliary stream (mixed batches,
         // eval_begin): whatever stream of ours writes results must come after that work.
-        if ((h->batch.aux_plain || h->batch.aux_split) && h->aux_stream >= 0) {
+        if (h->batch.aux_plain && h->aux_stream >= 0) {
             QSV_HIP(h, hipEventRecord(h->ev_join, h->stream));
             QSV_HIP(h, hipStreamWaitEvent(h->side_streams[size_t(h->aux_stream)], h->ev_join, 0));
         }
@@ -2396,6 +2376,9 @@ int qsv_set_option(qsv_t* h, const char* name, int value) {
         h->factor_enabled = value != 0;
     } else if (key == "fused_factor") {
         h->fused_factor = value != 0;
+    } else if (key == "split_max_keys") {
+        if (value < 0 || value > kMaxSplitKeys) return fail(h, QSV_E_ARG, "split_max_keys must be between 0 and 5");
+        h->split_max_keys = value;
     } else if (key == "split_sampling") {
         h->split_sampling = value != 0;
     } else if (key == "streams") {

@@ -2,7 +2,7 @@
 # rocprofv3 kernel-trace statistics of one short bench run (no counters): usage scripts/kstats.sh <tag> [env assignments..]
 tag=${1:-k}; shift || true
 cd "$(dirname "$0")/.."
-export TMPDIR=/tmp
+export TMPDIR=/tmp QSV_BENCH_WINDOWS=1 QSV_BENCH_PREWARM_S=0.02
 for kv in "$@"; do export "$kv"; done
 out=gpurun_out/kstats_$tag
 rm -rf $out; mkdir -p $out

@@ -4,7 +4,7 @@
 set -u
 tag=${1:-r02}; shift || true
 cd "$(dirname "$0")/.."
-export TMPDIR=/tmp
+export TMPDIR=/tmp QSV_BENCH_WINDOWS=1 QSV_BENCH_PREWARM_S=0.02
 out=gpurun_out/prof_$tag
 rm -rf $out; mkdir -p $out
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras "$@" > $out/bench_trace.log 2>&1

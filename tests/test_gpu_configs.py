@@ -548,6 +548,7 @@ def test_split_evaluations_with_four_and_five_keys(n, layers, count, c_oracle):
     assert max(keys) >= 4, keys
     op = helpers.random_ising_operator(n, seed=2020)
     ev = OperatorCircuitEvaluator(op)
+    ev.statevector_device.set_option("split_max_keys", 5)  # (off by default: DESIGN.md section 4.2)
     got = ev.evaluate_circuits(circuits, params)
     prof_dev = ev.statevector_device
     prof_dev.set_profiling(True)
@@ -566,10 +567,11 @@ def test_split_evaluations_with_four_and_five_keys(n, layers, count, c_oracle):
     if n == 20 and layers == 6:
         general = helpers.random_pauli_operator(n, 6, seed=4)
         sub_c, sub_p = [circuits[i] for i in big[:3]], [params[i] for i in big[:3]]
-        a = OperatorCircuitEvaluator(general).evaluate_circuits(sub_c, sub_p)
+        # (the same circuit objects, registered with five keys on `ev`'s device: another operator on that device)
+        a = OperatorCircuitEvaluator(general, statevector_device=ev.statevector_device).evaluate_circuits(sub_c, sub_p)
         b = OperatorCircuitEvaluator(general, statevector_device=_split_device(n, False)).evaluate_circuits(sub_c, sub_p)
         assert np.abs(np.asarray(a) - np.asarray(b)).max() < EXP_TOL
-        sampler = OperatorSamplerCircuitEvaluator(20000, op, alpha=1.0, seed=3)
+        sampler = OperatorSamplerCircuitEvaluator(20000, op, alpha=1.0, seed=3, statevector_device=ev.statevector_device)
         means = sampler.evaluate_circuits(sub_c, sub_p)
         spread = float(np.abs(op.coeffs).sum())
         assert np.abs(np.asarray(means) - np.asarray([got[i] for i in big[:3]])).max() < 0.05 * spread
