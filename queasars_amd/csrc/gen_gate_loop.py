@@ -66,6 +66,7 @@ MAT = {"A": 40, "B": 56}  # 16 SGPRs each: 8 doubles
 DESC = {"A": 72, "B": 76}  # w0, ct, cg, op
 SAVE = "s[80:81]"
 T0 = "s82"
+TX = "s83"  # second scalar temporary of the gate code (free while gates run; the round loop uses it between them)
 RP, MP, N = 84, 86, 88
 CLOBBER_RANGE = range(40, 89)
 
@@ -77,57 +78,76 @@ def sreg2(base: int) -> str:
 def gate(lines: list[str], r: int, x: str, tag: str) -> None:
     """Emit the code of one gate that reads register set x ('A' or 'B')."""
     m, d = MAT[x], DESC[x]
-    w0, ct, cg = f"s{d}", f"s{d + 1}", f"s{d + 2}"
-    m00, m01r, m01i = sreg2(m), sreg2(m + 4), sreg2(m + 6)
+    w0, ct, cg, fl = f"s{d}", f"s{d + 1}", f"s{d + 2}", f"s{d + 3}"
+    m00, m00i, m01r, m01i = sreg2(m), sreg2(m + 2), sreg2(m + 4), sreg2(m + 6)
     m10r, m10i, m11r, m11i = sreg2(m + 8), sreg2(m + 10), sreg2(m + 12), sreg2(m + 14)
     e = lines.append
+    # the entry's predicates: every listed bit set -- or, for the control-is-0 entry of a multiplexed gate (flag bit 0,
+    # plan.hpp FUSION), every listed bit clear
     e(f"s_and_b32 {T0}, %[base], {cg}")
-    e(f"s_cmp_eq_u32 {T0}, {cg}")
+    e(f"s_bitcmp1_b32 {fl}, 0")
+    e(f"s_cselect_b32 {TX}, 0, {cg}")
+    e(f"s_cmp_eq_u32 {T0}, {TX}")
     e(f"s_cbranch_scc0 Lskip{tag}_%=")
+    e(f"s_bitcmp1_b32 {fl}, 0")
+    e(f"s_cselect_b32 {TX}, 0, {ct}")
     e(f"v_and_b32 %[vt], {ct}, %[tid]")
-    e(f"v_cmp_eq_u32 vcc, {ct}, %[vt]")
+    e(f"v_cmp_eq_u32 vcc, {TX}, %[vt]")
     e(f"s_and_saveexec_b64 {SAVE}, vcc")
     e(f"s_cbranch_execz Lrest{tag}_%=")
-    if r > 1:
-        e(f"s_and_b32 {T0}, {w0}, 0xff")
-        for j in range(r - 1):
-            e(f"s_cmp_eq_u32 {T0}, {j}")
-            e(f"s_cbranch_scc1 Lj{j}{tag}_%=")
-    order = [r - 1] + list(range(r - 1))  # fall-through case first, then the branch targets
-    for pos, j in enumerate(order):
-        if j != r - 1:
-            e(f"Lj{j}{tag}_%=:")
-        pair = 0
-        for e0 in range(1 << r):
-            if e0 & (1 << j):
-                continue
-            e1 = e0 | (1 << j)
-            a0r, a0i, a1r, a1i = amp_re(e0), amp_im(e0), amp_re(e1), amp_im(e1)
-            if "pairtest" not in ABL:
-                e(f"s_bitcmp1_b32 {w0}, {16 + pair}")
-                e(f"s_cbranch_scc0 Ln{j}_{pair}{tag}_%=")
-            # four accumulation chains taken round-robin: every operation is four issue slots behind the one it
-            # depends on (the dependent issue of v_fma_f64 is longer than two slots), and every amplitude register
-            # is overwritten only after its last reader
-            if "gatevalu" not in ABL:
-                e(f"v_mul_f64 %[p], {m10r}, {a0r}")
-                e(f"v_mul_f64 %[q], {m10r}, {a0i}")
-                e(f"v_mul_f64 %[u], {m00}, {a0r}")
-                e(f"v_mul_f64 %[w], {m00}, {a0i}")
-                e(f"v_fma_f64 %[p], -{m10i}, {a0i}, %[p]")
-                e(f"v_fma_f64 %[q], {m10i}, {a0r}, %[q]")
-                e(f"v_fma_f64 %[u], {m01r}, {a1r}, %[u]")
-                e(f"v_fma_f64 %[w], {m01r}, {a1i}, %[w]")
-                e(f"v_fma_f64 %[p], {m11r}, {a1r}, %[p]")
-                e(f"v_fma_f64 %[q], {m11i}, {a1r}, %[q]")
-                e(f"v_fma_f64 {a0r}, -{m01i}, {a1i}, %[u]")
-                e(f"v_fma_f64 {a0i}, {m01i}, {a1r}, %[w]")
-                e(f"v_fma_f64 {a1r}, -{m11i}, {a1i}, %[p]")
-                e(f"v_fma_f64 {a1i}, {m11r}, {a1i}, %[q]")
-            e(f"Ln{j}_{pair}{tag}_%=:")
-            pair += 1
-        if pos + 1 < len(order):
-            e(f"s_branch Lrest{tag}_%=")
+    # flag bit 1: the matrix is a product, its m00 complex -> the 16-operation body
+    e(f"s_bitcmp1_b32 {fl}, 1")
+    e(f"s_cbranch_scc1 Lgen{tag}_%=")
+    for general in (False, True):
+        x = "g" if general else ""
+        if general:
+            e(f"Lgen{tag}_%=:")
+        if r > 1:
+            e(f"s_and_b32 {T0}, {w0}, 0xff")
+            for j in range(r - 1):
+                e(f"s_cmp_eq_u32 {T0}, {j}")
+                e(f"s_cbranch_scc1 Lj{x}{j}{tag}_%=")
+        order = [r - 1] + list(range(r - 1))  # fall-through case first, then the branch targets
+        for pos, j in enumerate(order):
+            if j != r - 1:
+                e(f"Lj{x}{j}{tag}_%=:")
+            pair = 0
+            for e0 in range(1 << r):
+                if e0 & (1 << j):
+                    continue
+                e1 = e0 | (1 << j)
+                a0r, a0i, a1r, a1i = amp_re(e0), amp_im(e0), amp_re(e1), amp_im(e1)
+                if "pairtest" not in ABL:
+                    e(f"s_bitcmp1_b32 {w0}, {16 + pair}")
+                    e(f"s_cbranch_scc0 Ln{x}{j}_{pair}{tag}_%=")
+                # four accumulation chains taken round-robin: every operation is four issue slots behind the one it
+                # depends on (the dependent issue of v_fma_f64 is longer than two slots), and every amplitude register
+                # is overwritten only after its last reader
+                if "gatevalu" not in ABL:
+                    e(f"v_mul_f64 %[p], {m10r}, {a0r}")
+                    e(f"v_mul_f64 %[q], {m10r}, {a0i}")
+                    e(f"v_mul_f64 %[u], {m00}, {a0r}")
+                    e(f"v_mul_f64 %[w], {m00}, {a0i}")
+                    e(f"v_fma_f64 %[p], -{m10i}, {a0i}, %[p]")
+                    e(f"v_fma_f64 %[q], {m10i}, {a0r}, %[q]")
+                    if general:  # (Im m00: the two operations a u-type matrix saves)
+                        e(f"v_fma_f64 %[u], -{m00i}, {a0i}, %[u]")
+                        e(f"v_fma_f64 %[w], {m00i}, {a0r}, %[w]")
+                        e(f"v_fma_f64 %[p], {m11r}, {a1r}, %[p]")
+                        e(f"v_fma_f64 %[q], {m11i}, {a1r}, %[q]")
+                    e(f"v_fma_f64 %[u], {m01r}, {a1r}, %[u]")
+                    e(f"v_fma_f64 %[w], {m01r}, {a1i}, %[w]")
+                    if not general:
+                        e(f"v_fma_f64 %[p], {m11r}, {a1r}, %[p]")
+                        e(f"v_fma_f64 %[q], {m11i}, {a1r}, %[q]")
+                    e(f"v_fma_f64 {a0r}, -{m01i}, {a1i}, %[u]")
+                    e(f"v_fma_f64 {a0i}, {m01i}, {a1r}, %[w]")
+                    e(f"v_fma_f64 {a1r}, -{m11i}, {a1i}, %[p]")
+                    e(f"v_fma_f64 {a1i}, {m11r}, {a1i}, %[q]")
+                e(f"Ln{x}{j}_{pair}{tag}_%=:")
+                pair += 1
+            if not (general and pos + 1 == len(order)):
+                e(f"s_branch Lrest{tag}_%=")
     e(f"Lrest{tag}_%=:")
     e(f"s_mov_b64 exec, {SAVE}")
     e(f"Lskip{tag}_%=:")

@@ -112,6 +112,39 @@ __device__ __forceinline__ void butterfly(cx<real> (&amp)[1 << R], const real (&
     }
 }
 
+// The same for an entry with flags (plan.hpp FUSION): a general matrix (m00 complex: 16 operations) on the pairs the
+// entry's pair mask names.  Only the C++ gate loop (fp32, diagnostic builds) comes here; fp64 runs gate_loop_gen.inc.
+template <typename real, int R, int J>
+__device__ __forceinline__ void butterfly_general(cx<real> (&amp)[1 << R], const real (&m)[8], uint32_t pair_mask) {
+    constexpr int tbit = 1 << J;
+    int pair = 0;
+#pragma unroll
+    for (int e0 = 0; e0 < (1 << R); ++e0) {
+        if (e0 & tbit) continue;
+        if ((pair_mask >> pair) & 1u) {
+            const real a0r = amp[e0].re, a0i = amp[e0].im, a1r = amp[e0 | tbit].re, a1i = amp[e0 | tbit].im;
+            amp[e0].re = m[0] * a0r - m[1] * a0i + m[2] * a1r - m[3] * a1i;
+            amp[e0].im = m[0] * a0i + m[1] * a0r + m[2] * a1i + m[3] * a1r;
+            amp[e0 | tbit].re = m[4] * a0r - m[5] * a0i + m[6] * a1r - m[7] * a1i;
+            amp[e0 | tbit].im = m[4] * a0i + m[5] * a0r + m[6] * a1i + m[7] * a1r;
+        }
+        ++pair;
+    }
+}
+template <typename real, int R, int J>
+struct GeneralDispatch {
+    static __device__ __forceinline__ void run(int j, cx<real> (&amp)[1 << R], const real (&m)[8], uint32_t pair_mask) {
+        if (j == J)
+            butterfly_general<real, R, J>(amp, m, pair_mask);
+        else
+            GeneralDispatch<real, R, J - 1>::run(j, amp, m, pair_mask);
+    }
+};
+template <typename real, int R>
+struct GeneralDispatch<real, R, -1> {
+    static __device__ __forceinline__ void run(int, cx<real> (&)[1 << R], const real (&)[8], uint32_t) {}
+};
+
 // sel = J * (R + 1) + (C + 1)
 template <typename real, int R, int SEL>
 struct ButterflyDispatch {
@@ -357,6 +390,29 @@ __device__ __forceinline__ void entry_matrix(const uint32_t* __restrict__ e, con
     }
 }
 
+// Matrix of one scheduled entry: the product of its factors (plan.hpp CHAIN INDEX), the factor that acts first rightmost.
+__device__ __forceinline__ void chain_matrix(const uint32_t* __restrict__ table, uint32_t chain_word,
+                                             const double* __restrict__ params, double* m) {
+    const uint32_t first = chain_word & 0xffffffu, count = chain_word >> 24;
+    entry_matrix(table + size_t(first) * kAngleEntryWords, params, m);
+    for (uint32_t i = 1; i < count; ++i) {
+        double b[8], c[8];
+        entry_matrix(table + size_t(first + i) * kAngleEntryWords, params, b);
+#pragma unroll
+        for (int row = 0; row < 2; ++row)
+#pragma unroll
+            for (int col = 0; col < 2; ++col) {
+                // c[row][col] = b[row][0] m[0][col] + b[row][1] m[1][col]
+                const double xr = b[4 * row], xi = b[4 * row + 1], yr = b[4 * row + 2], yi = b[4 * row + 3];
+                const double pr = m[2 * col], pi = m[2 * col + 1], qr = m[4 + 2 * col], qi = m[4 + 2 * col + 1];
+                c[4 * row + 2 * col] = xr * pr - xi * pi + yr * qr - yi * qi;
+                c[4 * row + 2 * col + 1] = xr * pi + xi * pr + yr * qi + yi * qr;
+            }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = c[e];
+    }
+}
+
 // What prepare_kernel does for ONE evaluation, by one workgroup (every thread of it calls this; `scratch` = LDS for
 // kPrepScratchDoubles doubles).  The pass kernel's synthesising instantiation runs it itself for the virtual circuits of split
 // evaluations (one launch and one dependent launch latency less in front of the contraction).
@@ -384,6 +440,8 @@ __device__ __forceinline__ void prepare_eval(const uint32_t* __restrict__ plan, 
     const uint32_t* __restrict__ table = cp + cp[3];
     const uint32_t* __restrict__ fold = cp + cp[4];
     const uint32_t n_fold = cp[5];
+    const uint32_t* __restrict__ chains = cp + cp[6];
+    const uint32_t n_factors = cp[7];  // the fold entries follow the scheduled entries' factors in the angle table
     const double* p = params + ev.param_base;
     double* __restrict__ out = mats + ev.mat_base;
     // The parameters live in pinned host memory: every read is a trip over PCIe, and a qubit's folded gates used to be
@@ -400,7 +458,10 @@ __device__ __forceinline__ void prepare_eval(const uint32_t* __restrict__ plan, 
     QSV_PSTAMP(3);  // parameters staged
     for (uint32_t j = threadIdx.x; j < n_real + (staged ? n_fold : 0u); j += blockDim.x) {
         double m[8];
-        entry_matrix(table + size_t(j) * kAngleEntryWords, p, m);
+        if (j < n_real)
+            chain_matrix(table, chains[j], p, m);
+        else
+            entry_matrix(table + size_t(n_factors + j - n_real) * kAngleEntryWords, p, m);
         double* dst = j < n_real ? out + size_t(j) * 8 : fm + size_t(j - n_real) * 8;
 #pragma unroll
         for (int i = 0; i < 8; ++i) dst[i] = m[i];
@@ -414,7 +475,7 @@ __device__ __forceinline__ void prepare_eval(const uint32_t* __restrict__ plan, 
             double m[8];
             if (staged) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) m[e] = fm[size_t(first + i - n_real) * 8 + e];
+                for (int e = 0; e < 8; ++e) m[e] = fm[size_t(first + i - n_factors) * 8 + e];
             } else {
                 entry_matrix(table + size_t(first + i) * kAngleEntryWords, p, m);
             }
@@ -958,13 +1019,22 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, FIRST>::waves_per_si
                 }
             } else {
                 // gate stream: descriptor and matrix of gate g+1 are fetched (scalar loads) while gate g runs
-                uint32_t w0 = rp[0], ct = rp[1], cg = rp[2];
-                double m0 = mp[0], m1 = mp[2], m2 = mp[3], m3 = mp[4], m4 = mp[5], m5 = mp[6], m6 = mp[7];
+                uint32_t w0 = rp[0], ct = rp[1], cg = rp[2], fl = rp[3];
+                double m0 = mp[0], mi = mp[1], m1 = mp[2], m2 = mp[3], m3 = mp[4], m4 = mp[5], m5 = mp[6], m6 = mp[7];
                 for (int g = 0; g < n_gates; ++g) {
                     rp += kGateWords;
                     mp += 8;
-                    const uint32_t nw0 = rp[0], nct = rp[1], ncg = rp[2];
-                    const double n0 = mp[0], n1 = mp[2], n2 = mp[3], n3 = mp[4], n4 = mp[5], n5 = mp[6], n6 = mp[7];
+                    const uint32_t nw0 = rp[0], nct = rp[1], ncg = rp[2], nfl = rp[3];
+                    const double n0 = mp[0], ni = mp[1], n1 = mp[2], n2 = mp[3], n3 = mp[4], n4 = mp[5], n5 = mp[6], n6 = mp[7];
+                    if (fl != 0) {
+                        // an entry of a multiplexed gate or a product of matrices (plan.hpp FUSION): negated predicates,
+                        // pairs by the entry's mask, general matrix
+                        const bool neg = fl & kGateNegated;
+                        if ((uint32_t(base) & cg) == (neg ? 0u : cg) && active && (tid & ct) == (neg ? 0u : ct)) {
+                            const real mm[8] = {real(m0), real(mi), real(m1), real(m2), real(m3), real(m4), real(m5), real(m6)};
+                            GeneralDispatch<real, R, R - 1>::run(int(w0 & 0xffu), amp, mm, w0 >> 16);
+                        }
+                    } else
                     if ((uint32_t(base) & cg) == cg) {  // else: the control is a fixed bit of this tile and it is 0
                         const uint32_t creg = (w0 >> 8) & 0xffu;
                         const int sel = int(w0 & 0xffu) * (R + 1) + (creg == 0xffu ? 0 : int(creg) + 1);
@@ -977,8 +1047,8 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, FIRST>::waves_per_si
                             ButterflyDispatch<real, R, R*(R + 1) - 1>::run(sel, amp, mm);
                         }
                     }
-                    w0 = nw0; ct = nct; cg = ncg;
-                    m0 = n0; m1 = n1; m2 = n2; m3 = n3; m4 = n4; m5 = n5; m6 = n6;
+                    w0 = nw0; ct = nct; cg = ncg; fl = nfl;
+                    m0 = n0; mi = ni; m1 = n1; m2 = n2; m3 = n3; m4 = n4; m5 = n5; m6 = n6;
                 }
             }
             QSV_STAMP(10);

@@ -302,6 +302,63 @@ CircuitPlan build_plan(int n, const std::vector<GateIn>& all_gates, const std::v
         }
     }
 
+    // ---- 1b. fusion (plan.hpp): u gates next to a gate on the same target are multiplied into it -------------
+    // chain1[i]: the ops whose matrices, multiplied in the order listed, give gate i's matrix (where its control is 1);
+    // chain0[i]: the u gates among them (the matrix where the control is 0), empty for a gate that is not multiplexed
+    std::vector<std::vector<int>> chain1, chain0;
+    {
+        std::vector<GateIn> fused;
+        std::vector<char> dead;
+        std::vector<int> last(size_t(n), -1);       // the latest gate that touches the qubit ..
+        std::vector<char> as_target(size_t(n), 0);  // .. and whether it targets it
+        for (const GateIn& g : gates) {
+            const int j = last[size_t(g.target)];
+            const bool open = cfg.fuse && j >= 0 && as_target[size_t(g.target)] && chain1[size_t(j)].size() < kMaxChain;
+            int at = -1;
+            if (open && g.control < 0) {
+                // a u joins the gate before it on this qubit (nothing touched the qubit since)
+                chain1[size_t(j)].push_back(g.op);
+                if (fused[size_t(j)].control >= 0) chain0[size_t(j)].push_back(g.op);
+                at = j;
+                out.stats.n_fused_gates += 1;
+            } else if (open && fused[size_t(j)].control < 0) {
+                // a cu3 takes in the u gates before it: they move here, to the cu3's place in the program
+                at = int(fused.size());
+                fused.push_back(g);
+                chain1.push_back(chain1[size_t(j)]);
+                chain1.back().push_back(g.op);
+                chain0.push_back(chain1[size_t(j)]);
+                dead.push_back(0);
+                dead[size_t(j)] = 1;
+                out.stats.n_fused_gates += int(chain1[size_t(j)].size());
+            } else {
+                at = int(fused.size());
+                fused.push_back(g);
+                chain1.push_back({g.op});
+                chain0.emplace_back();
+                dead.push_back(0);
+            }
+            last[size_t(g.target)] = at;
+            as_target[size_t(g.target)] = 1;
+            if (g.control >= 0) {
+                last[size_t(g.control)] = at;
+                as_target[size_t(g.control)] = 0;
+            }
+        }
+        size_t keep = 0;
+        for (size_t i = 0; i < fused.size(); ++i)
+            if (!dead[i]) {
+                fused[keep] = fused[i];
+                chain1[keep].swap(chain1[i]);
+                chain0[keep].swap(chain0[i]);
+                ++keep;
+            }
+        fused.resize(keep);
+        chain1.resize(keep);
+        chain0.resize(keep);
+        gates.swap(fused);
+    }
+
     // ---- 2. passes and rounds ----------------------------------------------------------------------------
     std::vector<int> default_regs;
     for (int b = k - r; b < k; ++b) default_regs.push_back(b);
@@ -438,11 +495,10 @@ CircuitPlan build_plan(int n, const std::vector<GateIn>& all_gates, const std::v
     std::vector<uint32_t>& w = out.words;
     w.assign(kCircuitHeaderWords, 0);
     w[0] = uint32_t(passes.size());
-    w[1] = uint32_t(gates.size());
-    w[2] = uint32_t(n);
+    w[2] = uint32_t(n);  // ([1], the number of scheduled entries, is known after the rounds are encoded)
     const size_t off_table = w.size();
     w.resize(w.size() + passes.size(), 0);
-    std::vector<int> schedule;  // real-gate indices in schedule order
+    std::vector<std::pair<int, int>> schedule;  // (real gate, 1: its matrix where the control is 1 / 0: where it is 0)
 
     // ---- COMPACT first pass (plan.hpp): worthwhile when there is a second pass to read the table and the outer
     // control patterns are far fewer than the tiles
@@ -710,7 +766,9 @@ CircuitPlan build_plan(int n, const std::vector<GateIn>& all_gates, const std::v
             const Layout& lay = layouts[m];
             const bool swap_round = by_swap[m] && !swaps[m].empty();
             const bool exch = m > 0 && !by_swap[m];
-            w.push_back(uint32_t(rd.gates.size()) | (exch ? 1u << 16 : 0u) | (exch && intra[m] ? 1u << 17 : 0u) |
+            size_t n_entries = 0;
+            for (int gi : rd.gates) n_entries += chain0[size_t(gi)].empty() ? 1 : 2;
+            w.push_back(uint32_t(n_entries) | (exch ? 1u << 16 : 0u) | (exch && intra[m] ? 1u << 17 : 0u) |
                         (swap_round ? 1u << 18 : 0u));
             if (swap_round) {
                 for (uint32_t i = 0; i < kMaxSwaps; ++i)
@@ -746,28 +804,43 @@ CircuitPlan build_plan(int n, const std::vector<GateIn>& all_gates, const std::v
                 // bit 16 + p: the p-th amplitude pair (register indices with the target bit clear, ascending) takes
                 // part; a register-held control switches off the pairs whose control bit is 0
                 const int jbit = reg_index_of[tb];
-                uint32_t pair_mask = 0;
-                for (int e0 = 0, pr = 0; e0 < (1 << r); ++e0) {
-                    if ((e0 >> jbit) & 1) continue;
-                    if (creg == 0xFF || ((e0 >> creg) & 1)) pair_mask |= 1u << pr;
-                    ++pr;
+                // a multiplexed gate (plan.hpp FUSION) takes two entries: where the control is 1, then where it is 0
+                for (int which = 1; which >= (chain0[size_t(gi)].empty() ? 1 : 0); --which) {
+                    uint32_t pair_mask = 0;
+                    for (int e0 = 0, pr = 0; e0 < (1 << r); ++e0) {
+                        if ((e0 >> jbit) & 1) continue;
+                        if (creg == 0xFF || int((e0 >> creg) & 1) == which) pair_mask |= 1u << pr;
+                        ++pr;
+                    }
+                    const size_t factors = which ? chain1[size_t(gi)].size() : chain0[size_t(gi)].size();
+                    w.push_back(uint32_t(jbit) | creg << 8 | pair_mask << 16);
+                    w.push_back(ct);
+                    w.push_back(cg);
+                    w.push_back((which ? 0u : kGateNegated) | (factors > 1 ? kGateGeneral : 0u));
+                    schedule.push_back({gi, which});
+                    // (a product's butterfly is 16 operations where a plain one is 14)
+                    pairs_this_pass += pass_tiles * double(uint64_t(1) << (k - 1)) * (g.control >= 0 ? 0.5 : 1.0) *
+                                       (factors > 1 ? 16.0 / 14.0 : 1.0);
                 }
-                w.push_back(uint32_t(jbit) | creg << 8 | pair_mask << 16);
-                w.push_back(ct);
-                w.push_back(cg);
-                w.push_back(uint32_t(g.op));
-                schedule.push_back(gi);
-                pairs_this_pass += pass_tiles * double(uint64_t(1) << (k - 1)) * (g.control >= 0 ? 0.5 : 1.0);
             }
             out.stats.n_rounds += 1;
         }
         out.stats.pass_pairs.push_back(pairs_this_pass);
     }
     // angle table: scheduled gates first, then the fold entries; fold index per qubit
+    w[1] = uint32_t(schedule.size());
     w[3] = uint32_t(w.size());
-    for (int gi : schedule) push_angle_entry(w, op_angles[size_t(gates[size_t(gi)].op)]);
+    std::vector<uint32_t> chain_index;
+    uint32_t entry = 0;
+    for (const auto& se : schedule) {
+        const std::vector<int>& chain = se.second ? chain1[size_t(se.first)] : chain0[size_t(se.first)];
+        chain_index.push_back(entry | uint32_t(chain.size()) << 24);
+        for (int op : chain) push_angle_entry(w, op_angles[size_t(op)]);
+        entry += uint32_t(chain.size());
+    }
+    if (entry >= (1u << 24)) throw std::invalid_argument("too many gates");
+    const uint32_t n_factors = entry;
     std::vector<std::pair<uint32_t, uint32_t>> fold_index(size_t(n), {0u, 0u});
-    uint32_t entry = uint32_t(schedule.size());
     for (int q = 0; q < n; ++q) {
         fold_index[size_t(q)] = {entry, uint32_t(folds[size_t(q)].size())};
         for (int op : folds[size_t(q)]) {
@@ -776,14 +849,17 @@ CircuitPlan build_plan(int n, const std::vector<GateIn>& all_gates, const std::v
         }
     }
     w[4] = uint32_t(w.size());
-    w[5] = entry - uint32_t(schedule.size());
+    w[5] = entry - n_factors;
     for (const auto& fi : fold_index) {
         w.push_back(fi.first);
         w.push_back(fi.second);
     }
+    w[6] = uint32_t(w.size());
+    w[7] = n_factors;
+    w.insert(w.end(), chain_index.begin(), chain_index.end());
     w.resize(w.size() + kPlanPadWords, 0);
     out.stats.n_passes = int(passes.size());
-    out.stats.n_real_gates = int(gates.size());
+    out.stats.n_real_gates = int(schedule.size());
     return out;
 }
 

@@ -18,6 +18,15 @@
 //    tile: it is a predicate on the register index, on the thread index or on the tile's fixed bits.  Between
 //    rounds the tile is transposed through LDS (an EXCHANGE) so that other tile bits become register bits.
 //
+// 1b. FUSION.  On the timeline of a qubit, a u gate that directly follows or precedes a cu3 TARGETING that qubit (nothing
+//    else touches the qubit in between) is multiplied into it: the pair becomes one MULTIPLEXED gate, matrix M1 = the
+//    product with the controlled matrix where the control is 1, M0 = the product of the u gates alone where it is 0.
+//    The schedule carries it as two entries with complementary predicates (a negated control for M0), each a plain
+//    2x2 butterfly -- every amplitude pair of the target is still updated exactly once, where the separate u swept all
+//    pairs and the cu3 half of them again (EVQE layers alternate rotations and controlled rotations: seven in ten u
+//    gates of a deep individual disappear this way).  Neighbouring u gates on one qubit merge the same way.  A product
+//    of u matrices no longer has a real m00: such entries carry a flag and take the 16-operation butterfly.
+//
 // All index maps (thread/register -> global offset, thread/register -> LDS offset) are GF(2)-linear, so each is
 // shipped to the device as one column per thread bit and per register bit; the kernel XORs columns together.
 #pragma once
@@ -45,6 +54,7 @@ struct PlanConfig {
     int retries = 16;    // randomised scheduling attempts when the first-come rule needs more than two passes
     bool swaps = true;   // relayouts that only trade register bits for lane bits 2..5 run as in-register lane swaps
                          // (v_permlane16/32_swap, DPP row shifts) instead of an LDS exchange, see "round" below
+    bool fuse = true;    // FUSION (below): u gates next to a cu3 on the same target become part of it
 };
 
 struct GateIn {
@@ -71,7 +81,8 @@ struct PlanStats {
     int n_swap_rounds = 0;           // relayouts done by lane swaps instead of an LDS exchange
     int n_swaps = 0;                 // ... and the (register bit, lane bit) transpositions they took
     int compact_bits = -1;           // >= 0: pass 0 is compact over this many outer control qubits
-    int n_real_gates = 0;
+    int n_real_gates = 0;     // scheduled entries (a multiplexed gate takes two)
+    int n_fused_gates = 0;    // u gates multiplied into a neighbouring gate on the same target
     int n_folded_gates = 0;   // u gates absorbed into the initial product state
     int n_dropped_gates = 0;  // cu3 gates whose control is still |0>: identity
     int lds_conflict_cycles = 0;  // extra LDS cycles per wave-instruction summed over exchanges (0 = conflict free)
@@ -87,8 +98,8 @@ struct CircuitPlan {
 };
 
 // ---- encoded layout (uint32 words; offsets relative to the circuit plan's first word) -------------------------
-// circuit: [0] n_passes  [1] n_real (scheduled gates)  [2] n_qubits  [3] offset of the ANGLE TABLE
-//          [4] offset of the FOLD INDEX  [5] n_fold_entries  [6..8) reserved
+// circuit: [0] n_passes  [1] n_real (scheduled ENTRIES = matrices)  [2] n_qubits  [3] offset of the ANGLE TABLE
+//          [4] offset of the FOLD INDEX  [5] n_fold_entries  [6] offset of the CHAIN INDEX  [7] n_factors
 //          [8 .. 8+n_passes) pass offsets
 // pass:    [0] k | r<<8 | t<<16 | n_rounds<<24      [1] index of the pass's first scheduled gate
 //          [2] flags: bit 0 COMPACT_STORE, bit 1 COMPACT_LOAD, bits 8..15 m (see COMPACT below)   [3] reserved
@@ -131,11 +142,16 @@ struct CircuitPlan {
 //                                     (bit p: the p-th amplitude pair, register indices with the target bit
 //                                     clear in ascending order, takes part)
 //                                 [1] ctrl mask over the thread index   [2] ctrl mask over the global index
-//                                 [3] index of the originating op (informational; the kernel does not read it)
-//          Gates are numbered in the order they appear here (the SCHEDULE ORDER); the matrix of scheduled gate s
+//                                 [3] flags: kGateNegated = the entry applies where its control is 0 (words [1] and [2]
+//                                     then list bits that must be CLEAR; a register-held control is in the pair mask
+//                                     either way), kGateGeneral = Im m00 may be non-zero (a product of matrices)
+//          Entries are numbered in the order they appear here (the SCHEDULE ORDER); the matrix of scheduled entry s
 //          of an evaluation lives at mats[mat_base + 8 s].
 // ANGLE TABLE: 9 words per entry {p_theta, p_phi, p_lambda (int32; <0 = literal), theta, phi, lambda (3 doubles)}:
-//          first the n_real scheduled gates in schedule order, then the fold entries.
+//          first the n_factors factors of the scheduled entries (entry by entry in schedule order, the factors of one
+//          entry in the order they act), then the fold entries.
+// CHAIN INDEX: per scheduled entry one word, first factor (index into the angle table) | number of factors << 24: the
+//          entry's matrix is the product of its factors' matrices, the one that acts first rightmost.
 // FOLD INDEX: per qubit q two words {first fold entry (index into the angle table), count}: the u gates folded
 //          into qubit q's initial factor, in program order.
 constexpr uint32_t kCircuitHeaderWords = 8;
@@ -157,6 +173,8 @@ constexpr uint32_t kMaxSwaps = 4, kSwapPad = 0xFFFFFFFFu;                       
 constexpr int kSwapLaneLo = 0, kSwapLaneHi = 6;                                 // lane bits a swap may use: [lo, hi)
 constexpr uint32_t kPosPad = 62;  // inserting a zero bit at position 62 leaves every index below 2^62 unchanged
 constexpr uint32_t kGateWords = 4;
+constexpr uint32_t kGateNegated = 1u, kGateGeneral = 2u;  // flags word of a gate entry
+constexpr uint32_t kMaxChain = 6;                         // factors per scheduled entry
 constexpr uint32_t kAngleEntryWords = 9;
 constexpr uint32_t kPlanPadWords = 32;  // readable padding after every plan (the kernel prefetches one gate ahead)
 

@@ -369,6 +369,10 @@ PlanConfig resolve_config(const qsv_plan_config* cfg, int dtype, int n_qubits) {
     if (const char* e = getenv("QSV_FOLD")) pc.fold = atoi(e) != 0;
     if (const char* e = getenv("QSV_COMPACT")) pc.compact = atoi(e) != 0;
     if (const char* e = getenv("QSV_SWAPS")) pc.swaps = atoi(e) != 0;
+    // multiplexed gates (plan.hpp FUSION): fp64's assembly gate loop takes their entries at full speed; fp32's C++ loop
+    // takes them correctly but through a generic butterfly, so they stay off there unless asked for
+    pc.fuse = dtype == QSV_F64;
+    if (const char* e = getenv("QSV_FUSE")) pc.fuse = atoi(e) != 0;
     if (const char* e = getenv("QSV_RETRIES")) pc.retries = atoi(e);
     if (cfg) {
         if (cfg->tile_bits > 0) pc.tile_bits = cfg->tile_bits;

@@ -16,6 +16,7 @@ GATE_WORDS = 4
 MAX_TILE_BITS, MAX_THREAD_BITS, MAX_REG_BITS, POS_PAD = 13, 9, 4, 62
 MAX_COMPACT_BITS, MAX_OUTER_BITS, COMPACT_STORE, COMPACT_LOAD = 8, 20, 1, 2
 MAX_SWAPS, SWAP_PAD, SWAP_LANE_LO, SWAP_LANE_HI = 4, 0xFFFFFFFF, 0, 6
+GATE_NEGATED, GATE_GENERAL, MAX_CHAIN = 1, 2, 6
 
 # lane groups of ds_read_b128 (MI355X_MICROARCH.md, LDS table)
 _READ_G0 = [0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27]
@@ -64,6 +65,14 @@ def _angle_entry(w: np.ndarray, off: int, params) -> tuple[float, float, float]:
 def _u_matrix(theta: float, phi: float, lam: float) -> np.ndarray:
     c, s = np.cos(theta / 2), np.sin(theta / 2)
     return np.array([[c, -np.exp(1j * lam) * s], [np.exp(1j * phi) * s, np.exp(1j * (phi + lam)) * c]])
+
+
+def _entry_matrix(w: np.ndarray, off: int, params) -> np.ndarray:
+    """One angle-table entry -> matrix; codes below -1 are the fixed matrices of the virtual circuits (split.hpp)."""
+    code = int(np.int32(w[off]))
+    if code >= -1:
+        return _u_matrix(*_angle_entry(w, off, params))
+    return {-2: np.array([[1, 0], [0, 0]]), -3: np.array([[1, 0], [1, 0]]), -4: np.array([[0, 1], [1, 0]])}[code].astype(np.complex128)
 
 
 def bank_conflicts_b64(thread_cols, is_write: bool) -> int:
@@ -146,31 +155,47 @@ def decode(words: np.ndarray) -> dict:
                 cur += MAX_THREAD_BITS + MAX_REG_BITS
             gates = []
             for _g in range(n_gates):
-                w0, ct, cg, op = (int(x) for x in w[cur : cur + GATE_WORDS])
+                w0, ct, cg, fl = (int(x) for x in w[cur : cur + GATE_WORDS])
                 cur += GATE_WORDS
                 creg = (w0 >> 8) & 0xFF
+                assert fl & ~(GATE_NEGATED | GATE_GENERAL) == 0, "unknown gate flags"
                 gates.append({"tbit": w0 & 0xFF, "creg": None if creg == 0xFF else creg, "pairs": w0 >> 16, "ct": ct, "cg": cg,
-                              "op": op, "sched": sched})
+                              "negated": bool(fl & GATE_NEGATED), "general": bool(fl & GATE_GENERAL), "sched": sched})
                 sched += 1
             rounds.append({"write_cols": wc, "read_cols": rc, "gates": gates, "intra_wave": bool(intra), "swaps": swaps})
         passes.append({"k": k, "r": r, "t": t, "pos": pos, "load_cols": gl, "store_cols": gs, "rounds": rounds,
                        "first_gate": first_gate, "compact": compact})
     fold_index = [(int(w[fold_off + 2 * q]), int(w[fold_off + 2 * q + 1])) for q in range(n_qubits)]
+    # chain index (plan.hpp): per scheduled entry its factors in the angle table
+    chain_off, n_factors = int(w[6]), int(w[7])
+    chains = [(int(w[chain_off + s]) & 0xFFFFFF, int(w[chain_off + s]) >> 24) for s in range(n_real)]
+    at = 0
+    for first, count in chains:
+        assert first == at and 1 <= count <= MAX_CHAIN, "chain index must tile the factors in schedule order"
+        at += count
+    assert at == n_factors
+    assert all(n_factors <= first and first + count <= n_factors + n_fold for first, count in fold_index if count)
     return {
         "n_passes": n_passes, "n_real": n_real, "n_qubits": n_qubits, "angle_off": angle_off, "n_fold": n_fold,
-        "fold_index": fold_index, "passes": passes, "words": w,
+        "fold_index": fold_index, "passes": passes, "words": w, "chains": chains, "n_factors": n_factors,
     }
 
 
 def prepare(plan: dict, params) -> tuple[np.ndarray, np.ndarray]:
     """What prepare_kernel computes: matrices of the scheduled gates and the initial product-state factors."""
     w, off = plan["words"], plan["angle_off"]
-    mats = np.array([_u_matrix(*_angle_entry(w, off + 9 * j, params)) for j in range(plan["n_real"])]).reshape(-1, 2, 2)
+    mats = []
+    for first, count in plan["chains"]:
+        m = np.eye(2, dtype=np.complex128)
+        for i in range(count):  # the factor that acts first rightmost
+            m = _entry_matrix(w, off + 9 * (first + i), params) @ m
+        mats.append(m)
+    mats = np.array(mats).reshape(-1, 2, 2)
     vecs = np.zeros((plan["n_qubits"], 2), dtype=np.complex128)
     for q, (first, count) in enumerate(plan["fold_index"]):
         v = np.array([1.0 + 0j, 0.0 + 0j])
         for i in range(count):
-            v = _u_matrix(*_angle_entry(w, off + 9 * (first + i), params)) @ v
+            v = _entry_matrix(w, off + 9 * (first + i), params) @ v
         vecs[q] = v
     return mats, vecs
 
@@ -185,7 +210,8 @@ def run(words: np.ndarray, n_qubits: int, params, stats: dict | None = None, lds
     all_gates = [g for ps in plan["passes"] for rd in ps["rounds"] for g in rd["gates"]]
     assert [g["sched"] for g in all_gates] == list(range(plan["n_real"])), "schedule order must be contiguous"
     if stats is not None:
-        stats.update({"passes": plan["n_passes"], "rounds": 0, "exchanges": 0, "swap_rounds": 0, "swaps": 0, "gates": plan["n_real"],
+        stats.update({"passes": plan["n_passes"], "rounds": 0, "exchanges": 0, "swap_rounds": 0, "swaps": 0,
+                      "gates": sum(1 for g in all_gates if not g["negated"]),
                       "folded": plan["n_fold"], "conflicts": 0, "wave_uniform_ctrl": 0, "lane_ctrl": 0})
     for pi, ps in enumerate(plan["passes"]):
         k, r, t = ps["k"], ps["r"], ps["t"]
@@ -249,7 +275,7 @@ def run(words: np.ndarray, n_qubits: int, params, stats: dict | None = None, lds
             stats["rounds"] += len(ps["rounds"])
             for rd in ps["rounds"]:
                 for g in rd["gates"]:
-                    if g["ct"]:
+                    if g["ct"] and not g["negated"]:  # (a multiplexed gate is counted once, by its control-is-1 entry)
                         stats["wave_uniform_ctrl" if (g["ct"] & 63) == 0 else "lane_ctrl"] += 1
 
         new_state = state.copy()
@@ -309,19 +335,22 @@ def run(words: np.ndarray, n_qubits: int, params, stats: dict | None = None, lds
                     differ = ((tt >> u) & 1) != ((ee >> v) & 1)
                     amp = np.where(differ, amp[tt ^ (1 << u), ee ^ (1 << v)], amp)
                 for g in rd["gates"]:
-                    if (base & g["cg"]) != g["cg"]:
+                    # (a negated entry -- the control-is-0 half of a multiplexed gate -- wants its listed bits CLEAR)
+                    if (base & g["cg"]) != (0 if g["negated"] else g["cg"]):
                         continue
                     m = mats[g["sched"]]
+                    assert g["general"] or abs(m[0, 0].imag) == 0.0, "a plain entry's m00 must be real"
                     bit = 1 << g["tbit"]
                     cbit = 0 if g["creg"] is None else 1 << g["creg"]
-                    lane_on = (np.arange(n_thr) & g["ct"]) == g["ct"]
+                    want = 0 if g["negated"] else cbit
+                    lane_on = (np.arange(n_thr) & g["ct"]) == (0 if g["negated"] else g["ct"])
                     pair = -1
                     for e0 in range(n_reg):
                         if e0 & bit:
                             continue
                         pair += 1  # the kernel's assembly gate loop goes by the pair mask: it must say the same
-                        assert ((g["pairs"] >> pair) & 1) == int((e0 & cbit) == cbit), "pair mask disagrees with creg"
-                        if (e0 & cbit) != cbit:
+                        assert ((g["pairs"] >> pair) & 1) == int((e0 & cbit) == want), "pair mask disagrees with creg"
+                        if (e0 & cbit) != want:
                             continue
                         a0, a1 = amp[:, e0].copy(), amp[:, e0 | bit].copy()
                         amp[:, e0] = np.where(lane_on, m[0, 0] * a0 + m[0, 1] * a1, a0)

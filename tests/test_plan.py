@@ -82,9 +82,28 @@ def test_every_gate_scheduled_once_in_dependency_order():
     for c in circuits:
         plan = pi.decode(build_plan_words(c, tile_bits=10, reg_bits=3, low_bits=3))
         ops = c.packed()
-        order = [g["op"] for ps in plan["passes"] for rd in ps["rounds"] for g in rd["gates"]]
-        assert len(order) == len(set(order)) == plan["n_real"]
-        seen_at = {op: i for i, op in enumerate(order)}
+        # every gate of an EVQE circuit has its own parameters: the index of its theta names the op
+        op_of_theta = {int(o["p_theta"]): i for i, o in enumerate(ops) if o["kind"] != 0}
+        assert len(op_of_theta) == sum(1 for o in ops if o["kind"] != 0)
+        w, off = plan["words"], plan["angle_off"]
+        entries = [g for ps in plan["passes"] for rd in ps["rounds"] for g in rd["gates"]]
+        # where each op acts: (scheduled entry, place in the entry's chain); the control-is-0 entry of a multiplexed gate
+        # repeats the u gates of the entry before it and nothing else
+        seen_at = {}
+        for g, (first, count) in zip(entries, plan["chains"]):
+            chain = [op_of_theta[int(np.int32(w[off + 9 * (first + i)]))] for i in range(count)]
+            if g["negated"]:
+                before = [op for op, (e, _) in seen_at.items() if e == g["sched"] - 1]
+                assert sorted(chain) == sorted(op for op in before if ops[op]["kind"] == 1) and chain
+                continue
+            for i, op in enumerate(chain):
+                assert op not in seen_at
+                seen_at[op] = (g["sched"], i)
+        folded = {op_of_theta[int(np.int32(w[off + 9 * (first + i)]))] for first, count in plan["fold_index"] for i in range(count)}
+        assert not folded & set(seen_at)
+        # (the rest are cu3 gates whose control is still |0>: dropped)
+        assert all(ops[i]["kind"] == 2 for i in set(op_of_theta.values()) - folded - set(seen_at))
+        order = sorted(seen_at)
         # two real gates that touch a common qubit (other than as shared control) keep their program order
         for i in order:
             for j in order:
@@ -142,7 +161,8 @@ def test_most_relayouts_are_lane_swaps():
     tot = _family_stats()
     assert tot["swap_rounds"] > 0 and tot["swaps"] >= tot["swap_rounds"]
     assert tot["exchanges"] < tot["swap_rounds"]
-    assert tot["lane"] <= 0.25 * tot["gates"]
+    # (of the gates left after fusion, which takes most u gates away: a third; a quarter of the 119 gates before it)
+    assert tot["lane"] <= 0.33 * tot["gates"]
 
 
 def test_without_swaps_some_exchanges_stay_inside_a_wave(monkeypatch):
@@ -151,7 +171,7 @@ def test_without_swaps_some_exchanges_stay_inside_a_wave(monkeypatch):
     monkeypatch.setenv("QSV_SWAPS", "0")
     tot = _family_stats()
     assert tot["swap_rounds"] == 0 and tot["intra"] > 0 and tot["intra"] <= tot["exchanges"]
-    assert tot["lane"] <= 0.15 * tot["gates"]
+    assert tot["lane"] <= 0.20 * tot["gates"]  # (of the gates left after fusion)
 
 
 def test_swap_rounds_bring_the_low_tile_bits_home():
