@@ -2419,17 +2419,27 @@ constexpr uint32_t kFactorSlices = kFactorParts / 2;
 // partial sums [side][slice][weight][entry], added in slice order by factor_combine_big_kernel.  Bound by the LDS reads
 // (two 16-byte reads per entry and row): about 1.7 us per block and workgroup.
 constexpr uint32_t kFactorBigEntries = 1024;  // J = 32
-constexpr size_t factor_big_slot_doubles_c() { return size_t(2) * kFactorSlices * kFactorWeights * kFactorBigEntries; }
+constexpr uint32_t kFactorBigSlices = 8;      // (a slice takes blocks slice, slice + 8, ..: at most four of a 2^11-row table)
+// per side-table slot: the slices' partial sums [side][slice][weight][entry], then the finished sums [side][weight][entry]
+constexpr size_t kFactorBigFinal = size_t(2) * kFactorBigSlices * kFactorWeights * kFactorBigEntries;
+constexpr size_t factor_big_slot_doubles_c() { return kFactorBigFinal + size_t(2) * kFactorWeights * kFactorBigEntries; }
 size_t factor_big_slot_doubles() { return factor_big_slot_doubles_c(); }
+// ... and one counter per (side, entry group): the workgroup of a (side, group) that finishes LAST adds the slices' partial sums
+// (in slice order: which one is last does not enter any sum); a counter only ever grows, by kFactorBigSlices per evaluation
+constexpr uint32_t kFactorBigCounters = 8;
+size_t factor_big_slot_counters() { return kFactorBigCounters; }
 
+// blockIdx.x = side + 2 * (slice + kFactorBigSlices * entry group).  The rows of the NEXT block are fetched (into registers)
+// before this block's sums are formed: unpipelined, a block cost one memory latency plus its arithmetic, 6 - 7 us of which
+// 1.5 were arithmetic -- few workgroups, one to a CU, nobody else to hide it.
 template <typename real, int J>
 __device__ __forceinline__ void factor_moments_big_body(const EvalDesc& ev, const uint32_t* __restrict__ sp,
                                                         const cx<real>* __restrict__ sides, uint64_t side_stride,
                                                         const double* __restrict__ diag, double* __restrict__ scratch,
-                                                        cx<real>* stage, double* dstage) {
-    constexpr uint32_t NQ = J * J, PITCH = J + 1;
+                                                        uint32_t* __restrict__ counters, cx<real>* stage, double* dstage) {
+    constexpr uint32_t NQ = J * J, PITCH = J + 1, PER = uint32_t(J) * 64u / 256u;  // amplitudes a thread stages per block
     const bool swap = sp[3] & 1u;
-    const uint32_t side = blockIdx.x & 1u, slice = (blockIdx.x >> 1) & (kFactorSlices - 1), group = blockIdx.x >> 3;
+    const uint32_t side = blockIdx.x & 1u, slice = (blockIdx.x >> 1) & (kFactorBigSlices - 1), group = blockIdx.x / (2 * kFactorBigSlices);
     if (group * 256u >= NQ) return;  // (uniform: before any barrier)
     const uint32_t bits = sp[1 + side], mask = sp[kSplitMaskX + side];
     const uint32_t tid = threadIdx.x;
@@ -2442,15 +2452,27 @@ __device__ __forceinline__ void factor_moments_big_body(const EvalDesc& ev, cons
     double acc_one = 0.0, acc_d = 0.0, acc_low[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, acc_high[10];
 #pragma unroll
     for (int q = 0; q < 10; ++q) acc_high[q] = 0.0;
-    for (uint32_t blk = slice; blk < n_blocks; blk += kFactorSlices) {
-        __syncthreads();  // (the block before is no longer read)
-        for (uint32_t idx = tid; idx < uint32_t(J) * 64u; idx += 256u) {
-            const uint32_t j = idx >> 6, xl = idx & 63u;
-            cx<real> v{real(0), real(0)};
-            if (xl < n_local) v = tab[(size_t(j) << bits) + size_t(blk) * 64 + xl];
-            stage[xl * PITCH + j] = v;
+    cx<real> next[PER];
+    double d_next = 0.0;
+    auto fetch = [&](uint32_t blk) {
+#pragma unroll
+        for (uint32_t i = 0; i < PER; ++i) {
+            const uint32_t idx = tid + i * 256u, j = idx >> 6, xl = idx & 63u;
+            next[i] = cx<real>{real(0), real(0)};
+            if (blk < n_blocks && xl < n_local) next[i] = tab[(size_t(j) << bits) + size_t(blk) * 64 + xl];
         }
-        if (tid < 64) dstage[tid] = tid < n_local ? diag[deposit_bits(blk * 64u + tid, mask)] : 0.0;
+        d_next = (tid < 64 && blk < n_blocks && tid < n_local) ? diag[deposit_bits(blk * 64u + tid, mask)] : 0.0;
+    };
+    fetch(slice);
+    for (uint32_t blk = slice; blk < n_blocks; blk += kFactorBigSlices) {
+        __syncthreads();  // (the block before is no longer read)
+#pragma unroll
+        for (uint32_t i = 0; i < PER; ++i) {
+            const uint32_t idx = tid + i * 256u, j = idx >> 6, xl = idx & 63u;
+            stage[xl * PITCH + j] = next[i];
+        }
+        if (tid < 64) dstage[tid] = d_next;
+        fetch(blk + kFactorBigSlices);
         __syncthreads();
         double s_one = 0.0, s_d = 0.0;
 #pragma unroll
@@ -2469,22 +2491,49 @@ __device__ __forceinline__ void factor_moments_big_body(const EvalDesc& ev, cons
         for (int q = 0; q < 10; ++q)  // (bits 6 and up are the block number's)
             if (blk >> q & 1u) acc_high[q] += s_one;
     }
-    double* mine = scratch + size_t(ev.state_slot) * factor_big_slot_doubles_c() +
-                   (size_t(side) * kFactorSlices + slice) * kFactorWeights * kFactorBigEntries;
-    mine[0 * kFactorBigEntries + pi] = acc_one;
-    mine[1 * kFactorBigEntries + pi] = acc_d;
+    // The slice's sums leave by write-through (agent-scope relaxed) stores, every storing wave drains them, workgroup barrier,
+    // one lane adds to the counter of this (side, entry group) at agent scope; the workgroup whose add completes the
+    // evaluation's kFactorBigSlices is the last: it reads all slices' sums back (agent-scope loads: the other workgroups may
+    // sit on other XCDs, whose L2s are not coherent -- the hand-off of fused_factor_tail) and adds them in slice order.
+    double* slot = scratch + size_t(ev.state_slot) * factor_big_slot_doubles_c();
+    double* mine = slot + (size_t(side) * kFactorBigSlices + slice) * kFactorWeights * kFactorBigEntries;
+    auto put = [&](uint32_t w, double v) { __hip_atomic_store(mine + size_t(w) * kFactorBigEntries + pi, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    put(0, acc_one);
+    put(1, acc_d);
 #pragma unroll
     for (int q = 0; q < 6; ++q)
-        if (uint32_t(q) < bits) mine[size_t(2 + q) * kFactorBigEntries + pi] = acc_low[q];
+        if (uint32_t(q) < bits) put(2 + q, acc_low[q]);
 #pragma unroll
     for (int q = 0; q < 10; ++q)
-        if (uint32_t(6 + q) < bits) mine[size_t(8 + q) * kFactorBigEntries + pi] = acc_high[q];
+        if (uint32_t(6 + q) < bits) put(8 + q, acc_high[q]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    uint32_t* flag = reinterpret_cast<uint32_t*>(dstage);
+    if (tid == 0) {
+        const uint32_t before = __hip_atomic_fetch_add(counters + size_t(ev.state_slot) * kFactorBigCounters + side * 4u + group, 1u,
+                                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *flag = (before & (kFactorBigSlices - 1)) == kFactorBigSlices - 1 ? 1u : 0u;  // (the add has returned: its value is used)
+    }
+    __syncthreads();
+    if (!*flag) return;
+    double* fin = slot + kFactorBigFinal + size_t(side) * kFactorWeights * kFactorBigEntries;
+#pragma unroll
+    for (uint32_t w = 0; w < kFactorWeights; ++w) {
+        if (w >= 2 + bits) break;
+        double v = 0.0;
+#pragma unroll
+        for (uint32_t g = 0; g < kFactorBigSlices; ++g)
+            v += __hip_atomic_load(slot + ((size_t(side) * kFactorBigSlices + g) * kFactorWeights + w) * kFactorBigEntries + pi,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        fin[size_t(w) * kFactorBigEntries + pi] = v;
+    }
 }
 
-// One workgroup per evaluation: a thread takes entries tid, tid + 256, ..; per entry the slices' partial sums in order, then
+// One workgroup of 1024 threads per evaluation, a thread per entry (J = 16: the first 256); per entry the slices' partial sums
+// in slice order -- every load of a thread independent of the others: they are all in flight together --, then
 //   sigma_e [ 4 sum_{ab} J_ab FX_{2+a}[e] FY_{2+b}[e] + FX_D[e] FY_1[e] + FX_1[e] FY_D[e] - D(0,0) FX_1[e] FY_1[e] ]
-// (sigma = 1 / 2 / -2 for a diagonal entry / the real / the imaginary part of a pair: factor_pairing entry by entry);
-// a thread's entries in ascending order, then the fixed-order block sum.
+// (sigma = 1 / 2 / -2 for a diagonal entry / the real / the imaginary part of a pair: factor_pairing entry by entry), and the
+// entries' terms are added in a fixed order (waves in order after the fixed shuffle tree of each).
 template <int J>
 __device__ __forceinline__ void factor_combine_big_body(const EvalDesc& ev, const uint32_t* __restrict__ sp, const double* __restrict__ scratch,
                                                         const double* __restrict__ quad, uint32_t n_qubits, const double* __restrict__ diag,
@@ -2493,6 +2542,8 @@ __device__ __forceinline__ void factor_combine_big_body(const EvalDesc& ev, cons
     const uint32_t bx = sp[1], by = sp[2];
     const uint32_t masks[2] = {sp[kSplitMaskX], sp[kSplitMaskY]};
     const uint32_t tid = threadIdx.x;
+    if (tid < 256) coupling[tid] = 0.0;
+    __syncthreads();
     if (tid < bx * by) {
         const uint32_t a = tid / by, b = tid % by;
         uint32_t qa = 0, qb = 0;
@@ -2502,37 +2553,40 @@ __device__ __forceinline__ void factor_combine_big_body(const EvalDesc& ev, cons
             if (k == b) qb = uint32_t(__builtin_ctz(m));
         coupling[a * 16 + b] = quad[qa * n_qubits + qb];
     }
-    __syncthreads();
     const double d00 = diag[0];
-    const double* base = scratch + size_t(ev.state_slot) * factor_big_slot_doubles_c();
-    auto gram = [&](uint32_t side, uint32_t w, uint32_t pi) {
-        double v = 0.0;
+    const double* fin = scratch + size_t(ev.state_slot) * factor_big_slot_doubles_c() + kFactorBigFinal;  // [side][weight][entry]
+    const uint32_t pi = tid;
+    double fx[kFactorWeights], fy[kFactorWeights];  // (fixed trip counts: the arrays stay in registers)
 #pragma unroll
-        for (uint32_t g = 0; g < kFactorSlices; ++g)
-            v += base[((size_t(side) * kFactorSlices + g) * kFactorWeights + w) * kFactorBigEntries + pi];
-        return v;
-    };
+    for (uint32_t w = 0; w < kFactorWeights; ++w) {
+        fx[w] = (pi < NQ && w < 2 + bx) ? fin[(size_t(0) * kFactorWeights + w) * kFactorBigEntries + pi] : 0.0;
+        fy[w] = (pi < NQ && w < 2 + by) ? fin[(size_t(1) * kFactorWeights + w) * kFactorBigEntries + pi] : 0.0;
+    }
+    __syncthreads();  // (the couplings)
     double acc = 0.0;
-    for (uint32_t pi = tid; pi < NQ; pi += 256) {
+    if (pi < NQ) {
         uint32_t ja, jb, part;
         split_entry_of<J>(pi, &ja, &jb, &part);
         const double sigma = part == 0 ? 1.0 : part == 1 ? 2.0 : -2.0;
-        double fy[kFactorWeights];  // (fixed trip counts: the array stays in registers)
+        double t = fma(fx[1], fy[0], fx[0] * fy[1]) - d00 * fx[0] * fy[0];
 #pragma unroll
-        for (uint32_t w = 0; w < kFactorWeights; ++w) fy[w] = w < 2 + by ? gram(1, w, pi) : 0.0;
-        const double fx_one = gram(0, 0, pi), fx_d = gram(0, 1, pi);
-        double t = fma(fx_d, fy[0], fx_one * fy[1]) - d00 * fx_one * fy[0];
-        for (uint32_t a = 0; a < bx; ++a) {
-            const double fxa = gram(0, 2 + a, pi);
+        for (uint32_t a = 0; a < 16; ++a) {
             double row = 0.0;
 #pragma unroll
-            for (uint32_t b = 0; b < 16; ++b) row = fma(b < by ? coupling[a * 16 + b] : 0.0, fy[2 + b], row);
-            t = fma(4.0 * fxa, row, t);
+            for (uint32_t b = 0; b < 16; ++b) row = fma(coupling[a * 16 + b], fy[2 + b], row);  // (zero beyond bx x by)
+            t = fma(4.0 * fx[2 + a], row, t);
         }
-        acc = fma(sigma, t, acc);
+        acc = sigma * t;
     }
-    const double total = block_sum_256(acc, red);
-    if (tid == 0) result_out[ev.out_index] = total;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if ((tid & 63u) == 0) red[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) {
+        double total = 0.0;
+        for (uint32_t w = 0; w < NQ / 64u; ++w) total += red[w];
+        result_out[ev.out_index] = total;
+    }
 }
 
 // Two launches.  factor_moments_kernel: kFactorParts workgroups of four waves per evaluation, the even ones on side X,
@@ -2546,7 +2600,7 @@ template <typename real>
 __global__ void __launch_bounds__(256, 2) factor_moments_kernel(const uint32_t* __restrict__ plan_arena, const EvalDesc* __restrict__ evals,
                                                                 const cx<real>* __restrict__ sides, uint64_t side_stride,
                                                                 const double* __restrict__ diag, double* __restrict__ scratch,
-                                                                double* __restrict__ scratch_big) {
+                                                                double* __restrict__ scratch_big, uint32_t* __restrict__ big_counters) {
     constexpr uint32_t kWaves = 4;
     // the waves' staging regions (9 x 64 amplitudes each) and, afterwards, their partial matrices (18 x 64 doubles each)
     __shared__ __align__(16) unsigned char raw[kWaves * kFactorWeights * 64 * sizeof(double)];
@@ -2559,9 +2613,9 @@ __global__ void __launch_bounds__(256, 2) factor_moments_kernel(const uint32_t* 
     const uint32_t n_keys = sp[0], NQ = 1u << (2 * n_keys);
     if (n_keys > 3) {  // sixteen / thirty-two product terms: a thread per entry (grid: up to four entry groups)
         if (n_keys == 4)
-            factor_moments_big_body<real, 16>(ev, sp, sides, side_stride, diag, scratch_big, reinterpret_cast<cx<real>*>(raw), dstage);
+            factor_moments_big_body<real, 16>(ev, sp, sides, side_stride, diag, scratch_big, big_counters, reinterpret_cast<cx<real>*>(raw), dstage);
         else
-            factor_moments_big_body<real, 32>(ev, sp, sides, side_stride, diag, scratch_big, reinterpret_cast<cx<real>*>(raw), dstage);
+            factor_moments_big_body<real, 32>(ev, sp, sides, side_stride, diag, scratch_big, big_counters, reinterpret_cast<cx<real>*>(raw), dstage);
         return;
     }
     if (blockIdx.x >= kFactorParts) return;  // (a grid widened for an evaluation of 32 terms)
@@ -2594,12 +2648,14 @@ __global__ void __launch_bounds__(256, 2) factor_moments_kernel(const uint32_t* 
     }
 }
 
-__global__ void __launch_bounds__(256) factor_combine_kernel(const uint32_t* __restrict__ plan_arena, const EvalDesc* __restrict__ evals,
-                                                             const double* __restrict__ scratch, const double* __restrict__ scratch_big,
-                                                             const double* __restrict__ quad, uint32_t n_qubits,
-                                                             const double* __restrict__ diag, double* __restrict__ result_out) {
+// (256 threads; 1024 when the launch holds evaluations of sixteen or thirty-two product terms, whose combination takes a
+// thread per entry -- the others' code does not care: its loops stride by the block size, its terms sit in the first 172 threads)
+__global__ void __launch_bounds__(1024) factor_combine_kernel(const uint32_t* __restrict__ plan_arena, const EvalDesc* __restrict__ evals,
+                                                              const double* __restrict__ scratch, const double* __restrict__ scratch_big,
+                                                              const double* __restrict__ quad, uint32_t n_qubits,
+                                                              const double* __restrict__ diag, double* __restrict__ result_out) {
     __shared__ double gram[2][kFactorWeights * kFactorPitch];
-    __shared__ double red[4];
+    __shared__ double red[16];
     const EvalDesc ev = evals[blockIdx.x];
     if (!(ev.flags & kEvalSide)) return;
     const uint32_t* sp = plan_arena + ev.split_base;
@@ -2766,19 +2822,19 @@ __device__ __forceinline__ void fused_factor_tail(const uint32_t* __restrict__ p
 }
 
 hipError_t launch_factor(int dtype, unsigned n_evals, double* scratch, const double* quad, int n_qubits, hipStream_t stream,
-                         const PassArgs& a, double* scratch_big, int most_keys) {
+                         const PassArgs& a, double* scratch_big, uint32_t* big_counters, int most_keys) {
     if (n_evals == 0) return hipSuccess;
-    if (most_keys > 3 && !scratch_big) return hipErrorInvalidValue;
+    if (most_keys > 3 && (!scratch_big || !big_counters)) return hipErrorInvalidValue;
     // (an evaluation of 32 product terms has four groups of 256 entries: four times the workgroups)
-    const dim3 grid(most_keys >= 5 ? 4 * kFactorParts : kFactorParts, n_evals);
+    const dim3 grid(most_keys >= 5 ? 2 * kFactorBigSlices * 4 : most_keys == 4 ? 2 * kFactorBigSlices : kFactorParts, n_evals);
     if (dtype == 0)
         hipLaunchKernelGGL(factor_moments_kernel<double>, grid, dim3(256), 0, stream, a.plan, a.evals,
-                           static_cast<const cx<double>*>(a.wtab), a.wtab_stride, a.diag, scratch, scratch_big);
+                           static_cast<const cx<double>*>(a.wtab), a.wtab_stride, a.diag, scratch, scratch_big, big_counters);
     else
         hipLaunchKernelGGL(factor_moments_kernel<float>, grid, dim3(256), 0, stream, a.plan, a.evals,
-                           static_cast<const cx<float>*>(a.wtab), a.wtab_stride, a.diag, scratch, scratch_big);
-    hipLaunchKernelGGL(factor_combine_kernel, dim3(n_evals), dim3(256), 0, stream, a.plan, a.evals, scratch, scratch_big, quad,
-                       uint32_t(n_qubits), a.diag, a.result_out);
+                           static_cast<const cx<float>*>(a.wtab), a.wtab_stride, a.diag, scratch, scratch_big, big_counters);
+    hipLaunchKernelGGL(factor_combine_kernel, dim3(n_evals), dim3(most_keys > 3 ? 1024 : 256), 0, stream, a.plan, a.evals, scratch,
+                       scratch_big, quad, uint32_t(n_qubits), a.diag, a.result_out);
     return hipGetLastError();
 }
 

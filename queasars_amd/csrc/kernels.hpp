@@ -159,9 +159,12 @@ constexpr size_t factor_slot_doubles() { return size_t(2) * 4 * 18 * 64; }
 // Evaluations with four or five cut keys (16 / 32 product terms) take the same two launches with a thread per matrix entry
 // (entry groups x slices x sides workgroups per evaluation): most_keys = the most keys of the range, scratch_big =
 // factor_big_slot_doubles() per side-table slot (may be null when most_keys <= 3).
+// big_counters: factor_big_slot_counters() uint32 per side-table slot, zero before the first launch (the workgroups of one
+// (side, entry group) count themselves: the last one adds the slices' partial sums, in slice order).
 size_t factor_big_slot_doubles();
+size_t factor_big_slot_counters();
 hipError_t launch_factor(int dtype, unsigned n_evals, double* scratch, const double* quad, int n_qubits, hipStream_t stream,
-                         const PassArgs& args, double* scratch_big = nullptr, int most_keys = 3);
+                         const PassArgs& args, double* scratch_big = nullptr, uint32_t* big_counters = nullptr, int most_keys = 3);
 
 // Split evaluations under ANY Pauli operator: for psi = sum_j X_j (x) Y_j and a Pauli string P = P_X (x) P_Y
 //     <psi|P|psi> = sum_{j'j} <X_j'|P_X|X_j> <Y_j'|P_Y|Y_j>

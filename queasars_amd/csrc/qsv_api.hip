@@ -158,6 +158,10 @@ struct qsv_handle {
                           // when a batch first needs it: a process has few hardware queues (four by default), and streams
                           // beyond them share queues -- with two handles alive, a third stream per handle made the two
                           // pushes of a 256-evaluation step run one after the other (262 -> 358 us).
+    int chain_stream = -1;  // index in side_streams of the stream that takes, in a push that holds both kinds, the split
+                            // evaluations that need launches of their own (virtual circuits, Gram matrices, combination) --
+                            // beside the one-launch ones on the push's lane instead of in front of them (eval_push)
+    bool chain_enabled = true;
     hipStream_t work = nullptr;  // stream of the push being issued (null: `stream`)
     hipEvent_t ev_join = nullptr;
     int n_streams = 2;           // streams a batch cycles over (QSV_STREAMS, 1 .. 4)
@@ -178,6 +182,7 @@ struct qsv_handle {
     DeviceBuffer d_factor;       // launch_factor's partial Gram matrices, one region per side-table slot
     DeviceBuffer d_factor_count; // kModeFusedFactor: one counter per side-table slot (each fused evaluation adds two)
     DeviceBuffer d_factor_big;   // launch_factor_big's partial Gram matrices (four and five keys), allocated on first need
+    DeviceBuffer d_factor_big_count;  // ... and their workgroup counters (zeroed once)
     uint32_t stream_mode = 0;    // kModeStreaming when a state is larger than the Infinity Cache (256 MiB), else 0
     mutable std::mutex mu;
     std::atomic<std::thread::id> batch_owner{};  // thread that holds `mu` between qsv_eval_begin and qsv_eval_end
@@ -262,6 +267,7 @@ struct qsv_handle {
         int ways = 1;           // streams this batch cycles over
         unsigned used_mask = 0; // side streams (bit i = side_streams[i]) with work of this batch in flight
         bool aux_plain = false; // the batch's ordinary evaluations run on the auxiliary stream (eval_begin)
+        bool chain_now = false; // this push: the split evaluations with launches of their own go to the chain stream (eval_push)
         size_t aux_count = 0;   // ... how many of them have been pushed (their state slots cycle over the whole group)
 
         size_t n_pushes = 0;
@@ -934,6 +940,7 @@ int run_group(qsv_t* h, const std::vector<Circuit*>& circs, size_t first, size_t
         n_unfused = 0;
         while (n_unfused < n_split && !circs[eval_of(first + n_unfused)]->split.fused) ++n_unfused;
     }
+    const bool two_chains = b.chain_now && h->chain_stream >= 0 && n_unfused > 0 && n_split > n_unfused && factor_path(h);
     if (any_split) {
         if (n_plain > 0) return fail(h, QSV_E_STATE, "internal: a launch group mixes split and ordinary evaluations");
         a.wtab = h->d_side.ptr;  // (the side tables' own slots)
@@ -994,7 +1001,12 @@ int run_group(qsv_t* h, const std::vector<Circuit*>& circs, size_t first, size_t
             return QSV_OK;
         };
         int rc2;
+        // (both kinds in one group: the ones with launches of their own start first, on the chain stream where the push
+        // has one -- theirs is the longer chain)
+        hipStream_t const lane_of_group = h->work;
+        if (two_chains) h->work = h->side_streams[size_t(h->chain_stream)];
         if (n_unfused > 0 && (rc2 = launch_sides(0, n_unfused, 0u))) return rc2;
+        h->work = lane_of_group;
         if (n_split > n_unfused && (rc2 = launch_sides(n_unfused, n_split, kModeFusedFactor))) return rc2;
         a.mode = mode | h->stream_mode;
         // what the side circuits move: they synthesise their input and write their final states
@@ -1069,19 +1081,31 @@ int run_group(qsv_t* h, const std::vector<Circuit*>& circs, size_t first, size_t
     }
     if (any_split && !(mode & kModeSidesOnly) && factor_path(h)) {
       if (n_unfused > 0) {
+        hipStream_t const lane_of_group = h->work;
+        struct Restore {
+            qsv_t* h;
+            hipStream_t st;
+            ~Restore() { h->work = st; }
+        } restore{h, lane_of_group};
+        if (two_chains) h->work = h->side_streams[size_t(h->chain_stream)];
         // quadratic operator: the expectation value from the two side tables alone, written straight to the result buffer
         int most_keys = 0;
         for (size_t i = 0; i < n_unfused; ++i) most_keys = std::max(most_keys, circs[eval_of(first + i)]->split.n_keys);
         if (most_keys > 3) {
             int rc3 = ensure(h, h->d_factor_big, factor_big_slot_doubles() * sizeof(double) * size_t(h->side_slots));
             if (rc3) return rc3;
+            if (!h->d_factor_big_count.ptr) {
+                const size_t cbytes = factor_big_slot_counters() * sizeof(uint32_t) * size_t(h->side_slots);
+                if ((rc3 = ensure(h, h->d_factor_big_count, cbytes))) return rc3;
+                QSV_HIP(h, hipMemsetAsync(h->d_factor_big_count.ptr, 0, cbytes, ws(h)));
+            }
         }
         a.evals = batch_evals(h) + first;
         a.result_out = h->out_target ? h->out_target : h->h_out;
         if (h->stamping) QSV_HIP(h, stamp(h, h->batch.launch_events[2], true));
         QSV_HIP(h, launch_factor(h->dtype, unsigned(n_unfused), static_cast<double*>(h->d_factor.ptr),
                                  static_cast<const double*>(h->d_quad.ptr), h->n, ws(h), a, static_cast<double*>(h->d_factor_big.ptr),
-                                 most_keys));
+                                 static_cast<uint32_t*>(h->d_factor_big_count.ptr), most_keys));
         if (h->stamping) QSV_HIP(h, stamp(h, h->batch.launch_events[2], false));
         h->prof.kernel_launches[2] += 1;  // (the launches of the route, timed as one)
       }
@@ -1278,6 +1302,29 @@ int eval_push(qsv_t* h, size_t first, size_t count, const double* values) {
         hd[P + first + j].state_slot = slot;
     }
     hipStream_t const lane_stream = h->work;  // (null: the handle's own)
+    // Split evaluations of both kinds in this push -- finished by the launch that runs their virtual circuits (kEvalFused) /
+    // with launches of their own: the second kind's chain (virtual circuits, Gram matrices, combination) goes to the chain
+    // stream and runs beside the first kind's one launch.  Every split evaluation of the push has its own slot then (n_split
+    // <= SG), so the two streams share nothing.
+    // The chain stream is the second lane's, idle when the push is the whole batch: a stream of its own would be the
+    // handle's fourth, and a process has four hardware queues by default -- it landed on the auxiliary stream's queue and
+    // the two chains ran one after the other (measured; L = 6 with five keys: 397 -> 449 us per step).
+    b.chain_now = false;
+    h->chain_stream = -1;
+    if (h->chain_enabled && first == 0 && count == b.circs.size() && h->n_lane_streams >= 1 && n_split > 0 && n_split <= SG &&
+        factor_path(h) && fused_route(h)) {
+        size_t n_fused = 0;
+        for (size_t j = 0; j < n_split; ++j) n_fused += b.circs[b.eval_at[first + j]]->split.fused ? 1 : 0;
+        b.chain_now = n_fused > 0 && n_fused < n_split;
+    }
+    if (b.chain_now) {
+        h->chain_stream = 0;
+        b.used_mask |= 1u << h->chain_stream;
+        if (h->out_target) {  // (the caller may have work queued on the handle's stream that the results must come after)
+            QSV_HIP(h, hipEventRecord(h->ev_join, h->stream));
+            QSV_HIP(h, hipStreamWaitEvent(h->side_streams[0], h->ev_join, 0));
+        }
+    }
     hipStream_t const plain_stream = b.aux_plain ? h->side_streams[size_t(h->aux_stream)] : lane_stream;
     if (b.aux_plain && n_split < count) b.used_mask |= 1u << h->aux_stream;
 
@@ -1547,6 +1594,7 @@ int qsv_create(int n_qubits, int dtype, int device, const qsv_plan_config* cfg, 
     if (const char* env = getenv("QSV_SPLIT_SAMPLE")) h->split_sampling = atoi(env) != 0;
     if (const char* env = getenv("QSV_FACTOR")) h->factor_enabled = atoi(env) != 0;
     if (getenv("QSV_NO_FUSED_FACTOR")) h->fused_factor = false;
+    if (const char* env = getenv("QSV_CHAIN_STREAM")) h->chain_enabled = atoi(env) != 0;
     if (const char* env = getenv("QSV_SPLIT_MAX_KEYS")) h->split_max_keys = std::max(0, std::min(kMaxSplitKeys, atoi(env)));
     h->stream_mode = state_bytes > (size_t(256) << 20) ? uint32_t(kModeStreaming) : 0u;
     if (const char* env = getenv("QSV_STREAMING")) h->stream_mode = atoi(env) ? uint32_t(kModeStreaming) : 0u;
@@ -1606,7 +1654,7 @@ void qsv_destroy(qsv_t* h) {
     }
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     for (DeviceBuffer* b : {&h->d_z, &h->d_cre, &h->d_diag, &h->d_order, &h->d_sorted, &h->d_term_partials, &h->d_groups, &h->d_term_odd, &h->d_arena,
-                            &h->d_states, &h->d_wtab, &h->d_side, &h->d_factor, &h->d_factor_count, &h->d_factor_big, &h->d_quad, &h->d_fterms, &h->d_fpart, &h->d_batch, &h->d_mats, &h->d_partials, &h->d_out, &h->d_scratch})
+                            &h->d_states, &h->d_wtab, &h->d_side, &h->d_factor, &h->d_factor_count, &h->d_factor_big, &h->d_factor_big_count, &h->d_quad, &h->d_fterms, &h->d_fpart, &h->d_batch, &h->d_mats, &h->d_partials, &h->d_out, &h->d_scratch})
         if (b->ptr) (void)hipFree(b->ptr);
     if (h->h_batch) (void)hipHostFree(h->h_batch);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
@@ -2380,6 +2428,8 @@ int qsv_set_option(qsv_t* h, const char* name, int value) {
         h->factor_enabled = value != 0;
     } else if (key == "fused_factor") {
         h->fused_factor = value != 0;
+    } else if (key == "chain_stream") {
+        h->chain_enabled = value != 0;
     } else if (key == "split_max_keys") {
         if (value < 0 || value > kMaxSplitKeys) return fail(h, QSV_E_ARG, "split_max_keys must be between 0 and 5");
         h->split_max_keys = value;

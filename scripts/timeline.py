@@ -12,6 +12,8 @@ for i, r in enumerate(rows[1:], 1):
         starts.append(i)
     busy_until = max(busy_until, int(r["End_Timestamp"]))
 lo, hi = (starts[-2], starts[-1]) if len(starts) > 2 else (starts[-1], len(rows))  # (the last complete step)
+if len(sys.argv) > 3:  # (steps that leave no idle gap: just the last so many launches)
+    lo, hi = max(0, len(rows) - int(sys.argv[3])), len(rows)
 t0 = int(rows[lo]["Start_Timestamp"])
 if lo:
     print(f"gap since the end of the step before: {(t0 - max(int(r['End_Timestamp']) for r in rows[:lo])) / 1e3:.1f} us")
