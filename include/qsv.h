@@ -236,8 +236,10 @@ int qsv_exact_cvar_batch(qsv_t* h, int n_evals, const int* circuit_ids, const in
  *                        created with splitting on.  Applies to circuits registered afterwards.
  *   "factor" 0|1         split evaluations use the factorised expectation kernels instead of the contraction sweep
  *   "fused_factor" 0|1   ... inside the launch that runs their virtual circuits, where a circuit qualifies (one launch per push)
- *   "split_max_keys" 0..5 most cut keys of a split form (default 3; four and five: quadratic operators only, worth it for
- *                        populations in which many circuits need them).  Applies to circuits registered afterwards.
+ *   "split_max_keys" 0..5 most cut keys of a split form (default 5; four and five: quadratic operators only).  Applies to
+ *                        circuits registered afterwards.
+ *   "chain_stream" 0|1   in a push that holds split evaluations of both kinds (finished by the launch that runs their
+ *                        virtual circuits / with launches of their own) the second kind runs on the second lane's stream
  *   "split_sampling" 0|1 split circuits are sampled from their side tables
  *   "streams" 1..4       HIP streams the pushes of a batch cycle over (at most as many as were created with the handle)
  * Returns QSV_E_ARG for an unknown name or a value out of range.

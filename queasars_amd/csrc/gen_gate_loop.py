@@ -66,9 +66,10 @@ MAT = {"A": 40, "B": 56}  # 16 SGPRs each: 8 doubles
 DESC = {"A": 72, "B": 76}  # w0, ct, cg, op
 SAVE = "s[80:81]"
 T0 = "s82"
-TX = "s83"  # second scalar temporary of the gate code (free while gates run; the round loop uses it between them)
+TP = "s[82:83]"    # (T0 and the round loop's T1 as a pair: the gate code's 64-bit temporary)
+BASEP = "s[96:97]"  # (base, ~base) of the tile, set up at the head of each block
 RP, MP, N = 84, 86, 88
-CLOBBER_RANGE = range(40, 89)
+CLOBBER_RANGE = list(range(40, 89)) + [96, 97]
 
 
 def sreg2(base: int) -> str:
@@ -78,25 +79,22 @@ def sreg2(base: int) -> str:
 def gate(lines: list[str], r: int, x: str, tag: str) -> None:
     """Emit the code of one gate that reads register set x ('A' or 'B')."""
     m, d = MAT[x], DESC[x]
-    w0, ct, cg, fl = f"s{d}", f"s{d + 1}", f"s{d + 2}", f"s{d + 3}"
+    w0, ct, cg = f"s{d}", f"s{d + 1}", f"s{d + 2}"
+    cgpair = sreg2(d + 2)  # (cg, ncg): global index bits that must be set / clear
     m00, m00i, m01r, m01i = sreg2(m), sreg2(m + 2), sreg2(m + 4), sreg2(m + 6)
     m10r, m10i, m11r, m11i = sreg2(m + 8), sreg2(m + 10), sreg2(m + 12), sreg2(m + 14)
     e = lines.append
-    # the entry's predicates: every listed bit set -- or, for the control-is-0 entry of a multiplexed gate (flag bit 0,
-    # plan.hpp FUSION), every listed bit clear
-    e(f"s_and_b32 {T0}, %[base], {cg}")
-    e(f"s_bitcmp1_b32 {fl}, 0")
-    e(f"s_cselect_b32 {TX}, 0, {cg}")
-    e(f"s_cmp_eq_u32 {T0}, {TX}")
+    # the entry's predicates (plan.hpp): the listed bits of (base, ~base) and of the extended thread index (tid, ~tid) all set --
+    # the control-is-0 entry of a multiplexed gate lists its control among the complemented bits, at no cost here
+    e(f"s_and_b64 {TP}, {BASEP}, {cgpair}")
+    e(f"s_cmp_eq_u64 {TP}, {cgpair}")
     e(f"s_cbranch_scc0 Lskip{tag}_%=")
-    e(f"s_bitcmp1_b32 {fl}, 0")
-    e(f"s_cselect_b32 {TX}, 0, {ct}")
     e(f"v_and_b32 %[vt], {ct}, %[tid]")
-    e(f"v_cmp_eq_u32 vcc, {TX}, %[vt]")
+    e(f"v_cmp_eq_u32 vcc, {ct}, %[vt]")
     e(f"s_and_saveexec_b64 {SAVE}, vcc")
     e(f"s_cbranch_execz Lrest{tag}_%=")
-    # flag bit 1: the matrix is a product, its m00 complex -> the 16-operation body
-    e(f"s_bitcmp1_b32 {fl}, 1")
+    # bit 24 of the first word: the matrix is a product, its m00 complex -> the 16-operation body
+    e(f"s_bitcmp1_b32 {w0}, 24")
     e(f"s_cbranch_scc1 Lgen{tag}_%=")
     for general in (False, True):
         x = "g" if general else ""
@@ -160,6 +158,8 @@ def loop_body(r: int) -> list[str]:
     e(f"s_mov_b64 {rp}, %[rp]")
     e(f"s_mov_b64 {mp}, %[mp]")
     e(f"s_mov_b32 s{N}, %[n]")
+    e("s_mov_b32 s96, %[base]")
+    e("s_not_b32 s97, %[base]")
     gate_loop_core(lines, r)
     return lines
 
@@ -324,7 +324,7 @@ def emit_swap(r: int) -> str:
 RH, ROUNDS, FLAGS, T1, T2, T3 = 89, 90, 91, 83, 92, 93
 SAVE2 = "s[94:95]"
 NEXT_RP, NEXT_MP = "s[92:93]", "s[94:95]"  # (the gate loop's exit values; T2 / T3 / SAVE2 are free while gates run)
-ROUND_CLOBBERS = range(40, 96)
+ROUND_CLOBBERS = range(40, 98)
 WC, RC = 40, 56  # scalar registers of the LDS write / read columns during an exchange (9 thread + 4 register columns)
 K_THREAD_COLS = 9
 
@@ -338,6 +338,8 @@ def emit_rounds(r: int) -> str:
     e(f"s_mov_b64 {mp}, %[mp]")
     e(f"s_mov_b32 s{ROUNDS}, %[rounds]")
     e(f"s_mov_b32 s{FLAGS}, %[flags]")
+    e("s_mov_b32 s96, %[base]")
+    e("s_not_b32 s97, %[base]")
     e("Lround_%=:")
     e(f"s_load_dword s{RH}, {rp}, 0x0")
     e("s_waitcnt lgkmcnt(0)")

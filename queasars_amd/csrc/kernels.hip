@@ -657,6 +657,7 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, FIRST>::waves_per_si
     const int k = hdr & 0xff, t = (hdr >> 16) & 0xff, n_rounds = hdr >> 24;
     const uint32_t pass_flags = pp[2];
     const uint32_t tid = threadIdx.x;
+    const uint32_t tid_ext = tid | (~tid & ((1u << kMaxThreadBits) - 1u)) << kMaxThreadBits;  // (gate predicates, plan.hpp)
     const bool all_active = blockDim.x == (1u << t);
     const bool active = tid < (1u << t);
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -848,7 +849,7 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, FIRST>::waves_per_si
 #endif
         if constexpr (kAsmRounds) {
             if (n_rounds > 0)
-                RoundLoopF64<R>::run(amp, rp, mp, uint32_t(n_rounds), uint32_t(base), tid, wave, active_mask,
+                RoundLoopF64<R>::run(amp, rp, mp, uint32_t(n_rounds), uint32_t(base), tid_ext, wave, active_mask,
                                      uint32_t(uintptr_t(lds_raw)), xflags);
             QSV_STAMP(10);
         } else
@@ -1012,27 +1013,26 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, FIRST>::waves_per_si
                     // (not under `if (active)`: threads beyond 2^t only exist in tiles smaller than a wave, their
                     // registers hold nothing anyone reads, and a conditional here makes hipcc carry the amplitudes
                     // through temporaries -- 16 v_mov_b64 into the block's fixed registers and 16 out, every round)
-                    GateLoopF64<R>::run(amp, rp, mp, uint32_t(n_gates), uint32_t(base), tid);
+                    GateLoopF64<R>::run(amp, rp, mp, uint32_t(n_gates), uint32_t(base), tid_ext);
 #endif
                     rp += size_t(n_gates) * kGateWords;
                     mp += size_t(n_gates) * 8;
                 }
             } else {
                 // gate stream: descriptor and matrix of gate g+1 are fetched (scalar loads) while gate g runs
-                uint32_t w0 = rp[0], ct = rp[1], cg = rp[2], fl = rp[3];
+                uint32_t w0 = rp[0], ct = rp[1], cg = rp[2], ncg = rp[3];
                 double m0 = mp[0], mi = mp[1], m1 = mp[2], m2 = mp[3], m3 = mp[4], m4 = mp[5], m5 = mp[6], m6 = mp[7];
                 for (int g = 0; g < n_gates; ++g) {
                     rp += kGateWords;
                     mp += 8;
-                    const uint32_t nw0 = rp[0], nct = rp[1], ncg = rp[2], nfl = rp[3];
+                    const uint32_t nw0 = rp[0], nct = rp[1], nxcg = rp[2], nxncg = rp[3];
                     const double n0 = mp[0], ni = mp[1], n1 = mp[2], n2 = mp[3], n3 = mp[4], n4 = mp[5], n5 = mp[6], n6 = mp[7];
-                    if (fl != 0) {
-                        // an entry of a multiplexed gate or a product of matrices (plan.hpp FUSION): negated predicates,
-                        // pairs by the entry's mask, general matrix
-                        const bool neg = fl & kGateNegated;
-                        if ((uint32_t(base) & cg) == (neg ? 0u : cg) && active && (tid & ct) == (neg ? 0u : ct)) {
+                    if ((w0 & (kGateGeneral | kGateNegated)) != 0) {
+                        // an entry of a multiplexed gate or a product of matrices (plan.hpp FUSION): predicates over the
+                        // complemented bits too, pairs by the entry's mask, general matrix
+                        if ((uint32_t(base) & cg) == cg && (~uint32_t(base) & ncg) == ncg && active && (tid_ext & ct) == ct) {
                             const real mm[8] = {real(m0), real(mi), real(m1), real(m2), real(m3), real(m4), real(m5), real(m6)};
-                            GeneralDispatch<real, R, R - 1>::run(int(w0 & 0xffu), amp, mm, w0 >> 16);
+                            GeneralDispatch<real, R, R - 1>::run(int(w0 & 0xffu), amp, mm, (w0 >> 16) & 0xffu);
                         }
                     } else
                     if ((uint32_t(base) & cg) == cg) {  // else: the control is a fixed bit of this tile and it is 0
@@ -1047,7 +1047,7 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, FIRST>::waves_per_si
                             ButterflyDispatch<real, R, R*(R + 1) - 1>::run(sel, amp, mm);
                         }
                     }
-                    w0 = nw0; ct = nct; cg = ncg; fl = nfl;
+                    w0 = nw0; ct = nct; cg = nxcg; ncg = nxncg;
                     m0 = n0; mi = ni; m1 = n1; m2 = n2; m3 = n3; m4 = n4; m5 = n5; m6 = n6;
                 }
             }

@@ -813,10 +813,13 @@ CircuitPlan build_plan(int n, const std::vector<GateIn>& all_gates, const std::v
                         ++pr;
                     }
                     const size_t factors = which ? chain1[size_t(gi)].size() : chain0[size_t(gi)].size();
-                    w.push_back(uint32_t(jbit) | creg << 8 | pair_mask << 16);
-                    w.push_back(ct);
-                    w.push_back(cg);
-                    w.push_back((which ? 0u : kGateNegated) | (factors > 1 ? kGateGeneral : 0u));
+                    // the control-is-0 entry lists its control among the COMPLEMENTED bits: thread bits 9 .. 17 of the
+                    // extended thread index (tid, ~tid), word [3] for the global index
+                    w.push_back(uint32_t(jbit) | creg << 8 | pair_mask << 16 | (factors > 1 ? kGateGeneral : 0u) |
+                                (which ? 0u : kGateNegated));
+                    w.push_back(which ? ct : ct << kMaxThreadBits);
+                    w.push_back(which ? cg : 0u);
+                    w.push_back(which ? 0u : cg);
                     schedule.push_back({gi, which});
                     // (a product's butterfly is 16 operations where a plain one is 14)
                     pairs_this_pass += pass_tiles * double(uint64_t(1) << (k - 1)) * (g.control >= 0 ? 0.5 : 1.0) *

@@ -140,11 +140,12 @@ struct CircuitPlan {
 //                           pass brings them back when gates on those qubits took them away.
 //          then 4 words per gate: [0] target register bit | control register bit<<8 (0xFF: none) | pair mask<<16
 //                                     (bit p: the p-th amplitude pair, register indices with the target bit
-//                                     clear in ascending order, takes part)
-//                                 [1] ctrl mask over the thread index   [2] ctrl mask over the global index
-//                                 [3] flags: kGateNegated = the entry applies where its control is 0 (words [1] and [2]
-//                                     then list bits that must be CLEAR; a register-held control is in the pair mask
-//                                     either way), kGateGeneral = Im m00 may be non-zero (a product of matrices)
+//                                     clear in ascending order, takes part; R = 4: eight pairs) | flags (bits 24 ..):
+//                                     kGateGeneral = Im m00 may be non-zero (a product of matrices), kGateNegated = the
+//                                     entry applies where its control is 0 (informational: the predicates say it all)
+//                                 [1] ctrl mask over the EXTENDED thread index (tid | (~tid & 511) << 9): a bit below 9 wants
+//                                     that thread bit set, bit 9 + u wants thread bit u clear
+//                                 [2] global index bits that must be set   [3] global index bits that must be clear
 //          Entries are numbered in the order they appear here (the SCHEDULE ORDER); the matrix of scheduled entry s
 //          of an evaluation lives at mats[mat_base + 8 s].
 // ANGLE TABLE: 9 words per entry {p_theta, p_phi, p_lambda (int32; <0 = literal), theta, phi, lambda (3 doubles)}:
@@ -173,7 +174,7 @@ constexpr uint32_t kMaxSwaps = 4, kSwapPad = 0xFFFFFFFFu;                       
 constexpr int kSwapLaneLo = 0, kSwapLaneHi = 6;                                 // lane bits a swap may use: [lo, hi)
 constexpr uint32_t kPosPad = 62;  // inserting a zero bit at position 62 leaves every index below 2^62 unchanged
 constexpr uint32_t kGateWords = 4;
-constexpr uint32_t kGateNegated = 1u, kGateGeneral = 2u;  // flags word of a gate entry
+constexpr uint32_t kGateGeneral = 1u << 24, kGateNegated = 1u << 25;  // flags in the first word of a gate entry
 constexpr uint32_t kMaxChain = 6;                         // factors per scheduled entry
 constexpr uint32_t kAngleEntryWords = 9;
 constexpr uint32_t kPlanPadWords = 32;  // readable padding after every plan (the kernel prefetches one gate ahead)

@@ -170,10 +170,10 @@ struct qsv_handle {
     bool factor_enabled = true;  // ... and, under a quadratic diagonal operator, need no sweep over the 2^n indices at all
                                  // (kernels.hpp: launch_factor)
     bool fused_factor = true;    // ... in the launch that runs the virtual circuits, where the circuit qualifies (kEvalFused)
-    int split_max_keys = 3;      // most cut keys of a split form: four and five (16 / 32 product terms, quadratic operators
-                                 // only) pay where MANY circuits of a batch need them -- populations of six-layer circuits:
-                                 // +50 % -- and cost latency where few do (their chain of launches is the longest of the
-                                 // step): off unless asked for (QSV_SPLIT_MAX_KEYS, qsv_set_option "split_max_keys")
+    int split_max_keys = 5;      // most cut keys of a split form: four and five (16 / 32 product terms, quadratic operators
+                                 // only) -- their chain of launches (virtual circuits of up to 16 qubits, Gram matrices of up to
+                                 // 1024 entries) runs beside the one-launch evaluations of the push on the second lane's stream
+                                 // (eval_push).  QSV_SPLIT_MAX_KEYS / qsv_set_option "split_max_keys" = 3: the round-2 limit
     bool quadratic = false;      // the operator is diagonal and every term has at most two Z factors
     DeviceBuffer d_quad;         // its couplings as an n x n matrix
     DeviceBuffer d_fterms;       // a general operator's terms as a plain list (kernels.hpp: launch_factor_terms)

@@ -7,11 +7,11 @@ from queasars_amd import workloads
 from queasars_amd.circuit_evaluation import OperatorCircuitEvaluator
 from queasars_amd.evqe import EVQEPopulation
 
-n, L, P = 20, 4, 64
+n, L, P = (int(x) for x in (sys.argv[1:4] + ["20", "4", "64"][len(sys.argv[1:4]):]))
 ev = OperatorCircuitEvaluator(workloads.random_ising_operator(n, seed=2020))
 dev = ev.statevector_device
 pops = []
-for s in range(8):
+for s in range(5):
     pop = EVQEPopulation.random_population(n, L, P, True, 1000 + s)
     pops.append(([i.get_parameterized_quantum_circuit() for i in pop.individuals], [list(i.parameter_values) for i in pop.individuals]))
 # (the library call inside _register_many, timed on its own)

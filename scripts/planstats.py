@@ -26,6 +26,7 @@ for n, L in cases:
                     tot["intra"] += rd["intra_wave"]
                     tot["conflicts"] += pi.bank_conflicts_b64(rd["write_cols"][:t], True) + pi.bank_conflicts_b64(rd["read_cols"][:t], False)
                 for g in rd["gates"]:
+                    g = dict(g, cg=g["cg"] | g["ncg"], ct=(g["ct"] | g["ct"] >> 9) & 0x1FF)  # (which index bit, set or clear)
                     tot["gates"] += 1
                     if g["creg"] is not None:
                         tot["ctrl_reg"] += 1; tot["units"] += 0.5

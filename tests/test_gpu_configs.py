@@ -548,7 +548,7 @@ def test_split_evaluations_with_four_and_five_keys(n, layers, count, c_oracle):
     assert max(keys) >= 4, keys
     op = helpers.random_ising_operator(n, seed=2020)
     ev = OperatorCircuitEvaluator(op)
-    ev.statevector_device.set_option("split_max_keys", 5)  # (off by default: DESIGN.md section 4.2)
+    ev.statevector_device.set_option("split_max_keys", 5)  # (the default since the chain stream; stated for the record)
     got = ev.evaluate_circuits(circuits, params)
     prof_dev = ev.statevector_device
     prof_dev.set_profiling(True)
