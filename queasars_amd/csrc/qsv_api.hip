@@ -25,6 +25,10 @@ using namespace qsv;
 
 namespace {
 
+// what a result slot holds until its evaluation's kernel writes it: a NaN whose payload no arithmetic produces
+constexpr uint64_t kResultSentinel = 0x7ff8dead5e4717e1ull;
+constexpr int kPollMicros = 200;
+
 // Error text is kept per calling thread (and per handle it belongs to): the thread that received a failing return code
 // is the one that asks for the text, and it must not race with another thread's failure on the same handle.
 constexpr size_t kInlineCacheLimit = 4096;  // structures qsv_eval_batch keeps registered between calls
@@ -162,6 +166,8 @@ struct qsv_handle {
                             // evaluations that need launches of their own (virtual circuits, Gram matrices, combination) --
                             // beside the one-launch ones on the push's lane instead of in front of them (eval_push)
     bool chain_enabled = true;
+    bool poll_results = true;  // a waiting end of a batch watches the (pinned) result buffer instead of the streams: the last
+                               // workgroups' stores are visible about 5 us before hipStreamSynchronize returns (eval_end)
     hipStream_t work = nullptr;  // stream of the push being issued (null: `stream`)
     hipEvent_t ev_join = nullptr;
     int n_streams = 2;           // streams a batch cycles over (QSV_STREAMS, 1 .. 4)
@@ -268,6 +274,7 @@ struct qsv_handle {
         unsigned used_mask = 0; // side streams (bit i = side_streams[i]) with work of this batch in flight
         bool aux_plain = false; // the batch's ordinary evaluations run on the auxiliary stream (eval_begin)
         bool chain_now = false; // this push: the split evaluations with launches of their own go to the chain stream (eval_push)
+        bool sentinels = false; // the result buffer was filled with kResultSentinel before the first push (eval_begin)
         size_t aux_count = 0;   // ... how many of them have been pushed (their state slots cycle over the whole group)
 
         size_t n_pushes = 0;
@@ -1224,6 +1231,13 @@ int eval_begin(qsv_t* h, const std::vector<Circuit*>& circs, const std::vector<i
     b.aux_count = 0;
     b.used_mask = 0;
     b.n_pushes = 0;
+    // Every evaluation's result is ONE 8-byte store to the pinned result buffer by the kernel that finishes it (diagonal
+    // operators): marked with a value no kernel writes, the buffer itself says when the batch is done (eval_end).
+    b.sentinels = h->poll_results && h->diagonal && !h->profiling && n_evals > 0;
+    if (b.sentinels) {
+        uint64_t* v = reinterpret_cast<uint64_t*>(h->h_out);
+        for (size_t i = 0; i < n_evals; ++i) v[i] = kResultSentinel;
+    }
     return QSV_OK;
 }
 
@@ -1428,10 +1442,34 @@ int eval_end(qsv_t* h, double* out) {
     if (!h->diagonal)
         QSV_HIP(h, hipMemcpyAsync(h->out_target ? h->out_target : h->h_out, h->d_out.ptr, n_evals * sizeof(double),
                                   h->out_target ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, h->stream));
-    // (polling hipStreamQuery instead was measured: no faster, and it slowed concurrent callers down threefold)
-    QSV_HIP(h, hipStreamSynchronize(h->stream));
-    for (size_t i = 0; i < h->side_streams.size(); ++i)
-        if (used_mask >> i & 1u) QSV_HIP(h, hipStreamSynchronize(h->side_streams[i]));
+    // The results themselves say when they are there: every evaluation's is one store to the pinned buffer, visible to the host
+    // about 5 us before the stream's completion signal is (scripts/ubench/flag_vs_sync.hip).  Watched for at most kPollMicros
+    // -- a step of a shallow population; longer batches wait on the streams as before.  Results that have all arrived ARE the
+    // end of the batch's work (every kernel that reads a staging buffer comes before the one that writes its evaluation's
+    // result): nothing is left for a later call to wait for, and the runtime retires its own bookkeeping with the next
+    // launches (synchronising at the start of the next call instead was measured: 77 -> 84 us per step, worse than not polling).
+    bool arrived = false;
+    if (b.sentinels && !h->out_target && out) {
+        const volatile uint64_t* v = reinterpret_cast<const volatile uint64_t*>(h->h_out);
+        const auto t0 = std::chrono::steady_clock::now();
+        size_t done = 0;
+        for (uint32_t spin = 1;; ++spin) {
+            while (done < n_evals && v[done] != kResultSentinel) ++done;
+            if (done == n_evals) {
+                arrived = true;
+                break;
+            }
+            if ((spin & 31u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(kPollMicros)) break;
+            __builtin_ia32_pause();
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+    }
+    if (!arrived) {
+        // (polling hipStreamQuery instead was measured: no faster, and it slowed concurrent callers down threefold)
+        QSV_HIP(h, hipStreamSynchronize(h->stream));
+        for (size_t i = 0; i < h->side_streams.size(); ++i)
+            if (used_mask >> i & 1u) QSV_HIP(h, hipStreamSynchronize(h->side_streams[i]));
+    }
     if (h->out_target) {  // (a waiting end of a batch with a device output: the caller also gets a host copy)
         if (out) QSV_HIP(h, hipMemcpy(out, h->out_target, n_evals * sizeof(double), hipMemcpyDeviceToHost));
     } else {
@@ -1595,6 +1633,7 @@ int qsv_create(int n_qubits, int dtype, int device, const qsv_plan_config* cfg, 
     if (const char* env = getenv("QSV_FACTOR")) h->factor_enabled = atoi(env) != 0;
     if (getenv("QSV_NO_FUSED_FACTOR")) h->fused_factor = false;
     if (const char* env = getenv("QSV_CHAIN_STREAM")) h->chain_enabled = atoi(env) != 0;
+    if (const char* env = getenv("QSV_POLL")) h->poll_results = atoi(env) != 0;
     if (const char* env = getenv("QSV_SPLIT_MAX_KEYS")) h->split_max_keys = std::max(0, std::min(kMaxSplitKeys, atoi(env)));
     h->stream_mode = state_bytes > (size_t(256) << 20) ? uint32_t(kModeStreaming) : 0u;
     if (const char* env = getenv("QSV_STREAMING")) h->stream_mode = atoi(env) ? uint32_t(kModeStreaming) : 0u;
@@ -2430,6 +2469,8 @@ int qsv_set_option(qsv_t* h, const char* name, int value) {
         h->fused_factor = value != 0;
     } else if (key == "chain_stream") {
         h->chain_enabled = value != 0;
+    } else if (key == "poll_results") {
+        h->poll_results = value != 0;
     } else if (key == "split_max_keys") {
         if (value < 0 || value > kMaxSplitKeys) return fail(h, QSV_E_ARG, "split_max_keys must be between 0 and 5");
         h->split_max_keys = value;
