@@ -257,6 +257,20 @@ struct SwapDispatch<real, R, -1> {
 #ifdef QSV_STAMPS
 __device__ unsigned long long qsv_stamp_table[kStampPasses * kStampPhases];
 #define QSV_STAMP_DECL unsigned long long st_acc[kStampPhases] = {}; unsigned long long st_last = qsv_stamp_now();
+// the waves' counters summed in LDS first: one global atomic per phase per workgroup (row `row` of the table)
+#define QSV_STAMP_FLUSH(row) do { \
+        unsigned long long* tab = reinterpret_cast<unsigned long long*>(lds_raw); \
+        __syncthreads(); \
+        if (tid < kStampPhases) tab[tid] = 0; \
+        __syncthreads(); \
+        if ((tid & 63u) == 0) { \
+            for (int ph = 0; ph < kStampPhases - 1; ++ph) atomicAdd(&tab[ph], st_acc[ph]); \
+            atomicAdd(&tab[kStampPhases - 1], 1ull); \
+        } \
+        __syncthreads(); \
+        if (tid < kStampPhases && (row) < kStampPasses) atomicAdd(&qsv_stamp_table[(row) * kStampPhases + tid], tab[tid]); \
+        __syncthreads(); \
+    } while (0)
 #define QSV_STAMP(ph) do { const unsigned long long st_t = qsv_stamp_now(); st_acc[ph] += st_t - st_last; st_last = st_t; } while (0)
 static __device__ __forceinline__ unsigned long long qsv_stamp_now() {
     unsigned long long t;
@@ -425,9 +439,11 @@ static_assert(kPrepScratchDoubles * sizeof(double) == kFusedPrepareLdsBytes, "ke
 #ifdef QSV_STAMPS  // (diagnostic build: phases 2 .. 8 of the stamp table take prepare_eval's steps)
 #define QSV_PSTAMP(ph) do { if (st_acc) { const unsigned long long st_t = qsv_stamp_now(); st_acc[ph] += st_t - *st_last; *st_last = st_t; } } while (0)
 #define QSV_PSTAMP_PARAMS , unsigned long long* st_acc = nullptr, unsigned long long* st_last = nullptr
+#define QSV_PSTAMP_PARAMS_DEF , unsigned long long* st_acc, unsigned long long* st_last
 #else
 #define QSV_PSTAMP(ph)
 #define QSV_PSTAMP_PARAMS
+#define QSV_PSTAMP_PARAMS_DEF
 #endif
 __device__ __forceinline__ void prepare_eval(const uint32_t* __restrict__ plan, const EvalDesc& ev,
                                              const double* __restrict__ params, double* __restrict__ mats,
@@ -587,7 +603,7 @@ template <typename real>
 __device__ __forceinline__ void fused_factor_tail(const uint32_t* __restrict__ plan_arena, const EvalDesc& ev,
                                                   const cx<real>* __restrict__ slot_tables, uint64_t side_stride,
                                                   const double* __restrict__ diag, const PassScalars& a, unsigned char* lds,
-                                                  uint32_t gram_waves);
+                                                  uint32_t gram_waves QSV_PSTAMP_PARAMS);
 
 // FIRST = the pass synthesises its input (pass 0 of an evaluation from |0..0>): two instantiations, so that neither
 // carries the other's load path through register allocation.
@@ -1125,8 +1141,16 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, FIRST>::waves_per_si
         // split evaluations whose virtual circuits are one tile and one pass each, under a quadratic operator: this side's
         // workgroup goes straight on to its weighted Gram matrices, and the side that finishes second combines
         if (side && (ev.flags & kEvalFused) && (a.mode & kModeFusedFactor)) {
+#ifdef QSV_STAMPS  // (diagnostic build: the virtual circuit's phases in row 0, the tail's in row 7: 0 drain, 1 Gram, 2 hand-off, 3 combine)
+            QSV_STAMP_FLUSH(0u);
+            for (int ph = 0; ph < kStampPhases; ++ph) st_acc[ph] = 0;
+            st_last = qsv_stamp_now();
+            fused_factor_tail<real>(plan_arena, ev, wt0, a.wtab_stride, diag, a, lds_raw, t >= 9 ? 8u : 4u, st_acc, &st_last);
+            QSV_STAMP_FLUSH(7u);
+#else
             // (Gram waves: by the virtual circuit's own geometry, never by the launch's block size)
             fused_factor_tail<real>(plan_arena, ev, wt0, a.wtab_stride, diag, a, lds_raw, t >= 9 ? 8u : 4u);
+#endif
             return;
         }
     }
@@ -1160,20 +1184,7 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, FIRST>::waves_per_si
     }
 #ifdef QSV_STAMPS
     QSV_STAMP(12);
-    {
-        // sum the waves' counters in LDS first: one global atomic per phase per workgroup
-        unsigned long long* tab = reinterpret_cast<unsigned long long*>(lds_raw);
-        __syncthreads();
-        if (tid < kStampPhases) tab[tid] = 0;
-        __syncthreads();
-        if ((tid & 63u) == 0) {
-            for (int ph = 0; ph < kStampPhases - 1; ++ph) atomicAdd(&tab[ph], st_acc[ph]);
-            atomicAdd(&tab[kStampPhases - 1], 1ull);
-        }
-        __syncthreads();
-        if (tid < kStampPhases && a.pass_index < kStampPasses)
-            atomicAdd(&qsv_stamp_table[a.pass_index * kStampPhases + tid], tab[tid]);
-    }
+    QSV_STAMP_FLUSH(a.pass_index);
 #endif
 }
 
@@ -2724,7 +2735,7 @@ template <typename real>
 __device__ __forceinline__ void fused_factor_tail(const uint32_t* __restrict__ plan_arena, const EvalDesc& ev,
                                                   const cx<real>* __restrict__ slot_tables, uint64_t side_stride,
                                                   const double* __restrict__ diag, const PassScalars& a, unsigned char* lds,
-                                                  uint32_t gram_waves) {
+                                                  uint32_t gram_waves QSV_PSTAMP_PARAMS_DEF) {
     constexpr uint32_t kMaxWaves = 8;
     const uint32_t kWaves = gram_waves;
     const uint32_t* sp = plan_arena + ev.split_base;
@@ -2737,6 +2748,7 @@ __device__ __forceinline__ void fused_factor_tail(const uint32_t* __restrict__ p
     // the side's state was stored by this workgroup: its waves' stores have to be in L2 before anybody reads them back
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    QSV_PSTAMP(0);  // the side's stores drained
     double* partial = reinterpret_cast<double*>(lds);                              // [wave][weight][64]
     double* dstage_all = partial + size_t(kMaxWaves) * kFactorWeights * 64;        // [wave][64]
     uint32_t* flag = reinterpret_cast<uint32_t*>(dstage_all + size_t(kMaxWaves) * 64);
@@ -2757,6 +2769,7 @@ __device__ __forceinline__ void fused_factor_tail(const uint32_t* __restrict__ p
             factor_side_body<real, 8, false>(tab, bits, mask, diag, first, step, stage, dstage_all + w * 64, sink);
     }
     __syncthreads();
+    QSV_PSTAMP(1);  // Gram matrices
     double* slot = a.factor_scratch + size_t(ev.state_slot) * factor_slot_doubles();
     double* mine = slot + size_t(xy) * kFactorSlices * kFactorWeights * 64;
     // (write-through stores: the few hundred bytes the other side will read must not wait for a write-back of everything
@@ -2774,6 +2787,7 @@ __device__ __forceinline__ void fused_factor_tail(const uint32_t* __restrict__ p
         *flag = before & 1u;  // (the add has returned: its value is used)
     }
     __syncthreads();
+    QSV_PSTAMP(2);  // partial matrices out, counter
     if (!*flag) return;
     // ---- the combination (factor_combine_kernel's, with one slice per side) ----
     const uint32_t bx = sp[1], by = sp[2];
@@ -2819,6 +2833,7 @@ __device__ __forceinline__ void fused_factor_tail(const uint32_t* __restrict__ p
     if ((tid & 63u) == 0 && wave < 4) red[wave] = v;
     __syncthreads();
     if (tid == 0) a.result_out[ev.out_index] = red[0] + red[1] + red[2] + red[3];
+    QSV_PSTAMP(3);  // combination
 }
 
 hipError_t launch_factor(int dtype, unsigned n_evals, double* scratch, const double* quad, int n_qubits, hipStream_t stream,

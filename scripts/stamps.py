@@ -59,6 +59,10 @@ def main() -> None:
         if wgs == 0:
             continue
         per = t[p, :NP] / wgs
+        if p == 7:  # (the tail of the one-launch route of split evaluations: its own phases)
+            names = ["stores drained", "Gram matrices", "hand-off", "combination (second side only)"]
+            print(f"tail  {wgs / reps:11.0f}   " + "   ".join(f"{nm} {c:.0f}" for nm, c in zip(names, per)) + f"   total {per[:4].sum():.0f}")
+            continue
         grand += t[p, :NP]
         print(f"{p:4d}  {wgs / reps:11.0f} " + " ".join(f"{c:10.0f}" for c in per) + f" {per.sum():10.0f}")
     print("share of all stamped cycles: " + "  ".join(f"{ph} {100 * g / grand.sum():.1f}%" for ph, g in zip(PHASES, grand)))
