@@ -1083,3 +1083,74 @@ def test_split_evaluations_on_the_largest_registers(n, count):
     exact = np.asarray([factor[i] for i in split_only])
     sigma = values.std(axis=1) / np.sqrt(shots) + 1e-9
     assert (np.abs(values.mean(axis=1) - exact) <= 6.0 * sigma).all()
+
+
+# ---- round 3, second half: multiplexed gates, the chain stream, results watched in the pinned buffer ------------------
+
+
+def _device_with_env(n, **env):
+    """A device created under the given environment (the library reads its plan and path switches when a handle is made)."""
+    import os
+
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update({k: str(v) for k, v in env.items()})
+    try:
+        return StatevectorDevice(n)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("n,layers,count", [(14, 8, 12), (20, 8, 6), (22, 6, 4)])
+def test_multiplexed_gates_agree_with_separate_gates(n, layers, count, c_oracle):
+    """Deep individuals through the multi-pass path with the u gates multiplied into their neighbouring cu3 (plan.hpp
+    FUSION: two schedule entries with complementary predicates, products with a complex m00) and without: the same
+    expectation values to 1e-12, both within 1e-10 of the C oracle; the amplitudes themselves at n = 14."""
+    _, circuits, params = helpers.population_circuits(n, layers, count, seed=7)
+    op = helpers.random_ising_operator(n, seed=n)
+    fused_dev, plain_dev = _device_with_env(n, QSV_FUSE=1, QSV_SPLIT=0), _device_with_env(n, QSV_FUSE=0, QSV_SPLIT=0)
+    fused = OperatorCircuitEvaluator(op, statevector_device=fused_dev).evaluate_circuits(circuits, params)
+    plain = OperatorCircuitEvaluator(op, statevector_device=plain_dev).evaluate_circuits(circuits, params)
+    assert np.abs(np.asarray(fused) - np.asarray(plain)).max() < 1e-12
+    table = c_oracle.diagonal_table(op)
+    scratch = np.zeros(2 << n)
+    for i in (0, count - 1):
+        want = c_oracle.evaluate(circuits[i], params[i], op, table, scratch)
+        assert abs(fused[i] - want) < EXP_TOL
+    if n <= 14:
+        for c, p in zip(circuits[:3], params[:3]):
+            a, b = fused_dev.statevector(c, p), plain_dev.statevector(c, p)
+            assert np.abs(a - b).max() < 1e-12
+            assert np.abs(a - helpers.oracle_state(c, p)).max() < 1e-12
+
+
+def test_chain_stream_and_result_polling_change_no_bit():
+    """A five-layer population at 20 qubits holds split evaluations of both kinds (one launch / launches of their own, among
+    them circuits with four and five keys) and unsplit ones: the chain stream (the second kind beside the first) and the
+    end of the batch read off the result buffer are scheduling only -- every value the same bits with either switched off,
+    in one push and in two, and over 100 repetitions (the last-arriving workgroup of the 32-term Gram matrices adds the
+    slices in slice order whoever it is)."""
+    n = 20
+    _, circuits, params = helpers.population_circuits(n, 5, 64, seed=0)
+    _, deeper, deeper_params = helpers.population_circuits(n, 6, 24, seed=0)
+    circuits, params = circuits + deeper, params + deeper_params
+    op = helpers.random_ising_operator(n, seed=2020)
+    ev = OperatorCircuitEvaluator(op)
+    dev = ev.statevector_device
+    base = np.asarray(ev.evaluate_circuits(circuits, params))
+    assert np.isfinite(base).all()
+    for name in ("chain_stream", "poll_results"):
+        dev.set_option(name, 0)
+        assert np.array_equal(np.asarray(ev.evaluate_circuits(circuits, params)), base), name
+        dev.set_option(name, 1)
+    for _ in range(100):
+        assert np.array_equal(np.asarray(ev.evaluate_circuits(circuits, params)), base)
+    # the first 64 alone (one push: the chain stream is in use), and one at a time
+    assert np.array_equal(np.asarray(ev.evaluate_circuits(circuits[:64], params[:64])), base[:64])
+    for i in (0, 17, 63, 70, 87):
+        assert ev.evaluate_circuits([circuits[i]], [params[i]])[0] == base[i]
+    plain = OperatorCircuitEvaluator(op, statevector_device=_split_device(n, False)).evaluate_circuits(circuits[60:70], params[60:70])
+    assert np.abs(np.asarray(plain) - base[60:70]).max() < EXP_TOL

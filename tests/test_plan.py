@@ -210,3 +210,32 @@ def test_compact_first_pass_reproduces_the_circuit(n_qubits, cfg):
         assert np.abs(pi.run(words, n_qubits, p) - helpers.oracle_state(c, p)).max() < 1e-13
     if cfg:
         assert seen >= 3, "small tiles leave several outer qubits: most plans should take the compact first pass"
+
+
+def test_multiplexed_gates_in_the_plan(monkeypatch):
+    """Fusion (plan.hpp): on the benchmark family most u gates that act are multiplied into a neighbouring cu3 on the same
+    target -- entries with a general matrix, entries with negated predicates, fewer matrices than gates -- and the plan's
+    state is the oracle's with it and without it (QSV_FUSE=0)."""
+    n = 14
+    _, circuits, params = helpers.population_circuits(n, 6, 4, seed=5)
+    for c, p in zip(circuits, params):
+        want = helpers.oracle_state(c, p)
+        fused = pi.decode(build_plan_words(c))
+        assert np.abs(pi.run(fused["words"], n, p) - want).max() < 1e-13
+        monkeypatch.setenv("QSV_FUSE", "0")
+        plain = pi.decode(build_plan_words(c))
+        assert np.abs(pi.run(plain["words"], n, p) - want).max() < 1e-13
+        monkeypatch.delenv("QSV_FUSE")
+        entries = [g for ps in fused["passes"] for rd in ps["rounds"] for g in rd["gates"]]
+        assert any(g["negated"] for g in entries) and any(g["general"] for g in entries)
+        assert not any(g["negated"] or g["general"] for ps in plain["passes"] for rd in ps["rounds"] for g in rd["gates"])
+        # every negated entry follows its control-is-1 twin: same target register, complementary pairs or predicates
+        for a, b in zip(entries, entries[1:]):
+            if b["negated"]:
+                assert not a["negated"] and a["tbit"] == b["tbit"] and a["creg"] == b["creg"]
+                if a["creg"] is not None:
+                    assert a["pairs"] ^ b["pairs"] == (1 << (1 << (fused["passes"][0]["r"] - 1))) - 1
+        # a multiplexed gate is one gate of the circuit fewer (the u gates it took in), and two entries
+        units = sum(1 for g in entries if not g["negated"])
+        assert units < plain["n_real"] and plain["n_factors"] == fused["n_factors"] - sum(
+            cnt for g, (_, cnt) in zip(entries, fused["chains"]) if g["negated"])
