@@ -1700,7 +1700,11 @@ int qsv_create(int n_qubits, int dtype, int device, const qsv_plan_config* cfg, 
     if (h->split_enabled && n_qubits > geo.k && n_qubits <= 28) {
         // side tables of split evaluations: two virtual circuits of at most tile + kSideExtraBits qubits per slot
         h->side_stride = uint64_t(2) << (geo.k + kSideExtraBits);
-        h->side_slots = 128;
+        // (a lane's split evaluations run in launch groups of its share of the slots: with 128 slots config 3's step --
+        // 256 evaluations at 24 qubits, two lanes -- was four groups of 64, two chains of launches per lane; with 256 it is
+        // one per lane: 0.276 -> 0.211 ms.  4 MiB per slot at 13-qubit tiles.)
+        h->side_slots = 256;
+        if (const char* env = getenv("QSV_SIDE_SLOTS")) h->side_slots = std::max(8, std::min(1024, atoi(env)));
         if ((e = hipMalloc(&h->d_side.ptr, size_t(h->side_stride) * h->amp_bytes * size_t(h->side_slots))) != hipSuccess)
             return bail(e, "hipMalloc(side tables)");
         h->d_side.bytes = size_t(h->side_stride) * h->amp_bytes * size_t(h->side_slots);
