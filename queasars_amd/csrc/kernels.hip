@@ -603,7 +603,7 @@ template <typename real>
 __device__ __forceinline__ void fused_factor_tail(const uint32_t* __restrict__ plan_arena, const EvalDesc& ev,
                                                   const cx<real>* __restrict__ slot_tables, uint64_t side_stride,
                                                   const double* __restrict__ diag, const PassScalars& a, unsigned char* lds,
-                                                  uint32_t gram_waves QSV_PSTAMP_PARAMS);
+                                                  uint32_t gram_waves, bool table_in_lds QSV_PSTAMP_PARAMS);
 
 // FIRST = the pass synthesises its input (pass 0 of an evaluation from |0..0>): two instantiations, so that neither
 // carries the other's load path through register allocation.
@@ -713,6 +713,11 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, FIRST>::waves_per_si
     // this workgroup reads it, and left dirty in L2 the side tables of a launch (12 MB at 64 evaluations) are written back
     // when the kernel ends -- ten microseconds between the last workgroup and the host seeing the results.
     const bool through = FIRST && R == 4 && side && (ev.flags & kEvalFused) && (a.mode & kModeFusedFactor);
+    // ... and a small enough side does not go to memory at all where the launch has the LDS for it (kModeFusedLdsTable): the
+    // table is laid out in LDS exactly as it would be in its slot (a fused side is one tile: offsets inside the tile ARE table
+    // indices), behind everything else this kernel keeps there
+    const bool table_in_lds = through && std::is_same<real, double>::value && (a.mode & kModeFusedLdsTable) &&
+                              n_qubits <= uint32_t(kFusedLdsTableBits);
 
     const uint32_t tg = xor_columns(pp + kPassLoadColsOffset, tid, wave);
     const uint32_t sg = xor_columns(pp + kPassStoreColsOffset, tid, wave);
@@ -1094,6 +1099,8 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, FIRST>::waves_per_si
                             typedef real vec2 __attribute__((ext_vector_type(2)));
                             const vec2 v = {amp[gray_index(i)].re, amp[gray_index(i)].im};
                             __builtin_nontemporal_store(v, reinterpret_cast<vec2*>(tile + ob));
+                        } else if (table_in_lds) {
+                            *reinterpret_cast<cxr*>(lds_raw + kFusedLdsTableOffset + ob) = amp[gray_index(i)];
                         } else if (through) {
                             store_through(tile + ob, amp[gray_index(i)]);
                         } else {
@@ -1145,11 +1152,11 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, FIRST>::waves_per_si
             QSV_STAMP_FLUSH(0u);
             for (int ph = 0; ph < kStampPhases; ++ph) st_acc[ph] = 0;
             st_last = qsv_stamp_now();
-            fused_factor_tail<real>(plan_arena, ev, wt0, a.wtab_stride, diag, a, lds_raw, t >= 9 ? 8u : 4u, st_acc, &st_last);
+            fused_factor_tail<real>(plan_arena, ev, wt0, a.wtab_stride, diag, a, lds_raw, t >= 9 ? 8u : 4u, table_in_lds, st_acc, &st_last);
             QSV_STAMP_FLUSH(7u);
 #else
             // (Gram waves: by the virtual circuit's own geometry, never by the launch's block size)
-            fused_factor_tail<real>(plan_arena, ev, wt0, a.wtab_stride, diag, a, lds_raw, t >= 9 ? 8u : 4u);
+            fused_factor_tail<real>(plan_arena, ev, wt0, a.wtab_stride, diag, a, lds_raw, t >= 9 ? 8u : 4u, table_in_lds);
 #endif
             return;
         }
@@ -2735,7 +2742,7 @@ template <typename real>
 __device__ __forceinline__ void fused_factor_tail(const uint32_t* __restrict__ plan_arena, const EvalDesc& ev,
                                                   const cx<real>* __restrict__ slot_tables, uint64_t side_stride,
                                                   const double* __restrict__ diag, const PassScalars& a, unsigned char* lds,
-                                                  uint32_t gram_waves QSV_PSTAMP_PARAMS_DEF) {
+                                                  uint32_t gram_waves, bool table_in_lds QSV_PSTAMP_PARAMS_DEF) {
     constexpr uint32_t kMaxWaves = 8;
     const uint32_t kWaves = gram_waves;
     const uint32_t* sp = plan_arena + ev.split_base;
@@ -2744,7 +2751,8 @@ __device__ __forceinline__ void fused_factor_tail(const uint32_t* __restrict__ p
     const uint32_t xy = (is_b == swap) ? 0u : 1u;  // this side's name in the contraction's terms (X is B's half when swapped)
     const uint32_t bits = sp[1 + xy], mask = sp[kSplitMaskX + xy];
     const uint32_t tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const cx<real>* tab = slot_tables + (is_b ? side_stride >> 1 : 0);
+    // (the side's state: in its half of the slot -- or still in LDS, where the pass left it for this tail alone)
+    const cx<real>* tab = table_in_lds ? reinterpret_cast<const cx<real>*>(lds + kFusedLdsTableOffset) : slot_tables + (is_b ? side_stride >> 1 : 0);
     // the side's state was stored by this workgroup: its waves' stores have to be in L2 before anybody reads them back
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();

@@ -62,6 +62,9 @@ enum PassMode : uint32_t {
                              // matrices of its final state (what launch_factor's first kernel computes), hands them over
                              // through PassArgs::factor_scratch, and the side that finishes second combines them and writes
                              // result_out[out_index] -- no further launch for these evaluations
+    kModeFusedLdsTable = 512u, // (with kModeFusedFactor, fp64) the launch has the LDS for it (kFusedLdsTableEnd) and at most one
+                               // workgroup per CU anyway: sides of up to kFusedLdsTableBits qubits hand their state to the
+                               // Gram matrices through LDS.  Same values, same order of every sum: a launch may choose.
     kModeFusedPrepare = 8u,  // (pass 0 only) every workgroup first does prepare_kernel's work for its evaluation, reading
                              // the descriptor from host_evals (PassArgs below); no prepare launch ran for these evaluations
 };
@@ -98,6 +101,11 @@ struct PassArgs {
 };
 // LDS bytes the fused factor tail of a pass launch needs (up to eight waves form a side's Gram matrices)
 constexpr size_t kFusedFactorLdsBytes = 8 * (18 * 64 + 64) * sizeof(double) + 64;
+// kModeFusedLdsTable: a side of at most kFusedLdsTableBits qubits keeps its final state in LDS, behind the tail's own scratch,
+// for the Gram matrices to read -- it is neither stored to the side table nor fetched back
+constexpr int kFusedLdsTableBits = 12;
+constexpr size_t kFusedLdsTableOffset = ((kFusedFactorLdsBytes + 1023) / 1024) * 1024;
+constexpr size_t kFusedLdsTableEnd = kFusedLdsTableOffset + (size_t(16) << kFusedLdsTableBits);  // 141 KiB
 
 // Diagnostic stamps (only in a -DQSV_STAMPS build): [pass][phase] shader cycles summed over WAVES; the last phase
 // slot counts waves.  Phases: 0 setup, 1 load / synthesis, 2 xor-column setup + wait for the previous exchange's

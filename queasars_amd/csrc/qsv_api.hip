@@ -167,6 +167,8 @@ struct qsv_handle {
                             // evaluations that need launches of their own (virtual circuits, Gram matrices, combination) --
                             // beside the one-launch ones on the push's lane instead of in front of them (eval_push)
     bool chain_enabled = true;
+    bool fused_lds_table = true;  // one-launch route: small sides hand their state to the Gram matrices through LDS (kModeFusedLdsTable)
+    int n_cus = 256;
     bool poll_results = true;  // a waiting end of a batch watches the (pinned) result buffer instead of the streams: the last
                                // workgroups' stores are visible about 5 us before hipStreamSynchronize returns (eval_end)
     hipStream_t work = nullptr;  // stream of the push being issued (null: `stream`)
@@ -1036,6 +1038,11 @@ int run_group(qsv_t* h, const std::vector<Circuit*>& circs, size_t first, size_t
                 size_t need = lds;
                 if (p == 0) need = std::max(need, kFusedPrepareLdsBytes);
                 if (p == 0 && (extra_mode & kModeFusedFactor)) need = std::max(need, kFusedFactorLdsBytes);
+                // at most one workgroup per CU in flight anyway (two per evaluation): room for the sides' states in LDS
+                if (p == 0 && (extra_mode & kModeFusedFactor) && h->dtype == QSV_F64 && h->fused_lds_table && 2 * (hi - lo) <= size_t(h->n_cus)) {
+                    a.mode |= kModeFusedLdsTable;
+                    need = std::max(need, kFusedLdsTableEnd);
+                }
                 if (h->stamping) QSV_HIP(h, stamp(h, h->batch.launch_events[kind], true));
                 QSV_HIP(h, launch_pass(h->dtype, h->geo.r, h->cfg.xmode, dim3(grid_x, unsigned(hi - lo), 2), threads, need, ws(h), a));
                 if (h->stamping) QSV_HIP(h, stamp(h, h->batch.launch_events[kind], false));
@@ -1671,6 +1678,11 @@ int qsv_create(int n_qubits, int dtype, int device, const qsv_plan_config* cfg, 
     if (getenv("QSV_NO_FUSED_FACTOR")) h->fused_factor = false;
     if (const char* env = getenv("QSV_CHAIN_STREAM")) h->chain_enabled = atoi(env) != 0;
     if (const char* env = getenv("QSV_POLL")) h->poll_results = atoi(env) != 0;
+    if (const char* env = getenv("QSV_FUSED_LDS")) h->fused_lds_table = atoi(env) != 0;
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) h->n_cus = cus;
+    }
     {
         int large_bar = 0;
         if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, device) != hipSuccess) large_bar = 0;
@@ -1723,7 +1735,7 @@ int qsv_create(int n_qubits, int dtype, int device, const qsv_plan_config* cfg, 
         // split circuit may have a tile one qubit larger than the handle's), the fused preparation, the fused factor tail
         const int side_tile = std::max(geo.k, std::min(geo.r + 9, int(kMaxTileBits)));
         const size_t plane = (size_t(1) << side_tile) * h->amp_bytes / (pc.xmode == 2 ? 2 : 1);
-        const size_t most = std::max({geo.lds_bytes, plane, kFusedPrepareLdsBytes, kFusedFactorLdsBytes});
+        const size_t most = std::max({geo.lds_bytes, plane, kFusedPrepareLdsBytes, kFusedFactorLdsBytes, kFusedLdsTableEnd});
         if ((e = configure_pass_kernels(dtype, geo.r, pc.xmode, most)) != hipSuccess) return bail(e, "hipFuncSetAttribute");
     }
     *out = h;
