@@ -240,6 +240,8 @@ int qsv_exact_cvar_batch(qsv_t* h, int n_evals, const int* circuit_ids, const in
  *                        circuits registered afterwards.
  *   "chain_stream" 0|1   in a push that holds split evaluations of both kinds (finished by the launch that runs their
  *                        virtual circuits / with launches of their own) the second kind runs on the second lane's stream
+ *   "poll_results" 0|1   a waiting qsv_eval_end watches the (pinned) result buffer instead of the streams: every result is one
+ *                        8-byte store, visible about 5 us before the stream's completion signal (diagonal operators)
  *   "split_sampling" 0|1 split circuits are sampled from their side tables
  *   "streams" 1..4       HIP streams the pushes of a batch cycle over (at most as many as were created with the handle)
  * Returns QSV_E_ARG for an unknown name or a value out of range.
