@@ -404,14 +404,36 @@ __device__ __forceinline__ void entry_matrix(const uint32_t* __restrict__ e, con
     }
 }
 
+// The same from sines and cosines somebody else has computed: trig = {sin, cos} of theta / 2, of phi, of lambda (prepare_eval
+// spreads the sincos calls over the workgroup, three threads per entry; the arithmetic below is u_matrix's, to the bit).
+__device__ __forceinline__ void entry_matrix_trig(const uint32_t* __restrict__ e, const double* trig, double* m) {
+    if (int32_t(e[0]) < -1) {
+        entry_matrix(e, nullptr, m);  // (a fixed matrix: no angles)
+        return;
+    }
+    const double s = trig[0], c = trig[1], sp = trig[2], cp = trig[3], sl = trig[4], cl = trig[5];
+    const double cpl = cp * cl - sp * sl, spl = sp * cl + cp * sl;
+    m[0] = c;        m[1] = 0.0;
+    m[2] = -cl * s;  m[3] = -sl * s;
+    m[4] = cp * s;   m[5] = sp * s;
+    m[6] = cpl * c;  m[7] = spl * c;
+}
+
 // Matrix of one scheduled entry: the product of its factors (plan.hpp CHAIN INDEX), the factor that acts first rightmost.
+// trig (may be null): 6 doubles per angle-table entry, see entry_matrix_trig.
 __device__ __forceinline__ void chain_matrix(const uint32_t* __restrict__ table, uint32_t chain_word,
-                                             const double* __restrict__ params, double* m) {
+                                             const double* __restrict__ params, double* m, const double* trig = nullptr) {
     const uint32_t first = chain_word & 0xffffffu, count = chain_word >> 24;
-    entry_matrix(table + size_t(first) * kAngleEntryWords, params, m);
+    if (trig)
+        entry_matrix_trig(table + size_t(first) * kAngleEntryWords, trig + size_t(first) * 6, m);
+    else
+        entry_matrix(table + size_t(first) * kAngleEntryWords, params, m);
     for (uint32_t i = 1; i < count; ++i) {
         double b[8], c[8];
-        entry_matrix(table + size_t(first + i) * kAngleEntryWords, params, b);
+        if (trig)
+            entry_matrix_trig(table + size_t(first + i) * kAngleEntryWords, trig + size_t(first + i) * 6, b);
+        else
+            entry_matrix(table + size_t(first + i) * kAngleEntryWords, params, b);
 #pragma unroll
         for (int row = 0; row < 2; ++row)
 #pragma unroll
@@ -432,8 +454,8 @@ __device__ __forceinline__ void chain_matrix(const uint32_t* __restrict__ table,
 // evaluations (one launch and one dependent launch latency less in front of the contraction).
 // LDS scratch of prepare_eval: the qubits' initial factors, the evaluation's parameter vector and the matrices of the
 // folded gates.
-constexpr uint32_t kPrepMaxParams = 1024, kPrepMaxFold = 128;
-constexpr uint32_t kPrepScratchDoubles = 4 * 32 + kPrepMaxParams + 8 * kPrepMaxFold;  // 17 KiB
+constexpr uint32_t kPrepMaxParams = 1024, kPrepMaxFold = 128, kPrepMaxTrig = 256;
+constexpr uint32_t kPrepScratchDoubles = 4 * 32 + kPrepMaxParams + 8 * kPrepMaxFold + 6 * kPrepMaxTrig;  // 29 KiB
 static_assert(kPrepScratchDoubles * sizeof(double) == kFusedPrepareLdsBytes, "kernels.hpp: kFusedPrepareLdsBytes");
 
 #ifdef QSV_STAMPS  // (diagnostic build: phases 2 .. 8 of the stamp table take prepare_eval's steps)
@@ -472,10 +494,32 @@ __device__ __forceinline__ void prepare_eval(const uint32_t* __restrict__ plan, 
         p = sp;
     }
     QSV_PSTAMP(3);  // parameters staged
+    // One sincos per thread: a gate's matrix takes three (theta / 2, phi, lambda), an entry that is a product of matrices
+    // (plan.hpp FUSION) up to nine, and they were the longest stretch of this function -- 9 % of the one-launch route's kernel.
+    // Thread 3 f + a takes angle a of angle-table entry f; the matrices are then put together from the table in LDS.
+    double* trig = fm + 8 * kPrepMaxFold;
+    const bool trig_staged = staged && n_factors + n_fold <= kPrepMaxTrig;
+    if (trig_staged) {
+        for (uint32_t i = threadIdx.x; i < 3u * (n_factors + n_fold); i += blockDim.x) {
+            const uint32_t f = i / 3u, which = i - 3u * f;
+            const uint32_t* __restrict__ e = table + size_t(f) * kAngleEntryWords;
+            if (int32_t(e[0]) < -1) continue;  // (a fixed matrix)
+            const int32_t pidx = int32_t(e[which]);
+            double angle = pidx >= 0 ? p[pidx] : __hiloint2double(int(e[4 + 2 * which]), int(e[3 + 2 * which]));
+            if (which == 0) angle *= 0.5;
+            double sn, cs;
+            sincos(angle, &sn, &cs);
+            trig[size_t(f) * 6 + 2 * which] = sn;
+            trig[size_t(f) * 6 + 2 * which + 1] = cs;
+        }
+        __syncthreads();
+    }
     for (uint32_t j = threadIdx.x; j < n_real + (staged ? n_fold : 0u); j += blockDim.x) {
         double m[8];
         if (j < n_real)
-            chain_matrix(table, chains[j], p, m);
+            chain_matrix(table, chains[j], p, m, trig_staged ? trig : nullptr);
+        else if (trig_staged)
+            entry_matrix_trig(table + size_t(n_factors + j - n_real) * kAngleEntryWords, trig + size_t(n_factors + j - n_real) * 6, m);
         else
             entry_matrix(table + size_t(n_factors + j - n_real) * kAngleEntryWords, p, m);
         double* dst = j < n_real ? out + size_t(j) * 8 : fm + size_t(j - n_real) * 8;

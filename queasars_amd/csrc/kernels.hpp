@@ -122,7 +122,7 @@ hipError_t read_stamps(unsigned long long* out, int reset);  // hipErrorNotSuppo
 // wave redid ~190 scalar and ~40 vector instructions per tile for that, and the masks it kept cost ~40 SGPRs).
 constexpr uint32_t kMatPadDoubles = 16;
 // LDS bytes a pass launch with kModeFusedPrepare needs at least (prepare_eval's scratch, kernels.hip)
-constexpr size_t kFusedPrepareLdsBytes = (4 * 32 + 1024 + 8 * 128) * sizeof(double);
+constexpr size_t kFusedPrepareLdsBytes = (4 * 32 + 1024 + 8 * 128 + 6 * 256) * sizeof(double);
 struct TileInfo {     // 16 bytes = 2 doubles
     uint32_t base_lo, base_hi;  // amplitude index of the tile's element 0: the tile number spread over the outer
                                 // qubits (a compact pass 0: the pattern number spread over its control qubits)
