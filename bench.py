@@ -34,6 +34,9 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
+# (several evaluators are alive at once below: see queasars_amd/__init__.py -- the package sets the same default, this line
+# only makes the dependence on import order explicit: it must happen before the process's first HIP call)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
