@@ -7,14 +7,16 @@ loop) hipcc merges the cases through PHI nodes it cannot coalesce and moves the 
 around every gate: 40-60 v_mov_b64 per gate next to the 56 useful fp64 operations, and a 64-bit move costs a
 v_fma_f64's issue time on gfx950.  Here every butterfly writes its results in place and the only branches are scalar.
 
-Per gate (descriptor = 4 words w0, ct, cg, op; matrix = 8 doubles m00 m01 m10 m11 as (re, im), Im m00 = 0):
-    skip if the global control bit of this tile is 0              (base & cg) != cg              scalar
-    mask lanes whose thread-held control bit is 0                  (tid & ct) == ct               exec
+Per gate entry (descriptor = 4 words w0, ct, cg, ncg; matrix = 8 doubles m00 m01 m10 m11 as (re, im); plan.hpp):
+    skip unless the listed global index bits of this tile are set / clear   ((base, ~base) & (cg, ncg)) == (cg, ncg)   scalar, 64-bit
+    mask lanes by the extended thread index (tid, ~tid): the listed bits set     (tid_ext & ct) == ct                  exec
+        (a control-is-0 entry of a multiplexed gate lists its control among the complemented bits: no extra instruction)
     J = w0 & 0xff picks the target register bit; for each of the 2^(R-1) amplitude pairs p, bit 16 + p of w0 says
     whether the pair takes part (a register-held control switches half of them off)                 scalar
-    pair update, 14 fp64 operations, in place, as four chains issued round-robin (p, q, u, w):
+    pair update, in place, as four chains issued round-robin (p, q, u, w) -- 14 fp64 operations for a u-type matrix (Im m00 = 0):
         a1r' = ((m10r a0r - m10i a0i) + m11r a1r) - m11i a1i      a1i' = ((m10r a0i + m10i a0r) + m11i a1r) + m11r a1i
         a0r' = (m00 a0r + m01r a1r) - m01i a1i                    a0i' = (m00 a0i + m01r a1i) + m01i a1r
+    16 for a product of matrices (bit 24 of w0: the two terms with Im m00 as well), a second copy of the body
 
 Descriptor and matrix of gate g + 1 are fetched with scalar loads while gate g runs (two register sets, loop unrolled
 by two).  Scalar registers are hard-coded and declared as clobbers; amplitudes and temporaries are operands.
