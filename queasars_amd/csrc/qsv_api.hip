@@ -284,6 +284,7 @@ struct qsv_handle {
         unsigned used_mask = 0; // side streams (bit i = side_streams[i]) with work of this batch in flight
         bool aux_plain = false; // the batch's ordinary evaluations run on the auxiliary stream (eval_begin)
         bool chain_now = false; // this push: the split evaluations with launches of their own go to the chain stream (eval_push)
+        bool chain_crossed = false; // some push of this batch put its chain on the other lane's stream (eval_push)
         bool sentinels = false; // the result buffer was filled with kResultSentinel before the first push (eval_begin)
         size_t aux_count = 0;   // ... how many of them have been pushed (their state slots cycle over the whole group)
 
@@ -986,7 +987,9 @@ int run_group(qsv_t* h, const std::vector<Circuit*>& circs, size_t first, size_t
         n_unfused = 0;
         while (n_unfused < n_split && !circs[eval_of(first + n_unfused)]->split.fused) ++n_unfused;
     }
-    const bool two_chains = b.chain_now && h->chain_stream >= 0 && n_unfused > 0 && n_split > n_unfused && factor_path(h);
+    const bool two_chains = b.chain_now && h->chain_stream != -1 && n_unfused > 0 && n_split > n_unfused && factor_path(h);
+    // (the chain's stream: the second lane's, or -- for a push on the second lane -- the handle's own, which `work` = null means)
+    hipStream_t const chain_st = h->chain_stream >= 0 ? h->side_streams[size_t(h->chain_stream)] : nullptr;
     if (any_split) {
         if (n_plain > 0) return fail(h, QSV_E_STATE, "internal: a launch group mixes split and ordinary evaluations");
         a.wtab = h->d_side.ptr;  // (the side tables' own slots)
@@ -1055,7 +1058,7 @@ int run_group(qsv_t* h, const std::vector<Circuit*>& circs, size_t first, size_t
         // (both kinds in one group: the ones with launches of their own start first, on the chain stream where the push
         // has one -- theirs is the longer chain)
         hipStream_t const lane_of_group = h->work;
-        if (two_chains) h->work = h->side_streams[size_t(h->chain_stream)];
+        if (two_chains) h->work = chain_st;
         if (n_unfused > 0 && (rc2 = launch_sides(0, n_unfused, 0u))) return rc2;
         h->work = lane_of_group;
         if (n_split > n_unfused && (rc2 = launch_sides(n_unfused, n_split, kModeFusedFactor))) return rc2;
@@ -1138,7 +1141,7 @@ int run_group(qsv_t* h, const std::vector<Circuit*>& circs, size_t first, size_t
             hipStream_t st;
             ~Restore() { h->work = st; }
         } restore{h, lane_of_group};
-        if (two_chains) h->work = h->side_streams[size_t(h->chain_stream)];
+        if (two_chains) h->work = chain_st;
         // quadratic operator: the expectation value from the two side tables alone, written straight to the result buffer
         int most_keys = 0;
         for (size_t i = 0; i < n_unfused; ++i) most_keys = std::max(most_keys, circs[eval_of(first + i)]->split.n_keys);
@@ -1275,6 +1278,7 @@ int eval_begin(qsv_t* h, const std::vector<Circuit*>& circs, const std::vector<i
     b.aux_count = 0;
     b.used_mask = 0;
     b.n_pushes = 0;
+    b.chain_crossed = false;
     // Every evaluation's result is ONE 8-byte store to the pinned result buffer by the kernel that finishes it (diagonal
     // operators): marked with a value no kernel writes, the buffer itself says when the batch is done (eval_end).
     b.sentinels = h->poll_results && h->diagonal && !h->profiling && n_evals > 0;
@@ -1364,23 +1368,37 @@ int eval_push(qsv_t* h, size_t first, size_t count, const double* values) {
     // with launches of their own: the second kind's chain (virtual circuits, Gram matrices, combination) goes to the chain
     // stream and runs beside the first kind's one launch.  Every split evaluation of the push has its own slot then (n_split
     // <= SG), so the two streams share nothing.
-    // The chain stream is the second lane's, idle when the push is the whole batch: a stream of its own would be the
-    // handle's fourth, and a process has four hardware queues by default -- it landed on the auxiliary stream's queue and
-    // the two chains ran one after the other (measured; L = 6 with five keys: 397 -> 449 us per step).
+    // The chain stream is the OTHER lane's: idle when the push is the whole batch, and in a batch of two pushes (one per lane)
+    // each stream then carries one push's single launch and the other push's chain -- 128 five-layer circuits: 230 -> see
+    // DESIGN.md 4.2.  (A stream of its own would be the handle's fourth, and a process has four hardware queues by default: it
+    // landed on the auxiliary stream's queue and the two chains ran one after the other; L = 6 with five keys: 397 -> 449 us
+    // per step.)  A lane's slots are reused by the lane's later pushes in stream order -- which a chain on the other lane's
+    // stream is outside of: a push that comes to a lane again after such a chain first joins the two lanes' streams.
     b.chain_now = false;
     h->chain_stream = -1;
-    if (h->chain_enabled && first == 0 && count == b.circs.size() && h->n_lane_streams >= 1 && n_split > 0 && n_split <= SG &&
-        factor_path(h) && fused_route(h)) {
+    const size_t push_index = b.n_pushes;
+    if (b.chain_crossed && push_index >= ways && h->n_lane_streams >= 1) {
+        QSV_HIP(h, hipEventRecord(h->ev_join, h->stream));
+        QSV_HIP(h, hipStreamWaitEvent(h->side_streams[0], h->ev_join, 0));
+        QSV_HIP(h, hipEventRecord(h->ev_join, h->side_streams[0]));
+        QSV_HIP(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
+        b.chain_crossed = false;
+    }
+    if (h->chain_enabled && ways <= 2 && lane <= 1 && h->n_lane_streams >= 1 && n_split > 0 && n_split <= SG && factor_path(h) &&
+        fused_route(h)) {
         size_t n_fused = 0;
         for (size_t j = 0; j < n_split; ++j) n_fused += b.circs[b.eval_at[first + j]]->split.fused ? 1 : 0;
         b.chain_now = n_fused > 0 && n_fused < n_split;
     }
     if (b.chain_now) {
-        h->chain_stream = 0;
-        b.used_mask |= 1u << h->chain_stream;
-        if (h->out_target) {  // (the caller may have work queued on the handle's stream that the results must come after)
-            QSV_HIP(h, hipEventRecord(h->ev_join, h->stream));
-            QSV_HIP(h, hipStreamWaitEvent(h->side_streams[0], h->ev_join, 0));
+        h->chain_stream = lane == 0 ? 0 : -2;  // (-2: the handle's own stream, lane 0's)
+        b.chain_crossed = true;
+        if (lane == 0) {
+            b.used_mask |= 1u;
+            if (h->out_target) {  // (the caller may have work queued on the handle's stream that the results must come after)
+                QSV_HIP(h, hipEventRecord(h->ev_join, h->stream));
+                QSV_HIP(h, hipStreamWaitEvent(h->side_streams[0], h->ev_join, 0));
+            }
         }
     }
     hipStream_t const plain_stream = b.aux_plain ? h->side_streams[size_t(h->aux_stream)] : lane_stream;
@@ -2104,7 +2122,9 @@ int qsv_eval_suggested_pushes(const qsv_t* h) {
     // (... up to about a launch group of the side circuits: 256 evaluations at 24 qubits take 0.29 ms in two pushes,
     // 0.42 ms in one)
     // (a mixed batch whose ordinary evaluations run beside the split ones on the auxiliary stream likewise)
-    return ((all_split && factor_path(h)) || b.aux_plain) && b.split.size() <= 96 ? 1 : 2;
+    // (128 since a push's split evaluations of both kinds run side by side, eval_push: 128 five-layer circuits at 20 qubits
+    // 678 k evals/s in two pushes, 827 k in one; six layers 268 k / 288 k; four layers 1.51 M / 1.48 M; 256: two pushes)
+    return ((all_split && factor_path(h)) || b.aux_plain) && b.split.size() <= 128 ? 1 : 2;
 }
 
 int qsv_eval_set_output(qsv_t* h, double* device_out) {
