@@ -159,6 +159,11 @@ int qsv_eval_coalesced(qsv_t* h, int circuit_id, const double* params, int n_par
  */
 int qsv_eval_begin(qsv_t* h, int n_evals, const int* circuit_ids, const int64_t* param_counts);
 int qsv_eval_push(qsv_t* h, int first, int count, const double* values);
+/* Where the library keeps the parameter values of evaluations [first, first + count) of the open batch until their kernels
+ * have read them (pinned host memory, sum of their param_counts doubles, back to back): a caller that writes them THERE and
+ * passes the same pointer to qsv_eval_push saves the library's copy (84 KB per population of the benchmark: 5 us of a 72 us
+ * step).  Valid until that push; evaluations must still be pushed in order. */
+int qsv_eval_staging(qsv_t* h, int first, int count, double** values);
 int qsv_eval_end(qsv_t* h, double* out_expectations);
 /*
  * Results into DEVICE memory (n_evals doubles, this handle's GPU), for a caller that feeds them to something on the

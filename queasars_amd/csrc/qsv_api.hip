@@ -874,7 +874,7 @@ int batch_ship(qsv_t* h, size_t first, size_t count, const double* values, size_
     const size_t p0 = b.param_base[first];
     const size_t p1 = size_t(b.param_base[first + count - 1]) + b.n_params[first + count - 1];
     double* hp = reinterpret_cast<double*>(static_cast<char*>(h->h_batch) + b.desc_bytes);
-    if (p1 > p0) std::memcpy(hp + p0, values, (p1 - p0) * sizeof(double));
+    if (p1 > p0 && values != hp + p0) std::memcpy(hp + p0, values, (p1 - p0) * sizeof(double));  // (qsv_eval_staging: in place)
     if (h->bar_ship) {
         // the push's descriptors (both regions of a batch with split evaluations) into the device copy: plain stores through
         // the write-combining BAR mapping, fenced before any launch that reads them is queued -- and only what differs from
@@ -2109,6 +2109,16 @@ int qsv_eval_push(qsv_t* h, int first, int count, const double* values) {
     if (first < 0 || count < 0) return fail(h, QSV_E_ARG, "bad arguments");
     static const double dummy = 0.0;
     return eval_push(h, size_t(first), size_t(count), values ? values : &dummy);
+}
+
+int qsv_eval_staging(qsv_t* h, int first, int count, double** values) {
+    if (!h || !values) return QSV_E_ARG;
+    if (!h->batch.open) return fail(h, QSV_E_STATE, "no open batch (call qsv_eval_begin first)");
+    const qsv_handle::Batch& b = h->batch;
+    if (first < 0 || count < 0 || size_t(first) + size_t(count) > b.circs.size()) return fail(h, QSV_E_ARG, "range exceeds the batch");
+    double* hp = reinterpret_cast<double*>(static_cast<char*>(h->h_batch) + b.desc_bytes);
+    *values = hp + (count > 0 ? size_t(b.param_base[size_t(first)]) : 0);
+    return QSV_OK;
 }
 
 int qsv_eval_suggested_pushes(const qsv_t* h) {
