@@ -336,10 +336,14 @@ class StatevectorDevice:
         over: both arrays are kept from the previous call, keyed by the objects' identities (the entry holds the
         circuits, so an identity cannot be recycled while it exists) and by the global edit counter."""
         n = len(circuits)
-        key = (CircuitIR.edits_of_registered, *map(id, circuits))
         cached = self._last_batch
-        if cached is not None and cached[0] == key:
-            return cached[2], cached[3], cached[4]
+        if cached is not None and cached[0][0] == CircuitIR.edits_of_registered:
+            fast = _load_pyhelp_module()
+            if fast is not None:
+                if fast.same_objects(cached[1], circuits):  # (the entry holds the circuits: identities cannot be recycled)
+                    return cached[2], cached[3], cached[4]
+            elif cached[0] == (CircuitIR.edits_of_registered, *map(id, circuits)):
+                return cached[2], cached[3], cached[4]
         if self._dead:
             with self._reg_lock:
                 self._reap()

@@ -125,12 +125,26 @@ Py_ssize_t qsv_pack_exact(PyObject* vectors, Py_ssize_t first, Py_ssize_t count,
     return pack_exact(vectors, first, count, take, out, capacity);
 }
 
+/* QSV_HOST_TIMING=1: where the host's share of a call goes (begin / packing / push / end), printed every 2000 calls */
+#include <time.h>
+static double now_us(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3;
+}
+static int host_timing = -1;
+static double t_acc[4];
+static long t_calls;
+
 static int expectation_values(qsv_t* h, Py_ssize_t n, const int* ids, const int64_t* counts, PyObject* vectors,
                               double* values, Py_ssize_t capacity, double* out, double* device_out) {
     int rc;
+    if (host_timing < 0) host_timing = getenv("QSV_HOST_TIMING") != NULL;
+    double t0 = host_timing ? now_us() : 0.0, t1, t_pack = 0.0, t_push = 0.0;
     Py_BEGIN_ALLOW_THREADS
     rc = qsv_eval_begin(h, (int)n, ids, counts);
     Py_END_ALLOW_THREADS
+    t1 = host_timing ? now_us() : 0.0;
     if (rc) return rc;
     if (device_out && (rc = qsv_eval_set_output(h, device_out))) {
         (void)qsv_eval_end(h, out);
@@ -158,20 +172,37 @@ static int expectation_values(qsv_t* h, Py_ssize_t n, const int* ids, const int6
         for (Py_ssize_t i = first; i < first + count; ++i) total += (Py_ssize_t)counts[i];
         /* straight into the library's staging buffer (qsv_eval_staging): no copy on the way to the kernels */
         double* dst = NULL;
+        const double ta = host_timing ? now_us() : 0.0;
         if (qsv_eval_staging(h, (int)first, (int)count, &dst) != QSV_OK || !dst) dst = values + offset;
         if (pack_exact(vectors, first, count, counts, dst, dst == values + offset ? capacity - offset : total) != total) {
             if (!PyErr_Occurred()) PyErr_SetString(PyExc_ValueError, "parameter vectors changed length while they were being packed");
             failed = py_error = 1;
             break;
         }
+        const double tb = host_timing ? now_us() : 0.0;
         rc = qsv_eval_push(h, (int)first, (int)count, total > 0 ? dst : NULL);
         if (rc) failed = 1;
         offset += total;
+        if (host_timing) {
+            t_pack += tb - ta;
+            t_push += now_us() - tb;
+        }
     }
     int rc_end;
+    const double t2 = host_timing ? now_us() : 0.0;
     Py_BEGIN_ALLOW_THREADS
     rc_end = qsv_eval_end(h, out);  /* must be called even after a failed push: it releases the handle */
     Py_END_ALLOW_THREADS
+    if (host_timing) {
+        t_acc[0] += t1 - t0;
+        t_acc[1] += t_pack;
+        t_acc[2] += t_push;
+        t_acc[3] += now_us() - t2;
+        if (++t_calls % 2000 == 0) {
+            fprintf(stderr, "host timing over %ld calls (us per call): begin %.2f  pack %.2f  push %.2f  end %.2f\n", t_calls,
+                    t_acc[0] / t_calls, t_acc[1] / t_calls, t_acc[2] / t_calls, t_acc[3] / t_calls);
+        }
+    }
     if (py_error) return -100;
     if (failed) return rc;
     return rc_end;
@@ -256,7 +287,28 @@ static PyObject* eval_one(PyObject* self, PyObject* const* args, Py_ssize_t narg
     return PyFloat_FromDouble(out);
 }
 
+/* same_objects(a, b) -> bool: two lists (or tuples) of the same length holding the same objects, position by position.
+ * The batch metadata of StatevectorDevice is keyed by the circuits' identities; as a tuple of 64 ids built and compared in
+ * Python the check cost 2.3 us of every call. */
+static PyObject* same_objects(PyObject* self, PyObject* const* args, Py_ssize_t nargs) {
+    (void)self;
+    if (nargs != 2) {
+        PyErr_SetString(PyExc_TypeError, "same_objects(a, b)");
+        return NULL;
+    }
+    PyObject *a = args[0], *b = args[1];
+    if (!((PyList_Check(a) || PyTuple_Check(a)) && (PyList_Check(b) || PyTuple_Check(b)))) Py_RETURN_FALSE;
+    const Py_ssize_t n = PySequence_Fast_GET_SIZE(a);
+    if (n != PySequence_Fast_GET_SIZE(b)) Py_RETURN_FALSE;
+    PyObject **x = PySequence_Fast_ITEMS(a), **y = PySequence_Fast_ITEMS(b);
+    for (Py_ssize_t i = 0; i < n; ++i)
+        if (x[i] != y[i]) Py_RETURN_FALSE;
+    Py_RETURN_TRUE;
+}
+
 static PyMethodDef helper_methods[] = {
+    {"same_objects", (PyCFunction)(void (*)(void))same_objects, METH_FASTCALL,
+     "same_objects(a, b): two lists or tuples hold the same objects, position by position"},
     {"eval_one", (PyCFunction)(void (*)(void))eval_one, METH_FASTCALL,
      "eval_one(handle, serial, circuit, vector, window_us): one evaluation, merged in the library with other threads'"},
     {NULL, NULL, 0, NULL}};
