@@ -166,6 +166,11 @@ struct qsv_handle {
     int chain_stream = -1;  // index in side_streams of the stream that takes, in a push that holds both kinds, the split
                             // evaluations that need launches of their own (virtual circuits, Gram matrices, combination) --
                             // beside the one-launch ones on the push's lane instead of in front of them (eval_push)
+    // Counts everything that could make the layout of an earlier batch stale: registrations, operators, options, every full
+    // batch_layout, a reallocated staging buffer.  A batch whose ids and counts are the previous batch's, with nothing counted
+    // in between, is that batch again (an optimiser's next iteration over the same population): eval_begin keeps its layout.
+    uint64_t epoch = 1;
+    bool repeat_enabled = true;
     bool chain_enabled = true;
     bool fused_lds_table = true;  // one-launch route: small sides hand their state to the Gram matrices through LDS (kModeFusedLdsTable)
     int n_cus = 256;
@@ -286,6 +291,15 @@ struct qsv_handle {
         bool chain_now = false; // this push: the split evaluations with launches of their own go to the chain stream (eval_push)
         bool chain_crossed = false; // some push of this batch put its chain on the other lane's stream (eval_push)
         bool sentinels = false; // the result buffer was filled with kResultSentinel before the first push (eval_begin)
+        // the batch as qsv_eval_begin was called (kept for the next call's comparison), and what the last COMPLETED batch left
+        // in place: valid while snap_epoch == the handle's epoch
+        std::vector<int> cur_ids, snap_ids;
+        std::vector<int64_t> cur_counts, snap_counts;
+        uint64_t snap_epoch = 0;
+        size_t snap_n_split = 0;
+        bool have_ids = false;     // cur_ids / cur_counts describe THIS batch (it came through qsv_eval_begin)
+        bool repeat = false;       // this batch reuses the previous batch's layout (descriptors as its one push left them)
+        bool whole_push = false;   // this batch was pushed in one piece
         size_t aux_count = 0;   // ... how many of them have been pushed (their state slots cycle over the whole group)
 
         size_t n_pushes = 0;
@@ -710,6 +724,7 @@ int ensure_host_batch(qsv_t* h, size_t bytes) {
         h->h_batch = nullptr;
     }
     size_t want = std::max(bytes * 2, size_t(1) << 16);
+    h->epoch += 1;
     QSV_HIP(h, hipHostMalloc(&h->h_batch, want, hipHostMallocDefault));
     h->h_batch_bytes = want;
     if (h->bar_ship) {
@@ -765,6 +780,8 @@ int batch_layout(qsv_t* h, const std::vector<Circuit*>& circs, const std::vector
     qsv_handle::Batch& b = h->batch;
     const size_t n_evals = circs.size();
     int rc;
+    h->epoch += 1;  // (whatever an earlier batch left in the staging buffer is overwritten below)
+    b.repeat = false;
     if (h->async_pending) {  // the kernels of a batch that ended without waiting read the staging buffers written below
         QSV_HIP(h, sync_streams(h));
         h->async_pending = false;
@@ -1343,9 +1360,19 @@ int eval_push(qsv_t* h, size_t first, size_t count, const double* values) {
     } guard{h};
     h->stamping = h->profiling;
     EvalDesc* hd = static_cast<EvalDesc*>(h->h_batch);  // pinned; prepare_kernel reads it after this point
+    if (b.repeat && !(first == 0 && count == b.circs.size())) {
+        // (pushed differently than the batch whose layout this one kept: lay it out afresh)
+        const std::vector<Circuit*> circs = b.circs;
+        const std::vector<int64_t> np(b.cur_counts.begin(), b.cur_counts.end());
+        const int rc0 = eval_begin(h, circs, np);
+        if (rc0) return rc0;
+        if (h->out_target) b.ways = 1;  // (qsv_eval_set_output's choice, made before this push)
+    }
+    b.whole_push = first == 0 && count == b.circs.size();
     const size_t ways = size_t(std::max(1, b.ways)), lane = ways > 1 ? size_t(b.n_pushes) % ways : 0;
     const size_t P = b.circs.size();
-    const size_t n_split = order_split_first(h, first, count);
+    const size_t n_split = b.repeat ? b.snap_n_split : order_split_first(h, first, count);
+    if (b.whole_push) b.snap_n_split = n_split;
     // Slots.  Ordinary evaluations: G states are resident together; on one stream the slot of an evaluation is its
     // position mod G and the stream orders every reuse; with several streams each push takes its stream's share of the
     // slots.  (The expectation kernels of the general-operator path index states by position in the launch group.)
@@ -1488,6 +1515,16 @@ int eval_end(qsv_t* h, double* out) {
             }
     b.used_mask = 0;
     if (h->profiling) QSV_HIP(h, hipEventRecord(b.ev1, h->stream));
+    // a batch that went through in one push leaves its layout for the next call to find (qsv_eval_begin)
+    if (b.have_ids && b.whole_push && h->repeat_enabled && !h->profiling) {
+        if (!b.repeat) {
+            b.snap_ids = b.cur_ids;
+            b.snap_counts = b.cur_counts;
+        }
+        b.snap_epoch = h->epoch;
+    } else {
+        b.snap_epoch = 0;
+    }
     if (h->out_target && !out && !h->profiling) {
         // Results go to the caller's device buffer: nothing to wait for here.  Whatever the caller enqueues on the
         // handle's stream next (a collective over the results) runs after every push, also those of the other streams.
@@ -1537,6 +1574,7 @@ int eval_end(qsv_t* h, double* out) {
     } else {
         std::memcpy(out, h->h_out, n_evals * sizeof(double));
     }
+
     if (h->profiling) {
         float ms = 0.f;
         QSV_HIP(h, hipEventElapsedTime(&ms, b.ev0, b.ev1));
@@ -1576,7 +1614,9 @@ void eval_close(qsv_t* h) {
     if (b.ev0) (void)hipEventDestroy(b.ev0);
     if (b.ev1) (void)hipEventDestroy(b.ev1);
     b.ev0 = b.ev1 = nullptr;
-    b.circs.clear();
+    if (b.snap_epoch != h->epoch) b.circs.clear();  // (kept with a layout the next batch may reuse)
+    b.have_ids = false;
+    b.repeat = false;
     b.open = false;
     h->out_target = nullptr;
     b.ways = 1;
@@ -1696,6 +1736,7 @@ int qsv_create(int n_qubits, int dtype, int device, const qsv_plan_config* cfg, 
     if (getenv("QSV_NO_FUSED_FACTOR")) h->fused_factor = false;
     if (const char* env = getenv("QSV_CHAIN_STREAM")) h->chain_enabled = atoi(env) != 0;
     if (const char* env = getenv("QSV_POLL")) h->poll_results = atoi(env) != 0;
+    if (const char* env = getenv("QSV_REPEAT")) h->repeat_enabled = atoi(env) != 0;
     if (const char* env = getenv("QSV_FUSED_LDS")) h->fused_lds_table = atoi(env) != 0;
     {
         int cus = 0;
@@ -1791,6 +1832,7 @@ const char* qsv_last_error(const qsv_t* h) {
 int qsv_set_stream(qsv_t* h, void* hip_stream) {
     if (!h) return QSV_E_ARG;
     std::lock_guard<std::mutex> lock(h->mu);
+    h->epoch += 1;
     QSV_HIP(h, hipSetDevice(h->device));
     QSV_HIP(h, hipStreamSynchronize(h->stream));
     if (h->own_stream) {
@@ -1813,6 +1855,7 @@ int qsv_set_operator(qsv_t* h, int n_terms, const uint64_t* x_mask, const uint64
                      const double* coeff_im) {
     if (!h) return QSV_E_ARG;
     std::lock_guard<std::mutex> lock(h->mu);
+    h->epoch += 1;
     if (n_terms < 1 || !x_mask || !z_mask || !coeff_re) return fail(h, QSV_E_ARG, "operator needs at least one term");
     (void)coeff_im;  // <P_k> is real for every Pauli string, so real(<H>) only needs the real parts
     const uint64_t limit = (uint64_t(1) << h->n) - 1;
@@ -1931,6 +1974,7 @@ int qsv_circuit_create(qsv_t* h, int n_ops, const qsv_op* ops, int n_params, int
     int rc = build_circuit(h, n_ops, ops, n_params, true, &c, &err);
     if (rc) return fail(h, rc, err);
     std::lock_guard<std::mutex> lock(h->mu);
+    h->epoch += 1;
     *out_circuit_id = insert_circuit(h, std::move(c));
     return QSV_OK;
 }
@@ -1949,6 +1993,7 @@ int qsv_circuits_create(qsv_t* h, int n_circuits, const int64_t* op_offsets, con
     for (int i = 0; i < n_circuits; ++i)
         if (built[size_t(i)].rc) return fail(h, built[size_t(i)].rc, built[size_t(i)].err + " (circuit " + std::to_string(i) + ")");
     std::lock_guard<std::mutex> lock(h->mu);
+    h->epoch += 1;
     for (int i = 0; i < n_circuits; ++i) out_circuit_ids[i] = insert_circuit(h, std::move(built[size_t(i)].circuit));
     return QSV_OK;
 }
@@ -1956,6 +2001,7 @@ int qsv_circuits_create(qsv_t* h, int n_circuits, const int64_t* op_offsets, con
 int qsv_circuit_destroy(qsv_t* h, int circuit_id) {
     if (!h) return QSV_E_ARG;
     std::lock_guard<std::mutex> lock(h->mu);
+    h->epoch += 1;
     if (h->circuits.erase(circuit_id) == 0) return fail(h, QSV_E_ARG, "unknown circuit id");
     // the arena space is reclaimed when the arena is next rebuilt
     return QSV_OK;
@@ -2083,6 +2129,41 @@ int qsv_eval_begin(qsv_t* h, int n_evals, const int* circuit_ids, const int64_t*
     if (h->batch.open) return fail(h, QSV_E_STATE, "a batch is already open on this handle");
     if (n_evals < 0 || (n_evals > 0 && (!circuit_ids || !param_counts))) return fail(h, QSV_E_ARG, "bad arguments");
     QSV_HIP(h, hipSetDevice(h->device));
+    {
+        // The previous batch again (same circuits, same counts, nothing changed in between -- an optimiser's next iteration):
+        // its layout is still in the staging buffer, descriptors ordered and slotted as its one push left them.
+        qsv_handle::Batch& b = h->batch;
+        b.cur_ids.assign(circuit_ids, circuit_ids + n_evals);
+        b.cur_counts.assign(param_counts, param_counts + n_evals);
+        b.have_ids = true;
+        if (h->repeat_enabled && n_evals > 0 && b.snap_epoch == h->epoch && !h->profiling &&
+            b.snap_ids == b.cur_ids && b.snap_counts == b.cur_counts && b.circs.size() == size_t(n_evals)) {
+            if (h->async_pending) {  // (the kernels of a batch that ended without waiting read the staging buffers)
+                QSV_HIP(h, sync_streams(h));
+                h->async_pending = false;
+            }
+            h->prof = qsv_profile{};
+            h->prof.n_evals = uint64_t(n_evals);
+            b.repeat = true;
+            b.whole_push = false;
+            b.pushed = 0;
+            b.n_pushes = 0;
+            b.aux_count = 0;
+            b.used_mask = 0;
+            b.chain_crossed = false;
+            b.ways = 1;
+            if (h->diagonal && n_evals >= 2) b.ways = std::max(1, std::min({h->n_streams, h->n_lane_streams + 1, h->group}));
+            b.sentinels = h->poll_results && h->diagonal;
+            if (b.sentinels) {
+                uint64_t* v = reinterpret_cast<uint64_t*>(h->h_out);
+                for (int i = 0; i < n_evals; ++i) v[i] = kResultSentinel;
+            }
+            b.open = true;
+            h->batch_owner.store(std::this_thread::get_id());
+            h->batch_lock = std::move(lock);
+            return QSV_OK;
+        }
+    }
     std::vector<Circuit*> circs(size_t(n_evals), nullptr);
     std::vector<int64_t> np(size_t(n_evals), 0);
     for (int i = 0; i < n_evals; ++i) {
@@ -2548,6 +2629,7 @@ int qsv_set_option(qsv_t* h, const char* name, int value) {
     if (!h) return QSV_E_ARG;
     if (!name) return fail(h, QSV_E_ARG, "option name is null");
     std::lock_guard<std::mutex> lock(h->mu);
+    h->epoch += 1;
     const std::string key(name);
     if (key == "split") {
         if (value != 0 && !h->d_side.ptr && h->n > h->geo.k && h->n <= 28)
@@ -2563,6 +2645,8 @@ int qsv_set_option(qsv_t* h, const char* name, int value) {
         h->chain_enabled = value != 0;
     } else if (key == "poll_results") {
         h->poll_results = value != 0;
+    } else if (key == "repeat_layout") {
+        h->repeat_enabled = value != 0;
     } else if (key == "split_max_keys") {
         if (value < 0 || value > kMaxSplitKeys) return fail(h, QSV_E_ARG, "split_max_keys must be between 0 and 5");
         h->split_max_keys = value;
@@ -2580,6 +2664,7 @@ int qsv_set_option(qsv_t* h, const char* name, int value) {
 int qsv_set_profiling(qsv_t* h, int enabled) {
     if (!h) return QSV_E_ARG;
     std::lock_guard<std::mutex> lock(h->mu);
+    h->epoch += 1;
     h->profiling = enabled != 0;
     return QSV_OK;
 }
