@@ -1154,3 +1154,53 @@ def test_chain_stream_and_result_polling_change_no_bit():
         assert ev.evaluate_circuits([circuits[i]], [params[i]])[0] == base[i]
     plain = OperatorCircuitEvaluator(op, statevector_device=_split_device(n, False)).evaluate_circuits(circuits[60:70], params[60:70])
     assert np.abs(np.asarray(plain) - base[60:70]).max() < EXP_TOL
+
+
+def test_repeated_batches_keep_their_layout_and_nothing_else(c_oracle):
+    """The previous batch again (same circuit ids and counts, nothing changed in between) reuses its layout in the staging
+    buffer.  Whatever comes between two calls must either leave that layout valid or invalidate it: new parameter values,
+    another batch, options, a registration, the same batch pushed in pieces -- every result against the C oracle, and
+    bitwise what a handle that never reuses a layout returns."""
+    n = 20
+    _, circuits, params = helpers.population_circuits(n, 5, 40, seed=3)
+    op = helpers.random_ising_operator(n, seed=2020)
+    table = c_oracle.diagonal_table(op)
+    scratch = np.zeros(2 << n)
+    ev = OperatorCircuitEvaluator(op)
+    dev = ev.statevector_device
+    ref_ev = OperatorCircuitEvaluator(op)
+    ref_ev.statevector_device.set_option("repeat_layout", 0)
+    rng = np.random.default_rng(5)
+
+    def check(cs, ps, oracle_at=()):
+        got = np.asarray(ev.evaluate_circuits(cs, ps))
+        want = np.asarray(ref_ev.evaluate_circuits(cs, ps))
+        assert np.array_equal(got, want)
+        for i in oracle_at:
+            assert abs(got[i] - c_oracle.evaluate(cs[i], ps[i], op, table, scratch)) < EXP_TOL
+        return got
+
+    first = check(circuits, params, oracle_at=(0, 39))
+    assert np.array_equal(check(circuits, params), first)                      # the same batch again
+    shifted = [[v + rng.normal(0.0, 0.3) for v in p] for p in params]
+    moved = check(circuits, shifted, oracle_at=(7,))                           # ... with other parameter values
+    assert np.abs(moved - first).max() > 1e-3
+    check(circuits[:13], params[:13], oracle_at=(12,))                         # another batch in between
+    assert np.array_equal(check(circuits, params), first)
+    dev.set_option("chain_stream", 0)                                          # an option in between
+    assert np.array_equal(check(circuits, params), first)
+    dev.set_option("chain_stream", 1)
+    assert np.array_equal(check(circuits, params), first)
+    _, extra, extra_params = helpers.population_circuits(n, 4, 3, seed=77)     # a registration in between
+    check(extra, extra_params, oracle_at=(1,))
+    assert np.array_equal(check(circuits, params), first)
+    assert np.array_equal(check(list(reversed(circuits)), list(reversed(params))), first[::-1])
+    # the same batch pushed in pieces right after it went through in one: the kept layout is given up
+    assert np.array_equal(check(circuits, params), first)
+    dev._push_evals = 16
+    try:
+        assert np.array_equal(np.asarray(ev.evaluate_circuits(circuits, params)), first)
+        assert np.array_equal(np.asarray(ev.evaluate_circuits(circuits, shifted)), moved)
+    finally:
+        dev._push_evals = 0
+    assert np.array_equal(check(circuits, shifted), moved)
