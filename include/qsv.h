@@ -247,6 +247,8 @@ int qsv_exact_cvar_batch(qsv_t* h, int n_evals, const int* circuit_ids, const in
  *                        virtual circuits / with launches of their own) the second kind runs on the second lane's stream
  *   "poll_results" 0|1   a waiting qsv_eval_end watches the (pinned) result buffer instead of the streams: every result is one
  *                        8-byte store, visible about 5 us before the stream's completion signal (diagonal operators)
+ *   "repeat_layout" 0|1  a batch with the previous batch's circuit ids and counts, nothing registered or set in between,
+ *                        keeps that batch's layout (an optimiser's next iteration)
  *   "split_sampling" 0|1 split circuits are sampled from their side tables
  *   "streams" 1..4       HIP streams the pushes of a batch cycle over (at most as many as were created with the handle)
  * Returns QSV_E_ARG for an unknown name or a value out of range.
