@@ -610,7 +610,7 @@ def main() -> None:
     kernels, prof = kernel_rooflines(device, step, min(args.steps, 10), traffic)
     config3 = config3_deep = None
     if not args.no_extras:
-        config3 = config3_block(world, rank, local_rank)
+        config3 = config3_block(world, rank, local_rank, steps=40)
         config3_deep = config3_block(world, rank, local_rank, steps=3, layers=8)
 
     if rank == 0:
