@@ -121,3 +121,30 @@ def load_c_oracle() -> COracle:
     oracle = COracle(C.CDLL(str(so_path)))
     oracle.lib.qsvo_set_threads(host_cpu_share())
     return oracle
+
+
+def textbook_cases():
+    """Circuits whose expectation values are textbook facts, independent of any simulator: (name, circuit, {label: value}).
+    Pauli labels in Qiskit's order (rightmost character = qubit 0).  They pin the roles of a cu3's control and target, the sign
+    conventions of U's phases and the Y phase of the expectation -- the semantics DESIGN.md section 2 lists as taken from
+    upstream documentation."""
+    pi = np.pi
+    h = (pi / 2, 0.0, pi)  # U(pi/2, 0, pi) = H
+    x = (pi, 0.0, pi)      # U(pi, 0, pi) = X
+    cases = []
+    bell = CircuitIR(2).u(*h, 0).cu3(*x, 0, 1)  # (|00> + |11>) / sqrt 2
+    cases.append(("Bell", bell, {"ZZ": 1.0, "XX": 1.0, "YY": -1.0, "ZI": 0.0, "IZ": 0.0, "XY": 0.0, "XI": 0.0}))
+    ghz = CircuitIR(3).u(*h, 0).cu3(*x, 0, 1).cu3(*x, 1, 2)  # (|000> + |111>) / sqrt 2: Mermin's signs
+    cases.append(("GHZ", ghz, {"XXX": 1.0, "XYY": -1.0, "YXY": -1.0, "YYX": -1.0, "ZZI": 1.0, "IZZ": 1.0, "ZIZ": 1.0, "ZII": 0.0}))
+    lam = 0.83
+    cphase = CircuitIR(2).u(*h, 0).u(*h, 1).cu3(0.0, 0.0, lam, 0, 1)  # (|00> + |01> + |10> + e^{i lam} |11>) / 2
+    cases.append(("controlled phase", cphase, {"XI": (1 + np.cos(lam)) / 2, "IX": (1 + np.cos(lam)) / 2, "YI": np.sin(lam) / 2,
+                                               "ZI": 0.0, "ZZ": 0.0, "XX": (1 + np.cos(lam)) / 2}))
+    theta, phi = 1.1, 0.45
+    bloch = CircuitIR(1).u(theta, phi, 0.3, 0)  # cos(theta/2)|0> + e^{i phi} sin(theta/2)|1>: the Bloch vector
+    cases.append(("Bloch vector", bloch, {"X": np.sin(theta) * np.cos(phi), "Y": np.sin(theta) * np.sin(phi), "Z": np.cos(theta)}))
+    # a controlled rotation whose control is |1>: the target carries the rotated state, the control is untouched
+    crot = CircuitIR(2).u(*x, 1).cu3(theta, phi, -0.2, 1, 0)
+    cases.append(("controlled rotation", crot, {"IX": np.sin(theta) * np.cos(phi), "IY": np.sin(theta) * np.sin(phi),
+                                                "IZ": np.cos(theta), "ZI": -1.0, "ZZ": -np.cos(theta)}))
+    return cases

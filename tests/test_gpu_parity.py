@@ -507,3 +507,17 @@ def test_config4_jssp_end_to_end_evqe():
     probs = evaluator.statevector_device.probabilities(best.get_parameterized_quantum_circuit(), list(best.parameter_values))
     schedule = enc.translate_result_bitstring(format(int(np.argmax(probs)), f"0{enc.n_qubits}b"))
     assert schedule.is_valid and schedule.makespan == 5
+
+
+def test_textbook_expectation_values_on_the_device():
+    """The same textbook facts the oracle is held to (tests/helpers.py textbook_cases: Bell and GHZ correlations with Mermin's
+    signs, a controlled phase, the Bloch vector, a controlled rotation behind a set control) through the device path, one
+    Pauli string at a time and all of a case's strings as one operator."""
+    for name, circuit, values in helpers.textbook_cases():
+        for label, want in values.items():
+            got = OperatorCircuitEvaluator(PauliOperator([label], [1.0])).evaluate_circuits([circuit], [[]])[0]
+            assert abs(got - want) < 1e-12, (name, label, got, want)
+        labels = list(values)
+        coeffs = [0.5 + 0.25 * i for i in range(len(labels))]
+        got = OperatorCircuitEvaluator(PauliOperator(labels, coeffs)).evaluate_circuits([circuit], [[]])[0]
+        assert abs(got - sum(c * values[l] for c, l in zip(coeffs, labels))) < 1e-12, name

@@ -120,3 +120,12 @@ def test_golden_fixtures():
         if "state_re" in case:
             want = np.asarray(case["state_re"]) + 1j * np.asarray(case["state_im"])
             assert np.abs(state - want).max() < 1e-13
+
+
+def test_textbook_expectation_values():
+    """Bell and GHZ correlations with Mermin's signs, a controlled phase on |++>, the Bloch vector of U(theta, phi, .)|0>, a
+    controlled rotation behind a set control: values any textbook gives, no simulator involved."""
+    for name, circuit, values in helpers.textbook_cases():
+        for label, want in values.items():
+            got = helpers.oracle_expectation(circuit, [], PauliOperator([label], [1.0]))
+            assert abs(got - want) < 1e-14, (name, label, got, want)
