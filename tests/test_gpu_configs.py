@@ -1204,3 +1204,21 @@ def test_repeated_batches_keep_their_layout_and_nothing_else(c_oracle):
     finally:
         dev._push_evals = 0
     assert np.array_equal(check(circuits, shifted), moved)
+
+
+def test_fp32_split_evaluations_with_four_and_five_keys():
+    """The 16- and 32-term Gram kernels (eight slices, last workgroup adds them) and the chain stream with fp32 side tables:
+    six-layer individuals at 20 qubits, most of them with four or five keys, within the fp32 bound of the fp64 values and
+    the same bits when the batch is evaluated again and one circuit at a time."""
+    n = 20
+    _, circuits, params = helpers.population_circuits(n, 6, 24, seed=0)
+    keys = [_split_keys(c, 16) for c in circuits]
+    assert sum(1 for k in keys if k >= 4) >= 6, keys
+    op = helpers.random_ising_operator(n, seed=2020)
+    want = np.asarray(OperatorCircuitEvaluator(op).evaluate_circuits(circuits, params))
+    ev32 = OperatorCircuitEvaluator(op, dtype="fp32")
+    got = np.asarray(ev32.evaluate_circuits(circuits, params))
+    assert np.abs(got - want).max() < FP32_REL * float(np.abs(op.coeffs).sum())
+    assert np.array_equal(np.asarray(ev32.evaluate_circuits(circuits, params)), got)
+    for i in (0, 11, 23):
+        assert ev32.evaluate_circuits([circuits[i]], [params[i]])[0] == got[i]
