@@ -1088,14 +1088,14 @@ def test_split_evaluations_on_the_largest_registers(n, count):
 # ---- round 3, second half: multiplexed gates, the chain stream, results watched in the pinned buffer ------------------
 
 
-def _device_with_env(n, **env):
+def _device_with_env(n, dtype="fp64", **env):
     """A device created under the given environment (the library reads its plan and path switches when a handle is made)."""
     import os
 
     old = {k: os.environ.get(k) for k in env}
     os.environ.update({k: str(v) for k, v in env.items()})
     try:
-        return StatevectorDevice(n)
+        return StatevectorDevice(n, dtype)
     finally:
         for k, v in old.items():
             if v is None:
@@ -1125,6 +1125,20 @@ def test_multiplexed_gates_agree_with_separate_gates(n, layers, count, c_oracle)
             a, b = fused_dev.statevector(c, p), plain_dev.statevector(c, p)
             assert np.abs(a - b).max() < 1e-12
             assert np.abs(a - helpers.oracle_state(c, p)).max() < 1e-12
+
+
+def test_multiplexed_gates_in_fp32_take_the_generic_butterfly():
+    """fp32 plans are not fused by default (their gate loop is the C++ one); with QSV_FUSE=1 its flagged entries -- negated
+    predicates, products with a complex m00 -- go through the generic butterfly: the same values as without, to fp32."""
+    n = 16
+    _, circuits, params = helpers.population_circuits(n, 7, 8, seed=9)
+    op = helpers.random_ising_operator(n, seed=n)
+    want = np.asarray(OperatorCircuitEvaluator(op, statevector_device=_device_with_env(n, QSV_SPLIT=0)).evaluate_circuits(circuits, params))
+    bound = FP32_REL * float(np.abs(op.coeffs).sum())
+    for fuse in (0, 1):
+        dev = _device_with_env(n, "fp32", QSV_FUSE=fuse, QSV_SPLIT=0)
+        got = np.asarray(OperatorCircuitEvaluator(op, statevector_device=dev).evaluate_circuits(circuits, params))
+        assert np.abs(got - want).max() < bound, fuse
 
 
 def test_chain_stream_and_result_polling_change_no_bit():
