@@ -684,6 +684,9 @@ def main() -> None:
                 "layers": N_LAYERS,
                 "pauli_terms": len(operator),
                 "parallelism": f"population sharded over {world} GPU(s), RCCL all-gather of fitness" if world > 1 else "1 GPU",
+                "path": "library defaults (DESIGN.md 4.2 / 5): register splitting with up to five cut keys, one launch per push "
+                        "where both virtual circuits are one tile, factorised Ising expectation, multiplexed gates, chain "
+                        "stream, end of a batch read off the pinned result buffer, a repeated batch keeps its layout",
             },
             "roofline": roofline,
         }
