@@ -122,6 +122,14 @@ def _load_pyhelp_module():
     return _pyhelp_module or None
 
 
+def _has_none(seq) -> bool:
+    """Some element IS None (by identity: a parameter vector may be a NumPy array, which answers ``==`` element by element)."""
+    fast = _load_pyhelp_module()
+    if fast is not None and isinstance(seq, (list, tuple)):
+        return fast.has_none(seq)
+    return any(v is None for v in seq)
+
+
 def _pack_slice(vectors: Sequence[Sequence[float]], first: int, last: int, total: int) -> np.ndarray:
     """The parameter vectors ``vectors[first:last]`` back to back as one float64 array of ``total`` values."""
     helper = _load_pyhelp()
@@ -707,7 +715,7 @@ class OperatorCircuitEvaluator(BaseCircuitEvaluator):
         return self._composed.get(circuit)
 
     def evaluate_circuits(self, circuits: list[CircuitIR], parameter_values: list[list[float]]) -> list[float]:
-        if None in circuits or None in parameter_values:
+        if _has_none(circuits) or _has_none(parameter_values):
             pairs = [(c, p) for c, p in zip(circuits, parameter_values) if c is not None and p is not None]
             circuits, parameter_values = [c for c, _ in pairs], [p for _, p in pairs]
         if self._initial_state_circuit is not None:
@@ -725,7 +733,7 @@ class OperatorCircuitEvaluator(BaseCircuitEvaluator):
         """:meth:`evaluate_circuits` with the values left in device memory and without waiting for them
         (:meth:`StatevectorDevice.expectation_values_to_device`).  Only the exact estimator without missing entries can do
         that; returns False -- nothing was started -- otherwise."""
-        if self._precision > 0 or None in circuits or None in parameter_values:
+        if self._precision > 0 or _has_none(circuits) or _has_none(parameter_values):
             return False
         if self._initial_state_circuit is not None:
             circuits = [self._with_initial_state(c) for c in circuits]

@@ -5,6 +5,7 @@
 #define PY_SSIZE_T_CLEAN
 #include <Python.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "../../include/qsv.h"
 
@@ -63,7 +64,40 @@ static Py_ssize_t pack_exact(PyObject* vectors, Py_ssize_t first, Py_ssize_t cou
         return -1;
     }
     for (Py_ssize_t i = first; i < first + count; ++i) {
-        PyObject* inner = PySequence_Fast(PySequence_Fast_GET_ITEM(outer, i), "a parameter vector must be a sequence of numbers");
+        PyObject* vec = PySequence_Fast_GET_ITEM(outer, i);
+        if (!PyList_CheckExact(vec) && !PyTuple_CheckExact(vec) && PyObject_CheckBuffer(vec)) {
+            /* a contiguous vector of doubles (a NumPy row, array('d')): copied as it stands -- what the vectorised optimiser
+             * loop of evqe/solver.py hands over; as a sequence it would be unpacked into one Python float per value first */
+            Py_buffer view;
+            if (PyObject_GetBuffer(vec, &view, PyBUF_FORMAT | PyBUF_C_CONTIGUOUS) == 0) {
+                const int is_double = view.ndim == 1 && view.itemsize == (Py_ssize_t)sizeof(double) && view.format &&
+                                      (strcmp(view.format, "d") == 0 || strcmp(view.format, "<d") == 0 || strcmp(view.format, "=d") == 0);
+                if (is_double) {
+                    const Py_ssize_t m = view.shape[0], want = (Py_ssize_t)take[i];
+                    int bad = 0;
+                    if (m < want) {
+                        PyErr_Format(PyExc_ValueError, "circuit %zd needs %zd parameter values, got %zd", i, want, m);
+                        bad = 1;
+                    } else if (want < 0 || n + want > capacity) {
+                        PyErr_SetString(PyExc_ValueError, "the batch needs more parameter values than its scratch buffer holds");
+                        bad = 1;
+                    } else {
+                        memcpy(out + n, view.buf, (size_t)want * sizeof(double));
+                        n += want;
+                    }
+                    PyBuffer_Release(&view);
+                    if (bad) {
+                        Py_DECREF(outer);
+                        return -1;
+                    }
+                    continue;
+                }
+                PyBuffer_Release(&view);
+            } else {
+                PyErr_Clear();
+            }
+        }
+        PyObject* inner = PySequence_Fast(vec, "a parameter vector must be a sequence of numbers");
         if (!inner) {
             Py_DECREF(outer);
             return -1;
@@ -306,7 +340,28 @@ static PyObject* same_objects(PyObject* self, PyObject* const* args, Py_ssize_t 
     Py_RETURN_TRUE;
 }
 
+/* has_none(seq) -> bool: some element of a list or tuple IS None.  (`None in seq` compares with ==, which an element that is
+ * a NumPy array answers element by element.) */
+static PyObject* has_none(PyObject* self, PyObject* const* args, Py_ssize_t nargs) {
+    (void)self;
+    if (nargs != 1) {
+        PyErr_SetString(PyExc_TypeError, "has_none(seq)");
+        return NULL;
+    }
+    PyObject* a = args[0];
+    if (!(PyList_Check(a) || PyTuple_Check(a))) {
+        PyErr_SetString(PyExc_TypeError, "has_none: a list or tuple");
+        return NULL;
+    }
+    const Py_ssize_t n = PySequence_Fast_GET_SIZE(a);
+    PyObject** x = PySequence_Fast_ITEMS(a);
+    for (Py_ssize_t i = 0; i < n; ++i)
+        if (x[i] == Py_None) Py_RETURN_TRUE;
+    Py_RETURN_FALSE;
+}
+
 static PyMethodDef helper_methods[] = {
+    {"has_none", (PyCFunction)(void (*)(void))has_none, METH_FASTCALL, "has_none(seq): some element of a list or tuple is None"},
     {"same_objects", (PyCFunction)(void (*)(void))same_objects, METH_FASTCALL,
      "same_objects(a, b): two lists or tuples hold the same objects, position by position"},
     {"eval_one", (PyCFunction)(void (*)(void))eval_one, METH_FASTCALL,

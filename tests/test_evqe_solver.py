@@ -182,3 +182,38 @@ def test_nft_mutation_lowers_the_sum_of_expectation_values():
     # and end to end: the solver with NFT finds x = 0, y = 3 too
     result = EVQEMinimumEigensolver(make_config(optimizer=NFT(maxfev=40))).compute_minimum_eigenvalue(OracleEvaluator(op))
     assert result.eigenvalue < -8.5
+
+
+def test_vectorised_spsa_driver_gives_every_run_its_own_iterates():
+    """The whole-array lock-step driver (evqe/solver.py _minimize_spsa_vectorised) against the same runs advanced one by one
+    through propose / accept: bitwise the same iterates and evaluation counts, for runs of different lengths, with the trust
+    region both binding and not, with and without a termination checker (which stops runs at different iterations)."""
+    from queasars_amd.evqe import solver as S
+
+    class Quadratic:
+        """f(x) = sum (x - 1)^2 scaled per 'circuit'; accepts whatever vectors the driver hands over (NumPy rows)."""
+
+        def evaluate_circuits(self, circuits, parameter_values):
+            return [float(c * np.sum((np.asarray(p) - 1.0) ** 2)) for c, p in zip(circuits, parameter_values)]
+
+    rng = np.random.default_rng(3)
+    for checker in (None, SPSATerminationChecker(0.05, 2)):
+        for lr, pert in ((0.2, 0.1), (1.5, 0.35)):
+            cfg = SPSA(maxiter=17, learning_rate=lr, perturbation=pert, trust_region=True, termination_checker=checker)
+            sizes = [1, 3, 7, 12, 12, 40]
+            starts = [rng.normal(size=n) for n in sizes]
+            scales = [0.3, 1.0, 2.5, 0.01, 4.0, 1.0]
+            ev = Quadratic()
+            one_by_one = []
+            for x0, scale, seed in zip(starts, scales, range(6)):
+                run = _SPSARun(cfg, x0, seed=seed)
+                while not run.done:
+                    plus, minus = run.propose()
+                    run.accept(*ev.evaluate_circuits([scale, scale], [plus, minus]))
+                one_by_one.append(run)
+            jobs = [(scale, _SPSARun(cfg, x0, seed=seed)) for x0, scale, seed in zip(starts, scales, range(6))]
+            S._minimize_batched(ev, jobs)
+            for (_, run), ref in zip(jobs, one_by_one):
+                assert run.done and np.array_equal(run.x, ref.x) and run.nfev == ref.nfev and run.iteration == ref.iteration
+            if checker is not None:
+                assert len({run.nfev for _, run in jobs}) > 1  # (the checker stopped runs at different iterations)

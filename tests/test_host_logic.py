@@ -466,3 +466,26 @@ class TestSharedDeviceScratch:
         assert (out[15:] == -1.0).all(), "nothing may be written beyond the capacity"
         with pytest.raises(ValueError, match="needs 6 parameter values, got 2"):
             helper.qsv_pack_exact([[1.0, 2.0]], 0, 1, take.ctypes.data, out.ctypes.data, 32)
+
+
+def test_packer_takes_numpy_rows_as_they_stand():
+    """Parameter vectors that are contiguous float64 buffers (rows of the optimiser's matrix) are copied, lists are
+    unpacked value by value; a short row is refused like a short list; None among the vectors is found by identity."""
+    from queasars_amd.circuit_evaluation.circuit_evaluation import _has_none, _load_pyhelp
+
+    helper = _load_pyhelp()
+    if helper is None:
+        pytest.skip("helper not built")
+    matrix = np.arange(40, dtype=np.float64).reshape(4, 10)
+    vectors = [matrix[0, :7], list(matrix[1]), matrix[2], np.float32(matrix[3]), tuple(matrix[0])]
+    take = np.array([7, 10, 4, 10, 2], dtype=np.int64)
+    out = np.full(40, -1.0)
+    n = helper.qsv_pack_exact(vectors, 0, 5, take.ctypes.data, out.ctypes.data, 40)
+    want = np.concatenate([matrix[0, :7], matrix[1], matrix[2, :4], matrix[3], matrix[0, :2]])
+    assert n == 33 and np.array_equal(out[:33], want) and (out[33:] == -1.0).all()
+    with pytest.raises(ValueError):
+        helper.qsv_pack_exact([matrix[0, :3]], 0, 1, np.array([5], dtype=np.int64).ctypes.data, out.ctypes.data, 40)
+    strided = np.arange(20, dtype=np.float64)[::2]  # (not contiguous: goes the slow way, still right)
+    assert helper.qsv_pack_exact([strided], 0, 1, np.array([10], dtype=np.int64).ctypes.data, out.ctypes.data, 40) == 10
+    assert np.array_equal(out[:10], strided)
+    assert not _has_none([matrix[0], matrix[1]]) and _has_none([matrix[0], None]) and not _has_none([])
