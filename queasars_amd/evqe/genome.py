@@ -122,6 +122,29 @@ def _layer_parameter_rank(layer_id: int, gates: tuple) -> dict:
     return sorted_parameter_rank(_parameter_names(layer_id, gates))
 
 
+@lru_cache(maxsize=8192)
+def _layer_template(gates: tuple) -> tuple:
+    """What a layer lowers to, apart from where its angles come from: one (kind, target, control, rank of theta, of phi, of
+    lambda) per emitted op, the ranks among the layer's own name-sorted parameters (-1: the op has none).  The names of a
+    layer share their ``layer{i}_`` prefix, so the order among them does not depend on the layer's position."""
+    from queasars_amd.ir import NO_CONTROL, OP_CU3, OP_ID, OP_U
+
+    rank = _layer_parameter_rank(0, gates)
+    ops = []
+    for gate in gates:
+        q = gate.qubit_index
+        if gate.kind is EVQEGateType.IDENTITY:
+            ops.append((OP_ID, q, NO_CONTROL, -1, -1, -1))
+        elif gate.kind is EVQEGateType.ROTATION or gate.kind is EVQEGateType.CONTROLLED_ROTATION:
+            ranks = tuple(rank[f"layer0_q{q}_{a}"] for a in _ANGLE_NAMES)
+            if gate.kind is EVQEGateType.ROTATION:
+                ops.append((OP_U, q, NO_CONTROL) + ranks)
+            else:
+                ops.append((OP_CU3, q, gate.partner_index) + ranks)
+        # CONTROL markers emit nothing (quantum_gate.py:125-126)
+    return tuple(ops), len(rank)
+
+
 def sorted_parameter_rank(names: Iterable[str]) -> dict[str, int]:
     """name -> position in Qiskit's ``circuit.parameters`` (plain string sort of the names)."""
     return {name: rank for rank, name in enumerate(sorted(names))}
@@ -141,6 +164,18 @@ class EVQECircuitLayer:
     @cached_property
     def n_parameters(self) -> int:
         return sum(g.n_parameters() for g in self.gates)
+
+    @cached_property
+    def _hash(self) -> int:
+        return hash((self.n_qubits, self.gates))
+
+    def __hash__(self) -> int:  # (species are dictionaries keyed by individuals: hashing a layer gate by gate, enum by enum,
+        return self._hash       # every time was a sixth of the driver's own time)
+
+    @cached_property
+    def template(self) -> tuple:
+        """:func:`_layer_template` of this layer's gates, kept on the layer (no hashing of the gates to find it again)."""
+        return _layer_template(self.gates)
 
     @cached_property
     def n_controlled_gates(self) -> int:
@@ -242,6 +277,13 @@ class EVQEIndividual:
         return len(self.parameter_values) == sum(layer.n_parameters for layer in self.layers)
 
     @cached_property
+    def _hash(self) -> int:
+        return hash((self.n_qubits, self.layers, self.parameter_values))
+
+    def __hash__(self) -> int:  # (computed once: individuals are dictionary keys in speciation and selection)
+        return self._hash
+
+    @cached_property
     def layer_parameter_indices(self) -> dict[int, tuple[int, ...]]:
         out, start = {}, 0
         for i, layer in enumerate(self.layers):
@@ -326,7 +368,8 @@ class EVQEIndividual:
     @staticmethod
     def get_genetic_distance(individual_1: "EVQEIndividual", individual_2: "EVQEIndividual") -> int:
         l1, l2 = len(individual_1.layers), len(individual_2.layers)
-        shared = sum(1 for a, b in zip(individual_1.layers, individual_2.layers) if a == b)
+        # (offspring share their parents' layer objects, and layers that differ almost always differ in their cached hash)
+        shared = sum(1 for a, b in zip(individual_1.layers, individual_2.layers) if a is b or (a._hash == b._hash and a == b))
         return math.ceil(0.5 * (l1 + l2)) - shared
 
     def get_parameter_values(self) -> tuple[float, ...]:
@@ -347,6 +390,33 @@ class EVQEIndividual:
         name-sorted order over all free parameters); every other layer is bound to this individual's
         values, the k-th value going to that layer's k-th *name-sorted* parameter, exactly as
         ``assign_parameters`` with a sequence does in the reference (circuit_layer.py:233-235)."""
+        chosen = {layer_id % len(self.layers) for layer_id in parameterized_layers}
+        # Fast form of the statement below (kept as _lower_by_names, which the tests hold it to): per layer a cached template
+        # of its ops with the ranks of their angles among the layer's name-sorted parameters; a free layer's parameters
+        # start where the layers whose names sort before its own end -- the names of a layer share the prefix layer{i}_, and
+        # a plain string sort of the prefixes is the order of the blocks.  Lowering an individual name by name (dictionaries
+        # of formatted names, one method call per op) was 58 % of the EVQE driver's own time.
+        offset, cursor = {}, 0
+        for i in sorted(chosen, key=lambda j: f"layer{j}_"):
+            offset[i] = cursor
+            cursor += self.layers[i].template[1]
+        rows = []
+        for i, layer in enumerate(self.layers):
+            ops, _ = layer.template
+            if i in chosen:
+                base = offset[i]
+                for kind, target, control, rt, rp, rl in ops:
+                    rows.append((kind, target, control, 0, base + rt, base + rp, base + rl, 0.0, 0.0, 0.0) if rt >= 0
+                                else (kind, target, control, 0, -1, -1, -1, 0.0, 0.0, 0.0))
+            else:
+                values = self.get_layer_parameter_values(i)
+                for kind, target, control, rt, rp, rl in ops:
+                    rows.append((kind, target, control, 0, -1, -1, -1, float(values[rt]), float(values[rp]), float(values[rl]))
+                                if rt >= 0 else (kind, target, control, 0, -1, -1, -1, 0.0, 0.0, 0.0))
+        return CircuitIR.from_rows(self.n_qubits, rows, cursor)
+
+    def _lower_by_names(self, parameterized_layers: set[int]) -> CircuitIR:
+        """The same circuit, stated name by name (the reference's own formulation; tests compare the two)."""
         chosen = {layer_id % len(self.layers) for layer_id in parameterized_layers}
         free_names: list[str] = []
         for i in sorted(chosen):

@@ -127,6 +127,20 @@ class CircuitIR:
             self._registered = {}
         return self
 
+    @classmethod
+    def from_rows(cls, n_qubits: int, rows: list, n_parameters: int) -> "CircuitIR":
+        """A circuit from complete ``qsv_op`` rows ``(kind, target, control, 0, p_theta, p_phi, p_lambda, theta, phi, lam)``
+        (control = NO_CONTROL for none; parameter indices -1 for literal angles) and its parameter count -- for a caller
+        that produces valid rows wholesale (the EVQE genome); qubit indices are still checked."""
+        out = cls(n_qubits)
+        for row in rows:
+            if not (0 <= row[1] < out._n_qubits and (row[2] == NO_CONTROL or (0 <= row[2] < out._n_qubits and row[2] != row[1]))):
+                raise ValueError("qubit index out of range")
+        out._rows = list(rows)
+        out._bytes = bytearray(b"".join([_ROW.pack(*row) for row in rows]))
+        out._n_parameters = int(n_parameters)
+        return out
+
     def id(self, qubit: int) -> "CircuitIR":
         return self._append(OP_ID, self._check_qubit(qubit), NO_CONTROL, 0.0, 0.0, 0.0)
 

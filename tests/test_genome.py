@@ -236,3 +236,22 @@ def test_committed_population_fixture_in_the_reference_wire_format():
     for ind, want in zip(population.individuals, data["expectations"]):
         got = helpers.oracle_expectation(ind.get_parameterized_quantum_circuit(), list(ind.parameter_values), op)
         assert abs(got - want) < 1e-12
+
+
+def test_fast_lowering_is_the_lowering_by_names():
+    """get_partially_parameterized_quantum_circuit builds its ops from cached per-layer templates; _lower_by_names states the
+    same circuit name by name (formatted parameter names, Qiskit's plain string sort over all free names).  The two must be
+    the same bytes for every choice of free layers -- also with more than ten layers, where layer10_ sorts before layer2_."""
+    import random
+
+    from queasars_amd.evqe.genome import EVQEIndividual
+
+    rng = random.Random(4)
+    for n_qubits, n_layers in ((4, 1), (6, 3), (7, 12), (12, 4)):
+        ind = EVQEIndividual.random_individual(n_qubits=n_qubits, n_layers=n_layers, randomize_parameter_values=True, random_seed=rng.randrange(1 << 30))
+        choices = [set(), set(range(n_layers)), {-1}, {0}] + [set(rng.sample(range(n_layers), rng.randint(1, n_layers))) for _ in range(6)]
+        for chosen in choices:
+            fast, slow = ind.get_partially_parameterized_quantum_circuit(chosen), ind._lower_by_names(chosen)
+            assert bytes(fast.packed().tobytes()) == bytes(slow.packed().tobytes()), (n_qubits, n_layers, chosen)
+            assert fast.num_parameters == slow.num_parameters and len(fast) == len(slow)
+            assert fast.bound_ops([0.1] * fast.num_parameters) == slow.bound_ops([0.1] * slow.num_parameters)
