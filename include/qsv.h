@@ -164,6 +164,15 @@ int qsv_eval_push(qsv_t* h, int first, int count, const double* values);
  * passes the same pointer to qsv_eval_push saves the library's copy (84 KB per population of the benchmark: 5 us of a 72 us
  * step).  Valid until that push; evaluations must still be pushed in order. */
 int qsv_eval_staging(qsv_t* h, int first, int count, double** values);
+/* qsv_eval_push for parameter values that ALREADY LIVE IN DEVICE MEMORY (this handle's GPU; an optimiser that runs on the
+ * device, a torch tensor): `device_values` points at the first value of evaluation `first`, the values of the push packed
+ * back to back by the counts given to qsv_eval_begin -- a row-major matrix of equal rows is such a packing when every
+ * evaluation declares the row length as its count (a circuit takes the first n_params values of its row).  Nothing is copied
+ * and nothing crosses PCIe: the kernels read the values where they are, so they must stay unchanged until qsv_eval_end has
+ * returned (for a batch that does not wait, qsv_eval_set_output: until its work is complete).  `ready_event`: a hipEvent_t
+ * after which the values are complete -- every stream of the handle waits for it --, or NULL when they already are (the
+ * caller synchronised, or wrote them on the handle's stream, qsv_set_stream).  Pushes of both kinds may be mixed in a batch. */
+int qsv_eval_push_device(qsv_t* h, int first, int count, const double* device_values, void* ready_event);
 int qsv_eval_end(qsv_t* h, double* out_expectations);
 /*
  * Results into DEVICE memory (n_evals doubles, this handle's GPU), for a caller that feeds them to something on the

@@ -81,6 +81,7 @@ SIGNATURES = {
     "qsv_eval_begin": (C.c_int, [_P, C.c_int, _P, _P]),
     "qsv_eval_push": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "qsv_eval_staging": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(_P)]),
+    "qsv_eval_push_device": (C.c_int, [_P, C.c_int, C.c_int, _P, _P]),
     "qsv_eval_end": (C.c_int, [_P, _P]),
     "qsv_eval_set_output": (C.c_int, [_P, _P]),
     "qsv_eval_suggested_pushes": (C.c_int, [_P]),

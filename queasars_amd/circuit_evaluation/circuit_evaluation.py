@@ -88,6 +88,9 @@ def _load_pyhelp():
                 lib.qsv_py_expectation_values_device.restype = C.c_int
                 lib.qsv_py_expectation_values_device.argtypes = [C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_void_p, C.py_object,
                                                                  C.c_void_p, C.c_ssize_t, C.c_void_p]
+                lib.qsv_py_expectation_values_devparams.restype = C.c_int
+                lib.qsv_py_expectation_values_devparams.argtypes = [C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                                    C.c_void_p, C.c_void_p, C.c_void_p]
                 lib.qsv_pack_exact.restype = C.c_ssize_t
                 lib.qsv_pack_exact.argtypes = [C.py_object, C.c_ssize_t, C.c_ssize_t, C.c_void_p, C.c_void_p, C.c_ssize_t]
                 _pyhelp = lib
@@ -208,6 +211,7 @@ class StatevectorDevice:
         # (identities, circuits, ids, parameter counts, their sum) of the previous call: ONE tuple, replaced as a whole, so
         # that a thread never pairs one call's counts with another call's total (evaluators may share a device)
         self._last_batch = None
+        self._row_counts = None
         self._push_evals = int(os.environ.get("QSV_PUSH_EVALS", "0"))  # measurement knob: evaluations per push
         self._push_plan = [int(x) for x in os.environ.get("QSV_PUSH_PLAN", "").split(",") if x]  # ... or explicit sizes
         self._operator: Optional[PauliOperator] = None
@@ -250,6 +254,11 @@ class StatevectorDevice:
     @property
     def n_qubits(self) -> int:
         return self._n_qubits
+
+    @property
+    def device_index(self) -> int:
+        """The HIP device this handle lives on."""
+        return self._args[2]
 
     @property
     def dtype(self) -> str:
@@ -395,6 +404,50 @@ class StatevectorDevice:
             rc = lib.qsv_eval_push(handle, 0, n, _lib.as_ptr(packed))
         rc_end = lib.qsv_eval_end(handle, None)
         self._check(rc if rc != _lib.QSV_OK else rc_end)
+
+    def expectation_values_of_device_parameters(
+        self,
+        circuits: Sequence[CircuitIR],
+        device_pointer: int,
+        row_length: int,
+        ready_event: int = 0,
+        out_device_pointer: int = 0,
+    ) -> Optional[np.ndarray]:
+        """:meth:`expectation_values` for parameter values that ALREADY LIVE IN DEVICE MEMORY (``qsv_eval_push_device``): a
+        row-major ``len(circuits) x row_length`` matrix of doubles at ``device_pointer`` on this handle's GPU, circuit i
+        taking the first ``num_parameters`` values of row i.  Nothing is packed and nothing crosses PCIe on the way in.
+        ``ready_event``: a ``hipEvent_t`` (as an integer) after which the matrix is complete, 0 when it already is.  The matrix
+        must stay unchanged until the call returns.  ``out_device_pointer``: as :meth:`expectation_values_to_device` (results
+        left on the device, no wait, None returned)."""
+        n = len(circuits)
+        if n == 0:
+            return None if out_device_pointer else np.zeros(0, dtype=np.float64)
+        if row_length < 0 or (row_length > 0 and not device_pointer):
+            raise ValueError("device_pointer / row_length do not describe a matrix")
+        ids, need, _total = self._batch_metadata(circuits)
+        cached = self._row_counts
+        if cached is None or cached[0] != (n, row_length):
+            cached = self._row_counts = ((n, row_length), np.full(n, row_length, dtype=np.int64))
+        counts = cached[1]
+        out = None if out_device_pointer else np.empty(n, dtype=np.float64)
+        helper = None if os.environ.get("QSV_LIBRARY") else _load_pyhelp()
+        if helper is not None:
+            self._check(helper.qsv_py_expectation_values_devparams(
+                self._handle, n, ids.ctypes.data, counts.ctypes.data, device_pointer or None, ready_event or None,
+                out.ctypes.data if out is not None else None, out_device_pointer or None))
+            return out
+        lib, handle = self._lib, self._handle
+        self._check(lib.qsv_eval_begin(handle, n, _lib.as_ptr(ids), _lib.as_ptr(counts)))
+        rc = lib.qsv_eval_set_output(handle, C.c_void_p(out_device_pointer)) if out_device_pointer else _lib.QSV_OK
+        if rc == _lib.QSV_OK:
+            rc = lib.qsv_eval_push_device(handle, 0, n, C.c_void_p(device_pointer) if row_length else None,
+                                          C.c_void_p(ready_event) if ready_event else None)
+        msg = _lib.last_error(lib, handle) if rc != _lib.QSV_OK else ""
+        rc_end = lib.qsv_eval_end(handle, _lib.as_ptr(out) if out is not None else None)
+        if rc != _lib.QSV_OK:
+            raise (ValueError if rc == _lib.QSV_E_ARG else CircuitEvaluatorException)(msg)
+        self._check(rc_end)
+        return out
 
     def expectation_values(self, circuits: Sequence[CircuitIR], parameter_values: Sequence[Sequence[float]]) -> np.ndarray:
         """Exact ``real(<psi_i|H|psi_i>)`` for every (circuit, parameter vector) pair, in input order.
@@ -595,6 +648,7 @@ class StatevectorDevice:
         A circuit keeps the form it was registered in; the cache of the previous batch is dropped."""
         self._check(self._lib.qsv_set_option(self._handle, name.encode(), int(value)))
         self._last_batch = None
+        self._row_counts = None
 
     def set_profiling(self, enabled: bool) -> None:
         self._check(self._lib.qsv_set_profiling(self._handle, 1 if enabled else 0))
@@ -710,12 +764,23 @@ class OperatorCircuitEvaluator(BaseCircuitEvaluator):
         with self._device.operator_lock:
             self._device.set_operator(operator)
         self._composed = _ComposedCircuits(initial_state_circuit)
+        self._ready_marker = None
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state["_ready_marker"] = None  # (a HIP event: made again where it is needed)
+        return state
 
     def _with_initial_state(self, circuit: CircuitIR) -> CircuitIR:
         return self._composed.get(circuit)
 
     def evaluate_circuits(self, circuits: list[CircuitIR], parameter_values: list[list[float]]) -> list[float]:
-        if _has_none(circuits) or _has_none(parameter_values):
+        """``parameter_values`` may also be a 2-D float64 tensor in THIS device's memory (anything with ``is_cuda`` /
+        ``data_ptr()``, i.e. a ``torch.Tensor``; one row per circuit, a circuit takes the first ``num_parameters`` values of its
+        row): the kernels then read the values where they are (``qsv_eval_push_device``), after the work queued so far on the
+        tensor's current stream."""
+        matrix = parameter_values if getattr(parameter_values, "is_cuda", False) else None
+        if matrix is None and (_has_none(circuits) or _has_none(parameter_values)):
             pairs = [(c, p) for c, p in zip(circuits, parameter_values) if c is not None and p is not None]
             circuits, parameter_values = [c for c, _ in pairs], [p for _, p in pairs]
         if self._initial_state_circuit is not None:
@@ -724,23 +789,66 @@ class OperatorCircuitEvaluator(BaseCircuitEvaluator):
         with self._device.operator_lock:
             if self._device._operator is not self._operator:
                 self._device.set_operator(self._operator)
-            values = self._device.expectation_values(circuits, parameter_values)
+            if matrix is not None:
+                values = self._evaluate_device_matrix(circuits, matrix)
+            else:
+                values = self._device.expectation_values(circuits, parameter_values)
         if self._precision > 0:
             values = values + self._rng.normal(0.0, self._precision, size=values.shape)
         return values.tolist()
+
+    def _evaluate_device_matrix(self, circuits, matrix, ready: bool = False, out_device_pointer: int = 0) -> Optional[np.ndarray]:
+        import torch
+
+        if matrix.dim() != 2 or matrix.dtype != torch.float64 or not matrix.is_contiguous():
+            raise ValueError("a device-resident parameter matrix must be a contiguous 2-D float64 tensor")
+        if matrix.shape[0] != len(circuits):
+            raise ValueError("circuits and parameter_values must have the same length")
+        if _has_none(circuits):
+            raise ValueError("a device-resident parameter matrix cannot skip circuits (None entries)")
+        if matrix.device.index != self._device.device_index:
+            raise ValueError("the parameter matrix lives on another device than the evaluator")
+        event = 0
+        stream = None if ready else torch.cuda.current_stream(matrix.device)
+        if stream is not None and not stream.query():
+            # (whatever produces the matrix was queued on the tensor's current stream and has not finished: the handle's
+            # streams wait for it.  An idle stream -- the usual case -- costs one query instead of an event and four waits.)
+            marker = self._ready_marker
+            if marker is None:
+                marker = self._ready_marker = torch.cuda.Event()
+            marker.record(stream)
+            event = marker.cuda_event
+        return self._device.expectation_values_of_device_parameters(circuits, matrix.data_ptr(), int(matrix.shape[1]), event,
+                                                                    out_device_pointer)
+
+    def evaluate_device_parameters(self, circuits: list[CircuitIR], matrix, ready: bool = False) -> np.ndarray:
+        """:meth:`evaluate_circuits` for a device-resident parameter matrix, as a NumPy array.  ``ready=True``: the matrix is
+        complete already (the caller synchronised, or it has not changed since an earlier call): no event is recorded."""
+        if self._precision > 0:
+            raise ValueError("estimator_precision > 0 is emulated on the host: use evaluate_circuits")
+        if self._initial_state_circuit is not None:
+            circuits = [self._with_initial_state(c) for c in circuits]
+        with self._device.operator_lock:
+            if self._device._operator is not self._operator:
+                self._device.set_operator(self._operator)
+            return self._evaluate_device_matrix(circuits, matrix, ready)
 
     def evaluate_circuits_to_device(self, circuits: list[CircuitIR], parameter_values: list[list[float]], device_pointer: int) -> bool:
         """:meth:`evaluate_circuits` with the values left in device memory and without waiting for them
         (:meth:`StatevectorDevice.expectation_values_to_device`).  Only the exact estimator without missing entries can do
         that; returns False -- nothing was started -- otherwise."""
-        if self._precision > 0 or _has_none(circuits) or _has_none(parameter_values):
+        matrix = parameter_values if getattr(parameter_values, "is_cuda", False) else None
+        if self._precision > 0 or _has_none(circuits) or (matrix is None and _has_none(parameter_values)):
             return False
         if self._initial_state_circuit is not None:
             circuits = [self._with_initial_state(c) for c in circuits]
         with self._device.operator_lock:
             if self._device._operator is not self._operator:
                 self._device.set_operator(self._operator)
-            self._device.expectation_values_to_device(circuits, parameter_values, device_pointer)
+            if matrix is not None:
+                self._evaluate_device_matrix(circuits, matrix, out_device_pointer=device_pointer)
+            else:
+                self._device.expectation_values_to_device(circuits, parameter_values, device_pointer)
         return True
 
     @property

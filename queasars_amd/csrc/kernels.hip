@@ -675,6 +675,8 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, FIRST>::waves_per_si
         // point (the pointer the loads use is only known to the compiler from here on).
         const size_t slot = size_t(blockIdx.y) + size_t(blockIdx.z) * a.region_stride;
         ev = a.host_evals[slot];
+        // (the device copy first, also of a null descriptor: a repeated batch reads its descriptors from that copy)
+        if (threadIdx.x == 0 && blockIdx.x == 0) a.evals_out[slot] = ev;
         if (ev.flags & kEvalNull) return;
         {
             // a launch's grid is as wide as its largest evaluation: a workgroup beyond THIS evaluation's tiles leaves before
@@ -685,7 +687,6 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, FIRST>::waves_per_si
             const uint32_t tiles0 = (f0 & kPassCompactStore) ? 1u << ((f0 >> 8) & 0xffu) : 1u << (c0[2] - (p0[0] & 0xffu));
             if (blockIdx.x >= tiles0) return;
         }
-        if (threadIdx.x == 0 && blockIdx.x == 0) a.evals_out[slot] = ev;
 #ifdef QSV_STAMPS
         QSV_STAMP(0);  // descriptor
         prepare_eval(plan_arena, ev, a.host_params, a.mats_out, reinterpret_cast<double*>(lds_raw), st_acc, &st_last);

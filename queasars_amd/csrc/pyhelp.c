@@ -254,6 +254,38 @@ int qsv_py_expectation_values_device(qsv_t* h, Py_ssize_t n, const int* ids, con
     return expectation_values(h, n, ids, counts, vectors, values, capacity, NULL, (double*)device_out);
 }
 
+/* Parameter values that already live in device memory (qsv_eval_push_device): `device_values` = the values of evaluation 0,
+ * the batch packed back to back by `counts` (a row-major matrix: every count the row length).  begin / push(es) / end in one
+ * call, nothing packed, the GIL released throughout.  device_out as above (NULL: results to `out`, waited for). */
+int qsv_py_expectation_values_devparams(qsv_t* h, Py_ssize_t n, const int* ids, const int64_t* counts, const double* device_values,
+                                        void* ready_event, double* out, void* device_out) {
+    int rc, rc_end;
+    Py_BEGIN_ALLOW_THREADS
+    rc = qsv_eval_begin(h, (int)n, ids, counts);
+    if (!rc) {
+        if (device_out) rc = qsv_eval_set_output(h, (double*)device_out);
+        if (!rc) {
+            int pushes = qsv_eval_suggested_pushes(h);
+            if (pushes < 1) pushes = 2;
+            if (device_out && n <= 96) pushes = 1;
+            const Py_ssize_t step = (n + pushes - 1) / pushes > 8 ? (n + pushes - 1) / pushes : 8;
+            Py_ssize_t offset = 0;
+            for (Py_ssize_t first = 0; first < n && !rc; first += step) {
+                const Py_ssize_t count = first + step <= n ? step : n - first;
+                Py_ssize_t total = 0;
+                for (Py_ssize_t i = first; i < first + count; ++i) total += (Py_ssize_t)counts[i];
+                rc = qsv_eval_push_device(h, (int)first, (int)count, total > 0 ? device_values + offset : NULL,
+                                          first == 0 ? ready_event : NULL);
+                offset += total;
+            }
+        }
+        rc_end = qsv_eval_end(h, device_out ? NULL : out);  /* (must be called even after a failed push: it releases the handle) */
+        if (!rc) rc = rc_end;
+    }
+    Py_END_ALLOW_THREADS
+    return rc;
+}
+
 /* ---- the reference's calling pattern: one circuit per call from population_size threads ---------------------------------
  * (queasars/minimum_eigensolvers/evqe/evolutionary_algorithm/selection.py:75-82, mutation.py:63-75).  The whole call in
  * ONE C function, reached as a method of an extension module (no ctypes argument conversion): circuit id out of the

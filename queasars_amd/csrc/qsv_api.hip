@@ -264,6 +264,8 @@ struct qsv_handle {
     uint32_t* h_stage = nullptr;  // pinned staging buffer for plan uploads
     size_t h_stage_words = 0;
     double* h_out = nullptr;  // pinned
+    bool repeat_device_descs = true;  // (QSV_REPEAT_DESCS=0: a repeated batch reads its descriptors from pinned memory again)
+    const double* dev_params_checked = nullptr;  // the last qsv_eval_push_device pointer found to be this device's memory
     double* out_target = nullptr;  // qsv_eval_set_output: device memory the open batch's results go to instead of h_out
     bool async_pending = false;    // a batch ended without waiting (qsv_eval_end with a device output): the staging buffers
                                    // may still be read by its kernels
@@ -303,6 +305,8 @@ struct qsv_handle {
         size_t aux_count = 0;   // ... how many of them have been pushed (their state slots cycle over the whole group)
 
         size_t n_pushes = 0;
+        const double* dev_params = nullptr;  // this push's parameter values live in device memory (qsv_eval_push_device):
+                                             // where evaluation 0's values would be -- descriptors index it like the staging buffer
     } batch;
     std::unique_lock<std::mutex> batch_lock;  // held from begin to end
 
@@ -738,6 +742,18 @@ int ensure_host_batch(qsv_t* h, size_t bytes) {
 
 // where the kernels read a batch's descriptors and parameters from
 const void* ship_base(const qsv_t* h) { return h->bar_ship ? h->d_ship : h->h_batch; }
+// where the kernels read the descriptors of the current batch from: a batch that repeats the one before it (same layout, kept:
+// qsv_eval_begin) finds them in the device copy that batch's kernels left -- one PCIe round trip less at the start of every
+// workgroup
+const EvalDesc* descs_base(const qsv_t* h) {
+    if (h->batch.repeat && !h->bar_ship && h->repeat_device_descs) return static_cast<const EvalDesc*>(h->d_batch.ptr);
+    return static_cast<const EvalDesc*>(ship_base(h));
+}
+// where the kernels of the current push read parameter values from: the pinned staging buffer, or the caller's device memory
+const double* params_base(const qsv_t* h) {
+    if (h->batch.dev_params) return h->batch.dev_params;
+    return reinterpret_cast<const double*>(static_cast<const char*>(h->h_batch) + h->batch.desc_bytes);
+}
 
 int ensure_host_out(qsv_t* h, size_t count) {
     if (h->h_out_count >= count) return QSV_OK;
@@ -891,7 +907,7 @@ int batch_ship(qsv_t* h, size_t first, size_t count, const double* values, size_
     const size_t p0 = b.param_base[first];
     const size_t p1 = size_t(b.param_base[first + count - 1]) + b.n_params[first + count - 1];
     double* hp = reinterpret_cast<double*>(static_cast<char*>(h->h_batch) + b.desc_bytes);
-    if (p1 > p0 && values != hp + p0) std::memcpy(hp + p0, values, (p1 - p0) * sizeof(double));  // (qsv_eval_staging: in place)
+    if (p1 > p0 && !b.dev_params && values != hp + p0) std::memcpy(hp + p0, values, (p1 - p0) * sizeof(double));  // (qsv_eval_staging: in place)
     if (h->bar_ship) {
         // the push's descriptors (both regions of a batch with split evaluations) into the device copy: plain stores through
         // the write-combining BAR mapping, fenced before any launch that reads them is queued -- and only what differs from
@@ -911,8 +927,8 @@ int batch_ship(qsv_t* h, size_t first, size_t count, const double* values, size_
         }
         if (wrote) _mm_sfence();
     }
-    const EvalDesc* host_evals = static_cast<const EvalDesc*>(ship_base(h));
-    const double* ship_params = hp;
+    const EvalDesc* host_evals = descs_base(h);
+    const double* ship_params = params_base(h);
     if (count > n_fused)
         QSV_HIP(h, launch_prepare(static_cast<const uint32_t*>(h->d_arena.ptr), host_evals + first + n_fused,
                                   static_cast<EvalDesc*>(h->d_batch.ptr) + first + n_fused, ship_params,
@@ -1017,7 +1033,7 @@ int run_group(qsv_t* h, const std::vector<Circuit*>& circs, size_t first, size_t
         a.n_full = uint32_t(h->n);
         a.result_out = h->out_target ? h->out_target : h->h_out;
         a.tiles_per_block = 1;
-        a.host_params = reinterpret_cast<const double*>(static_cast<const char*>(h->h_batch) + h->batch.desc_bytes);
+        a.host_params = params_base(h);
         a.mats_out = static_cast<double*>(h->d_mats.ptr);
         // threads and LDS of a launch over split evaluations [lo, hi) of the group: a side's tile may be larger than the
         // handle's (build_circuit)
@@ -1049,7 +1065,7 @@ int run_group(qsv_t* h, const std::vector<Circuit*>& circs, size_t first, size_t
             const unsigned grid_x = (extra_mode & kModeFusedFactor) ? 1u : tiles;
             // (pass 0 prepares the virtual circuits' matrices and tables itself: no prepare launch ran for them)
             a.evals = batch_evals(h) + first + lo;
-            a.host_evals = static_cast<const EvalDesc*>(ship_base(h)) + first + lo;
+            a.host_evals = descs_base(h) + first + lo;
             a.evals_out = static_cast<EvalDesc*>(h->d_batch.ptr) + first + lo;
             for (int p = 0; p < passes; ++p) {
                 a.pass_index = uint32_t(p);
@@ -1110,9 +1126,9 @@ int run_group(qsv_t* h, const std::vector<Circuit*>& circs, size_t first, size_t
     if (mode & kModeFinalProbs) a.partials = static_cast<double*>(h->d_scratch.ptr);  // [slot][2^n] probabilities
     if (fused) {
         a.mode |= kModeFusedPrepare;
-        a.host_evals = static_cast<const EvalDesc*>(ship_base(h)) + first + n_split;
+        a.host_evals = descs_base(h) + first + n_split;
         a.evals_out = static_cast<EvalDesc*>(h->d_batch.ptr) + first + n_split;
-        a.host_params = reinterpret_cast<const double*>(static_cast<const char*>(h->h_batch) + h->batch.desc_bytes);
+        a.host_params = params_base(h);
         a.mats_out = static_cast<double*>(h->d_mats.ptr);
         a.result_out = h->out_target ? h->out_target : h->h_out;
     }
@@ -1343,7 +1359,7 @@ size_t order_split_first(qsv_t* h, size_t first, size_t count) {
     return n_split;
 }
 
-int eval_push(qsv_t* h, size_t first, size_t count, const double* values) {
+int eval_push(qsv_t* h, size_t first, size_t count, const double* values, const double* device_values = nullptr) {
     qsv_handle::Batch& b = h->batch;
     if (first != b.pushed) return fail(h, QSV_E_STATE, "evaluations must be pushed in order");
     if (first + count > b.circs.size()) return fail(h, QSV_E_ARG, "push exceeds the batch");
@@ -1356,6 +1372,7 @@ int eval_push(qsv_t* h, size_t first, size_t count, const double* values) {
         ~WorkGuard() {
             h->work = nullptr;
             h->stamping = false;
+            h->batch.dev_params = nullptr;  // (a property of the push: other paths lay batches out and ship them too)
         }
     } guard{h};
     h->stamping = h->profiling;
@@ -1369,6 +1386,9 @@ int eval_push(qsv_t* h, size_t first, size_t count, const double* values) {
         if (h->out_target) b.ways = 1;  // (qsv_eval_set_output's choice, made before this push)
     }
     b.whole_push = first == 0 && count == b.circs.size();
+    // (values in device memory: the descriptors' offsets are those of the staging buffer, so the base is where evaluation 0's
+    // values would be)
+    b.dev_params = device_values && count > 0 ? device_values - b.param_base[first] : nullptr;
     const size_t ways = size_t(std::max(1, b.ways)), lane = ways > 1 ? size_t(b.n_pushes) % ways : 0;
     const size_t P = b.circs.size();
     const size_t n_split = b.repeat ? b.snap_n_split : order_split_first(h, first, count);
@@ -1737,6 +1757,7 @@ int qsv_create(int n_qubits, int dtype, int device, const qsv_plan_config* cfg, 
     if (const char* env = getenv("QSV_CHAIN_STREAM")) h->chain_enabled = atoi(env) != 0;
     if (const char* env = getenv("QSV_POLL")) h->poll_results = atoi(env) != 0;
     if (const char* env = getenv("QSV_REPEAT")) h->repeat_enabled = atoi(env) != 0;
+    if (const char* env = getenv("QSV_REPEAT_DESCS")) h->repeat_device_descs = atoi(env) != 0;
     if (const char* env = getenv("QSV_FUSED_LDS")) h->fused_lds_table = atoi(env) != 0;
     {
         int cus = 0;
@@ -2190,6 +2211,28 @@ int qsv_eval_push(qsv_t* h, int first, int count, const double* values) {
     if (first < 0 || count < 0) return fail(h, QSV_E_ARG, "bad arguments");
     static const double dummy = 0.0;
     return eval_push(h, size_t(first), size_t(count), values ? values : &dummy);
+}
+
+int qsv_eval_push_device(qsv_t* h, int first, int count, const double* device_values, void* ready_event) {
+    if (!h) return QSV_E_ARG;
+    if (!h->batch.open) return fail(h, QSV_E_STATE, "no open batch (call qsv_eval_begin first)");
+    if (first < 0 || count < 0) return fail(h, QSV_E_ARG, "bad arguments");
+    if (!device_values) return qsv_eval_push(h, first, count, nullptr);  // (only legal for evaluations without parameters)
+    if (device_values != h->dev_params_checked) {  // (an optimiser hands over the same buffer call after call: asked once)
+        hipPointerAttribute_t attr{};
+        if (hipPointerGetAttributes(&attr, device_values) != hipSuccess || attr.type != hipMemoryTypeDevice || attr.device != h->device) {
+            (void)hipGetLastError();
+            return fail(h, QSV_E_ARG, "device_values is not memory of this handle's device");
+        }
+        h->dev_params_checked = device_values;
+    }
+    if (ready_event) {
+        // whichever of the handle's streams runs a part of this push reads the values: all of them wait
+        QSV_HIP(h, hipStreamWaitEvent(h->stream, static_cast<hipEvent_t>(ready_event), 0));
+        for (hipStream_t st : h->side_streams) QSV_HIP(h, hipStreamWaitEvent(st, static_cast<hipEvent_t>(ready_event), 0));
+    }
+    static const double dummy = 0.0;
+    return eval_push(h, size_t(first), size_t(count), &dummy, device_values);
 }
 
 int qsv_eval_staging(qsv_t* h, int first, int count, double** values) {

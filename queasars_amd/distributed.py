@@ -26,11 +26,20 @@ def shard_bounds(n_items: int, world_size: int, rank: int) -> tuple[int, int]:
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def _rows(parameter_values, lo: int, hi: int):
+    """Rows [lo, hi) of the population's parameter values: a list of vectors, or -- for a matrix that lives in device memory
+    (a torch tensor; ``OperatorCircuitEvaluator.evaluate_circuits`` reads it where it is) -- a view of its rows."""
+    if getattr(parameter_values, "is_cuda", False):
+        return parameter_values[lo:hi]
+    return list(parameter_values[lo:hi])
+
+
 def evaluate_population_sharded(evaluator, circuits: Sequence, parameter_values: Sequence, group=None, device=None) -> list[float]:
     """Evaluate this rank's block of the population and all-gather the fitness values.
 
     ``evaluator`` is any object with ``evaluate_circuits(circuits, parameter_values)``; every rank must pass the
-    same full ``circuits`` / ``parameter_values`` lists.  Returns all values, ordered by population index, on
+    same full ``circuits`` / ``parameter_values`` lists (or, for evaluators that take it, the population's parameter matrix
+    in the rank's own device memory).  Returns all values, ordered by population index, on
     every rank.  Without an initialised process group (or with world size 1) it evaluates everything locally.
     """
     import torch
@@ -38,7 +47,7 @@ def evaluate_population_sharded(evaluator, circuits: Sequence, parameter_values:
 
     n = len(circuits)
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return list(evaluator.evaluate_circuits(list(circuits), list(parameter_values)))
+        return list(evaluator.evaluate_circuits(list(circuits), _rows(parameter_values, 0, n)))
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     lo, hi = shard_bounds(n, world, rank)
     if device is None and dist.get_backend(group) == "nccl" and os.environ.get("QSV_GATHER_CHAIN", "1") != "0":
@@ -47,7 +56,7 @@ def evaluate_population_sharded(evaluator, circuits: Sequence, parameter_values:
                                            torch.device("cuda", torch.cuda.current_device()))
         if chained is not None:
             return chained
-    local = evaluator.evaluate_circuits(list(circuits[lo:hi]), list(parameter_values[lo:hi])) if hi > lo else []
+    local = evaluator.evaluate_circuits(list(circuits[lo:hi]), _rows(parameter_values, lo, hi)) if hi > lo else []
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
     owner = id(getattr(evaluator, "statevector_device", None) or evaluator)
@@ -89,7 +98,7 @@ def evaluate_block_and_gather(evaluator, circuits: Sequence, parameter_values: S
     try:
         if hi - lo < width:
             send.fill_(float("nan"))
-        if hi > lo and not to_device(circuits[lo:hi], parameter_values[lo:hi], send.data_ptr()):
+        if hi > lo and not to_device(circuits[lo:hi], _rows(parameter_values, lo, hi), send.data_ptr()):
             return None
         dist.all_gather_into_tensor(recv, send, group=group)
         recv_host.copy_(recv, non_blocking=True)
@@ -100,7 +109,7 @@ def evaluate_block_and_gather(evaluator, circuits: Sequence, parameter_values: S
     values = _unpack(recv_host, n, world, width)
     verified = state["verified"]
     if id(group) not in verified:
-        local = evaluator.evaluate_circuits(list(circuits[lo:hi]), list(parameter_values[lo:hi])) if hi > lo else []
+        local = evaluator.evaluate_circuits(list(circuits[lo:hi]), _rows(parameter_values, lo, hi)) if hi > lo else []
         staged = _gather(local, n, world, rank, group, device, state["key"])
         same = len(staged) == len(values) and all(a == b for a, b in zip(staged, values))
         # every rank must take the same path from now on: agree on the verdict (a collective itself, staged way)

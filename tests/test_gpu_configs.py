@@ -1236,3 +1236,93 @@ def test_fp32_split_evaluations_with_four_and_five_keys():
     assert np.array_equal(np.asarray(ev32.evaluate_circuits(circuits, params)), got)
     for i in (0, 11, 23):
         assert ev32.evaluate_circuits([circuits[i]], [params[i]])[0] == got[i]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,layers,count", [(12, 3, 20), (16, 5, 24), (20, 4, 64), (20, 6, 24), (22, 4, 12)])
+def test_parameter_values_resident_in_device_memory(n, layers, count, c_oracle):
+    """qsv_eval_push_device: the kernels read the parameter values from a matrix in device memory (one row per circuit, rows
+    padded to the longest) instead of the pinned staging buffer.  Bitwise what the same values give as host lists, whatever
+    route an evaluation takes (one tile, split, one launch, multi-pass, mixed), also with the matrix produced on the torch
+    stream right before the call (the ready event), with rubbish in the padding, and again with other values in place."""
+    import torch
+
+    _, circuits, params = helpers.population_circuits(n, layers, count, seed=n + layers)
+    op = helpers.random_ising_operator(n, seed=2020)
+    ev = OperatorCircuitEvaluator(op)
+    width = max(len(p) for p in params) + 3
+    host = np.full((count, width), 1e300)  # (never read: a circuit takes the first num_parameters values of its row)
+    for i, p in enumerate(params):
+        host[i, : len(p)] = p
+    want = np.asarray(ev.evaluate_circuits(circuits, params))
+    matrix = torch.from_numpy(host).cuda()
+    torch.cuda.synchronize()
+    got = np.asarray(ev.evaluate_circuits(circuits, matrix))
+    assert np.array_equal(got, want)
+    assert np.array_equal(ev.evaluate_device_parameters(circuits, matrix, ready=True), want)  # (the kept layout, no event)
+    table = c_oracle.diagonal_table(op)
+    scratch = np.zeros(2 << n)
+    for i in (0, count - 1):
+        assert abs(got[i] - c_oracle.evaluate(circuits[i], params[i], op, table, scratch)) < EXP_TOL
+    # other values, written into the same matrix by a kernel queued right before the call
+    shifted = host.copy()
+    for i, p in enumerate(params):
+        shifted[i, : len(p)] += 0.25
+    want2 = np.asarray(ev.evaluate_circuits(circuits, [row[: len(p)].tolist() for row, p in zip(shifted, params)]))
+    staged = torch.from_numpy(shifted).pin_memory()
+    big = torch.empty(64 << 20, dtype=torch.float64, device="cuda")
+    big.fill_(1.0)                       # (something for the stream to be busy with)
+    matrix.copy_(staged, non_blocking=True)
+    got2 = np.asarray(ev.evaluate_circuits(circuits, matrix))
+    assert np.array_equal(got2, want2)
+    assert np.abs(got2 - got).max() > 1e-6
+    # a part of the population, as a view of rows (contiguous), and the host path right after on the same handle
+    assert np.array_equal(np.asarray(ev.evaluate_circuits(circuits[3:11], matrix[3:11])), want2[3:11])
+    assert np.array_equal(np.asarray(ev.evaluate_circuits(circuits, params)), want)
+
+
+@pytest.mark.gpu
+def test_device_resident_parameters_argument_checks_and_mixed_pushes():
+    import torch
+
+    n, count = 16, 12
+    _, circuits, params = helpers.population_circuits(n, 4, count, seed=9)
+    op = helpers.random_ising_operator(n, seed=2020)
+    ev = OperatorCircuitEvaluator(op)
+    dev = ev.statevector_device
+    want = np.asarray(ev.evaluate_circuits(circuits, params))
+    width = max(len(p) for p in params)
+    host = np.zeros((count, width))
+    for i, p in enumerate(params):
+        host[i, : len(p)] = p
+    matrix = torch.from_numpy(host).cuda()
+    with pytest.raises(ValueError):
+        ev.evaluate_circuits(circuits, matrix.float())
+    with pytest.raises(ValueError):
+        ev.evaluate_circuits(circuits[:-1], matrix)
+    with pytest.raises(ValueError):
+        ev.evaluate_circuits(circuits, matrix[:, : width - 1].contiguous())  # rows shorter than the longest circuit needs
+    with pytest.raises(ValueError):
+        ev.evaluate_circuits(circuits, matrix.t().contiguous().t())          # not row-major
+    assert np.array_equal(np.asarray(ev.evaluate_circuits(circuits, matrix)), want)  # the handle is fine after the errors
+    # raw C ABI: a host pointer is refused; host and device pushes in one batch
+    lib, handle = dev._lib, dev._handle
+    ids, _need, _ = dev._batch_metadata(circuits)
+    counts = np.full(count, width, dtype=np.int64)
+    out = np.zeros(count)
+    assert lib.qsv_eval_begin(handle, count, _lib.as_ptr(ids), _lib.as_ptr(counts)) == 0
+    assert lib.qsv_eval_push_device(handle, 0, 5, _lib.as_ptr(host), None) == _lib.QSV_E_ARG
+    assert lib.qsv_eval_end(handle, _lib.as_ptr(out)) != 0  # (not every evaluation was pushed)
+    torch.cuda.synchronize()
+    assert lib.qsv_eval_begin(handle, count, _lib.as_ptr(ids), _lib.as_ptr(counts)) == 0
+    first_rows = np.ascontiguousarray(host[:5])
+    assert lib.qsv_eval_push(handle, 0, 5, _lib.as_ptr(first_rows)) == 0
+    assert lib.qsv_eval_push_device(handle, 5, count - 5, C.c_void_p(matrix.data_ptr() + 5 * width * 8), None) == 0
+    assert lib.qsv_eval_end(handle, _lib.as_ptr(out)) == 0
+    assert np.array_equal(out, want)
+    # results left on the device as well: nothing of the step touches the host but the launch
+    result = torch.zeros(count, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    assert dev.expectation_values_of_device_parameters(circuits, matrix.data_ptr(), width, 0, result.data_ptr()) is None
+    torch.cuda.synchronize()
+    assert np.array_equal(result.cpu().numpy(), want)
