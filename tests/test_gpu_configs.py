@@ -1024,6 +1024,15 @@ def test_chained_all_gather_of_a_sharded_population():
             assert qd.evaluate_block_and_gather(ev, circuits, params, len(circuits), 1, 0, None, device) == want
         assert qd._gather(want, len(circuits), 1, 0, None, device) == want
         assert ev.evaluate_circuits(circuits, params) == want  # (the evaluator keeps working on the chain's stream)
+        # the population's parameters as a matrix in device memory: the chain then touches the host only for the launches
+        width = max(len(p) for p in params)
+        host = np.zeros((len(params), width))
+        for i, p in enumerate(params):
+            host[i, : len(p)] = p
+        matrix = torch.from_numpy(host).cuda()
+        for _ in range(2):
+            assert qd.evaluate_block_and_gather(ev, circuits, matrix, len(circuits), 1, 0, None, device) == want
+        assert qd.evaluate_population_sharded(ev, circuits, matrix) == want
     finally:
         dist.destroy_process_group()
 
