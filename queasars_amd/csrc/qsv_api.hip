@@ -680,6 +680,8 @@ int upload_plans(qsv_t* h, const std::vector<Circuit*>& circs) {
             }
         for (Circuit* c : fresh) c->staged = false;
         h->arena_used_words = 0;
+        if (getenv("QSV_ARENA_DEBUG"))
+            fprintf(stderr, "plan arena: rebuilt for a batch of %zu plans, %zu words of %zu%s\n", fresh.size(), need, cap, need > cap ? " (grows)" : "");
         if (need > cap) {
             const size_t new_cap = std::max(need * 2, size_t(1) << 20);
             if (h->d_arena.ptr) QSV_HIP(h, hipFree(h->d_arena.ptr));

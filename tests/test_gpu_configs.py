@@ -1335,3 +1335,52 @@ def test_device_resident_parameters_argument_checks_and_mixed_pushes():
     assert dev.expectation_values_of_device_parameters(circuits, matrix.data_ptr(), width, 0, result.data_ptr()) is None
     torch.cuda.synchronize()
     assert np.array_equal(result.cpu().numpy(), want)
+
+
+@pytest.mark.gpu
+def test_generations_of_fresh_structures_outgrow_the_plan_arena(c_oracle):
+    """An EVQE run registers new structures every generation and drops old ones.  The device-side plan arena (4 MB at first)
+    fills up, is rebuilt from the plans still in use and finally grows: survivors of early generations must keep evaluating
+    to the same bits through every rebuild, new structures must agree with the C oracle, and the ids of collected circuits
+    are destroyed on the way (the handle's circuit table does not grow without bound)."""
+    import gc
+
+    n = 16
+    op = helpers.random_ising_operator(n, seed=2020)
+    table = c_oracle.diagonal_table(op)
+    scratch = np.zeros(2 << n)
+    ev = OperatorCircuitEvaluator(op)
+    dev = ev.statevector_device
+    rng = np.random.default_rng(11)
+    survivors, survivor_params, survivor_values = [], [], []
+    registered_high_water = 0
+    for generation in range(24):
+        _, fresh, fresh_params = helpers.population_circuits(n, 3 + generation % 4, 72, seed=100 + generation)
+        circuits, params = survivors + fresh, survivor_params + fresh_params
+        feed = params if generation % 3 else [np.asarray(p, dtype=np.float64) for p in params]
+        got = np.asarray(ev.evaluate_circuits(circuits, feed))
+        assert np.array_equal(got[: len(survivors)], np.asarray(survivor_values)), f"generation {generation}: a survivor's value moved"
+        for i in rng.choice(len(fresh), size=2, replace=False):
+            j = len(survivors) + int(i)
+            assert abs(got[j] - c_oracle.evaluate(circuits[j], params[j], op, table, scratch)) < EXP_TOL
+        assert np.array_equal(np.asarray(ev.evaluate_circuits(circuits, feed)), got)  # (the kept layout, right after a rebuild too)
+        # three of this generation live on, the rest is dropped (their plans stay in the arena until it is rebuilt)
+        base = len(circuits) - len(fresh)
+        for i in rng.choice(len(fresh), size=3, replace=False):
+            survivors.append(fresh[int(i)])
+            survivor_params.append(fresh_params[int(i)])
+            survivor_values.append(got[base + int(i)])
+        del fresh, circuits, feed
+        gc.collect()
+        registered_high_water = max(registered_high_water, len(dev._watched))
+    # 24 generations of 72 structures were registered, at most a generation and the survivors are alive at any time
+    assert registered_high_water <= 72 + 3 * 24 + 72
+    final = np.asarray(ev.evaluate_circuits(survivors, survivor_params))
+    assert np.array_equal(final, np.asarray(survivor_values))
+    # one batch whose plans alone exceed the arena: it grows
+    _, many, many_params = helpers.population_circuits(n, 5, 520, seed=999)
+    got = np.asarray(ev.evaluate_circuits(survivors + many, survivor_params + many_params))
+    assert np.array_equal(got[: len(survivors)], np.asarray(survivor_values))
+    for j in (0, 519):
+        assert abs(got[len(survivors) + j] - c_oracle.evaluate(many[j], many_params[j], op, table, scratch)) < EXP_TOL
+    assert np.array_equal(np.asarray(ev.evaluate_circuits(survivors, survivor_params)), np.asarray(survivor_values))
