@@ -1,0 +1,41 @@
+"""Soak: (a) 150,000 evaluations of the same batch, (b) 300 generations of fresh structures with the old ones collected;
+resident set size of the process and free device memory before and after each.  python scripts/soak.py"""
+import gc, os, sys, time
+from pathlib import Path
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+import numpy as np
+import psutil
+import torch
+from queasars_amd import workloads
+from queasars_amd.circuit_evaluation import OperatorCircuitEvaluator
+
+proc = psutil.Process(os.getpid())
+
+
+def state(tag):
+    free, total = torch.cuda.mem_get_info()
+    print(f"{tag:46s} RSS {proc.memory_info().rss / 2**20:8.1f} MiB   device memory in use {(total - free) / 2**20:8.1f} MiB", flush=True)
+
+
+n = 20
+ev = OperatorCircuitEvaluator(workloads.random_ising_operator(n, seed=2020))
+_, circuits, params = workloads.population_circuits(n, 4, 64, seed=0)
+first = ev.evaluate_circuits(circuits, params)
+state("start")
+t0 = time.perf_counter()
+for _ in range(150000):
+    ev.evaluate_circuits(circuits, params)
+state(f"after 150,000 steps of one batch ({time.perf_counter() - t0:.1f} s)")
+assert ev.evaluate_circuits(circuits, params) == first
+t0 = time.perf_counter()
+for g in range(300):
+    _, fresh, fresh_params = workloads.population_circuits(n, 3 + g % 4, 64, seed=5000 + g)
+    ev.evaluate_circuits(fresh, fresh_params)
+    if g % 100 == 99:
+        gc.collect()
+        state(f"after {g + 1} generations of 64 fresh structures")
+del fresh
+gc.collect()
+assert ev.evaluate_circuits(circuits, params) == first
+state(f"end ({time.perf_counter() - t0:.1f} s of generations), registered now: {len(ev.statevector_device._watched)}")
