@@ -217,3 +217,101 @@ def test_vectorised_spsa_driver_gives_every_run_its_own_iterates():
                 assert run.done and np.array_equal(run.x, ref.x) and run.nfev == ref.nfev and run.iteration == ref.iteration
             if checker is not None:
                 assert len({run.nfev for _, run in jobs}) > 1  # (the checker stopped runs at different iterations)
+
+
+# ---- the reference's operator tests (test/minimum_eigensolvers/evqe/test_evqe_operators.py), against the solver's own operators ----
+# Same model (min x^2 - y^2 on four qubits), same initial population (ten individuals of two layers, seed 0), the evaluator
+# backed by the oracle instead of Aer.  One deviation: the reference starts from zero angles and relies on its estimator's
+# noise to leave that point (with exact values f(+eps) = f(-eps) there, SPSA's update is exactly zero); where an optimiser
+# has to move, the population here starts from random angles.
+
+
+def _reference_population(randomize: bool = True):
+    return EVQEPopulation.random_population(4, 2, 10, randomize, 0)
+
+
+def _population_values(evaluator, population):
+    return evaluator.evaluate_circuits([ind.get_parameterized_quantum_circuit() for ind in population.individuals],
+                                       [list(ind.parameter_values) for ind in population.individuals])
+
+
+def test_reference_last_layer_search_lowers_the_expectation_values():
+    """test_evqe_operators.py:64-93: the sum over the population after the mutation is below the sum before."""
+    ev = OracleEvaluator(xy_hamiltonian())
+    solver = EVQEMinimumEigensolver(make_config(population_size=10, optimizer=SPSA(maxiter=20, learning_rate=0.4, perturbation=0.3)))
+    population = _reference_population()
+    before = sum(_population_values(ev, population))
+    searched, nfev = solver._last_layer_search(ev, population)
+    assert nfev == 10 * 20 * 2  # (every individual, two evaluations per SPSA iteration)
+    assert sum(_population_values(ev, searched)) < before
+    for old, new in zip(population.individuals, searched.individuals):
+        assert new.layers == old.layers  # (only parameter values move, and only the last layer's)
+        keep = sum(layer.n_parameters for layer in old.layers[:-1])
+        assert new.parameter_values[:keep] == old.parameter_values[:keep]
+
+
+def test_reference_parameter_search_lowers_the_expectation_values():
+    """test_evqe_operators.py:95-124."""
+    ev = OracleEvaluator(xy_hamiltonian())
+    solver = EVQEMinimumEigensolver(make_config(population_size=10, parameter_search_probability=0.3,
+                                                optimizer=SPSA(maxiter=20, learning_rate=0.4, perturbation=0.3)))
+    population = _reference_population()
+    before = _population_values(ev, population)
+    searched, nfev = solver._parameter_search(ev, population)
+    after = _population_values(ev, searched)
+    changed = [i for i, (a, b) in enumerate(zip(population.individuals, searched.individuals)) if a != b]
+    assert changed and nfev == len(changed) * 2 * 20 * 2  # (both layers of every chosen individual)
+    assert sum(after) < sum(before)
+    assert all(after[i] == before[i] for i in range(10) if i not in changed)
+
+
+def test_reference_topological_search_and_layer_removal_change_the_layer_count():
+    """test_evqe_operators.py:126-147: with probability 0.5 topological search adds layers, layer removal takes some away."""
+    population = _reference_population(randomize=False)
+    layers = sum(len(ind.layers) for ind in population.individuals)
+    grown = EVQEMinimumEigensolver(make_config(population_size=10, topological_search_probability=0.5))._topological_search(population)
+    assert sum(len(ind.layers) for ind in grown.individuals) > layers
+    shrunk = EVQEMinimumEigensolver(make_config(population_size=10, layer_removal_probability=0.5))._layer_removal(population)
+    assert sum(len(ind.layers) for ind in shrunk.individuals) < layers
+    assert all(len(ind.layers) >= 1 for ind in shrunk.individuals)
+
+
+def test_reference_speciation_keeps_members_within_the_genetic_distance():
+    """test_evqe_operators.py:149-182: after search, selection, growth and search again every member of a species is closer
+    to its representative than the threshold, and the three species tables describe the whole population."""
+    from queasars_amd.evqe.genome import EVQEIndividual
+
+    distance = 2
+    ev = OracleEvaluator(xy_hamiltonian())
+    solver = EVQEMinimumEigensolver(make_config(population_size=10, speciation_genetic_distance_threshold=distance,
+                                                topological_search_probability=1.0,
+                                                optimizer=SPSA(maxiter=10, learning_rate=0.4, perturbation=0.3)))
+    population, _ = solver._last_layer_search(ev, _reference_population())
+    population = solver._speciation(population)
+    population = solver._selection(population, _population_values(ev, population))
+    population = solver._topological_search(population)
+    population, _ = solver._last_layer_search(ev, population)
+    population = solver._speciation(population)
+    assert population.species_representatives and population.species_members and population.species_membership
+    seen = set()
+    for representative in population.species_representatives:
+        for member in population.species_members[representative]:
+            seen.add(member)
+            if representative != population.individuals[member]:
+                assert EVQEIndividual.get_genetic_distance(representative, population.individuals[member]) < distance
+            assert population.species_membership[member] == representative
+    assert seen == set(range(10))
+
+
+def test_reference_selection_lowers_the_expectation_values():
+    """test_evqe_operators.py:184-209: three rounds of speciation and selection, the population's sum falls every round."""
+    ev = OracleEvaluator(xy_hamiltonian())
+    solver = EVQEMinimumEigensolver(make_config(population_size=10, optimizer=SPSA(maxiter=20, learning_rate=0.4, perturbation=0.3)))
+    population, _ = solver._last_layer_search(ev, _reference_population())
+    sums = [sum(_population_values(ev, population))]
+    for _ in range(3):
+        population = solver._speciation(population)
+        population = solver._selection(population, _population_values(ev, population))
+        assert len(population.individuals) == 10
+        sums.append(sum(_population_values(ev, population)))
+    assert all(later < earlier for earlier, later in zip(sums, sums[1:])), sums
