@@ -382,6 +382,11 @@ class EVQEIndividual:
     def get_n_controlled_gates(self) -> int:
         return sum(layer.n_controlled_gates for layer in self.layers)
 
+    def get_quantum_circuit(self) -> CircuitIR:
+        """The circuit with every angle bound to this individual's values: no free parameters (reference:
+        base/evolutionary_algorithm.py:20-27, ``get_parameterized_quantum_circuit().assign_parameters(values)``)."""
+        return self.get_partially_parameterized_quantum_circuit(set())
+
     def get_parameterized_quantum_circuit(self) -> CircuitIR:
         return self.get_partially_parameterized_quantum_circuit(set(range(len(self.layers))))
 

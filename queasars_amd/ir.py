@@ -209,6 +209,19 @@ class CircuitIR:
             out.append((kind, target, -1 if control == NO_CONTROL else control, theta, phi, lam))
         return out
 
+    def depth(self) -> int:
+        """Length of the longest chain of ops that follow each other on some qubit, every op (``id`` included) counting one --
+        what ``QuantumCircuit.depth()`` returns for the same op list (the reference's tests hold an individual's circuit to
+        one level per layer, test_evqe_individual.py:325-343)."""
+        level = [0] * self._n_qubits
+        for row in self._rows:
+            target, control = row[1], row[2]
+            if control == NO_CONTROL:
+                level[target] += 1
+            else:
+                level[target] = level[control] = max(level[target], level[control]) + 1
+        return max(level, default=0)
+
     def count_ops(self) -> dict[str, int]:
         names = {OP_ID: "id", OP_U: "u", OP_CU3: "cu3"}
         out: dict[str, int] = {}

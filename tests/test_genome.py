@@ -255,3 +255,68 @@ def test_fast_lowering_is_the_lowering_by_names():
             assert bytes(fast.packed().tobytes()) == bytes(slow.packed().tobytes()), (n_qubits, n_layers, chosen)
             assert fast.num_parameters == slow.num_parameters and len(fast) == len(slow)
             assert fast.bound_ops([0.1] * fast.num_parameters) == slow.bound_ops([0.1] * slow.num_parameters)
+
+
+class TestReferenceIndividualTests:
+    """The reference's individual tests that had no literal counterpart here (test_evqe_individual.py:263-369), on the same
+    fixture: a random individual of eight qubits and ten layers."""
+
+    @pytest.fixture
+    def individual(self):
+        return EVQEIndividual.random_individual(8, 10, True, random_seed=0)
+
+    def test_add_0_random_layers(self, individual):
+        with pytest.raises(EVQEIndividualException):
+            EVQEIndividual.add_random_layers(individual, 0, False, random_seed=0)
+
+    def test_add_random_layers(self, individual):
+        grown = EVQEIndividual.add_random_layers(individual, 3, False, random_seed=0)
+        assert grown.is_valid() and grown.n_qubits == individual.n_qubits
+        assert len(grown.layers) == len(individual.layers) + 3 and grown.layers[: len(individual.layers)] == individual.layers
+        assert grown.get_parameter_values()[: len(individual.get_parameter_values())] == individual.get_parameter_values()
+
+    def test_remove_0_and_all_layers(self, individual):
+        with pytest.raises(EVQEIndividualException):
+            EVQEIndividual.remove_layers(individual, 0)
+        with pytest.raises(EVQEIndividualException):
+            EVQEIndividual.remove_layers(individual, len(individual.layers))
+
+    def test_remove_layers(self, individual):
+        kept = sum(layer.n_parameters for layer in individual.layers[:-4])
+        shorter = EVQEIndividual.remove_layers(individual, 4)
+        assert shorter.n_qubits == individual.n_qubits and shorter.layers == individual.layers[:-4]
+        assert shorter.get_parameter_values() == individual.get_parameter_values()[:kept]
+
+    def test_change_parameter_values(self, individual):
+        zeros = (0,) * len(individual.get_parameter_values())
+        changed = EVQEIndividual.change_parameter_values(individual, zeros)
+        assert changed.n_qubits == individual.n_qubits and changed.layers == individual.layers and changed.parameter_values == zeros
+
+    def test_change_layer_parameter_values(self, individual):
+        before = sum(layer.n_parameters for layer in individual.layers[:4])
+        count = individual.layers[4].n_parameters
+        changed = EVQEIndividual.change_layer_parameter_values(individual, 4, (0,) * count)
+        old, new = individual.get_parameter_values(), changed.get_parameter_values()
+        assert changed.layers == individual.layers
+        assert new[:before] == old[:before] and new[before : before + count] == (0,) * count and new[before + count :] == old[before + count :]
+
+    def test_get_genetic_distance(self, individual):
+        assert EVQEIndividual.get_genetic_distance(individual, EVQEIndividual.add_random_layers(individual, 1, False, random_seed=0)) == 1
+        assert EVQEIndividual.get_genetic_distance(individual, EVQEIndividual.remove_layers(individual, 2)) == 1
+
+    def test_circuits_have_one_level_per_layer(self, individual):
+        bound = individual.get_quantum_circuit()
+        assert bound.depth() == len(individual.layers) and bound.num_parameters == 0
+        free = individual.get_parameterized_quantum_circuit()
+        assert free.depth() == len(individual.layers) and free.num_parameters == len(individual.get_parameter_values())
+        partly = individual.get_partially_parameterized_quantum_circuit({2, 5})
+        assert partly.depth() == len(individual.layers)
+        assert partly.num_parameters == individual.layers[2].n_parameters + individual.layers[5].n_parameters
+        # the bound circuit is the free one with the individual's values put in
+        values = list(individual.get_parameter_values())
+        assert bound.bound_ops([]) == free.bound_ops(values)
+
+    def test_parameter_counts_and_controlled_gates(self, individual):
+        assert len(individual.get_parameter_values()) == sum(layer.n_parameters for layer in individual.layers)
+        assert len(individual.get_layer_parameter_values(7)) == individual.layers[7].n_parameters
+        assert individual.get_n_controlled_gates() == individual.get_quantum_circuit().count_ops().get("cu3", 0)
