@@ -41,24 +41,48 @@ from queasars_amd.evqe.genome import EVQEIndividual, EVQEPopulation, new_random_
 
 class SPSATerminationChecker:
     """Stop when |f_k - f_{k-1}| / f_{k-1} stayed below ``minimum_relative_change`` for
-    ``allowed_consecutive_violations + 1`` consecutive iterations (or ``maxfev`` is reached)."""
+    ``allowed_consecutive_violations + 1`` consecutive accepted iterations, or when ``maxfev`` evaluations are reached
+    (reference: queasars/utility/spsa_termination.py:9-134; held to sequences the reference's class itself answered,
+    tests/golden/spsa_termination_reference.json).  One object may serve one optimisation after another: a call after it has
+    said "stop", or with fewer evaluations than the call before, starts a new history."""
 
     def __init__(self, minimum_relative_change: float, allowed_consecutive_violations: int, maxfev: Optional[int] = None):
         self.minimum_relative_change = minimum_relative_change
         self.allowed_consecutive_violations = allowed_consecutive_violations
         self.maxfev = maxfev
+        self._start_over()
+
+    def _start_over(self) -> None:
         self.function_value_history: list[float] = []
+        self.n_function_evaluation_history: list[int] = []
         self._changes: list[float] = []
+        self.n_function_evaluations = 0
+        self.best_function_value = float("inf")
+        self._best_parameter_values = None
+        self._done = False
+
+    @property
+    def best_parameter_values(self):
+        if self._best_parameter_values is None:
+            raise ValueError("The termination checker has stored no parameter values (no accepted step since its history began)!")
+        return self._best_parameter_values
 
     def fresh(self) -> "SPSATerminationChecker":
         return SPSATerminationChecker(self.minimum_relative_change, self.allowed_consecutive_violations, self.maxfev)
 
     def termination_check(self, n_function_evaluations: int, parameter_values, function_value: float, step_size: float, accepted: bool) -> bool:
+        if self._done or n_function_evaluations < self.n_function_evaluations:
+            self._start_over()
+        self.n_function_evaluations = n_function_evaluations
         if self.maxfev is not None and n_function_evaluations >= self.maxfev:
             return True
         if not accepted:
             return False
         self.function_value_history.append(function_value)
+        self.n_function_evaluation_history.append(n_function_evaluations)
+        if function_value < self.best_function_value:
+            self.best_function_value = function_value
+            self._best_parameter_values = parameter_values
         if len(self.function_value_history) < 2:
             return False
         previous = self.function_value_history[-2]
@@ -66,7 +90,10 @@ class SPSATerminationChecker:
         window = self.allowed_consecutive_violations + 1
         if len(self._changes) < window:
             return False
-        return max(self._changes[-window:]) < self.minimum_relative_change
+        if max(self._changes[-window:]) < self.minimum_relative_change:
+            self._done = True
+            return True
+        return False
 
 
 @dataclass

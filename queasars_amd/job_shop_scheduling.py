@@ -76,6 +76,10 @@ class Job:
         if any(op.job_name != self.name for op in self.operations):
             raise JobShopSchedulingProblemException("Every operation must carry the name of its job!")
 
+    def is_consistent_with_machines(self, machines: tuple[Machine, ...]) -> bool:
+        """Does every operation of the job run on one of ``machines``?  (reference: problem_instances.py:91-103)"""
+        return all(op.machine in machines for op in self.operations)
+
 
 @dataclass(frozen=True)
 class JobShopSchedulingProblemInstance:
@@ -84,35 +88,106 @@ class JobShopSchedulingProblemInstance:
     jobs: tuple[Job, ...]
 
     def __post_init__(self):
+        if self.name == "":
+            raise JobShopSchedulingProblemException("The name of a problem instance cannot be an empty string!")
         if len({m.name for m in self.machines}) != len(self.machines):
             raise JobShopSchedulingProblemException("Machine names must be unique!")
         if len({j.name for j in self.jobs}) != len(self.jobs):
             raise JobShopSchedulingProblemException("Job names must be unique!")
         for job in self.jobs:
-            if any(op.machine not in self.machines for op in job.operations):
+            if not job.is_consistent_with_machines(self.machines):
                 raise JobShopSchedulingProblemException("A job uses a machine the instance does not have!")
 
 
 @dataclass(frozen=True)
-class JobShopSchedulingResult:
-    """Start time per operation (``None`` = the variable's qubits do not hold a valid domain-wall state)."""
+class PotentiallyScheduledOperation:
+    """An operation of a result's schedule: with a start time (:class:`ScheduledOperation`) or without one
+    (:class:`UnscheduledOperation`: the qubits of its variable hold no valid domain-wall state).  Reference:
+    problem_instances.py:204-266."""
 
-    problem_instance: JobShopSchedulingProblemInstance
-    start_times: dict[Operation, Optional[int]]
+    operation: Operation
 
     @property
-    def is_valid(self) -> bool:
-        if any(t is None for t in self.start_times.values()):
-            return False
-        per_machine: dict[Machine, list[tuple[int, int]]] = {m: [] for m in self.problem_instance.machines}
-        for job in self.problem_instance.jobs:
+    def is_scheduled(self) -> bool:
+        raise NotImplementedError
+
+
+@dataclass(frozen=True)
+class UnscheduledOperation(PotentiallyScheduledOperation):
+    @property
+    def is_scheduled(self) -> bool:
+        return False
+
+
+@dataclass(frozen=True)
+class ScheduledOperation(PotentiallyScheduledOperation):
+    start_time: int
+
+    @property
+    def is_scheduled(self) -> bool:
+        return True
+
+    @property
+    def end_time(self) -> int:
+        return self.start_time + self.operation.processing_duration
+
+
+class JobShopSchedulingResult:
+    """A (possibly incomplete, possibly infeasible) schedule of a problem instance: per job one entry per operation, in the
+    job's order (reference: problem_instances.py:289-427).  Valid = every operation scheduled, the operations of a job one
+    after the other, no two operations on a machine at the same time; the makespan of a valid schedule is its latest end."""
+
+    def __init__(self, problem_instance: JobShopSchedulingProblemInstance,
+                 schedule: dict[Job, tuple[PotentiallyScheduledOperation, ...]]):
+        if set(schedule) != set(problem_instance.jobs):
+            raise JobShopSchedulingProblemException("The schedule must hold exactly the jobs of the problem instance!")
+        for job, entries in schedule.items():
+            if tuple(entry.operation for entry in entries) != job.operations:
+                raise JobShopSchedulingProblemException("A job's schedule must hold the job's operations, in their order!")
+        self._problem_instance = problem_instance
+        self._schedule = {job: tuple(entries) for job, entries in schedule.items()}
+        self._is_valid = self._check()
+
+    @classmethod
+    def from_start_times(cls, problem_instance: JobShopSchedulingProblemInstance,
+                         start_times: dict[Operation, Optional[int]]) -> "JobShopSchedulingResult":
+        """From a start time per operation (``None`` = not scheduled)."""
+        return cls(problem_instance, {
+            job: tuple(UnscheduledOperation(op) if start_times[op] is None else ScheduledOperation(op, start_times[op])
+                       for op in job.operations)
+            for job in problem_instance.jobs})
+
+    @property
+    def problem_instance(self) -> JobShopSchedulingProblemInstance:
+        return self._problem_instance
+
+    @property
+    def schedule(self) -> dict[Job, tuple[PotentiallyScheduledOperation, ...]]:
+        return self._schedule
+
+    @property
+    def valid_schedule(self) -> dict[Job, tuple[ScheduledOperation, ...]]:
+        if not self._is_valid:
+            raise JobShopSchedulingProblemException("The schedule is not valid!")
+        return self._schedule  # (every entry of a valid schedule is a ScheduledOperation)
+
+    @property
+    def start_times(self) -> dict[Operation, Optional[int]]:
+        """Start time per operation, ``None`` where it has none."""
+        return {entry.operation: (entry.start_time if entry.is_scheduled else None)
+                for entries in self._schedule.values() for entry in entries}
+
+    def _check(self) -> bool:
+        per_machine: dict[Machine, list[tuple[int, int]]] = {m: [] for m in self._problem_instance.machines}
+        for job in self._problem_instance.jobs:
             previous_end = None
-            for op in job.operations:
-                start = self.start_times[op]
-                if previous_end is not None and start < previous_end:
+            for entry in self._schedule[job]:
+                if not entry.is_scheduled:
                     return False
-                previous_end = start + op.processing_duration
-                per_machine[op.machine].append((start, previous_end))
+                if previous_end is not None and entry.start_time < previous_end:
+                    return False
+                previous_end = entry.end_time
+                per_machine[entry.operation.machine].append((entry.start_time, entry.end_time))
         for spans in per_machine.values():
             spans.sort()
             if any(b[0] < a[1] for a, b in zip(spans, spans[1:])):
@@ -120,10 +195,24 @@ class JobShopSchedulingResult:
         return True
 
     @property
+    def is_valid(self) -> bool:
+        return self._is_valid
+
+    @property
     def makespan(self) -> Optional[int]:
-        if not self.is_valid:
+        if not self._is_valid:
             return None
-        return max(self.start_times[job.operations[-1]] + job.operations[-1].processing_duration for job in self.problem_instance.jobs)
+        return max(entries[-1].end_time for entries in self._schedule.values())
+
+    def __eq__(self, other) -> bool:
+        return (isinstance(other, JobShopSchedulingResult) and self._problem_instance == other._problem_instance
+                and self._schedule == other._schedule)
+
+    def __hash__(self) -> int:
+        return hash((self._problem_instance, tuple(sorted((job.name, entries) for job, entries in self._schedule.items()))))
+
+    def __repr__(self) -> str:
+        return f"JobShopSchedulingResult(valid={self._is_valid}, makespan={self.makespan}, start_times={self.start_times})"
 
 
 class _Poly(dict):
@@ -333,7 +422,7 @@ class JSSPDomainWallHamiltonianEncoder:
         if set(bitstring) - {"0", "1"}:
             raise ValueError("The bitstring may not contain any value apart from 1 or 0!")
         bits = [int(ch) for ch in bitstring[::-1]]
-        return JobShopSchedulingResult(
+        return JobShopSchedulingResult.from_start_times(
             self.jssp_instance, {op: var.value_from_bits(bits) for op, var in self._variables.items()}
         )
 
@@ -345,3 +434,117 @@ class JSSPDomainWallHamiltonianEncoder:
             for i in range(wall):
                 bits[var._start + i] = 1
         return "".join(str(b) for b in bits[::-1])
+
+
+# ---- random instances (reference: queasars/job_shop_scheduling/random_problem_instances.py:50-101) ------------------------
+
+
+def random_job_shop_scheduling_instance(instance_name: str, n_jobs: int, n_machines: int, relative_op_amount, op_duration,
+                                        random_seed: Optional[int] = None) -> JobShopSchedulingProblemInstance:
+    """A random instance with machines ``m0 ..`` and jobs ``job0 ..`` whose operations ``op0 ..`` visit a random selection of
+    the machines in random order.  ``relative_op_amount`` (operations per job as a share of the machines) and ``op_duration``
+    are either plain values or distributions ``{value: probability}``.  The generator is consumed exactly as the reference
+    consumes it -- per job: the share (if it is a distribution), a sample of the machines, a shuffle, then one duration per
+    operation (if durations are a distribution) -- so a seed names the same instance on both sides (held to vectors the
+    reference produced: tests/golden/jssp_reference.json)."""
+    from math import isclose
+    from random import Random
+
+    rng = Random(random_seed)
+
+    def draw(value_or_distribution):
+        if not isinstance(value_or_distribution, dict):
+            return value_or_distribution
+        if not isclose(sum(value_or_distribution.values()), 1, abs_tol=0.001):
+            raise ValueError("The probabilities in the distribution should add up to 1!")
+        return rng.choices(list(value_or_distribution), weights=list(value_or_distribution.values()), k=1)[0]
+
+    machines = tuple(Machine(f"m{i}") for i in range(n_machines))
+    jobs = []
+    for i in range(n_jobs):
+        visited = rng.sample(machines, k=round(draw(relative_op_amount) * n_machines))
+        rng.shuffle(visited)
+        jobs.append(Job(f"job{i}", tuple(Operation(f"op{j}", f"job{i}", machine, draw(op_duration)) for j, machine in enumerate(visited))))
+    return JobShopSchedulingProblemInstance(instance_name, machines, tuple(jobs))
+
+
+# ---- JSON wire format of the datatypes above (reference: queasars/job_shop_scheduling/serialization.py:18-196) ------------
+# Key names and nesting are the reference's, so files written by either side load in the other: a tuple is {"tuple": [...]},
+# a dictionary {"dict": [item, ...]} with every item a two-element tuple, and each dataclass a dictionary of prefixed keys.
+
+import json as _json
+
+_WIRE_KEYS = {
+    "machine": ("machine_name",),
+    "operation": ("operation_name", "operation_job_name", "operation_machine", "operation_processing_duration"),
+    "job": ("job_name", "job_operations"),
+    "instance": ("jssp_instance_name", "jssp_instance_machines", "jssp_instance_jobs"),
+    "unscheduled": ("unscheduled_operation",),
+    "scheduled": ("scheduled_operation", "scheduled_start_time"),
+    "result": ("jssp_result_problem_instance", "jssp_result_schedule"),
+}
+
+
+def jssp_to_wire(obj):
+    """The JSON-ready form of a JSSP object (or of tuples / lists / dictionaries of them)."""
+    if isinstance(obj, tuple):
+        return {"tuple": [jssp_to_wire(x) for x in obj]}
+    if isinstance(obj, list):
+        return [jssp_to_wire(x) for x in obj]
+    if isinstance(obj, dict):
+        return {"dict": [jssp_to_wire(item) for item in obj.items()]}
+    fields = None
+    if isinstance(obj, Machine):
+        kind, fields = "machine", (obj.name,)
+    elif isinstance(obj, Operation):
+        kind, fields = "operation", (obj.name, obj.job_name, obj.machine, obj.processing_duration)
+    elif isinstance(obj, Job):
+        kind, fields = "job", (obj.name, obj.operations)
+    elif isinstance(obj, JobShopSchedulingProblemInstance):
+        kind, fields = "instance", (obj.name, obj.machines, obj.jobs)
+    elif isinstance(obj, UnscheduledOperation):
+        kind, fields = "unscheduled", (obj.operation,)
+    elif isinstance(obj, ScheduledOperation):
+        kind, fields = "scheduled", (obj.operation, obj.start_time)
+    elif isinstance(obj, JobShopSchedulingResult):
+        kind, fields = "result", (obj.problem_instance, obj.schedule)
+    if fields is None:
+        return obj
+    return {key: jssp_to_wire(value) for key, value in zip(_WIRE_KEYS[kind], fields)}
+
+
+def _jssp_from_wire_dict(d: dict):
+    """``object_hook`` of the decoder: called innermost first, so the values of ``d`` are decoded already."""
+    if len(d) == 1 and "tuple" in d:
+        return tuple(d["tuple"])
+    if len(d) == 1 and "dict" in d:
+        return {key: value for key, value in d["dict"]}
+    makers = {
+        "machine": Machine, "operation": Operation, "job": Job, "instance": JobShopSchedulingProblemInstance,
+        "unscheduled": UnscheduledOperation, "scheduled": ScheduledOperation, "result": JobShopSchedulingResult,
+    }
+    for kind, keys in _WIRE_KEYS.items():
+        if any(key in d for key in keys):
+            missing = [key for key in keys if key not in d]
+            if missing:
+                raise ValueError(f"JSSP JSON: {kind} without {missing}")
+            return makers[kind](*(d[key] for key in keys))
+    return d
+
+
+class JSSPJSONEncoder(_json.JSONEncoder):
+    """``json.dumps(obj, cls=JSSPJSONEncoder)`` for Machine, Operation, Job, JobShopSchedulingProblemInstance,
+    (Un)ScheduledOperation and JobShopSchedulingResult."""
+
+    def iterencode(self, o, _one_shot=False):
+        # (tuples and dictionaries keyed by objects never reach default(): the whole object is translated first;
+        # json.dumps and json.dump both come through here, once)
+        return super().iterencode(jssp_to_wire(o), _one_shot)
+
+
+class JSSPJSONDecoder(_json.JSONDecoder):
+    """``json.loads(text, cls=JSSPJSONDecoder)``."""
+
+    def __init__(self, *args, **kwargs):
+        kwargs.pop("object_hook", None)
+        super().__init__(*args, object_hook=_jssp_from_wire_dict, **kwargs)

@@ -315,3 +315,38 @@ def test_reference_selection_lowers_the_expectation_values():
         assert len(population.individuals) == 10
         sums.append(sum(_population_values(ev, population)))
     assert all(later < earlier for earlier, later in zip(sums, sums[1:])), sums
+
+
+def test_spsa_termination_checker_answers_as_the_references_does():
+    """242 calls along 18 optimisations (six configurations, one checker object serving three optimisations in a row each):
+    every answer, and the bookkeeping after the last call, as the reference's own class gave them
+    (tests/golden/make_host_golden.py ran queasars/utility/spsa_termination.py)."""
+    import json
+    from pathlib import Path
+
+    from queasars_amd.evqe.genome import new_random_seed
+
+    data = json.loads((Path(__file__).parent / "golden" / "spsa_termination_reference.json").read_text())
+    n_stop = 0
+    for case in data["termination"]:
+        checker = SPSATerminationChecker(case["minimum_relative_change"], case["allowed_consecutive_violations"], case["maxfev"])
+        for call in case["calls"]:
+            answer = checker.termination_check(call["nfev"], np.asarray(call["x"]), call["value"], call["step_size"], call["accepted"])
+            assert bool(answer) == call["answer"]
+            n_stop += call["answer"]
+        after = case["after"]
+        assert checker.n_function_evaluations == after["n_function_evaluations"]
+        assert checker.function_value_history == after["function_value_history"]
+        assert checker.n_function_evaluation_history == after["n_function_evaluation_history"]
+        assert checker.best_function_value == after["best_function_value"]
+        if after["best_parameter_values"] is None:
+            with pytest.raises(ValueError):
+                checker.best_parameter_values
+        else:
+            assert list(checker.best_parameter_values) == after["best_parameter_values"]
+    assert n_stop >= 20
+    from random import Random
+
+    for seed, chain in data["seed_chains"].items():
+        rng = Random(int(seed))
+        assert [new_random_seed(rng) for _ in chain] == chain
