@@ -4,7 +4,6 @@ import gc, os, sys, time
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
-import numpy as np
 import psutil
 import torch
 from queasars_amd import workloads

@@ -8,7 +8,7 @@ sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
 import numpy as np
 import jssp_instances as inst
 from queasars_amd.circuit_evaluation.circuit_evaluation import BaseCircuitEvaluator
-from queasars_amd.evqe.solver import (SPSA, BestIndividualRelativeChangeTolerance, EVQEMinimumEigensolver,
+from queasars_amd.evqe.solver import (SPSA, EVQEMinimumEigensolver,
                                       EVQEMinimumEigensolverConfiguration, SPSATerminationChecker)
 from queasars_amd.job_shop_scheduling import JSSPDomainWallHamiltonianEncoder
 
