@@ -764,12 +764,6 @@ class OperatorCircuitEvaluator(BaseCircuitEvaluator):
         with self._device.operator_lock:
             self._device.set_operator(operator)
         self._composed = _ComposedCircuits(initial_state_circuit)
-        self._ready_marker = None
-
-    def __getstate__(self):
-        state = dict(self.__dict__)
-        state["_ready_marker"] = None  # (a HIP event: made again where it is needed)
-        return state
 
     def _with_initial_state(self, circuit: CircuitIR) -> CircuitIR:
         return self._composed.get(circuit)
@@ -813,9 +807,8 @@ class OperatorCircuitEvaluator(BaseCircuitEvaluator):
         if stream is not None and not stream.query():
             # (whatever produces the matrix was queued on the tensor's current stream and has not finished: the handle's
             # streams wait for it.  An idle stream -- the usual case -- costs one query instead of an event and four waits.)
-            marker = self._ready_marker
-            if marker is None:
-                marker = self._ready_marker = torch.cuda.Event()
+            # (an event of this call's own: evaluators are shared by threads, whose tensors may come from different streams)
+            marker = torch.cuda.Event()
             marker.record(stream)
             event = marker.cuda_event
         return self._device.expectation_values_of_device_parameters(circuits, matrix.data_ptr(), int(matrix.shape[1]), event,
