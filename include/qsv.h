@@ -184,6 +184,41 @@ int qsv_eval_end(qsv_t* h, double* out_expectations);
  * waits and also copies the results to the host.  The next call on the handle waits for an unfinished batch first.
  */
 int qsv_eval_set_output(qsv_t* h, double* device_out);
+/*
+ * The optimiser's share of one iteration of R lock-step SPSA runs as ONE launch on the handle's stream, for a parameter search
+ * whose state lives in device memory (evqe/device_search.py; the reference runs one qiskit_algorithms SPSA per individual on a
+ * worker thread, mutation.py:28-89): with qsv_eval_push_device and qsv_eval_set_output an iteration is this launch plus the
+ * evaluation's, and the host waits for neither.  All pointers are device memory of the handle's GPU, row-major, rows of
+ * `width` doubles (a run shorter than the widest is padded with zero signs).
+ *   accept  (values != NULL): values[2r], values[2r + 1] = f(x_r + eps delta_r), f(x_r - eps delta_r) measured with
+ *           delta_accept; update = (f+ - f-) / (2 eps) * delta, divided by its norm if trust_region and the norm exceeds 1, times
+ *           lr; x_r -= update for runs with active[r] != 0; iterations[r] counts them; a run stops (active[r] = 0) at maxiter,
+ *           at 2 * iterations >= maxfev (maxfev >= 0), or by the reference's SPSATerminationChecker rule over `window` =
+ *           allowed_consecutive_violations + 1 relative changes of 0.5 (f+ + f-) below min_rel (window = 0: no rule;
+ *           previous / n_values / changes are its state: zeros, zeros, +inf before the first call).
+ *   propose (delta_propose != NULL): points[2r] = x_r + eps delta, points[2r + 1] = x_r - eps delta.
+ * Products and sums are rounded one by one as the host's NumPy expressions are; the norm is a fixed-order sum of its own.
+ */
+typedef struct qsv_spsa_step_args {
+    int32_t n_runs, width;
+    double* x;
+    uint8_t* active;
+    int64_t* iterations;
+    const double* delta_accept;
+    const double* values;
+    const double* delta_propose;
+    double* points;
+    double eps, lr;
+    int32_t trust_region, maxiter;
+    int32_t window;
+    int32_t reserved;
+    double min_rel;
+    int64_t maxfev;
+    double* previous;
+    int64_t* n_values;
+    double* changes;
+} qsv_spsa_step_args;
+int qsv_spsa_step(qsv_t* h, const qsv_spsa_step_args* args);
 /* How many pushes the open batch is best delivered in (1 or 2): measurement-backed advice, any number works. */
 int qsv_eval_suggested_pushes(const qsv_t* h);
 /* Launch-group size of the handle (evaluations whose states are resident at the same time). */

@@ -40,6 +40,33 @@ class QsvPlanConfig(C.Structure):
     ]
 
 
+class QsvSpsaStepArgs(C.Structure):
+    """``qsv_spsa_step_args`` of include/qsv.h (device pointers as integers)."""
+
+    _fields_ = [
+        ("n_runs", C.c_int32),
+        ("width", C.c_int32),
+        ("x", C.c_void_p),
+        ("active", C.c_void_p),
+        ("iterations", C.c_void_p),
+        ("delta_accept", C.c_void_p),
+        ("values", C.c_void_p),
+        ("delta_propose", C.c_void_p),
+        ("points", C.c_void_p),
+        ("eps", C.c_double),
+        ("lr", C.c_double),
+        ("trust_region", C.c_int32),
+        ("maxiter", C.c_int32),
+        ("window", C.c_int32),
+        ("reserved", C.c_int32),
+        ("min_rel", C.c_double),
+        ("maxfev", C.c_int64),
+        ("previous", C.c_void_p),
+        ("n_values", C.c_void_p),
+        ("changes", C.c_void_p),
+    ]
+
+
 class QsvProfile(C.Structure):
     _fields_ = [
         ("n_evals", C.c_uint64),
@@ -82,6 +109,7 @@ SIGNATURES = {
     "qsv_eval_push": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "qsv_eval_staging": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(_P)]),
     "qsv_eval_push_device": (C.c_int, [_P, C.c_int, C.c_int, _P, _P]),
+    "qsv_spsa_step": (C.c_int, [_P, _P]),
     "qsv_eval_end": (C.c_int, [_P, _P]),
     "qsv_eval_set_output": (C.c_int, [_P, _P]),
     "qsv_eval_suggested_pushes": (C.c_int, [_P]),

@@ -764,6 +764,7 @@ class OperatorCircuitEvaluator(BaseCircuitEvaluator):
         with self._device.operator_lock:
             self._device.set_operator(operator)
         self._composed = _ComposedCircuits(initial_state_circuit)
+        self._composed_lists = None
 
     def _with_initial_state(self, circuit: CircuitIR) -> CircuitIR:
         return self._composed.get(circuit)
@@ -825,6 +826,35 @@ class OperatorCircuitEvaluator(BaseCircuitEvaluator):
             if self._device._operator is not self._operator:
                 self._device.set_operator(self._operator)
             return self._evaluate_device_matrix(circuits, matrix, ready)
+
+    def device_resident_search_possible(self) -> bool:
+        """Can an optimiser keep its points and values in this evaluator's device memory (:meth:`evaluate_device_to_device`)?
+        Only the exact estimator: noise is emulated on the host."""
+        if self._precision > 0:
+            return False
+        try:
+            import torch
+        except ImportError:
+            return False
+        return torch.cuda.is_available()
+
+    def evaluate_device_to_device(self, circuits: list[CircuitIR], matrix, out) -> None:
+        """Parameter values from a device matrix (one row per circuit), expectation values into the device tensor ``out``
+        (``len(circuits)`` doubles), nothing waited for and nothing copied: both tensors belong to the stream the evaluator's
+        handle launches on (``StatevectorDevice.set_stream``) -- work queued there before the call is seen, work queued after
+        it sees the values.  ``circuits`` should be the same list object call after call (its composition with an initial
+        state and its device-side ids are kept by identity)."""
+        if self._precision > 0:
+            raise ValueError("estimator_precision > 0 is emulated on the host")
+        if self._initial_state_circuit is not None:
+            kept = self._composed_lists
+            if kept is None or kept[0] is not circuits:
+                kept = self._composed_lists = (circuits, [self._with_initial_state(c) for c in circuits])
+            circuits = kept[1]
+        with self._device.operator_lock:
+            if self._device._operator is not self._operator:
+                self._device.set_operator(self._operator)
+            self._evaluate_device_matrix(circuits, matrix, ready=True, out_device_pointer=out.data_ptr())
 
     def evaluate_circuits_to_device(self, circuits: list[CircuitIR], parameter_values: list[list[float]], device_pointer: int) -> bool:
         """:meth:`evaluate_circuits` with the values left in device memory and without waiting for them

@@ -1617,6 +1617,97 @@ __global__ void __launch_bounds__(256) reduce_partials_kernel(const double* __re
     if (threadIdx.x == 0) out[e] = total;
 }
 
+// ---- qsv_spsa_step ----------------------------------------------------------------------------------------------------------
+// The arithmetic of _SPSARun.accept / propose (queasars_amd/evqe/solver.py; constant-gain SPSA as the reference's notebook
+// configures qiskit_algorithms' optimiser) for one run per workgroup, every product and sum rounded on its own (no contraction:
+// the host computes x + eps * delta in two roundings), and the reference's termination rule (queasars/utility/
+// spsa_termination.py:46-94 with accepted = True) in thread 0.  The norm of an update is a fixed-order sum over the run's row
+// (strided partial sums, then a tree): deterministic, not the host's order.
+__global__ void __launch_bounds__(256) spsa_step_kernel(const SpsaStepArgs a) {
+    __shared__ double red[256];
+    __shared__ double s_scale;
+    const int r = blockIdx.x, tid = threadIdx.x;
+    double* x = a.x + size_t(r) * size_t(a.width);
+    if (a.values) {
+        const double* delta = a.delta_accept + size_t(r) * size_t(a.width);
+        const double f_plus = a.values[2 * r], f_minus = a.values[2 * r + 1];
+        const double g = __ddiv_rn(__dsub_rn(f_plus, f_minus), __dmul_rn(2.0, a.eps));
+        const bool was_active = a.active[r] != 0;
+        double scale = 1.0;
+        if (a.trust_region) {
+            double acc = 0.0;
+            for (int j = tid; j < a.width; j += 256) {
+                const double u = __dmul_rn(g, delta[j]);
+                acc = __fma_rn(u, u, acc);
+            }
+            red[tid] = acc;
+            __syncthreads();
+            for (int half = 128; half > 0; half >>= 1) {
+                if (tid < half) red[tid] = __dadd_rn(red[tid], red[tid + half]);
+                __syncthreads();
+            }
+            if (tid == 0) {
+                const double norm = sqrt(red[0]);
+                s_scale = norm > 1.0 ? norm : 1.0;
+            }
+            __syncthreads();
+            scale = s_scale;
+        }
+        if (was_active)
+            for (int j = tid; j < a.width; j += 256) {
+                double u = __dmul_rn(g, delta[j]);
+                if (a.trust_region) u = __ddiv_rn(u, scale);
+                u = __dmul_rn(u, a.lr);
+                x[j] = __dsub_rn(x[j], u);
+            }
+        if (tid == 0) {
+            const long long it = a.iterations[r] + (was_active ? 1 : 0);
+            bool stop = it >= a.maxiter;
+            if (a.window > 0) {
+                const bool over = a.maxfev >= 0 && 2 * it >= a.maxfev;
+                stop = stop || over;
+                const bool fed = was_active && !over;  // (the reference returns before it stores anything)
+                if (fed) {
+                    const double value = __dmul_rn(0.5, __dadd_rn(f_plus, f_minus));
+                    double* ch = a.changes + size_t(r) * size_t(a.window);
+                    if (a.n_values[r] >= 1) {
+                        const double prev = a.previous[r];
+                        const double change = __ddiv_rn(fabs(__dsub_rn(value, prev)), prev);
+                        double most = change;
+                        for (int w = 0; w + 1 < a.window; ++w) {
+                            ch[w] = ch[w + 1];
+                            most = ch[w] > most ? ch[w] : most;  // (+inf where the window is not full yet)
+                        }
+                        ch[a.window - 1] = change;
+                        if (most < a.min_rel) stop = true;
+                    }
+                    a.previous[r] = value;
+                    a.n_values[r] += 1;
+                }
+            }
+            a.iterations[r] = it;
+            a.active[r] = was_active && !stop;
+        }
+        __syncthreads();  // (x is complete before the proposal below reads it)
+    }
+    if (a.delta_propose) {
+        const double* delta = a.delta_propose + size_t(r) * size_t(a.width);
+        double* p_plus = a.points + size_t(2 * r) * size_t(a.width);
+        double* p_minus = p_plus + a.width;
+        for (int j = tid; j < a.width; j += 256) {
+            const double shift = __dmul_rn(delta[j], a.eps);
+            p_plus[j] = __dadd_rn(x[j], shift);
+            p_minus[j] = __dsub_rn(x[j], shift);
+        }
+    }
+}
+
+hipError_t launch_spsa_step(const SpsaStepArgs& args, hipStream_t stream) {
+    if (args.n_runs <= 0 || args.width <= 0) return hipSuccess;
+    hipLaunchKernelGGL(spsa_step_kernel, dim3(unsigned(args.n_runs)), dim3(256), 0, stream, args);
+    return hipGetLastError();
+}
+
 hipError_t launch_reduce_partials(const double* partials, uint32_t blocks, int n_evals, double* out,
                                   hipStream_t stream, const EvalDesc* evals) {
     if (n_evals <= 0) return hipSuccess;

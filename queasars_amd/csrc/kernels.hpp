@@ -269,6 +269,29 @@ hipError_t launch_cvar_exact(int dtype, const double* probs, uint64_t dim, unsig
                              const double* sorted_values, double alpha, double* chunk_scratch, double* out, hipStream_t stream,
                              const PassArgs& args);
 
+// ---- the optimiser's share of a lock-step SPSA iteration (qsv.h: qsv_spsa_step) -----------------------------------------------
+// One workgroup per run: accept the iteration whose two values are in `values` (update x, count, stopping rules), then write
+// the two points of the next iteration.  Either half may be left out (values / delta_propose null).
+struct SpsaStepArgs {
+    int n_runs, width;
+    double* x;                    // [n_runs][width]
+    unsigned char* active;        // [n_runs]
+    long long* iterations;        // [n_runs]
+    const double* delta_accept;   // [n_runs][width], the signs the values were measured with
+    const double* values;         // [2 n_runs]: f(x + eps delta), f(x - eps delta) per run
+    const double* delta_propose;  // [n_runs][width]
+    double* points;               // [2 n_runs][width]
+    double eps, lr;
+    int trust_region, maxiter;
+    int window;                   // termination rule: allowed_consecutive_violations + 1, 0 = no rule
+    double min_rel;
+    long long maxfev;             // < 0: none
+    double* previous;             // [n_runs]
+    long long* n_values;          // [n_runs]
+    double* changes;              // [n_runs][window]
+};
+hipError_t launch_spsa_step(const SpsaStepArgs& args, hipStream_t stream);
+
 hipError_t launch_probabilities(int dtype, const void* state, uint64_t dim, int n_slots, double* probs,
                                 hipStream_t stream);
 hipError_t launch_state_to_f64(int dtype, const void* state, uint64_t dim, double* out_re_im, hipStream_t stream);

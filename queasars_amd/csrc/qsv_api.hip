@@ -1387,6 +1387,10 @@ int eval_push(qsv_t* h, size_t first, size_t count, const double* values, const 
         if (rc0) return rc0;
         if (h->out_target) b.ways = 1;  // (qsv_eval_set_output's choice, made before this push)
     }
+    if (!device_values && h->async_pending) {  // (the staging buffer is about to be written: see qsv_eval_begin)
+        QSV_HIP(h, sync_streams(h));
+        h->async_pending = false;
+    }
     b.whole_push = first == 0 && count == b.circs.size();
     // (values in device memory: the descriptors' offsets are those of the staging buffer, so the base is where evaluation 0's
     // values would be)
@@ -2161,10 +2165,10 @@ int qsv_eval_begin(qsv_t* h, int n_evals, const int* circuit_ids, const int64_t*
         b.have_ids = true;
         if (h->repeat_enabled && n_evals > 0 && b.snap_epoch == h->epoch && !h->profiling &&
             b.snap_ids == b.cur_ids && b.snap_counts == b.cur_counts && b.circs.size() == size_t(n_evals)) {
-            if (h->async_pending) {  // (the kernels of a batch that ended without waiting read the staging buffers)
-                QSV_HIP(h, sync_streams(h));
-                h->async_pending = false;
-            }
+            // (A batch that ended without waiting may still be running.  Its kernels read the staging buffers: whoever WRITES
+            // them waits for it first -- qsv_eval_push with host values, qsv_eval_staging --, and a batch whose values come from
+            // device memory, qsv_eval_push_device, writes nothing: such batches follow each other on the stream without the
+            // host ever waiting, which is what an optimiser that lives on the device needs.)
             h->prof = qsv_profile{};
             h->prof.n_evals = uint64_t(n_evals);
             b.repeat = true;
@@ -2242,8 +2246,46 @@ int qsv_eval_staging(qsv_t* h, int first, int count, double** values) {
     if (!h->batch.open) return fail(h, QSV_E_STATE, "no open batch (call qsv_eval_begin first)");
     const qsv_handle::Batch& b = h->batch;
     if (first < 0 || count < 0 || size_t(first) + size_t(count) > b.circs.size()) return fail(h, QSV_E_ARG, "range exceeds the batch");
+    if (h->async_pending) {  // (the caller is about to write where an unfinished batch's kernels may still read)
+        QSV_HIP(h, sync_streams(h));
+        h->async_pending = false;
+    }
     double* hp = reinterpret_cast<double*>(static_cast<char*>(h->h_batch) + b.desc_bytes);
     *values = hp + (count > 0 ? size_t(b.param_base[size_t(first)]) : 0);
+    return QSV_OK;
+}
+
+int qsv_spsa_step(qsv_t* h, const qsv_spsa_step_args* in) {
+    if (!h || !in) return QSV_E_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    if (in->n_runs < 0 || in->width < 0 || !in->x || !in->active || !in->iterations) return fail(h, QSV_E_ARG, "bad arguments");
+    if (in->values && !in->delta_accept) return fail(h, QSV_E_ARG, "values without the signs they were measured with");
+    if (in->delta_propose && !in->points) return fail(h, QSV_E_ARG, "a proposal needs somewhere to go");
+    if (in->window < 0 || (in->window > 0 && (!in->previous || !in->n_values || !in->changes)))
+        return fail(h, QSV_E_ARG, "the termination rule needs its state");
+    if (!(in->eps > 0)) return fail(h, QSV_E_ARG, "eps must be positive");
+    QSV_HIP(h, hipSetDevice(h->device));
+    SpsaStepArgs a{};
+    a.n_runs = in->n_runs;
+    a.width = in->width;
+    a.x = in->x;
+    a.active = in->active;
+    a.iterations = reinterpret_cast<long long*>(in->iterations);
+    a.delta_accept = in->delta_accept;
+    a.values = in->values;
+    a.delta_propose = in->delta_propose;
+    a.points = in->points;
+    a.eps = in->eps;
+    a.lr = in->lr;
+    a.trust_region = in->trust_region;
+    a.maxiter = in->maxiter;
+    a.window = in->window;
+    a.min_rel = in->min_rel;
+    a.maxfev = in->maxfev;
+    a.previous = in->previous;
+    a.n_values = reinterpret_cast<long long*>(in->n_values);
+    a.changes = in->changes;
+    QSV_HIP(h, launch_spsa_step(a, h->stream));
     return QSV_OK;
 }
 

@@ -25,17 +25,27 @@ def jobs():
     return out
 
 
-for mode in ("vectorised", "run by run"):
+if len(sys.argv) > 4 and sys.argv[4] == "checker":
+    cfg = S.SPSA(termination_checker=S.SPSATerminationChecker(0.01, 2))
+reference_x = None
+for mode in ("on device", "vectorised", "run by run"):
     if mode == "run by run":
         os.environ["QSV_SCALAR_SPSA"] = "1"
-    S._minimize_batched(ev, jobs())  # (registers the circuits, warms everything)
+    S._minimize_batched(ev, jobs(), on_device=mode == "on device")  # (registers the circuits, warms everything)
     t = []
     for _ in range(5):
         j = jobs()
         t0 = time.perf_counter()
-        S._minimize_batched(ev, j)
+        S._minimize_batched(ev, j, on_device=mode == "on device")
         t.append(time.perf_counter() - t0)
     evals = sum(run.nfev for _, run in j)
     best = min(t)
+    xs = np.concatenate([run.x for _, run in j])
+    if mode == "vectorised":
+        reference_x = xs
+    note = "" if mode != "run by run" else f"; max |x - vectorised x| = {np.abs(xs - reference_x).max():.1e}"
+    if mode == "on device":
+        device_x = xs
     print(f"{mode:11s}: {best * 1e3:7.2f} ms per search of {P} individuals ({evals} evaluations, {best / cfg.maxiter * 1e6:6.1f} us per "
-          f"iteration, {evals / best:9.0f} evaluations per second); x[0][:3] = {j[0][1].x[:3]}")
+          f"iteration, {evals / best:9.0f} evaluations per second); x[0][:3] = {j[0][1].x[:3]}{note}")
+print(f"max |x on device - x vectorised| = {np.abs(device_x - reference_x).max():.2e}")

@@ -1384,3 +1384,59 @@ def test_generations_of_fresh_structures_outgrow_the_plan_arena(c_oracle):
     for j in (0, 519):
         assert abs(got[len(survivors) + j] - c_oracle.evaluate(many[j], many_params[j], op, table, scratch)) < EXP_TOL
     assert np.array_equal(np.asarray(ev.evaluate_circuits(survivors, survivor_params)), np.asarray(survivor_values))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("with_checker,with_initial_state", [(False, False), (True, False), (True, True)])
+def test_spsa_search_with_its_state_on_the_device(with_checker, with_initial_state):
+    """evqe/device_search.py: iterates, sign vectors, points and values in device memory, every iteration queued on one stream
+    without the host waiting.  Against the host driver (which gives every run bit for bit its own SPSA's iterates): the same
+    stopping iteration for every run, iterates to 1e-9 (the trust region's norm is summed in another order), with the
+    reference's termination rule as array operations, and with an initial-state circuit in front of every circuit."""
+    from queasars_amd.evqe import EVQEPopulation
+    from queasars_amd.evqe import solver as S
+
+    n = 14
+    pop = EVQEPopulation.random_population(n, 3, 24, True, 5)
+    initial = None
+    if with_initial_state:
+        initial = CircuitIR(n)
+        for q in range(n):
+            initial.u(q, 0.3 + 0.1 * q, 0.2, -0.4)
+    ev = OperatorCircuitEvaluator(helpers.random_ising_operator(n, seed=2020), initial_state_circuit=initial)
+    checker = S.SPSATerminationChecker(0.02, 1) if with_checker else None
+    cfg = S.SPSA(maxiter=20, termination_checker=checker)
+
+    def jobs():
+        return [(ind.get_partially_parameterized_quantum_circuit({-1}), cfg.new_run(ind.get_layer_parameter_values(-1), seed=k))
+                for k, ind in enumerate(pop.individuals)]
+
+    host = jobs()
+    S._minimize_batched(ev, host)
+    for _ in range(2):  # (twice: the second search finds the stream, the buffers and the layouts of the first)
+        device = jobs()
+        S._minimize_batched(ev, device, on_device=True)
+        assert [run.iteration for _, run in device] == [run.iteration for _, run in host]
+        assert [run.nfev for _, run in device] == [run.nfev for _, run in host]
+        assert all(run.done for _, run in device)
+        for (_, a), (_, b) in zip(device, host):
+            assert np.abs(a.x - b.x).max() < 1e-9
+    if with_checker:
+        assert len({run.iteration for _, run in host}) > 1  # (the runs did stop at different iterations)
+    # the same arithmetic as torch operations instead of the library's one launch per iteration
+    import os
+
+    os.environ["QSV_DEVICE_SEARCH_TORCH"] = "1"
+    try:
+        by_torch = jobs()
+        S._minimize_batched(ev, by_torch, on_device=True)
+    finally:
+        del os.environ["QSV_DEVICE_SEARCH_TORCH"]
+    assert [run.iteration for _, run in by_torch] == [run.iteration for _, run in host]
+    for (_, a), (_, b) in zip(by_torch, device):
+        assert np.abs(a.x - b.x).max() < 1e-12
+    # the evaluator serves ordinary calls right after
+    circuits = [ind.get_parameterized_quantum_circuit() for ind in pop.individuals[:4]]
+    params = [list(ind.parameter_values) for ind in pop.individuals[:4]]
+    again = OperatorCircuitEvaluator(helpers.random_ising_operator(n, seed=2020), initial_state_circuit=initial)
+    assert ev.evaluate_circuits(circuits, params) == again.evaluate_circuits(circuits, params)
