@@ -296,6 +296,41 @@ def sampler_block(operator, circuits, params, shots: int = 1024, alpha: float = 
                     "operator values and CVaR); wall clock of whole calls"}
 
 
+def search_block(operator, population, reps: int = 5):
+    """What the evaluations are made FOR: one EVQE last-layer parameter search of the benchmark population (one SPSA run per
+    individual, the notebooks' 33 iterations of two evaluations, all runs in lock-step; reference: mutation.py:28-89, one
+    optimiser per individual on a worker thread) -- with the optimiser's state on the device (evqe/device_search.py,
+    qsv_spsa_step) and with the whole-array driver on the host."""
+    from queasars_amd.circuit_evaluation import OperatorCircuitEvaluator
+    from queasars_amd.evqe import solver as S
+
+    evaluator = OperatorCircuitEvaluator(operator)
+    cfg = S.SPSA()
+
+    def jobs():
+        return [(ind.get_partially_parameterized_quantum_circuit({-1}), cfg.new_run(ind.get_layer_parameter_values(-1), seed=k))
+                for k, ind in enumerate(population.individuals)]
+
+    out = {"individuals": len(population.individuals), "iterations": cfg.maxiter, "unit": "circuit-evals/s",
+           "note": "wall clock of whole searches, registration of the 64 partially parameterised circuits included; best of five"}
+    final = {}
+    for name, on_device in (("state_on_device", True), ("whole_array_on_host", False)):
+        S._minimize_batched(evaluator, jobs(), on_device=on_device)
+        best, evals = None, 0
+        for _ in range(reps):
+            j = jobs()
+            t0 = time.perf_counter()
+            S._minimize_batched(evaluator, j, on_device=on_device)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+            evals = sum(run.nfev for _, run in j)
+        final[name] = np.concatenate([run.x for _, run in j])
+        out[name] = {"ms_per_search": best * 1e3, "value": evals / best, "evaluations": evals}
+    out["max_abs_diff_of_final_iterates"] = float(np.abs(final["state_on_device"] - final["whole_array_on_host"]).max())
+    evaluator.statevector_device.close()
+    return out
+
+
 # ---- the deep (unsplit) multi-pass path: the statevector sweep north_star names ----------------------------------------
 
 DEEP_ROWS = {
@@ -739,6 +774,7 @@ def main() -> None:
             result["threaded_b1_noop_tasks_per_s"] = noop
             result["threaded_b1_blocking_tasks_per_s"] = blocking
             result["sampler_branch"] = sampler_block(operator, circuits, params)
+            result["parameter_search"] = search_block(operator, population)
             result["calling_pattern_note"] = (
                 "cold: every step evaluates 64 circuit structures the device has never seen (plan building + upload "
                 "inside the timed region); threaded: 64 host threads, one circuit per call (the reference's selection "
