@@ -1619,11 +1619,12 @@ __global__ void __launch_bounds__(256) reduce_partials_kernel(const double* __re
 
 // ---- qsv_spsa_step ----------------------------------------------------------------------------------------------------------
 // The arithmetic of _SPSARun.accept / propose (queasars_amd/evqe/solver.py; constant-gain SPSA as the reference's notebook
-// configures qiskit_algorithms' optimiser) for one run per workgroup, every product and sum rounded on its own (no contraction:
+// configures qiskit_algorithms' optimiser) for one run per workgroup, every product and sum rounded on its own (contraction off:
 // the host computes x + eps * delta in two roundings), and the reference's termination rule (queasars/utility/
 // spsa_termination.py:46-94 with accepted = True) in thread 0.  The norm of an update is a fixed-order sum over the run's row
 // (strided partial sums, then a tree): deterministic, not the host's order.
 __global__ void __launch_bounds__(256) spsa_step_kernel(const SpsaStepArgs a) {
+#pragma clang fp contract(off)  // (every product and sum below is rounded on its own, as NumPy's are: x - u * lr must not become one fma)
     __shared__ double red[256];
     __shared__ double s_scale;
     const int r = blockIdx.x, tid = threadIdx.x;
@@ -1631,19 +1632,19 @@ __global__ void __launch_bounds__(256) spsa_step_kernel(const SpsaStepArgs a) {
     if (a.values) {
         const double* delta = a.delta_accept + size_t(r) * size_t(a.width);
         const double f_plus = a.values[2 * r], f_minus = a.values[2 * r + 1];
-        const double g = __ddiv_rn(__dsub_rn(f_plus, f_minus), __dmul_rn(2.0, a.eps));
+        const double g = (f_plus - f_minus) / (2.0 * a.eps);
         const bool was_active = a.active[r] != 0;
         double scale = 1.0;
         if (a.trust_region) {
             double acc = 0.0;
             for (int j = tid; j < a.width; j += 256) {
-                const double u = __dmul_rn(g, delta[j]);
-                acc = __fma_rn(u, u, acc);
+                const double u = g * delta[j];
+                acc = acc + u * u;
             }
             red[tid] = acc;
             __syncthreads();
             for (int half = 128; half > 0; half >>= 1) {
-                if (tid < half) red[tid] = __dadd_rn(red[tid], red[tid + half]);
+                if (tid < half) red[tid] = red[tid] + red[tid + half];
                 __syncthreads();
             }
             if (tid == 0) {
@@ -1655,10 +1656,10 @@ __global__ void __launch_bounds__(256) spsa_step_kernel(const SpsaStepArgs a) {
         }
         if (was_active)
             for (int j = tid; j < a.width; j += 256) {
-                double u = __dmul_rn(g, delta[j]);
-                if (a.trust_region) u = __ddiv_rn(u, scale);
-                u = __dmul_rn(u, a.lr);
-                x[j] = __dsub_rn(x[j], u);
+                double u = g * delta[j];
+                if (a.trust_region) u = u / scale;
+                u = u * a.lr;
+                x[j] = x[j] - u;
             }
         if (tid == 0) {
             const long long it = a.iterations[r] + (was_active ? 1 : 0);
@@ -1668,11 +1669,11 @@ __global__ void __launch_bounds__(256) spsa_step_kernel(const SpsaStepArgs a) {
                 stop = stop || over;
                 const bool fed = was_active && !over;  // (the reference returns before it stores anything)
                 if (fed) {
-                    const double value = __dmul_rn(0.5, __dadd_rn(f_plus, f_minus));
+                    const double value = 0.5 * (f_plus + f_minus);
                     double* ch = a.changes + size_t(r) * size_t(a.window);
                     if (a.n_values[r] >= 1) {
                         const double prev = a.previous[r];
-                        const double change = __ddiv_rn(fabs(__dsub_rn(value, prev)), prev);
+                        const double change = fabs(value - prev) / prev;
                         double most = change;
                         for (int w = 0; w + 1 < a.window; ++w) {
                             ch[w] = ch[w + 1];
@@ -1695,9 +1696,9 @@ __global__ void __launch_bounds__(256) spsa_step_kernel(const SpsaStepArgs a) {
         double* p_plus = a.points + size_t(2 * r) * size_t(a.width);
         double* p_minus = p_plus + a.width;
         for (int j = tid; j < a.width; j += 256) {
-            const double shift = __dmul_rn(delta[j], a.eps);
-            p_plus[j] = __dadd_rn(x[j], shift);
-            p_minus[j] = __dsub_rn(x[j], shift);
+            const double shift = delta[j] * a.eps;
+            p_plus[j] = x[j] + shift;
+            p_minus[j] = x[j] - shift;
         }
     }
 }

@@ -1440,3 +1440,68 @@ def test_spsa_search_with_its_state_on_the_device(with_checker, with_initial_sta
     params = [list(ind.parameter_values) for ind in pop.individuals[:4]]
     again = OperatorCircuitEvaluator(helpers.random_ising_operator(n, seed=2020), initial_state_circuit=initial)
     assert ev.evaluate_circuits(circuits, params) == again.evaluate_circuits(circuits, params)
+
+
+@pytest.mark.gpu
+def test_spsa_step_entry_point_by_hand():
+    """qsv_spsa_step through raw ctypes: argument checks; a proposal is x +- eps * delta rounded as NumPy rounds it; an accepted
+    step is NumPy's expression for runs that are active, nothing for those that are not; maxiter stops a run."""
+    import torch
+
+    dev = StatevectorDevice(8)
+    lib, handle = dev._lib, dev._handle
+    rng = np.random.default_rng(3)
+    n_runs, width, eps, lr = 5, 37, 0.35, 0.43
+    x0 = rng.normal(size=(n_runs, width))
+    delta = 1.0 - 2.0 * rng.integers(0, 2, size=(2, n_runs, width))
+    f = rng.normal(size=2 * n_runs)
+    x = torch.from_numpy(x0.copy()).cuda()
+    signs = torch.from_numpy(delta.copy()).cuda()
+    values = torch.from_numpy(f.copy()).cuda()
+    points = torch.zeros((2 * n_runs, width), dtype=torch.float64, device="cuda")
+    active = torch.tensor([1, 1, 0, 1, 1], dtype=torch.uint8, device="cuda")
+    iterations = torch.tensor([0, 0, 0, 2, 0], dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+
+    def args(**kw):
+        a = _lib.QsvSpsaStepArgs(n_runs=n_runs, width=width, x=x.data_ptr(), active=active.data_ptr(), iterations=iterations.data_ptr(),
+                                 delta_accept=None, values=None, delta_propose=None, points=points.data_ptr(), eps=eps, lr=lr,
+                                 trust_region=0, maxiter=3, window=0, reserved=0, min_rel=0.0, maxfev=-1, previous=None, n_values=None,
+                                 changes=None)
+        for k, v in kw.items():
+            setattr(a, k, v)
+        return a
+
+    assert lib.qsv_spsa_step(handle, None) == _lib.QSV_E_ARG
+    assert lib.qsv_spsa_step(handle, C.byref(args(x=None))) == _lib.QSV_E_ARG
+    assert lib.qsv_spsa_step(handle, C.byref(args(values=values.data_ptr()))) == _lib.QSV_E_ARG       # no signs to go with them
+    assert lib.qsv_spsa_step(handle, C.byref(args(delta_propose=signs.data_ptr(), points=None))) == _lib.QSV_E_ARG
+    assert lib.qsv_spsa_step(handle, C.byref(args(window=2))) == _lib.QSV_E_ARG                       # a rule without its state
+    assert lib.qsv_spsa_step(handle, C.byref(args(eps=0.0))) == _lib.QSV_E_ARG
+    # propose only
+    assert lib.qsv_spsa_step(handle, C.byref(args(delta_propose=signs[0].data_ptr()))) == 0
+    torch.cuda.synchronize()
+    got = points.cpu().numpy()
+    assert np.array_equal(got[0::2], x0 + eps * delta[0]) and np.array_equal(got[1::2], x0 - eps * delta[0])
+    # accept with signs[0], propose with signs[1]
+    assert lib.qsv_spsa_step(handle, C.byref(args(delta_accept=signs[0].data_ptr(), values=values.data_ptr(),
+                                                  delta_propose=signs[1].data_ptr()))) == 0
+    torch.cuda.synchronize()
+    update = ((f[0::2] - f[1::2]) / (2 * eps))[:, None] * delta[0]
+    want = x0 - (update * lr) * np.array([1, 1, 0, 1, 1])[:, None]
+    assert np.array_equal(x.cpu().numpy(), want)
+    assert iterations.cpu().tolist() == [1, 1, 0, 3, 1] and active.cpu().tolist() == [1, 1, 0, 0, 1]  # (run 3 reached maxiter)
+    got = points.cpu().numpy()
+    assert np.array_equal(got[0::2], want + eps * delta[1]) and np.array_equal(got[1::2], want - eps * delta[1])
+    # with the trust region: updates longer than 1 are divided by their norm (summed in the device's order: to the last bits)
+    x.copy_(torch.from_numpy(x0))
+    active.fill_(1)
+    iterations.zero_()
+    torch.cuda.synchronize()
+    assert lib.qsv_spsa_step(handle, C.byref(args(delta_accept=signs[0].data_ptr(), values=values.data_ptr(), trust_region=1))) == 0
+    torch.cuda.synchronize()
+    norm = np.sqrt((update * update).sum(axis=1))
+    assert (norm > 1).any() and (norm < 1).any()
+    scaled = np.where(norm[:, None] > 1, update / norm[:, None], update) * lr
+    assert np.abs(x.cpu().numpy() - (x0 - scaled)).max() < 1e-14
+    dev.close()
