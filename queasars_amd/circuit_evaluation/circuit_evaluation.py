@@ -765,6 +765,12 @@ class OperatorCircuitEvaluator(BaseCircuitEvaluator):
             self._device.set_operator(operator)
         self._composed = _ComposedCircuits(initial_state_circuit)
         self._composed_lists = None
+        self._last_matrix = None
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state["_last_matrix"] = None  # (a weak reference to a tensor of this process)
+        return state
 
     def _with_initial_state(self, circuit: CircuitIR) -> CircuitIR:
         return self._composed.get(circuit)
@@ -773,7 +779,8 @@ class OperatorCircuitEvaluator(BaseCircuitEvaluator):
         """``parameter_values`` may also be a 2-D float64 tensor in THIS device's memory (anything with ``is_cuda`` /
         ``data_ptr()``, i.e. a ``torch.Tensor``; one row per circuit, a circuit takes the first ``num_parameters`` values of its
         row): the kernels then read the values where they are (``qsv_eval_push_device``), after the work queued so far on the
-        tensor's current stream."""
+        tensor's current stream.  (A tensor that something torch does not see writes to -- another library, through its
+        pointer -- has to be complete when it is handed over.)"""
         matrix = parameter_values if getattr(parameter_values, "is_cuda", False) else None
         if matrix is None and (_has_none(circuits) or _has_none(parameter_values)):
             pairs = [(c, p) for c, p in zip(circuits, parameter_values) if c is not None and p is not None]
@@ -804,6 +811,14 @@ class OperatorCircuitEvaluator(BaseCircuitEvaluator):
         if matrix.device.index != self._device.device_index:
             raise ValueError("the parameter matrix lives on another device than the evaluator")
         event = 0
+        # (the matrix this evaluator read last, untouched by any torch operation since -- same storage owner, same version
+        # counter, same place and shape: an optimiser's population evaluated again, a benchmark's resident input -- is as
+        # complete as it was then)
+        owner = matrix._base if matrix._base is not None else matrix
+        stamp = (matrix._version, matrix.data_ptr(), tuple(matrix.shape))
+        last = self._last_matrix
+        if not ready and last is not None and last[0]() is owner and last[1] == stamp:
+            ready = True
         stream = None if ready else torch.cuda.current_stream(matrix.device)
         if stream is not None and not stream.query():
             # (whatever produces the matrix was queued on the tensor's current stream and has not finished: the handle's
@@ -812,8 +827,10 @@ class OperatorCircuitEvaluator(BaseCircuitEvaluator):
             marker = torch.cuda.Event()
             marker.record(stream)
             event = marker.cuda_event
-        return self._device.expectation_values_of_device_parameters(circuits, matrix.data_ptr(), int(matrix.shape[1]), event,
-                                                                    out_device_pointer)
+        out = self._device.expectation_values_of_device_parameters(circuits, matrix.data_ptr(), int(matrix.shape[1]), event,
+                                                                   out_device_pointer)
+        self._last_matrix = (weakref.ref(owner), stamp)
+        return out
 
     def evaluate_device_parameters(self, circuits: list[CircuitIR], matrix, ready: bool = False) -> np.ndarray:
         """:meth:`evaluate_circuits` for a device-resident parameter matrix, as a NumPy array.  ``ready=True``: the matrix is
