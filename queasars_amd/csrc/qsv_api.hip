@@ -2257,6 +2257,9 @@ int qsv_eval_staging(qsv_t* h, int first, int count, double** values) {
 
 int qsv_spsa_step(qsv_t* h, const qsv_spsa_step_args* in) {
     if (!h || !in) return QSV_E_ARG;
+    // (between qsv_eval_begin and qsv_eval_end the calling thread holds the handle: it would wait for itself)
+    if (h->batch_owner.load() == std::this_thread::get_id())
+        return fail(h, QSV_E_STATE, "a batch is open on this handle (qsv_spsa_step goes between batches)");
     std::lock_guard<std::mutex> lock(h->mu);
     if (in->n_runs < 0 || in->width < 0 || !in->x || !in->active || !in->iterations) return fail(h, QSV_E_ARG, "bad arguments");
     if (in->values && !in->delta_accept) return fail(h, QSV_E_ARG, "values without the signs they were measured with");
