@@ -212,6 +212,7 @@ class StatevectorDevice:
         # that a thread never pairs one call's counts with another call's total (evaluators may share a device)
         self._last_batch = None
         self._row_counts = None
+        self._ids_address = None
         self._push_evals = int(os.environ.get("QSV_PUSH_EVALS", "0"))  # measurement knob: evaluations per push
         self._push_plan = [int(x) for x in os.environ.get("QSV_PUSH_PLAN", "").split(",") if x]  # ... or explicit sizes
         self._operator: Optional[PauliOperator] = None
@@ -427,9 +428,20 @@ class StatevectorDevice:
         ids, need, _total = self._batch_metadata(circuits)
         cached = self._row_counts
         if cached is None or cached[0] != (n, row_length):
-            cached = self._row_counts = ((n, row_length), np.full(n, row_length, dtype=np.int64))
+            counts = np.full(n, row_length, dtype=np.int64)
+            cached = self._row_counts = ((n, row_length), counts, counts.ctypes.data)
         counts = cached[1]
         out = None if out_device_pointer else np.empty(n, dtype=np.float64)
+        fast = None if os.environ.get("QSV_LIBRARY") else _load_pyhelp_module()
+        if fast is not None:
+            # (the whole batch in one call of the extension module; the address of the id array is kept with the array)
+            kept = self._ids_address
+            if kept is None or kept[0] is not ids:
+                kept = self._ids_address = (ids, ids.ctypes.data)
+            rc = fast.eval_device_matrix(self._handle.value, n, kept[1], cached[2], device_pointer, ready_event,
+                                         out.ctypes.data if out is not None else 0, out_device_pointer)
+            self._check(rc)
+            return out
         helper = None if os.environ.get("QSV_LIBRARY") else _load_pyhelp()
         if helper is not None:
             self._check(helper.qsv_py_expectation_values_devparams(
@@ -649,6 +661,7 @@ class StatevectorDevice:
         self._check(self._lib.qsv_set_option(self._handle, name.encode(), int(value)))
         self._last_batch = None
         self._row_counts = None
+        self._ids_address = None
 
     def set_profiling(self, enabled: bool) -> None:
         self._check(self._lib.qsv_set_profiling(self._handle, 1 if enabled else 0))
@@ -802,22 +815,26 @@ class OperatorCircuitEvaluator(BaseCircuitEvaluator):
     def _evaluate_device_matrix(self, circuits, matrix, ready: bool = False, out_device_pointer: int = 0) -> Optional[np.ndarray]:
         import torch
 
-        if matrix.dim() != 2 or matrix.dtype != torch.float64 or not matrix.is_contiguous():
-            raise ValueError("a device-resident parameter matrix must be a contiguous 2-D float64 tensor")
-        if matrix.shape[0] != len(circuits):
+        # (the matrix this evaluator read last, untouched by any torch operation since -- same storage owner, same version
+        # counter, same place and shape: an optimiser's population evaluated again, a benchmark's resident input -- is as
+        # complete as it was then, and as well-formed)
+        base = matrix._base
+        owner = base if base is not None else matrix
+        shape = matrix.shape
+        stamp = (matrix._version, matrix.data_ptr(), shape[0], shape[1] if len(shape) == 2 else -1)
+        last = self._last_matrix
+        seen = last is not None and last[0]() is owner and last[1] == stamp
+        if not seen:
+            if matrix.dim() != 2 or matrix.dtype != torch.float64 or not matrix.is_contiguous():
+                raise ValueError("a device-resident parameter matrix must be a contiguous 2-D float64 tensor")
+            if matrix.device.index != self._device.device_index:
+                raise ValueError("the parameter matrix lives on another device than the evaluator")
+        if shape[0] != len(circuits):
             raise ValueError("circuits and parameter_values must have the same length")
         if _has_none(circuits):
             raise ValueError("a device-resident parameter matrix cannot skip circuits (None entries)")
-        if matrix.device.index != self._device.device_index:
-            raise ValueError("the parameter matrix lives on another device than the evaluator")
         event = 0
-        # (the matrix this evaluator read last, untouched by any torch operation since -- same storage owner, same version
-        # counter, same place and shape: an optimiser's population evaluated again, a benchmark's resident input -- is as
-        # complete as it was then)
-        owner = matrix._base if matrix._base is not None else matrix
-        stamp = (matrix._version, matrix.data_ptr(), tuple(matrix.shape))
-        last = self._last_matrix
-        if not ready and last is not None and last[0]() is owner and last[1] == stamp:
+        if seen:
             ready = True
         stream = None if ready else torch.cuda.current_stream(matrix.device)
         if stream is not None and not stream.query():
@@ -827,9 +844,9 @@ class OperatorCircuitEvaluator(BaseCircuitEvaluator):
             marker = torch.cuda.Event()
             marker.record(stream)
             event = marker.cuda_event
-        out = self._device.expectation_values_of_device_parameters(circuits, matrix.data_ptr(), int(matrix.shape[1]), event,
-                                                                   out_device_pointer)
-        self._last_matrix = (weakref.ref(owner), stamp)
+        out = self._device.expectation_values_of_device_parameters(circuits, stamp[1], stamp[3], event, out_device_pointer)
+        if not seen:
+            self._last_matrix = (weakref.ref(owner), stamp)
         return out
 
     def evaluate_device_parameters(self, circuits: list[CircuitIR], matrix, ready: bool = False) -> np.ndarray:

@@ -30,7 +30,7 @@ def _rows(parameter_values, lo: int, hi: int):
     """Rows [lo, hi) of the population's parameter values: a list of vectors, or -- for a matrix that lives in device memory
     (a torch tensor; ``OperatorCircuitEvaluator.evaluate_circuits`` reads it where it is) -- a view of its rows."""
     if getattr(parameter_values, "is_cuda", False):
-        return parameter_values[lo:hi]
+        return parameter_values if lo == 0 and hi == len(parameter_values) else parameter_values[lo:hi]
     return list(parameter_values[lo:hi])
 
 
