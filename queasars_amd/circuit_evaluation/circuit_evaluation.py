@@ -476,9 +476,19 @@ class StatevectorDevice:
         out = np.empty(n, dtype=np.float64)
         lib, handle = self._lib, self._handle
         helper = None if (self._push_evals or self._push_plan or os.environ.get("QSV_LIBRARY")) else _load_pyhelp()
+        fast = _load_pyhelp_module() if helper is not None else None
+        if fast is not None:
+            # the whole begin / pack / push / end sequence in one call of the helper's extension module (csrc/pyhelp.c: no
+            # ctypes argument conversion), which takes the first need[i] values of vector i and complains about a shorter one
+            kept = self._ids_address
+            if kept is None or kept[0] is not ids or len(kept) < 4:
+                kept = self._ids_address = (ids, ids.ctypes.data, need, need.ctypes.data)
+            scratch = np.empty(total + 1, dtype=np.float64)
+            self._check(fast.eval_vectors(handle.value, n, kept[1], kept[3], parameter_values, scratch.ctypes.data, total,
+                                          out.ctypes.data))
+            return out
         if helper is not None:
-            # the whole begin / pack / push / end sequence in one call of the CPython-API helper (csrc/pyhelp.c), which
-            # takes the first need[i] values of vector i and complains about a shorter one itself
+            # (the same through ctypes.PyDLL)
             scratch = np.empty(total + 1, dtype=np.float64)
             rc = helper.qsv_py_expectation_values(handle, n, ids.ctypes.data, need.ctypes.data, parameter_values,
                                                   scratch.ctypes.data, total, out.ctypes.data)

@@ -382,6 +382,32 @@ static PyObject* eval_device_matrix(PyObject* self, PyObject* const* args, Py_ss
     return PyLong_FromLong(rc);
 }
 
+/* qsv_py_expectation_values the same way: eval_vectors(handle, n, ids_address, counts_address, vectors, scratch_address,
+ * capacity, out_address) -> rc (-100: a Python exception is set and is raised instead). */
+static PyObject* eval_vectors(PyObject* self, PyObject* const* args, Py_ssize_t nargs) {
+    (void)self;
+    if (nargs != 8) {
+        PyErr_SetString(PyExc_TypeError, "eval_vectors(handle, n, ids, counts, vectors, scratch, capacity, out)");
+        return NULL;
+    }
+    void* h = PyLong_AsVoidPtr(args[0]);
+    const Py_ssize_t n = PyLong_AsSsize_t(args[1]);
+    void* ids = PyLong_AsVoidPtr(args[2]);
+    void* counts = PyLong_AsVoidPtr(args[3]);
+    void* scratch = PyLong_AsVoidPtr(args[5]);
+    const Py_ssize_t capacity = PyLong_AsSsize_t(args[6]);
+    void* out = PyLong_AsVoidPtr(args[7]);
+    if (PyErr_Occurred()) return NULL;
+    if (!h || n <= 0 || !ids || !counts || !scratch || !out) {
+        PyErr_SetString(PyExc_ValueError, "eval_vectors: null handle or arrays");
+        return NULL;
+    }
+    const int rc = expectation_values((qsv_t*)h, n, (const int*)ids, (const int64_t*)counts, args[4], (double*)scratch, capacity,
+                                      (double*)out, NULL);
+    if (rc == -100 && PyErr_Occurred()) return NULL;
+    return PyLong_FromLong(rc);
+}
+
 static PyObject* same_objects(PyObject* self, PyObject* const* args, Py_ssize_t nargs) {
     (void)self;
     if (nargs != 2) {
@@ -421,6 +447,8 @@ static PyObject* has_none(PyObject* self, PyObject* const* args, Py_ssize_t narg
 static PyMethodDef helper_methods[] = {
     {"eval_device_matrix", (PyCFunction)(void (*)(void))eval_device_matrix, METH_FASTCALL,
      "eval_device_matrix(handle, n, ids, counts, device_values, ready_event, out, device_out) -> rc: a batch whose parameter values live in device memory"},
+    {"eval_vectors", (PyCFunction)(void (*)(void))eval_vectors, METH_FASTCALL,
+     "eval_vectors(handle, n, ids, counts, vectors, scratch, capacity, out) -> rc: a batch of host parameter vectors"},
     {"has_none", (PyCFunction)(void (*)(void))has_none, METH_FASTCALL, "has_none(seq): some element of a list or tuple is None"},
     {"same_objects", (PyCFunction)(void (*)(void))same_objects, METH_FASTCALL,
      "same_objects(a, b): two lists or tuples hold the same objects, position by position"},
