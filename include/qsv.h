@@ -171,7 +171,9 @@ int qsv_eval_staging(qsv_t* h, int first, int count, double** values);
  * and nothing crosses PCIe: the kernels read the values where they are, so they must stay unchanged until qsv_eval_end has
  * returned (for a batch that does not wait, qsv_eval_set_output: until its work is complete).  `ready_event`: a hipEvent_t
  * after which the values are complete -- every stream of the handle waits for it --, or NULL when they already are (the
- * caller synchronised, or wrote them on the handle's stream, qsv_set_stream).  Pushes of both kinds may be mixed in a batch. */
+ * caller synchronised, or wrote them on the handle's stream, qsv_set_stream).  Pushes of both kinds may be mixed in a batch.
+ * (An evaluation that declares more than 1024 values -- rows padded that far -- is prepared without the LDS copy of its vector:
+ * the same result to the last bits, not bit for bit.) */
 int qsv_eval_push_device(qsv_t* h, int first, int count, const double* device_values, void* ready_event);
 int qsv_eval_end(qsv_t* h, double* out_expectations);
 /*

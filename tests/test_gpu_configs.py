@@ -1287,6 +1287,13 @@ def test_parameter_values_resident_in_device_memory(n, layers, count, c_oracle):
     assert np.abs(got2 - got).max() > 1e-6
     # a part of the population, as a view of rows (contiguous), and the host path right after on the same handle
     assert np.array_equal(np.asarray(ev.evaluate_circuits(circuits[3:11], matrix[3:11])), want2[3:11])
+    # rows wider than the preparation's LDS staging of a parameter vector (1024 values): read straight from the matrix
+    wide = torch.full((count, 1100), 7.0, dtype=torch.float64, device="cuda")
+    wide[:, :width] = torch.from_numpy(host).cuda()
+    torch.cuda.synchronize()
+    # (that path takes every angle's sine and cosine where it needs them instead of once per angle in LDS: the same values
+    # to the last bits, not bit for bit)
+    assert np.abs(np.asarray(ev.evaluate_circuits(circuits, wide)) - want).max() < 1e-12
     assert np.array_equal(np.asarray(ev.evaluate_circuits(circuits, params)), want)
 
 
