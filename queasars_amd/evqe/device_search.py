@@ -55,13 +55,19 @@ def minimize_spsa_on_device(evaluator, jobs, look_every: int = 8) -> None:
     runs = [run for _, run in jobs]
     cfg = runs[0].config
     n_iter = int(cfg.maxiter)
-    sizes = np.array([run.x.size for run in runs])
-    width, n_runs = int(sizes.max()), len(runs)
+    # A run's variables may be entries of a longer parameter vector (run.embed: a layer inside the individual's fully
+    # parameterised circuit): the row is that vector, the signs are zero everywhere else -- x +- eps * 0 leaves the other
+    # entries where they are, the update is zero there and the norm does not see them.
+    where = [run.embed[1] if run.embed is not None else np.arange(run.x.size) for run in runs]
+    lengths = np.array([run.embed[0].size if run.embed is not None else run.x.size for run in runs])
+    width, n_runs = int(lengths.max()), len(runs)
     x_host = np.zeros((n_runs, width))
     signs_host = np.zeros((n_iter, n_runs, width))
     for i, run in enumerate(runs):
-        x_host[i, : sizes[i]] = run.x
-        signs_host[:, i, : sizes[i]] = 1 - 2 * run.rng.binomial(1, 0.5, size=(n_iter, int(sizes[i])))
+        if run.embed is not None:
+            x_host[i, : lengths[i]] = run.embed[0]
+        x_host[i, where[i]] = run.x
+        signs_host[:, i, where[i]] = 1 - 2 * run.rng.binomial(1, 0.5, size=(n_iter, run.x.size))
     circuits = [circuit for circuit, _ in jobs for _ in (0, 1)]
     checker = cfg.termination_checker
     window = checker.allowed_consecutive_violations + 1 if checker is not None else 0
@@ -105,7 +111,7 @@ def minimize_spsa_on_device(evaluator, jobs, look_every: int = 8) -> None:
         done_iterations = iterations.cpu().numpy()
     caller.wait_stream(stream)
     for i, run in enumerate(runs):
-        run.x = x_final[i, : sizes[i]].copy()
+        run.x = x_final[i, where[i]].copy()
         run.iteration = int(done_iterations[i])
         run.nfev = 2 * int(done_iterations[i])
         run.done = True
@@ -119,14 +125,17 @@ def _minimize_with_torch_operations(evaluator, jobs, look_every: int = 8) -> Non
     runs = [run for _, run in jobs]
     cfg = runs[0].config
     eps, lr, n_iter = cfg.perturbation, cfg.learning_rate, int(cfg.maxiter)
-    sizes = np.array([run.x.size for run in runs])
-    width, n_runs = int(sizes.max()), len(runs)
+    where = [run.embed[1] if run.embed is not None else np.arange(run.x.size) for run in runs]
+    lengths = np.array([run.embed[0].size if run.embed is not None else run.x.size for run in runs])
+    width, n_runs = int(lengths.max()), len(runs)
     x_host = np.zeros((n_runs, width))
     signs_host = np.zeros((n_iter, n_runs, width))
     for i, run in enumerate(runs):
-        x_host[i, : sizes[i]] = run.x
+        if run.embed is not None:
+            x_host[i, : lengths[i]] = run.embed[0]
+        x_host[i, where[i]] = run.x
         # (what propose() would draw call by call: one draw of the lot gives the same numbers)
-        signs_host[:, i, : sizes[i]] = 1 - 2 * run.rng.binomial(1, 0.5, size=(n_iter, int(sizes[i])))
+        signs_host[:, i, where[i]] = 1 - 2 * run.rng.binomial(1, 0.5, size=(n_iter, run.x.size))
     circuits = [circuit for circuit, _ in jobs for _ in (0, 1)]
     checker = cfg.termination_checker
     window = checker.allowed_consecutive_violations + 1 if checker is not None else 0
@@ -189,7 +198,7 @@ def _minimize_with_torch_operations(evaluator, jobs, look_every: int = 8) -> Non
         done_iterations = iterations.cpu().numpy()
     caller.wait_stream(stream)
     for i, run in enumerate(runs):
-        run.x = x_final[i, : sizes[i]].copy()
+        run.x = x_final[i, where[i]].copy()
         run.iteration = int(done_iterations[i])
         run.nfev = 2 * int(done_iterations[i])
         run.done = True

@@ -36,6 +36,11 @@ from queasars_amd.ir import CircuitIR, ParamRef
 _ANGLE_NAMES = ("theta", "phi", "lambda")
 
 
+# structure (n_qubits, layers) -> its fully parameterised circuit (EVQEIndividual.get_parameterized_quantum_circuit(shared=True))
+_SHARED_CIRCUITS: dict = {}
+_SHARED_CIRCUITS_LIMIT = 4096
+
+
 def new_random_seed(random_generator: Random) -> int:
     """Seed chaining helper (reference: queasars/utility/random.py:15)."""
     return random_generator.randint(0, 2147483647)
@@ -387,8 +392,22 @@ class EVQEIndividual:
         base/evolutionary_algorithm.py:20-27, ``get_parameterized_quantum_circuit().assign_parameters(values)``)."""
         return self.get_partially_parameterized_quantum_circuit(set())
 
-    def get_parameterized_quantum_circuit(self) -> CircuitIR:
-        return self.get_partially_parameterized_quantum_circuit(set(range(len(self.layers))))
+    def get_parameterized_quantum_circuit(self, shared: bool = False) -> CircuitIR:
+        """Every layer with free parameters.  ``shared=True``: ONE circuit object per structure (qubits and layers), handed
+        to every individual that has it -- the circuit depends on nothing else, evaluators keep what they know about a circuit
+        (its composition with an initial state, its plans on the device) by object, and offspring mostly keep their parents'
+        layers: the EVQE driver registers a structure once instead of once per individual, generation and search.  The shared
+        object must not be edited."""
+        if not shared:
+            return self.get_partially_parameterized_quantum_circuit(set(range(len(self.layers))))
+        key = (self.n_qubits, self.layers)
+        circuit = _SHARED_CIRCUITS.get(key)
+        if circuit is None:
+            if len(_SHARED_CIRCUITS) >= _SHARED_CIRCUITS_LIMIT:  # (the oldest half goes: dictionaries keep insertion order)
+                for old in list(_SHARED_CIRCUITS)[: _SHARED_CIRCUITS_LIMIT // 2]:
+                    del _SHARED_CIRCUITS[old]
+            circuit = _SHARED_CIRCUITS[key] = self.get_partially_parameterized_quantum_circuit(set(range(len(self.layers))))
+        return circuit
 
     def get_partially_parameterized_quantum_circuit(self, parameterized_layers: set[int]) -> CircuitIR:
         """Lower to ops.  Layers in ``parameterized_layers`` keep free parameters (indices follow the

@@ -126,6 +126,9 @@ class _SPSARun:
         self.iteration = 0
         self.done = self.x.size == 0 or config.maxiter <= 0
         self._delta = None
+        # (base vector, positions): the run's variables are entries `positions` of a longer parameter vector whose other
+        # entries stay at `base` -- a layer of an individual inside the individual's fully parameterised circuit
+        self.embed = None
 
     def propose(self) -> list[np.ndarray]:
         """The two points the next iteration evaluates."""
@@ -185,6 +188,7 @@ class _NFTRun:
         self.done = self.x.size == 0 or config.maxfev <= 0
         self._recycled: Optional[float] = None
         self._needs_base = True
+        self.embed = None  # (as _SPSARun.embed)
 
     def propose(self) -> list[np.ndarray]:
         cfg = self.config
@@ -214,6 +218,16 @@ class _NFTRun:
         self.done = self.nfev >= cfg.maxfev or (cfg.maxiter is not None and self.iteration >= cfg.maxiter)
 
 
+def _full_point(run, point: np.ndarray) -> np.ndarray:
+    """The parameter vector the evaluator gets for a run's point (run.embed)."""
+    if run.embed is None:
+        return point
+    base, positions = run.embed
+    full = base.copy()
+    full[positions] = point
+    return full
+
+
 def _minimize_spsa_vectorised(evaluator, jobs: list) -> None:
     """:func:`_minimize_batched` for SPSA runs of one configuration, with the arithmetic of all runs in whole-array NumPy
     operations: as written per run (propose / accept of :class:`_SPSARun`: a binomial draw, two array expressions and two
@@ -240,19 +254,45 @@ def _minimize_spsa_vectorised(evaluator, jobs: list) -> None:
     nfev = np.array([run.nfev for run in runs])
     any_checker = any(run.checker is not None for run in runs)
     active = np.array([i for i, run in enumerate(runs) if not run.done], dtype=np.int64)
+    embedded = any(run.embed is not None for run in runs)
+    if embedded:
+        # (every run's variables are entries of a longer vector: the rows the evaluator gets are the base vectors with the
+        # points scattered into them)
+        full_sizes = np.array([run.embed[0].size if run.embed is not None else run.x.size for run in runs])
+        full = np.zeros((n_runs, int(full_sizes.max())))
+        for i, run in enumerate(runs):
+            if run.embed is not None:
+                full[i, : full_sizes[i]] = run.embed[0]
     circuits_of = {}
     while active.size:
         key = active.tobytes()
         cached = circuits_of.get(key)
         if cached is None:  # (the same list object while the same runs are active: the evaluator's caches key on it)
+            scatter = None
+            if embedded:
+                rows, cols, src = [], [], []
+                for a, i in enumerate(active):
+                    positions = runs[i].embed[1] if runs[i].embed is not None else np.arange(sizes[i])
+                    rows.append(np.full(positions.size, 2 * a))
+                    cols.append(positions)
+                    src.append(np.arange(positions.size))
+                scatter = (np.concatenate(rows), np.concatenate(cols), np.concatenate(src))
+            lengths = full_sizes if embedded else sizes
             cached = circuits_of[key] = ([jobs[i][0] for i in active for _ in (0, 1)],
-                                         [slice(0, int(sizes[i])) for i in active for _ in (0, 1)])
-        circuits, cuts = cached
+                                         [slice(0, int(lengths[i])) for i in active for _ in (0, 1)], scatter)
+        circuits, cuts, scatter = cached
         delta = signs[active, iteration[active]]
         points = np.empty((2 * active.size, width))
         points[0::2] = x[active] + eps * delta
         points[1::2] = x[active] - eps * delta
-        values = np.asarray(evaluator.evaluate_circuits(circuits, [row[cut] for row, cut in zip(points, cuts)]), dtype=np.float64)
+        if embedded:
+            rows, cols, src = scatter
+            sent = np.repeat(full[active], 2, axis=0)
+            sent[rows, cols] = points[rows, src]
+            sent[rows + 1, cols] = points[rows + 1, src]
+        else:
+            sent = points
+        values = np.asarray(evaluator.evaluate_circuits(circuits, [row[cut] for row, cut in zip(sent, cuts)]), dtype=np.float64)
         f_plus, f_minus = values[0::2], values[1::2]
         update = ((f_plus - f_minus) / (2 * eps))[:, None] * delta
         if cfg.trust_region:
@@ -284,6 +324,21 @@ def _minimize_spsa_vectorised(evaluator, jobs: list) -> None:
         run.nfev = int(nfev[i])
 
 
+def _device_search_wanted(evaluator, n_runs: int, flag: Optional[bool], optimizer) -> bool:
+    """Will a search of ``n_runs`` fresh runs of ``optimizer`` keep its state on the device (_minimize_batched's rule)?"""
+    env = os.environ.get("QSV_DEVICE_SEARCH")
+    if env == "0" or os.environ.get("QSV_SCALAR_SPSA") or not isinstance(optimizer, SPSA) or n_runs < 2:
+        return False
+    if flag is None:
+        flag = n_runs >= _DEVICE_SEARCH_MIN_RUNS
+    if not (flag or env == "1"):
+        return False
+    if not hasattr(evaluator, "evaluate_device_to_device") or not evaluator.device_resident_search_possible():
+        return False
+    checker = optimizer.termination_checker
+    return optimizer.maxiter > 0 and (checker is None or type(checker) is SPSATerminationChecker)
+
+
 _DEVICE_SEARCH_MIN_RUNS = 16  # (config 4 on one MI355X: searches of 25 - 64 runs 1.5 x faster end to end, of 10 runs no faster)
 
 
@@ -311,7 +366,7 @@ def _minimize_batched(evaluator, jobs: list, on_device: Optional[bool] = False) 
             points = run.propose()
             counts.append(len(points))
             circuits += [circuit] * len(points)
-            params += [p.tolist() for p in points]
+            params += [_full_point(run, p).tolist() for p in points]
         values = evaluator.evaluate_circuits(circuits, params)
         cur = 0
         for (_, run), k in zip(active, counts):
@@ -403,6 +458,8 @@ class EVQEMinimumEigensolver:
     def __init__(self, configuration: EVQEMinimumEigensolverConfiguration, log: Optional[Callable[[str], None]] = None):
         self.configuration = configuration
         self._log = log or (lambda message: None)
+        # (QSV_SHARE_CIRCUITS=0: a circuit per individual and search, the other layers' values bound into it, as the reference has it)
+        self.share_circuits = os.environ.get("QSV_SHARE_CIRCUITS", "1") != "0"
         rng = Random(configuration.random_seed)
         # one seed per consumer, drawn in the reference's order (evqe.py:188-229)
         self._population_seed = new_random_seed(rng)
@@ -425,10 +482,25 @@ class EVQEMinimumEigensolver:
 
     def _optimize_layers(self, evaluator, individuals: list[EVQEIndividual], layer_ids: list[int], seeds: list[int]):
         """optimize_layer_of_individual (mutation.py:28-89) for many individuals at once."""
+        # The reference binds every other layer's values into the circuit (a new circuit per individual, layer and search:
+        # get_partially_parameterized_quantum_circuit).  Here the search runs on the individual's FULLY parameterised circuit --
+        # one shared object per structure, registered once --, the other layers' values travelling as parameter values that
+        # do not move: the same matrices, gate for gate, hence the same numbers (tests hold the two forms to equality).
+        # (Where the points are packed on the host -- small searches, evaluators that sample -- the wider rows cost more than the
+        # registrations they save, measured on config 4's sampler branch: there the circuits are bound as the reference binds them.)
+        embed = self.share_circuits and _device_search_wanted(evaluator, len(individuals), self.configuration.device_resident_search,
+                                                              self.configuration.optimizer)
+        if os.environ.get("QSV_SHARE_CIRCUITS") == "2":  # (measurements, tests: embedded also where the host packs the points)
+            embed = True
         jobs = []
         for individual, layer_id, seed in zip(individuals, layer_ids, seeds):
-            circuit = individual.get_partially_parameterized_quantum_circuit({layer_id})
             run = self.configuration.optimizer.new_run(individual.get_layer_parameter_values(layer_id), seed)
+            if embed:
+                circuit = individual.get_parameterized_quantum_circuit(shared=True)
+                positions = np.asarray(individual.layer_parameter_indices[layer_id % len(individual.layers)], dtype=np.int64)
+                run.embed = (np.asarray(individual.parameter_values, dtype=np.float64), positions)
+            else:
+                circuit = individual.get_partially_parameterized_quantum_circuit({layer_id})
             jobs.append((circuit, run))
         _minimize_batched(evaluator, jobs, on_device=self.configuration.device_resident_search)
         out, nfev = [], 0
@@ -565,7 +637,7 @@ class EVQEMinimumEigensolver:
             population = self._speciation(population)
             if not budget_left(len(population.individuals)):
                 break
-            circuits = [ind.get_parameterized_quantum_circuit() for ind in population.individuals]
+            circuits = [ind.get_parameterized_quantum_circuit(shared=self.share_circuits) for ind in population.individuals]
             values = evaluator.evaluate_circuits(circuits, [list(ind.parameter_values) for ind in population.individuals])
             evaluations[-1] += len(values)
             best = int(np.argmin(values))

@@ -350,3 +350,37 @@ def test_spsa_termination_checker_answers_as_the_references_does():
     for seed, chain in data["seed_chains"].items():
         rng = Random(int(seed))
         assert [new_random_seed(rng) for _ in chain] == chain
+
+
+def test_search_on_shared_fully_parameterised_circuits_is_the_search_on_bound_ones(monkeypatch):
+    """The driver searches a layer inside the individual's fully parameterised circuit (one shared object per structure, the
+    other layers' values as parameter values that do not move) where the reference binds them into a fresh circuit: the same
+    matrices gate for gate, so the same run -- eigenvalue, best individual, evaluations per generation --, with far fewer
+    circuit objects handed to the evaluator."""
+    op = xy_hamiltonian()
+
+    class Counting(OracleEvaluator):
+        def __init__(self, operator):
+            super().__init__(operator)
+            self.seen = set()
+
+        def evaluate_circuits(self, circuits, parameter_values):
+            self.seen.update(id(c) for c in circuits)
+            self.keep = getattr(self, "keep", []) + list(circuits)  # (ids stay unique while the objects live)
+            return super().evaluate_circuits(circuits, parameter_values)
+
+    results = {}
+    for share in ("2", "0"):  # ("2": embedded also where the host packs the points, as here)
+        monkeypatch.setenv("QSV_SHARE_CIRCUITS", share)
+        ev = Counting(op)
+        results[share] = (EVQEMinimumEigensolver(make_config()).compute_minimum_eigenvalue(ev), len(ev.seen))
+    shared, bound = results["2"][0], results["0"][0]
+    assert shared.eigenvalue == bound.eigenvalue and shared.best_individual == bound.best_individual
+    assert shared.circuit_evaluations == bound.circuit_evaluations
+    assert shared.best_expectation_values == bound.best_expectation_values
+    assert results["2"][1] * 3 < results["0"][1]  # (distinct circuit objects the evaluator was shown)
+    # the same for the run-by-run driver
+    monkeypatch.setenv("QSV_SCALAR_SPSA", "1")
+    monkeypatch.setenv("QSV_SHARE_CIRCUITS", "2")
+    scalar = EVQEMinimumEigensolver(make_config()).compute_minimum_eigenvalue(OracleEvaluator(op))
+    assert scalar.eigenvalue == shared.eigenvalue and scalar.circuit_evaluations == shared.circuit_evaluations

@@ -1512,3 +1512,47 @@ def test_spsa_step_entry_point_by_hand():
     scaled = np.where(norm[:, None] > 1, update / norm[:, None], update) * lr
     assert np.abs(x.cpu().numpy() - (x0 - scaled)).max() < 1e-14
     dev.close()
+
+
+@pytest.mark.gpu
+def test_a_layer_searched_inside_the_fully_parameterised_circuit_gives_the_bound_circuits_values():
+    """The EVQE driver evaluates a layer's points on the individual's fully parameterised circuit (shared per structure) with
+    the other layers' values as parameter values; the reference binds those into the circuit.  Bit for bit the same
+    expectation values on the device (the plan of a circuit does not depend on whether an angle is a literal), for split and
+    unsplit individuals; and a whole EVQE run is the same run either way."""
+    import os
+
+    from queasars_amd.evqe import EVQEPopulation
+    from queasars_amd.evqe import solver as S
+
+    n = 16
+    op = helpers.random_ising_operator(n, seed=2020)
+    ev = OperatorCircuitEvaluator(op)
+    rng = np.random.default_rng(2)
+    for layers in (3, 7):
+        pop = EVQEPopulation.random_population(n, layers, 10, True, layers)
+        bound_circuits, bound_rows, full_circuits, full_rows = [], [], [], []
+        for ind in pop.individuals:
+            layer = int(rng.integers(0, layers))
+            positions = list(ind.layer_parameter_indices[layer])
+            point = rng.uniform(0, 6.28, size=len(positions))
+            bound_circuits.append(ind.get_partially_parameterized_quantum_circuit({layer}))
+            bound_rows.append(point.tolist())
+            full = np.asarray(ind.parameter_values, dtype=np.float64)
+            full[positions] = point
+            full_circuits.append(ind.get_parameterized_quantum_circuit(shared=True))
+            full_rows.append(full.tolist())
+        assert ev.evaluate_circuits(bound_circuits, bound_rows) == ev.evaluate_circuits(full_circuits, full_rows)
+    cfg = dict(optimizer=S.SPSA(maxiter=8), population_size=12, max_generations=3, random_seed=4, n_initial_layers=2,
+               randomize_initial_population_parameters=True, use_tournament_selection=True, tournament_size=2,
+               parameter_search_probability=0.5, topological_search_probability=0.6, device_resident_search=False)
+    results = []
+    for share in ("2", "0"):  # ("2": embedded also where the host packs the points, as in this run)
+        os.environ["QSV_SHARE_CIRCUITS"] = share
+        try:
+            results.append(S.EVQEMinimumEigensolver(S.EVQEMinimumEigensolverConfiguration(**cfg)).compute_minimum_eigenvalue(
+                OperatorCircuitEvaluator(op)))
+        finally:
+            del os.environ["QSV_SHARE_CIRCUITS"]
+    assert results[0].eigenvalue == results[1].eigenvalue and results[0].best_individual == results[1].best_individual
+    assert results[0].circuit_evaluations == results[1].circuit_evaluations
