@@ -4,7 +4,8 @@ plain Python / NumPy and import in the build container from /root/reference):
 * ``SPSATerminationChecker.termination_check`` (queasars/utility/spsa_termination.py:46-94): what it answers, call by call,
   along sequences of (evaluations so far, function value, accepted) -- converging, noisy, with rejected steps, with a budget,
   and with one object serving several optimisations in a row; plus its bookkeeping after the last call;
-* ``new_random_seed`` (queasars/utility/random.py:7-15): the seed chain of a ``random.Random``.
+* ``new_random_seed`` (queasars/utility/random.py:7-15): the seed chain of a ``random.Random``;
+* ``BitstringEvaluator.evaluate_bitstring`` (queasars/circuit_evaluation/bitstring_evaluation.py:35-46): values and refusals.
 
     python tests/golden/make_host_golden.py        # writes tests/golden/spsa_termination_reference.json
 """
@@ -53,13 +54,24 @@ def main() -> None:
                          "n_function_evaluation_history": list(checker.n_function_evaluation_history),
                          "best_function_value": checker.best_function_value,
                          "best_parameter_values": None if best is None else [float(v) for v in best]}
+    # BitstringEvaluator (queasars/circuit_evaluation/bitstring_evaluation.py:7-57): what it returns or raises
+    from queasars.circuit_evaluation.bitstring_evaluation import BitstringEvaluator, BitstringEvaluatorException
+
+    evaluator = BitstringEvaluator(input_length=5, evaluation_function=lambda bits: float(int(bits, 2)) / 4 - bits.count("1"))
+    bitstrings = []
+    for text in ["00000", "11111", "01010", "10011", "0101", "010101", "", "01a10", "0 101", "01012", "１0101"]:
+        try:
+            bitstrings.append({"bitstring": text, "value": evaluator.evaluate_bitstring(text)})
+        except BitstringEvaluatorException:
+            bitstrings.append({"bitstring": text, "raises": "BitstringEvaluatorException"})
     seeds = {}
     for seed in (0, 1, 7, 2024):
         rng = Random(seed)
         seeds[str(seed)] = [new_random_seed(rng) for _ in range(6)]
     path = Path(__file__).resolve().parent / "spsa_termination_reference.json"
     path.write_text(json.dumps({"source": "the reference's own modules, run by tests/golden/make_host_golden.py",
-                                "termination": cases, "seed_chains": seeds}, separators=(",", ":")) + "\n")
+                                "termination": cases, "seed_chains": seeds, "bitstring_evaluator": {"input_length": 5, "cases": bitstrings}},
+                               separators=(",", ":")) + "\n")
     print(path, sum(len(c["calls"]) for c in cases), "calls,", sum(call["answer"] for c in cases for call in c["calls"]), "answered stop")
 
 

@@ -489,3 +489,22 @@ def test_packer_takes_numpy_rows_as_they_stand():
     assert helper.qsv_pack_exact([strided], 0, 1, np.array([10], dtype=np.int64).ctypes.data, out.ctypes.data, 40) == 10
     assert np.array_equal(out[:10], strided)
     assert not _has_none([matrix[0], matrix[1]]) and _has_none([matrix[0], None]) and not _has_none([])
+
+
+def test_bitstring_evaluator_answers_as_the_references_does():
+    """Values and refusals of the reference's own BitstringEvaluator (tests/golden/make_host_golden.py ran
+    queasars/circuit_evaluation/bitstring_evaluation.py), among them a wrong length, other characters and a full-width digit."""
+    import json
+    from pathlib import Path
+
+    from queasars_amd.circuit_evaluation.bitstring_evaluation import BitstringEvaluator, BitstringEvaluatorException
+
+    data = json.loads((Path(__file__).parent / "golden" / "spsa_termination_reference.json").read_text())["bitstring_evaluator"]
+    evaluator = BitstringEvaluator(data["input_length"], lambda bits: float(int(bits, 2)) / 4 - bits.count("1"))
+    assert evaluator.input_length == data["input_length"]
+    for case in data["cases"]:
+        if "raises" in case:
+            with pytest.raises(BitstringEvaluatorException):
+                evaluator.evaluate_bitstring(case["bitstring"])
+        else:
+            assert evaluator.evaluate_bitstring(case["bitstring"]) == case["value"]
