@@ -37,6 +37,9 @@ class Machine:
         if self.name == "":
             raise JobShopSchedulingProblemException("The name of a Machine cannot be an empty string!")
 
+    def __repr__(self) -> str:  # (the texts a notebook prints are the reference's, line for line: tests/golden/jssp_reference.json)
+        return self.name
+
 
 @dataclass(frozen=True)
 class Operation:
@@ -57,6 +60,9 @@ class Operation:
     def identifier(self) -> str:
         return self.job_name + "_" + self.name
 
+    def __repr__(self) -> str:
+        return f"{self.identifier}({self.machine.name}, {self.processing_duration})"
+
 
 @dataclass(frozen=True)
 class Job:
@@ -75,6 +81,9 @@ class Job:
             raise JobShopSchedulingProblemException("A job may visit every machine at most once!")
         if any(op.job_name != self.name for op in self.operations):
             raise JobShopSchedulingProblemException("Every operation must carry the name of its job!")
+
+    def __repr__(self) -> str:
+        return f"{self.name}:\n" + "".join(f"  {operation!r}\n" for operation in self.operations)
 
     def is_consistent_with_machines(self, machines: tuple[Machine, ...]) -> bool:
         """Does every operation of the job run on one of ``machines``?  (reference: problem_instances.py:91-103)"""
@@ -98,6 +107,12 @@ class JobShopSchedulingProblemInstance:
             if not job.is_consistent_with_machines(self.machines):
                 raise JobShopSchedulingProblemException("A job uses a machine the instance does not have!")
 
+    def __repr__(self) -> str:
+        lines = [self.name, "  Machines:"] + [f"    {machine!r}" for machine in self.machines] + ["  Jobs:"]
+        for job in self.jobs:
+            lines += ["    " + line for line in repr(job).splitlines()]
+        return "\n".join(lines) + "\n"
+
 
 @dataclass(frozen=True)
 class PotentiallyScheduledOperation:
@@ -118,6 +133,9 @@ class UnscheduledOperation(PotentiallyScheduledOperation):
     def is_scheduled(self) -> bool:
         return False
 
+    def __repr__(self) -> str:
+        return f"{self.operation!r} was not scheduled."
+
 
 @dataclass(frozen=True)
 class ScheduledOperation(PotentiallyScheduledOperation):
@@ -130,6 +148,9 @@ class ScheduledOperation(PotentiallyScheduledOperation):
     @property
     def end_time(self) -> int:
         return self.start_time + self.operation.processing_duration
+
+    def __repr__(self) -> str:
+        return f"{self.operation!r} starts at: {self.start_time} and ends at: {self.end_time}"
 
 
 class JobShopSchedulingResult:
@@ -212,7 +233,11 @@ class JobShopSchedulingResult:
         return hash((self._problem_instance, tuple(sorted((job.name, entries) for job, entries in self._schedule.items()))))
 
     def __repr__(self) -> str:
-        return f"JobShopSchedulingResult(valid={self._is_valid}, makespan={self.makespan}, start_times={self.start_times})"
+        lines = [f"{self._problem_instance.name} solution with makespan {self.makespan}"]
+        for job in self._problem_instance.jobs:
+            lines.append(f"  {job.name}:")
+            lines += [f"    {entry!r}" for entry in self._schedule[job]]
+        return "\n".join(lines) + "\n"
 
 
 class _Poly(dict):

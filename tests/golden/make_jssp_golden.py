@@ -64,11 +64,13 @@ def main() -> None:
             })
             if k in (0, 5):  # (the whole result in the wire format, instance included: two per case are enough)
                 schedules[-1]["wire"] = json.loads(json.dumps(result, cls=JSSPJSONEncoder))
+                schedules[-1]["repr"] = repr(result)  # (what a notebook prints)
         jsonable_args = dict(args)
         for key in ("relative_op_amount", "op_duration"):  # (JSON objects have string keys: distributions as pair lists)
             if isinstance(jsonable_args[key], dict):
                 jsonable_args[key] = {"distribution": [[k, v] for k, v in jsonable_args[key].items()]}
-        out.append({"arguments": jsonable_args, "wire": json.loads(text), "text_indent_2": text, "schedules": schedules})
+        out.append({"arguments": jsonable_args, "wire": json.loads(text), "text_indent_2": text, "repr": repr(instance),
+                    "schedules": schedules})
     path = Path(__file__).resolve().parent / "jssp_reference.json"
     path.write_text(json.dumps({"source": "the reference's own modules, run by tests/golden/make_jssp_golden.py", "cases": out},
                                separators=(",", ":")) + "\n")

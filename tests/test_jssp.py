@@ -265,6 +265,7 @@ def test_random_instances_are_the_references_for_the_same_seed():
         assert json.loads(json.dumps(case["wire"]), cls=jss.JSSPJSONDecoder) == instance
         assert json.dumps(instance, cls=jss.JSSPJSONEncoder, indent=2) == case["text_indent_2"]
         assert json.loads(case["text_indent_2"], cls=jss.JSSPJSONDecoder) == instance
+        assert repr(instance) == case["repr"] and str(instance) == case["repr"]  # (what a notebook prints)
     with pytest.raises(ValueError):
         jss.random_job_shop_scheduling_instance("x", 2, 2, {0.5: 0.4, 1.0: 0.4}, 1, random_seed=0)
 
@@ -284,4 +285,5 @@ def test_schedule_validity_and_makespan_are_the_references():
             if "wire" in entry:
                 assert json.loads(json.dumps(result, cls=jss.JSSPJSONEncoder)) == entry["wire"]
                 assert json.loads(json.dumps(entry["wire"]), cls=jss.JSSPJSONDecoder) == result
+                assert repr(result) == entry["repr"]
     assert n_valid >= 15
