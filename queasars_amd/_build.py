@@ -54,12 +54,13 @@ def build_pyhelp(force: bool = False) -> "Path | None":
     gcc = shutil.which("gcc")
     if not gcc or not include or not (Path(include) / "Python.h").exists():
         return None
-    tmp = PYHELP_PATH.with_suffix(".so.tmp")
+    tmp = PYHELP_PATH.with_suffix(f".so.{os.getpid()}.tmp")  # (ranks that start together each write their own file)
     if not LIB_PATH.exists():
         return None  # the helper links against libqsv.so (it drives qsv_eval_begin / push / end itself)
     res = subprocess.run([gcc, "-O2", "-shared", "-fPIC", f"-I{include}", str(src), "-o", str(tmp), f"-L{PKG_DIR}", "-lqsv",
                           "-Wl,-rpath,$ORIGIN"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if res.returncode != 0:
+        tmp.unlink(missing_ok=True)
         return None
     os.replace(tmp, PYHELP_PATH)
     return PYHELP_PATH
@@ -102,7 +103,7 @@ def build(force: bool = False, verbose: bool = False, defines: tuple = (), lib_p
             raise RuntimeError(f"hipcc failed on {src}:\n{out}")
         if verbose and out.strip():
             print(out)
-    tmp = lib_path.with_suffix(".so.tmp")
+    tmp = lib_path.with_suffix(f".so.{os.getpid()}.tmp")
     link = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(tmp), *objs]
     res = subprocess.run(link, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if res.returncode != 0:

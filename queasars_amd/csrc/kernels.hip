@@ -1634,6 +1634,7 @@ __global__ void __launch_bounds__(256) spsa_step_kernel(const SpsaStepArgs a) {
         const double f_plus = a.values[2 * r], f_minus = a.values[2 * r + 1];
         const double g = (f_plus - f_minus) / (2.0 * a.eps);
         const bool was_active = a.active[r] != 0;
+        __syncthreads();  // (every wave has read the flag before thread 0 may store the new one further down)
         double scale = 1.0;
         if (a.trust_region) {
             double acc = 0.0;

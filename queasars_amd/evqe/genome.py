@@ -296,6 +296,28 @@ class EVQEIndividual:
             start += layer.n_parameters
         return out
 
+    @cached_property
+    def circuit_parameter_offsets(self) -> dict[int, int]:
+        """layer -> where its parameters start in the FULLY parameterised circuit, whose flat parameter list is name
+        sorted: the blocks follow the string order of their prefixes layer{i}_ (layer10_ sorts before layer2_), not the
+        layer order ``parameter_values`` is kept in (the offsets of get_partially_parameterized_quantum_circuit with
+        every layer chosen)."""
+        out, cursor = {}, 0
+        for i in sorted(range(len(self.layers)), key=lambda j: f"layer{j}_"):
+            out[i] = cursor
+            cursor += self.layers[i].n_parameters
+        return out
+
+    def parameter_values_in_circuit_order(self) -> tuple[float, ...]:
+        """This individual's values laid out so that the fully parameterised circuit gives every layer ITS values (what
+        binding layer by layer does, individual.py:288-322); equal to ``parameter_values`` up to ten layers."""
+        out = [0.0] * len(self.parameter_values)
+        for i in range(len(self.layers)):
+            start = self.circuit_parameter_offsets[i]
+            for k, j in enumerate(self.layer_parameter_indices[i]):
+                out[start + k] = self.parameter_values[j]
+        return tuple(out)
+
     @staticmethod
     def random_individual(
         n_qubits: int, n_layers: int, randomize_parameter_values: bool, random_seed: Optional[int] = None
@@ -390,7 +412,17 @@ class EVQEIndividual:
     def get_quantum_circuit(self) -> CircuitIR:
         """The circuit with every angle bound to this individual's values: no free parameters (reference:
         base/evolutionary_algorithm.py:20-27, ``get_parameterized_quantum_circuit().assign_parameters(values)``)."""
-        return self.get_partially_parameterized_quantum_circuit(set())
+        if len(self.layers) <= 10:
+            return self.get_partially_parameterized_quantum_circuit(set())
+        # From eleven layers on the reference's flat binding is NOT the layer-by-layer one: assign_parameters takes the values
+        # in name-sorted order, where the block of layer10_ comes before that of layer2_ -- layer i gets the values that sit at
+        # its block's place in the flat list (the fitness evaluation, selection.py:75-82, binds the same way).  Followed as is.
+        effective = list(self.parameter_values)
+        for i, layer in enumerate(self.layers):
+            start = self.circuit_parameter_offsets[i]
+            for k, j in enumerate(self.layer_parameter_indices[i]):
+                effective[j] = self.parameter_values[start + k]
+        return EVQEIndividual(self.n_qubits, self.layers, tuple(effective)).get_partially_parameterized_quantum_circuit(set())
 
     def get_parameterized_quantum_circuit(self, shared: bool = False) -> CircuitIR:
         """Every layer with free parameters.  ``shared=True``: ONE circuit object per structure (qubits and layers), handed

@@ -497,8 +497,12 @@ class EVQEMinimumEigensolver:
             run = self.configuration.optimizer.new_run(individual.get_layer_parameter_values(layer_id), seed)
             if embed:
                 circuit = individual.get_parameterized_quantum_circuit(shared=True)
-                positions = np.asarray(individual.layer_parameter_indices[layer_id % len(individual.layers)], dtype=np.int64)
-                run.embed = (np.asarray(individual.parameter_values, dtype=np.float64), positions)
+                # (positions and the other layers' values in the CIRCUIT's parameter order -- name-sorted blocks, which is
+                # the layer order only up to ten layers: layer10_ sorts before layer2_)
+                layer = layer_id % len(individual.layers)
+                start = individual.circuit_parameter_offsets[layer]
+                positions = np.arange(start, start + individual.layers[layer].n_parameters, dtype=np.int64)
+                run.embed = (np.asarray(individual.parameter_values_in_circuit_order(), dtype=np.float64), positions)
             else:
                 circuit = individual.get_partially_parameterized_quantum_circuit({layer_id})
             jobs.append((circuit, run))

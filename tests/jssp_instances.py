@@ -23,6 +23,14 @@ def notebook_2x3():
     return JobShopSchedulingProblemInstance("2_jobs_3_machines_seed_121", m, (j0, j1))
 
 
+def runtime_simple_instance():
+    """examples/using_the_ibm_runtime.ipynb cell 2 ("Simple Instance"): 8 qubits at makespan_limit 5 (cell 6's output)."""
+    m = (Machine("m0"), Machine("m1"))
+    j0 = Job("j0", (Operation("j0op0", "j0", m[0], 2), Operation("j0op1", "j0", m[1], 1)))
+    j1 = Job("j1", (Operation("j1op1", "j1", m[0], 1), Operation("j1op2", "j1", m[1], 2)))
+    return JobShopSchedulingProblemInstance("Simple Instance", m, (j0, j1))
+
+
 def small_2x2():
     """examples/evqe_jssp_small_examples.ipynb cell 4: 4 qubits at makespan_limit 3."""
     m = (Machine("m0"), Machine("m1"))

@@ -384,3 +384,42 @@ def test_search_on_shared_fully_parameterised_circuits_is_the_search_on_bound_on
     monkeypatch.setenv("QSV_SHARE_CIRCUITS", "2")
     scalar = EVQEMinimumEigensolver(make_config()).compute_minimum_eigenvalue(OracleEvaluator(op))
     assert scalar.eigenvalue == shared.eigenvalue and scalar.circuit_evaluations == shared.circuit_evaluations
+
+
+def test_embedded_search_of_an_individual_with_more_than_ten_layers(monkeypatch):
+    """The fully parameterised circuit numbers its parameters in name-sorted block order (layer10_ before layer2_), the
+    individual keeps its values in layer order: from eleven layers on the two differ, and the embedded search has to place
+    the searched layer's point -- and every other layer's values -- by the circuit's order.  Every point of the embedded
+    form gives the ops of the bound circuit (mutation.py:57-59: a layer alone, the others bound), and the two searches
+    return the same individuals."""
+    from queasars_amd.evqe.genome import EVQEIndividual
+    from queasars_amd.evqe.solver import _full_point
+
+    individual = EVQEIndividual.random_individual(4, 12, True, random_seed=5)
+    full = individual.get_parameterized_quantum_circuit(shared=True)
+    base = np.asarray(individual.parameter_values_in_circuit_order())
+    assert sorted(base.tolist()) == sorted(individual.parameter_values) and base.tolist() != list(individual.parameter_values)
+    for layer in (5, 10, 1, 11, -1):
+        layer %= 12
+        bound = individual.get_partially_parameterized_quantum_circuit({layer})
+        start = individual.circuit_parameter_offsets[layer]
+        positions = np.arange(start, start + individual.layers[layer].n_parameters)
+
+        class Run:
+            embed = (base, positions)
+
+        point = np.linspace(0.1, 0.9, positions.size)
+        assert full.bound_ops(_full_point(Run, point).tolist()) == bound.bound_ops(point.tolist())
+    # the individual's own values at its own layer: the bound circuit again
+    assert full.bound_ops(base.tolist()) == individual.get_partially_parameterized_quantum_circuit(set()).bound_ops([])
+
+    op = xy_hamiltonian()
+    solver_results = {}
+    for share in ("2", "0"):
+        monkeypatch.setenv("QSV_SHARE_CIRCUITS", share)
+        solver = EVQEMinimumEigensolver(make_config(optimizer=SPSA(maxiter=6, learning_rate=0.4, perturbation=0.3)))
+        individuals = [EVQEIndividual.random_individual(4, 12, True, random_seed=s) for s in (5, 6, 7)]
+        solver_results[share] = solver._optimize_layers(OracleEvaluator(op), individuals, [5, 10, -1], [11, 12, 13])
+    assert solver_results["2"][1] == solver_results["0"][1]
+    for a, b in zip(solver_results["2"][0], solver_results["0"][0]):
+        assert a == b

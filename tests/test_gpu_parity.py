@@ -479,6 +479,32 @@ def test_jssp_notebook_energy_on_gpu():
     assert np.abs(np.asarray(got) - np.asarray(ref)).max() < 1e-9
 
 
+def test_runtime_notebook_energy_on_gpu():
+    """examples/using_the_ibm_runtime.ipynb: the 8-qubit "Simple Instance" (cell 2, encoder arguments of cell 6) has minimum
+    energy 22.75 (cell 8's output), at the makespan-4 schedule cell 14 prints -- through the estimator, the sampler / CVaR
+    branch and the exact-probability CVaR."""
+    import jssp_instances as inst
+    from queasars_amd.circuit_evaluation import OperatorSamplerCircuitEvaluator
+    from queasars_amd.job_shop_scheduling import JSSPDomainWallHamiltonianEncoder
+
+    enc = JSSPDomainWallHamiltonianEncoder(inst.runtime_simple_instance(), makespan_limit=5, **inst.NOTEBOOK_PENALTIES)
+    assert enc.n_qubits == 8
+    op = enc.get_problem_hamiltonian()
+    starts = {}
+    for job, times in zip(enc.jssp_instance.jobs, [(1, 3), (0, 1)]):
+        starts.update(dict(zip(job.operations, times)))
+    bitstring = enc.bitstring_of(starts)
+    prep = CircuitIR(enc.n_qubits)
+    for q, bit in enumerate(bitstring[::-1]):
+        if bit == "1":
+            prep.u(np.pi, 0.0, np.pi, q)
+        else:
+            prep.id(q)
+    assert abs(OperatorCircuitEvaluator(op).evaluate_circuits([prep], [[]])[0] - 22.75) < 1e-10
+    assert abs(OperatorSamplerCircuitEvaluator(512, op, alpha=0.5, seed=1).evaluate_circuits([prep], [[]])[0] - 22.75) < 1e-9
+    assert abs(OperatorSamplerCircuitEvaluator(None, op, alpha=0.5).evaluate_circuits([prep], [[]])[0] - 22.75) < 1e-10
+
+
 def test_config4_jssp_end_to_end_evqe():
     """BASELINE config 4: EVQE (sampler + CVaR 0.5, 512 shots, SPSA 33 iterations, population 10) on the notebook's
     12-qubit JSSP instance reaches the notebook's final energy 22.75 with a valid makespan-5 schedule

@@ -41,6 +41,22 @@ def test_notebook_energy_22_75():
     assert abs(valid_min - 22.75) < 1e-9 and abs(all_e.min() - 22.75) < 1e-9
 
 
+def test_runtime_notebook_energy_22_75():
+    """The fourth energy the reference holds: examples/using_the_ibm_runtime.ipynb, cell 8's output ("Current best expectation
+    value: 22.750000" from generation 1 on) on the 8-qubit "Simple Instance" of cell 2 with cell 6's encoder arguments; cell
+    14 prints the makespan-4 schedule (j0: 1, 3; j1: 0, 1) as the most probable state of the result."""
+    enc = JSSPDomainWallHamiltonianEncoder(inst.runtime_simple_instance(), makespan_limit=5, **inst.NOTEBOOK_PENALTIES)
+    assert enc.n_qubits == 8  # cell 6: "needed qubits:  8"
+    value, result = energy_of(enc, [(1, 3), (0, 1)])
+    assert result.is_valid and result.makespan == 4
+    assert abs(value - 22.75) < 1e-9
+    all_e = energies(enc)
+    assert abs(all_e.min() - 22.75) < 1e-9
+    # the other schedule cell 14 prints (j0: 0, 3; j1: 0, 1) overlaps on m0: not valid, and dearer
+    other, result = energy_of(enc, [(0, 3), (0, 1)])
+    assert not result.is_valid and other > 22.75
+
+
 def test_small_example_energies():
     enc = JSSPDomainWallHamiltonianEncoder(inst.small_2x2(), makespan_limit=3, **inst.NOTEBOOK_PENALTIES)
     assert enc.n_qubits == 4
