@@ -132,6 +132,43 @@ int qsv_circuits_create(qsv_t* h, int n_circuits, const int64_t* op_offsets, con
 int qsv_circuit_destroy(qsv_t* h, int circuit_id);
 
 /*
+ * KEPT STATES.  A layer search evaluates one circuit over and over with only one layer's angles changing
+ * (reference: optimize_layer_of_individual binds every other layer, mutation.py:57-59,
+ * individual.py:288-322 get_partially_parameterized_quantum_circuit): everything in front of that layer is the same state
+ * in every evaluation.  qsv_prefix_create runs n_states (circuit, parameter vector) pairs from |0..0> ONCE and keeps their
+ * final states resident (2^n amplitudes each); a circuit registered with qsv_circuit(s)_create_on_prefix(es) starts from
+ * such a state instead of |0..0> and is evaluated by every qsv_eval_* entry point like any other circuit id (qsv_statevector
+ * too; the sampling entry points refuse it).  Unsplittable (deep) individuals then cost the passes of the layers from the
+ * searched one on, not of the whole circuit.  A kept state lives until qsv_prefix_destroy AND the last circuit registered on
+ * it is destroyed; its memory is reused afterwards.
+ */
+int qsv_prefix_create(qsv_t* h, int n_states, const int* circuit_ids, const int64_t* param_offsets, const double* params,
+                      int* out_prefix_ids);
+int qsv_prefix_destroy(qsv_t* h, int n_states, const int* prefix_ids);
+/* Kept states alive on the handle (held by the caller or by a circuit). */
+int qsv_prefix_count(const qsv_t* h);
+int qsv_circuit_create_on_prefix(qsv_t* h, int prefix_id, int n_ops, const qsv_op* ops, int n_params, int* out_circuit_id);
+int qsv_circuits_create_on_prefixes(qsv_t* h, int n_circuits, const int64_t* op_offsets, const qsv_op* ops, const int* n_params,
+                                    const int* prefix_ids, int* out_circuit_ids);
+
+/*
+ * Which way an expectation value of a registered circuit goes under the operator set now, and about what it costs: what a
+ * scheduler needs to deal individuals of unequal depth to several GPUs (the reference balances dynamically, one future per
+ * individual on a pool: selection.py:75-82, mutation.py:206-216), and what decides whether a layer search is worth a kept
+ * state.  microseconds: GPU time per evaluation inside a full launch, from the measured figures of DESIGN.md (an estimate:
+ * only ratios matter to its users).
+ */
+enum { QSV_ROUTE_ONE_TILE = 0, QSV_ROUTE_SPLIT_ONE_LAUNCH = 1, QSV_ROUTE_SPLIT = 2, QSV_ROUTE_PASSES = 3 };
+typedef struct qsv_circuit_cost_t {
+    int32_t route;         /* QSV_ROUTE_* */
+    int32_t n_keys;        /* split routes: cut keys (2^keys product terms) */
+    int32_t n_passes;      /* gate passes (split routes: of the longer virtual circuit) */
+    int32_t on_kept_state; /* the circuit continues a kept state */
+    double microseconds;
+} qsv_circuit_cost_t;
+int qsv_circuit_cost(qsv_t* h, int circuit_id, qsv_circuit_cost_t* out);
+
+/*
  * Expectation values real(<psi_i|H|psi_i>) of n_evals (circuit, parameter vector) pairs, |psi_i> prepared from
  * |0..0>.  params holds the vectors back to back, vector i at params[param_offsets[i] .. param_offsets[i+1]).
  * Replaces `estimator.run(pubs, precision=0).result()` + `real(res.data.evs)` (circuit_evaluation.py:210-215).

@@ -88,6 +88,20 @@ class QsvProfile(C.Structure):
     ]
 
 
+class QsvCircuitCost(C.Structure):
+    """``qsv_circuit_cost_t`` of include/qsv.h."""
+
+    _fields_ = [
+        ("route", C.c_int32),
+        ("n_keys", C.c_int32),
+        ("n_passes", C.c_int32),
+        ("on_kept_state", C.c_int32),
+        ("microseconds", C.c_double),
+    ]
+
+
+ROUTE_NAMES = ("one tile", "split, one launch", "split", "gate passes")
+
 assert C.sizeof(QsvOp) == 40
 
 # every symbol include/qsv.h declares: (restype, argtypes)
@@ -103,6 +117,12 @@ SIGNATURES = {
     "qsv_circuit_create": (C.c_int, [_P, C.c_int, _P, C.c_int, C.POINTER(C.c_int)]),
     "qsv_circuits_create": (C.c_int, [_P, C.c_int, _P, _P, _P, _P]),
     "qsv_circuit_destroy": (C.c_int, [_P, C.c_int]),
+    "qsv_prefix_create": (C.c_int, [_P, C.c_int, _P, _P, _P, _P]),
+    "qsv_prefix_destroy": (C.c_int, [_P, C.c_int, _P]),
+    "qsv_prefix_count": (C.c_int, [_P]),
+    "qsv_circuit_create_on_prefix": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, C.POINTER(C.c_int)]),
+    "qsv_circuits_create_on_prefixes": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P]),
+    "qsv_circuit_cost": (C.c_int, [_P, C.c_int, C.POINTER(QsvCircuitCost)]),
     "qsv_eval_circuits": (C.c_int, [_P, C.c_int, _P, _P, _P, _P]),
     "qsv_eval_coalesced": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_double, C.POINTER(C.c_double)]),
     "qsv_eval_begin": (C.c_int, [_P, C.c_int, _P, _P]),

@@ -5,6 +5,7 @@ from queasars_amd.circuit_evaluation.circuit_evaluation import (  # noqa: F401
     BaseCircuitEvaluator,
     BitstringCircuitEvaluator,
     CircuitEvaluatorException,
+    KeptState,
     OperatorCircuitEvaluator,
     OperatorSamplerCircuitEvaluator,
     StatevectorDevice,

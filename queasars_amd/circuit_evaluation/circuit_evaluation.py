@@ -172,6 +172,33 @@ def _make_gone(dead: list, watched: dict):
     return gone
 
 
+class KeptState:
+    """A state kept resident on a device (``StatevectorDevice.keep_states``): what a layer search's evaluations have in common
+    (reference: optimize_layer_of_individual, mutation.py:57-59).  Circuits made to start from it with
+    ``CircuitIR.continue_from`` hold it; its memory on the device is reused once it and they are gone."""
+
+    __slots__ = ("_owner", "_serial", "_id", "n_qubits", "__weakref__")
+
+    def __init__(self, owner: "StatevectorDevice", prefix_id: int):
+        self._owner = weakref.ref(owner)
+        self._serial = owner._serial
+        self._id = int(prefix_id)
+        self.n_qubits = owner.n_qubits
+
+    def release(self) -> None:
+        """Let go now (idempotent).  Circuits that continue this state keep it alive on the device until they are gone."""
+        pid, self._id = self._id, -1
+        owner = self._owner()
+        if pid >= 0 and owner is not None:
+            owner._dead_states.append(pid)  # (destroyed at the next registration: never from inside an open batch)
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:  # pragma: no cover
+            pass
+
+
 class StatevectorDevice:
     """Owns one ``qsv_t`` handle: the resident state buffers, plans and operator tables of one GPU.
 
@@ -223,6 +250,7 @@ class StatevectorDevice:
         # allocation, also between qsv_eval_begin and qsv_eval_end, where a call into the library would wait for the
         # handle this very thread holds); the ids are destroyed at the start of the next call that registers circuits.
         self._dead: list[int] = []
+        self._dead_states: list[int] = []  # (ids of kept states whose KeptState objects are gone, likewise)
         self._watched: dict[int, tuple] = {}  # id(weak reference) -> (weak reference to a CircuitIR, its circuit id)
         self._gone = _make_gone(self._dead, self._watched)  # (holds the two containers, not the device)
         # held across "set the operator, then evaluate" by evaluators that share this device
@@ -300,9 +328,14 @@ class StatevectorDevice:
             if cid is None:
                 ops = circuit.packed()
                 out = C.c_int(0)
-                self._check(
-                    self._lib.qsv_circuit_create(self._handle, len(ops), _lib.as_ptr(ops), circuit.num_parameters, C.byref(out))
-                )
+                kept = circuit._kept_state
+                if kept is not None:
+                    self._check(self._lib.qsv_circuit_create_on_prefix(self._handle, self._kept_id(kept), len(ops), _lib.as_ptr(ops),
+                                                                       circuit.num_parameters, C.byref(out)))
+                else:
+                    self._check(
+                        self._lib.qsv_circuit_create(self._handle, len(ops), _lib.as_ptr(ops), circuit.num_parameters, C.byref(out))
+                    )
                 cid = out.value
                 circuit._registered[self._serial] = cid
                 # drop the device-side plan when the circuit object goes away
@@ -320,6 +353,11 @@ class StatevectorDevice:
                 raise ValueError(f"circuit has {c.n_qubits} qubits, the evaluator {self._n_qubits}")
         with self._reg_lock:
             fresh = [c for c in fresh if self._serial not in c._registered]
+            continued = [c for c in fresh if c._kept_state is not None]
+            if continued:
+                fresh = [c for c in fresh if c._kept_state is None]
+                if len(continued) >= 2:
+                    self._register_continued(continued)
             if len(fresh) < 2:
                 return
             joined = b"".join([c._bytes for c in fresh])
@@ -335,6 +373,76 @@ class StatevectorDevice:
                 c._registered[self._serial] = cid
                 self._watch(c, cid)
 
+    def _register_continued(self, circuits: Sequence[CircuitIR]) -> None:
+        """``qsv_circuits_create_on_prefixes`` for circuits that continue kept states (caller holds ``_reg_lock``)."""
+        joined = b"".join([c._bytes for c in circuits])
+        ops = np.frombuffer(joined, dtype=QSV_OP_DTYPE) if joined else np.zeros(1, dtype=QSV_OP_DTYPE)
+        offsets = np.zeros(len(circuits) + 1, dtype=np.int64)
+        np.cumsum([len(c._bytes) for c in circuits], out=offsets[1:])
+        offsets //= QSV_OP_DTYPE.itemsize
+        counts = np.asarray([c.num_parameters for c in circuits], dtype=np.int32)
+        states = np.asarray([self._kept_id(c._kept_state) for c in circuits], dtype=np.int32)
+        out = np.zeros(len(circuits), dtype=np.int32)
+        self._check(self._lib.qsv_circuits_create_on_prefixes(self._handle, len(circuits), _lib.as_ptr(offsets), _lib.as_ptr(ops),
+                                                              _lib.as_ptr(counts), _lib.as_ptr(states), _lib.as_ptr(out)))
+        for c, cid in zip(circuits, out.tolist()):
+            c._registered[self._serial] = cid
+            self._watch(c, cid)
+
+    def _kept_id(self, kept: "KeptState") -> int:
+        if kept._serial != self._serial or kept._id < 0:
+            raise ValueError("the circuit continues a state that is not kept on this device (or was released)")
+        return kept._id
+
+    # -- kept states ------------------------------------------------------------------------------
+    def keep_states(self, circuits: Sequence[CircuitIR], parameter_values: Sequence[Sequence[float]]) -> list[KeptState]:
+        """Run every (circuit, parameter vector) pair from |0..0> once and keep its final state resident
+        (``qsv_prefix_create``): circuits made with ``CircuitIR.continue_from(state)`` then start there.  What a layer search
+        does with everything in front of the searched layer (reference: mutation.py:57-59)."""
+        n = len(circuits)
+        if len(parameter_values) != n:
+            raise ValueError("circuits and parameter_values must have the same length")
+        if n == 0:
+            return []
+        if any(c._kept_state is not None for c in circuits):
+            raise ValueError("a kept state of a circuit that itself continues a kept state is not supported")
+        self._register_many([c for c in circuits if self._serial not in c._registered])
+        ids = np.fromiter((self.circuit_id(c) for c in circuits), dtype=np.int32, count=n)
+        need = [c.num_parameters for c in circuits]
+        counts = np.fromiter(map(len, parameter_values), dtype=np.int64, count=n)
+        for i in range(n):
+            if counts[i] < need[i]:
+                raise ValueError(f"circuit {i} needs {need[i]} parameter values, got {int(counts[i])}")
+        offsets = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(counts, out=offsets[1:])
+        flat = _pack_slice(parameter_values, 0, n, int(offsets[-1])) if offsets[-1] else np.zeros(1)
+        out = np.zeros(n, dtype=np.int32)
+        with self._reg_lock:
+            self._reap()
+        self._check(self._lib.qsv_prefix_create(self._handle, n, _lib.as_ptr(ids), _lib.as_ptr(offsets), _lib.as_ptr(flat), _lib.as_ptr(out)))
+        return [KeptState(self, pid) for pid in out.tolist()]
+
+    def forget_last_batch(self) -> None:
+        """Drop what the device remembers of the previous call (its circuit objects, by identity): circuits that continue kept
+        states then die with their last user, and the states' memory is free for the next search."""
+        self._last_batch = None
+        self._row_counts = None
+        self._ids_address = None
+
+    def kept_state_count(self) -> int:
+        """Kept states alive on the device (held by a ``KeptState`` or by a registered circuit)."""
+        with self._reg_lock:
+            self._reap()
+        return int(self._lib.qsv_prefix_count(self._handle))
+
+    def circuit_cost(self, circuit: CircuitIR) -> dict:
+        """Which way an expectation value of ``circuit`` goes on this device under the operator set now, and about what it
+        costs (``qsv_circuit_cost``): {"route", "n_keys", "n_passes", "on_kept_state", "microseconds"}."""
+        cost = _lib.QsvCircuitCost()
+        self._check(self._lib.qsv_circuit_cost(self._handle, self.circuit_id(circuit), C.byref(cost)))
+        return {"route": _lib.ROUTE_NAMES[cost.route], "n_keys": cost.n_keys, "n_passes": cost.n_passes,
+                "on_kept_state": bool(cost.on_kept_state), "microseconds": cost.microseconds}
+
     def _watch(self, circuit: CircuitIR, cid: int) -> None:
         """Note the device-side plan ``cid`` for destruction once ``circuit`` is garbage collected.  (A plain weak
         reference with a callback, kept alive in a dict: ``weakref.finalize`` cost 1.4 us per circuit -- 90 us of the
@@ -348,6 +456,10 @@ class StatevectorDevice:
             cid = self._dead.pop()
             if self._handle:
                 self._lib.qsv_circuit_destroy(self._handle, cid)
+        while self._dead_states:
+            pid = C.c_int(self._dead_states.pop())
+            if self._handle:
+                self._lib.qsv_prefix_destroy(self._handle, 1, C.byref(pid))
 
     def _batch_metadata(self, circuits: Sequence[CircuitIR]) -> tuple[np.ndarray, np.ndarray, int]:
         """(circuit ids, parameter counts, sum of the counts) of a batch.  An optimiser calls with the same circuit objects over and
@@ -362,7 +474,7 @@ class StatevectorDevice:
                     return cached[2], cached[3], cached[4]
             elif cached[0] == (CircuitIR.edits_of_registered, *map(id, circuits)):
                 return cached[2], cached[3], cached[4]
-        if self._dead:
+        if self._dead or self._dead_states:
             with self._reg_lock:
                 self._reap()
         self._register_many([c for c in circuits if self._serial not in c._registered])
@@ -726,7 +838,7 @@ class _ComposedCircuits:
         return (_ComposedCircuits, (self._initial, self._limit))
 
     def get(self, circuit: CircuitIR) -> CircuitIR:
-        if self._initial is None:
+        if self._initial is None or circuit._kept_state is not None:  # (a kept state already has the initial state in it)
             return circuit
         key = id(circuit)
         hit = self._entries.get(key)
@@ -870,6 +982,29 @@ class OperatorCircuitEvaluator(BaseCircuitEvaluator):
             if self._device._operator is not self._operator:
                 self._device.set_operator(self._operator)
             return self._evaluate_device_matrix(circuits, matrix, ready)
+
+    def keep_states(self, circuits: list[CircuitIR], parameter_values: list[list[float]]) -> list[KeptState]:
+        """The final states of the (circuit, parameter vector) pairs -- behind this evaluator's initial state, if it has one --
+        kept resident on the device (:meth:`StatevectorDevice.keep_states`); circuits made with
+        ``CircuitIR.continue_from(state)`` are then evaluated from there by every method of this class."""
+        if self._initial_state_circuit is not None:
+            circuits = [self._with_initial_state(c) for c in circuits]
+        return self._device.keep_states(circuits, parameter_values)
+
+    def forget_circuits(self) -> None:
+        """:meth:`StatevectorDevice.forget_last_batch`, and this evaluator's own memory of its last list of circuits."""
+        self._composed_lists = None
+        self._device.forget_last_batch()
+
+    def circuit_costs(self, circuits: list[CircuitIR]) -> list[dict]:
+        """:meth:`StatevectorDevice.circuit_cost` of every circuit as this evaluator would run it (its operator set)."""
+        if self._initial_state_circuit is not None:
+            circuits = [self._with_initial_state(c) for c in circuits]
+        with self._device.operator_lock:
+            if self._device._operator is not self._operator:
+                self._device.set_operator(self._operator)
+            self._device._register_many([c for c in circuits if self._device._serial not in c._registered])
+            return [self._device.circuit_cost(c) for c in circuits]
 
     def device_resident_search_possible(self) -> bool:
         """Can an optimiser keep its points and values in this evaluator's device memory (:meth:`evaluate_device_to_device`)?

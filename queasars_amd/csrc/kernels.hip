@@ -323,6 +323,7 @@ struct PassScalars {
     double* factor_scratch;
     uint32_t* factor_counters;
     uint32_t n_full;
+    const void* prefix_states;
 };
 
 // XMODE selects how a tile is transposed through LDS:
@@ -706,6 +707,7 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, FIRST>::waves_per_si
         ev.state_slot = e[2];
         ev.out_index = e[3];
         ev.flags = e[6];
+        ev.split_base = e[7];
     }
     if (ev.flags & kEvalNull) return;
     const bool side = ev.flags & kEvalSide;  // a virtual circuit of a split evaluation (split.hpp)
@@ -742,6 +744,11 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, FIRST>::waves_per_si
     // (a side of a split evaluation is one tile: its state goes to the side's half of the slot's table)
     cxr* __restrict__ st0 = side ? wt0 + ((ev.flags & kEvalSideB) ? a.wtab_stride >> 1 : 0)
                                  : states + uint64_t(ev.state_slot) * a.state_stride;
+    // (a circuit that continues a kept state reads its first pass's input there, kernels.hpp kEvalPrefix)
+    const cxr* __restrict__ ld0 = st0;
+    if constexpr (!FIRST)
+        if ((ev.flags & kEvalPrefix) && a.pass_index == 0)
+            ld0 = static_cast<const cxr*>(a.prefix_states) + uint64_t(ev.split_base) * a.state_stride;
     // Global offsets inside a state are XORs of plan columns.  While a state's byte size fits 32 bits (n <= 28 in
     // fp64) they are kept as BYTE offsets in one 32-bit register per element next to a uniform tile pointer (one
     // v_xor per access, scalar-base addressing); larger states take the 64-bit path.
@@ -840,7 +847,7 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, FIRST>::waves_per_si
             const uint32_t wbase = ti[2], fbase = ti[3];  // (zero unless this is a COMPACT_LOAD pass)
             if (active) {
                 if (!wide || cload) {
-                    const unsigned char* tile = reinterpret_cast<const unsigned char*>(cload ? wt0 : st0 + base);
+                    const unsigned char* tile = reinterpret_cast<const unsigned char*>(cload ? wt0 : ld0 + base);
                     cu32p rcols = cload ? pp + kPassCompactWCols + kMaxThreadBits : glr;
                     uint32_t ob = (cload ? wbase ^ wthr : tgv) << ASH;
 #pragma unroll
@@ -865,7 +872,7 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, FIRST>::waves_per_si
 #pragma unroll
                     for (int i = 0; i < NR; ++i) {
                         off = gray_step(i, off, glr);
-                        amp[gray_index(i)] = st0[base + off];
+                        amp[gray_index(i)] = ld0[base + off];
                     }
                 }
 #ifndef QSV_ABL_NOF
@@ -1246,7 +1253,8 @@ static hipError_t launch_pass_t(dim3 grid, int threads, size_t lds_bytes, hipStr
     const size_t lds = lds_bytes < 256 ? 256 : lds_bytes;
     const PassScalars sc{args.state_stride, args.wtab_stride, args.pass_index, args.mode, args.tiles_per_block,
                          args.partial_chunks, args.region_stride, args.host_evals, args.evals_out, args.host_params,
-                         args.mats_out, args.result_out, args.quad, args.factor_scratch, args.factor_counters, args.n_full};
+                         args.mats_out, args.result_out, args.quad, args.factor_scratch, args.factor_counters, args.n_full,
+                         args.prefix_states};
     cx<real>* st = reinterpret_cast<cx<real>*>(args.states);
     const bool first = args.pass_index == 0 && (args.mode & kModeSynthFirst);
     if (first)
@@ -1291,7 +1299,8 @@ static hipError_t pass_dispatch(int op, int dtype, int r, int xmode, dim3 grid, 
     if (op) return hipSuccess;
     const PassScalars sc{args->state_stride, args->wtab_stride, args->pass_index, args->mode, args->tiles_per_block,
                          args->partial_chunks, args->region_stride, args->host_evals, args->evals_out, args->host_params,
-                         args->mats_out, args->result_out, args->quad, args->factor_scratch, args->factor_counters, args->n_full};
+                         args->mats_out, args->result_out, args->quad, args->factor_scratch, args->factor_counters, args->n_full,
+                          args->prefix_states};
     if (args->pass_index == 0 && (args->mode & kModeSynthFirst))
         hipLaunchKernelGGL((pass_kernel<double, QSV_PROBE_R, 2, true>), grid, dim3(threads), lds_bytes, stream, args->plan,
                            args->mats, args->evals, reinterpret_cast<cx<double>*>(args->states),

@@ -26,6 +26,10 @@ constexpr uint32_t kEvalSide = 1u, kEvalSideB = 2u, kEvalNull = 4u;
 // workgroup per side, sweeping the side's tiles one after the other) also forms their weighted Gram matrices and combines
 // them (kModeFusedFactor) -- one launch per push
 constexpr uint32_t kEvalFused = 8u;
+// The circuit continues a KEPT state (qsv.h: qsv_prefix_create -- the state a layer search's evaluations have in common,
+// reference mutation.py:57-59): its plan is unfolded, its first pass runs the later-pass instantiation and reads slot
+// `split_base` of PassArgs::prefix_states instead of the evaluation's own state slot (which it then writes as usual).
+constexpr uint32_t kEvalPrefix = 16u;
 // A virtual circuit (a side's own qubits + one per key) may be this many qubits larger than a tile: it then takes the pass
 // kernel a few passes over up to 16 tiles -- nothing next to what a split evaluation saves.  (With + 2 only, populations of
 // 26 and 28 qubits mostly found no split form: 21 k and 2 k evaluations per second against 550 k at 24 qubits.)
@@ -98,6 +102,7 @@ struct PassArgs {
     double* factor_scratch;
     uint32_t* factor_counters;
     uint32_t n_full;
+    const void* prefix_states;  // kEvalPrefix: kept states, slot s at s * state_stride amplitudes (may be null otherwise)
 };
 // LDS bytes the fused factor tail of a pass launch needs (up to eight waves form a side's Gram matrices)
 constexpr size_t kFusedFactorLdsBytes = 8 * (18 * 64 + 64) * sizeof(double) + 64;

@@ -70,6 +70,15 @@ struct Circuit {
     bool uploaded = false;
     bool staged = false;            // scratch flag of upload_plans (a circuit may appear several times in a batch)
     uint32_t plan_base = 0;         // word offset in the device arena
+    int prefix_id = -1;             // >= 0: the circuit continues that kept state (qsv_circuit_create_on_prefix) instead of |0..0>
+};
+
+// A kept state (qsv_prefix_create): one slot of the handle's prefix buffer, alive while the caller holds it or a circuit
+// continues it.
+struct PrefixState {
+    uint32_t slot = 0;
+    int refs = 0;          // circuits registered on it
+    bool released = false; // the caller has let go (qsv_prefix_destroy): the slot is recycled once refs == 0
 };
 
 struct DeviceBuffer {
@@ -214,6 +223,13 @@ struct qsv_handle {
     // circuits
     std::unordered_map<int, Circuit> circuits;
     int next_circuit_id = 1;
+    // kept states (qsv_prefix_create): slots of one buffer that grows by doubling
+    std::unordered_map<int, PrefixState> prefixes;
+    int next_prefix_id = 1;
+    DeviceBuffer d_prefix;
+    size_t prefix_slots = 0;           // capacity
+    std::vector<uint32_t> prefix_free; // recycled slots
+    size_t prefix_used = 0;            // slots handed out so far (below capacity)
     std::unordered_map<std::string, int> inline_cache;
     std::unique_ptr<WorkerPool> pool;  // created on first use (qsv_circuits_create, qsv_eval_batch)
     std::mutex pool_mu;
@@ -286,6 +302,8 @@ struct qsv_handle {
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
         bool split_any = false; // some evaluation of the batch runs split: the descriptor array has a second region
         std::vector<char> split;  // per evaluation
+        bool cont_any = false;  // some evaluation continues a kept state (Circuit::prefix_id): a push puts those last
+        size_t snap_n_cont = 0;
         std::vector<uint32_t> eval_at;  // descriptor position -> evaluation (a push puts its split evaluations first)
         int ways = 1;           // streams this batch cycles over
         unsigned used_mask = 0; // side streams (bit i = side_streams[i]) with work of this batch in flight
@@ -633,6 +651,16 @@ void build_many(qsv_t* h, size_t count, const std::function<void(size_t, BuiltCi
     pool->run(count, [&](size_t i) { build(i, out[i]); });
 }
 
+// a circuit that continued kept state `id` is gone (caller holds h->mu)
+void prefix_unref(qsv_t* h, int id) {
+    auto it = h->prefixes.find(id);
+    if (it == h->prefixes.end()) return;
+    if (--it->second.refs <= 0 && it->second.released) {
+        h->prefix_free.push_back(it->second.slot);
+        h->prefixes.erase(it);
+    }
+}
+
 // (caller holds h->mu)
 int insert_circuit(qsv_t* h, Circuit&& c) {
     const int id = h->next_circuit_id++;
@@ -845,6 +873,7 @@ int batch_layout(qsv_t* h, const std::vector<Circuit*>& circs, const std::vector
     size_t total_params = 0, total_mats = 0;
     b.split.assign(n_evals, 0);
     b.split_any = false;
+    b.cont_any = false;
     b.eval_at.resize(n_evals);
     for (size_t i = 0; i < n_evals; ++i) b.eval_at[i] = uint32_t(i);
     for (size_t i = 0; i < n_evals; ++i) {
@@ -873,7 +902,13 @@ int batch_layout(qsv_t* h, const std::vector<Circuit*>& circs, const std::vector
         const Circuit& c = *circs[i];
         const uint32_t slot = uint32_t(i % size_t(h->group));
         if (!b.split[i]) {
-            hd[i] = EvalDesc{c.plan_base + c.off_plan, uint32_t(mcur), slot, uint32_t(i), uint32_t(pcur), uint32_t(n_params[i]), 0, 0};
+            uint32_t flags = 0, kept_slot = 0;
+            if (c.prefix_id >= 0) {  // (alive: a circuit registered on a kept state holds it)
+                flags = kEvalPrefix;
+                kept_slot = h->prefixes.find(c.prefix_id)->second.slot;
+                b.cont_any = true;
+            }
+            hd[i] = EvalDesc{c.plan_base + c.off_plan, uint32_t(mcur), slot, uint32_t(i), uint32_t(pcur), uint32_t(n_params[i]), flags, kept_slot};
             mcur += mat_doubles_of(h, c, false, 0);
             if (b.split_any) hd[n_evals + i] = EvalDesc{0, 0, slot, uint32_t(i), 0, 0, kEvalNull, 0};
         } else {
@@ -980,16 +1015,25 @@ bool fused_route(const qsv_t* h) { return factor_path(h) && h->d_factor_count.pt
 int run_group(qsv_t* h, const std::vector<Circuit*>& circs, size_t first, size_t count, uint32_t mode) {
     const qsv_handle::Batch& b = h->batch;
     const bool batch_split = b.split_any && b.split.size() == circs.size();
-    // descriptor position -> evaluation (eval_push put the push's split evaluations first)
-    auto eval_of = [&](size_t pos) { return batch_split ? size_t(b.eval_at[pos]) : pos; };
-    size_t n_split = 0;
+    const bool reordered = (b.split_any || b.cont_any) && b.split.size() == circs.size();
+    // descriptor position -> evaluation (eval_push put the push's split evaluations first, those on kept states last)
+    auto eval_of = [&](size_t pos) { return reordered ? size_t(b.eval_at[pos]) : pos; };
+    size_t n_split = 0, n_cont = 0;
     int max_passes = 0;
     for (size_t i = 0; i < count; ++i) {
         const size_t e = eval_of(first + i);
-        if (batch_split && b.split[e])
+        if (batch_split && b.split[e]) {
             n_split = i + 1;  // (split evaluations lead each push, so also each group of it)
-        else
+        } else {
             max_passes = std::max(max_passes, circs[e]->plan.stats.n_passes);
+            n_cont += circs[e]->prefix_id >= 0 ? 1 : 0;
+        }
+    }
+    // Evaluations that continue a kept state read it in their first pass (the later-pass instantiation of the kernel, no
+    // synthesis): a launch group holds only such evaluations, or none
+    if (n_cont > 0) {
+        if (n_cont != count) return fail(h, QSV_E_STATE, "internal: a launch group mixes evaluations on kept states with others");
+        mode &= ~uint32_t(kModeSynthFirst | kModeFusedPrepare | kModeDirectResult);
     }
     const bool any_split = n_split > 0;
     const size_t n_plain = count - n_split;
@@ -1004,6 +1048,7 @@ int run_group(qsv_t* h, const std::vector<Circuit*>& circs, size_t first, size_t
     a.partials = static_cast<double*>(h->d_partials.ptr);
     a.state_stride = uint64_t(1) << h->n;
     a.mode = mode | h->stream_mode;
+    a.prefix_states = h->d_prefix.ptr;
     // Pass 0 and the later passes have their own grids (tiles per workgroup): a compact pass 0 has few tiles and wants
     // them spread, a later pass sweeps all of them and amortises its set-up over more.  Which grid an evaluation's
     // LAST pass runs on depends on its own pass count only, so its partial sums are laid out (and added) the same
@@ -1330,13 +1375,28 @@ int eval_begin(qsv_t* h, const std::vector<Circuit*>& circs, const std::vector<i
 // it has nothing to do still costs its dispatch, and a mixed launch was mostly such workgroups.  Among the split ones
 // those with more keys first: their workgroups of the contraction take longest and should not be the tail of the
 // launch.  Returns the number of split evaluations; batch.eval_at maps positions back to evaluations.
-size_t order_split_first(qsv_t* h, size_t first, size_t count) {
+// Evaluations that continue a kept state (Circuit::prefix_id) come LAST, behind the ordinary ones: their first pass runs the
+// later-pass instantiation of the kernel, so they are launch groups of their own; *n_cont receives their number.
+size_t order_split_first(qsv_t* h, size_t first, size_t count, size_t* n_cont = nullptr) {
     qsv_handle::Batch& b = h->batch;
-    if (!b.split_any) return 0;
+    if (n_cont) *n_cont = 0;
+    if (!b.split_any && !b.cont_any) return 0;
     EvalDesc* hd = static_cast<EvalDesc*>(h->h_batch);
     const size_t P = b.circs.size();
-    std::vector<EvalDesc> tmp(hd + first, hd + first + count), tmp2(hd + P + first, hd + P + first + count);
+    std::vector<EvalDesc> tmp(hd + first, hd + first + count), tmp2;
+    if (b.split_any) tmp2.assign(hd + P + first, hd + P + first + count);
     size_t at = first, n_split = 0;
+    if (!b.split_any) {
+        for (int cont = 0; cont <= 1; ++cont)
+            for (size_t j = 0; j < count; ++j) {
+                if (int(b.circs[first + j]->prefix_id >= 0) != cont) continue;
+                hd[at] = tmp[j];
+                b.eval_at[at] = uint32_t(first + j);
+                ++at;
+                if (cont && n_cont) *n_cont += 1;
+            }
+        return 0;
+    }
     // (among the split ones first those that need launches of their own after the virtual circuits -- kEvalFused ones are
     // finished by the launch that runs theirs --, so that each kind is one contiguous range of every launch group)
     for (int fused = 0; fused <= 1; ++fused)
@@ -1351,13 +1411,15 @@ size_t order_split_first(qsv_t* h, size_t first, size_t count) {
                 ++at;
                 ++n_split;
             }
-    for (size_t j = 0; j < count; ++j) {
-        if (b.split[first + j]) continue;
-        hd[at] = tmp[j];
-        hd[P + at] = tmp2[j];
-        b.eval_at[at] = uint32_t(first + j);
-        ++at;
-    }
+    for (int cont = 0; cont <= 1; ++cont)
+        for (size_t j = 0; j < count; ++j) {
+            if (b.split[first + j] || int(b.circs[first + j]->prefix_id >= 0) != cont) continue;
+            hd[at] = tmp[j];
+            hd[P + at] = tmp2[j];
+            b.eval_at[at] = uint32_t(first + j);
+            ++at;
+            if (cont && n_cont) *n_cont += 1;
+        }
     return n_split;
 }
 
@@ -1397,8 +1459,12 @@ int eval_push(qsv_t* h, size_t first, size_t count, const double* values, const 
     b.dev_params = device_values && count > 0 ? device_values - b.param_base[first] : nullptr;
     const size_t ways = size_t(std::max(1, b.ways)), lane = ways > 1 ? size_t(b.n_pushes) % ways : 0;
     const size_t P = b.circs.size();
-    const size_t n_split = b.repeat ? b.snap_n_split : order_split_first(h, first, count);
-    if (b.whole_push) b.snap_n_split = n_split;
+    size_t n_cont = b.snap_n_cont;
+    const size_t n_split = b.repeat ? b.snap_n_split : order_split_first(h, first, count, &n_cont);
+    if (b.whole_push) {
+        b.snap_n_split = n_split;
+        b.snap_n_cont = n_cont;
+    }
     // Slots.  Ordinary evaluations: G states are resident together; on one stream the slot of an evaluation is its
     // position mod G and the stream orders every reuse; with several streams each push takes its stream's share of the
     // slots.  (The expectation kernels of the general-operator path index states by position in the launch group.)
@@ -1471,17 +1537,19 @@ int eval_push(qsv_t* h, size_t first, size_t count, const double* values, const 
     b.n_pushes += 1;
     const uint32_t mode = kModeSynthFirst | (h->diagonal ? kModeFinalDiag : kModeFinalStore) |
                           (h->has_diag_part ? kModeFinalDiag : 0u);
-    bool direct = single_workgroup_path(h, mode);
+    bool direct = single_workgroup_path(h, mode) && n_cont == 0;  // (an evaluation on a kept state does not synthesise its input)
     for (size_t j = 0; direct && j < count; ++j) direct = b.circs[first + j]->plan.stats.n_passes == 1;
     h->work = plain_stream;  // (the preparation launch concerns the ordinary evaluations only)
     int rc = batch_ship(h, first, count, values, direct ? count : n_split);
     h->work = lane_stream;
     if (rc) return rc;
     const uint32_t group_mode = mode | (direct ? uint32_t(kModeDirectResult) : 0u);
-    // launch groups: the split evaluations of the push in groups of SG, then the ordinary ones in groups of G
+    // launch groups: the split evaluations of the push in groups of SG, then the ordinary ones in groups of G, then -- in
+    // groups of their own -- those that continue a kept state
+    const size_t cont0 = first + count - n_cont;
     for (size_t g0 = first; g0 < first + count;) {
         const bool in_split = g0 < first + n_split;
-        const size_t gc = in_split ? std::min(SG, first + n_split - g0) : std::min(G, first + count - g0);
+        const size_t gc = in_split ? std::min(SG, first + n_split - g0) : std::min(G, (g0 < cont0 ? cont0 : first + count) - g0);
         struct Advance {
             size_t& g0;
             size_t gc;
@@ -1840,7 +1908,7 @@ void qsv_destroy(qsv_t* h) {
     }
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     for (DeviceBuffer* b : {&h->d_z, &h->d_cre, &h->d_diag, &h->d_order, &h->d_sorted, &h->d_term_partials, &h->d_groups, &h->d_term_odd, &h->d_arena,
-                            &h->d_states, &h->d_wtab, &h->d_side, &h->d_factor, &h->d_factor_count, &h->d_factor_big, &h->d_factor_big_count, &h->d_quad, &h->d_fterms, &h->d_fpart, &h->d_batch, &h->d_mats, &h->d_partials, &h->d_out, &h->d_scratch})
+                            &h->d_states, &h->d_wtab, &h->d_side, &h->d_factor, &h->d_factor_count, &h->d_factor_big, &h->d_factor_big_count, &h->d_quad, &h->d_fterms, &h->d_fpart, &h->d_batch, &h->d_mats, &h->d_partials, &h->d_out, &h->d_scratch, &h->d_prefix})
         if (b->ptr) (void)hipFree(b->ptr);
     if (h->h_batch) (void)hipHostFree(h->h_batch);
     if (h->d_ship) (void)hipFree(h->d_ship);
@@ -2029,8 +2097,230 @@ int qsv_circuit_destroy(qsv_t* h, int circuit_id) {
     if (!h) return QSV_E_ARG;
     std::lock_guard<std::mutex> lock(h->mu);
     h->epoch += 1;
-    if (h->circuits.erase(circuit_id) == 0) return fail(h, QSV_E_ARG, "unknown circuit id");
+    auto it = h->circuits.find(circuit_id);
+    if (it == h->circuits.end()) return fail(h, QSV_E_ARG, "unknown circuit id");
+    if (it->second.prefix_id >= 0) prefix_unref(h, it->second.prefix_id);
+    h->circuits.erase(it);
     // the arena space is reclaimed when the arena is next rebuilt
+    return QSV_OK;
+}
+
+// ---- kept states ---------------------------------------------------------------------------------------------------------
+// (reference: mutation.py:57-59 -- optimize_layer_of_individual evaluates get_partially_parameterized_quantum_circuit({layer_id})
+// over and over: everything in front of that layer is the same state in every evaluation of the search)
+
+int qsv_prefix_create(qsv_t* h, int n_states, const int* circuit_ids, const int64_t* param_offsets, const double* params,
+                      int* out_prefix_ids) {
+    if (!h) return QSV_E_ARG;
+    if (h->batch_owner.load() == std::this_thread::get_id())
+        return fail(h, QSV_E_STATE, "a batch is open on this handle (qsv_prefix_create goes between batches)");
+    std::lock_guard<std::mutex> lock(h->mu);
+    if (n_states < 0 || (n_states > 0 && (!circuit_ids || !param_offsets || !out_prefix_ids))) return fail(h, QSV_E_ARG, "bad arguments");
+    if (n_states == 0) return QSV_OK;
+    QSV_HIP(h, hipSetDevice(h->device));
+    const size_t n = size_t(n_states);
+    std::vector<Circuit*> circs(n, nullptr);
+    std::vector<int64_t> np(n);
+    size_t total = 0;
+    for (size_t i = 0; i < n; ++i) {
+        auto it = h->circuits.find(circuit_ids[i]);
+        if (it == h->circuits.end()) return fail(h, QSV_E_ARG, "unknown circuit id " + std::to_string(circuit_ids[i]));
+        if (it->second.prefix_id >= 0) return fail(h, QSV_E_UNSUPPORTED, "a kept state of a circuit that itself continues a kept state");
+        circs[i] = &it->second;
+        np[i] = param_offsets[i + 1] - param_offsets[i];
+        if (np[i] < 0) return fail(h, QSV_E_ARG, "param_offsets must be non-decreasing");
+        total += size_t(np[i]);
+    }
+    std::vector<double> packed(total + 1, 0.0);
+    for (size_t i = 0, cur = 0; i < n; cur += size_t(np[i]), ++i)
+        if (np[i]) std::memcpy(packed.data() + cur, params + param_offsets[i], size_t(np[i]) * sizeof(double));
+    // room for n more states
+    const size_t state_bytes = (size_t(1) << h->n) * h->amp_bytes;
+    const size_t fresh_needed = n > h->prefix_free.size() ? n - h->prefix_free.size() : 0;
+    if (h->prefix_used + fresh_needed > h->prefix_slots) {
+        const size_t want = h->prefix_used + fresh_needed;
+        size_t cap = std::max(want, h->prefix_slots * 2);
+        void* fresh = nullptr;
+        hipError_t e = hipMalloc(&fresh, cap * state_bytes);
+        if (e != hipSuccess && cap > want) {
+            (void)hipGetLastError();
+            cap = want;
+            e = hipMalloc(&fresh, cap * state_bytes);
+        }
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(h, QSV_E_DEVICE, std::string("hipMalloc(kept states): ") + hipGetErrorString(e));
+        }
+        if (h->d_prefix.ptr) {
+            hipError_t e2 = sync_streams(h);  // (nothing may still read the old buffer)
+            if (e2 == hipSuccess && h->prefix_used)
+                e2 = hipMemcpy(fresh, h->d_prefix.ptr, h->prefix_used * state_bytes, hipMemcpyDeviceToDevice);
+            if (e2 != hipSuccess) {
+                (void)hipFree(fresh);
+                return fail(h, QSV_E_DEVICE, std::string("moving the kept states: ") + hipGetErrorString(e2));
+            }
+            (void)hipFree(h->d_prefix.ptr);
+        }
+        h->d_prefix.ptr = fresh;
+        h->d_prefix.bytes = cap * state_bytes;
+        h->prefix_slots = cap;
+    }
+    // the circuits run their ordinary plans (a state is wanted, not an expectation value), a launch group at a time, on the
+    // handle's stream; each final state is copied from its slot of the group to its kept slot
+    h->prof = qsv_profile{};
+    int rc = batch_layout(h, circs, np);
+    if (rc) return rc;
+    const size_t G = size_t(h->group);
+    {
+        EvalDesc* hd = static_cast<EvalDesc*>(h->h_batch);
+        for (size_t j = 0; j < n; ++j) hd[j].state_slot = uint32_t(j % G);
+    }
+    if (!rc) rc = ensure(h, h->d_partials, std::max<size_t>(1, n) * partials_per_state(h) * sizeof(double));
+    if (!rc) rc = batch_ship(h, 0, n, packed.data());
+    std::vector<uint32_t> slots(n);
+    for (size_t i = 0; i < n; ++i) {
+        if (!h->prefix_free.empty()) {
+            slots[i] = h->prefix_free.back();
+            h->prefix_free.pop_back();
+        } else {
+            slots[i] = uint32_t(h->prefix_used++);
+        }
+    }
+    auto give_back = [&]() {
+        for (uint32_t sl : slots) h->prefix_free.push_back(sl);
+        h->batch.circs.clear();
+        (void)sync_streams(h);
+    };
+    for (size_t g0 = 0; !rc && g0 < n; g0 += G) {
+        const size_t gc = std::min(G, n - g0);
+        rc = run_group(h, circs, g0, gc, kModeSynthFirst | kModeFinalStore);
+        for (size_t i = g0; !rc && i < g0 + gc; ++i) {
+            hipError_t e = hipMemcpyAsync(static_cast<char*>(h->d_prefix.ptr) + size_t(slots[i]) * state_bytes,
+                                          static_cast<const char*>(h->d_states.ptr) + (i % G) * state_bytes, state_bytes,
+                                          hipMemcpyDeviceToDevice, h->stream);
+            if (e != hipSuccess) rc = fail(h, QSV_E_DEVICE, std::string("hipMemcpyAsync(kept state): ") + hipGetErrorString(e));
+        }
+    }
+    if (rc) {
+        give_back();
+        return rc;
+    }
+    h->batch.circs.clear();
+    // (the staging buffers this batch's preparation read are free again, and whatever stream continues a kept state finds it)
+    hipError_t e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) {
+        give_back();
+        return fail(h, QSV_E_DEVICE, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
+    }
+    for (size_t i = 0; i < n; ++i) {
+        const int id = h->next_prefix_id++;
+        h->prefixes.emplace(id, PrefixState{slots[i], 0, false});
+        out_prefix_ids[i] = id;
+    }
+    return QSV_OK;
+}
+
+int qsv_prefix_destroy(qsv_t* h, int n_states, const int* prefix_ids) {
+    if (!h) return QSV_E_ARG;
+    if (n_states < 0 || (n_states > 0 && !prefix_ids)) return fail(h, QSV_E_ARG, "bad arguments");
+    // (finalizers of host objects call this: it must not wait for a handle its own thread holds between begin and end)
+    if (h->batch_owner.load() == std::this_thread::get_id()) return fail(h, QSV_E_STATE, "a batch is open on this handle");
+    std::lock_guard<std::mutex> lock(h->mu);
+    int rc = QSV_OK;
+    for (int i = 0; i < n_states; ++i) {
+        auto it = h->prefixes.find(prefix_ids[i]);
+        if (it == h->prefixes.end() || it->second.released) {
+            rc = fail(h, QSV_E_ARG, "unknown kept state " + std::to_string(prefix_ids[i]));
+            continue;
+        }
+        it->second.released = true;
+        if (it->second.refs == 0) {
+            h->prefix_free.push_back(it->second.slot);
+            h->prefixes.erase(it);
+        }
+    }
+    return rc;
+}
+
+int qsv_prefix_count(const qsv_t* h) {
+    if (!h) return QSV_E_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    return int(h->prefixes.size());
+}
+
+int qsv_circuits_create_on_prefixes(qsv_t* h, int n_circuits, const int64_t* op_offsets, const qsv_op* ops, const int* n_params,
+                                    const int* prefix_ids, int* out_circuit_ids) {
+    if (!h) return QSV_E_ARG;
+    if (n_circuits < 0 || (n_circuits > 0 && (!op_offsets || !n_params || !prefix_ids || !out_circuit_ids)))
+        return fail(h, QSV_E_ARG, "bad arguments");
+    for (int i = 0; i < n_circuits; ++i)
+        if (op_offsets[i + 1] < op_offsets[i] || n_params[i] < 0) return fail(h, QSV_E_ARG, "bad offsets or parameter counts");
+    // unfolded plans (the input is an arbitrary state, not a product state), never split
+    std::vector<BuiltCircuit> built;
+    build_many(h, size_t(n_circuits), [&](size_t i, BuiltCircuit& b) {
+        b.rc = build_circuit(h, int(op_offsets[i + 1] - op_offsets[i]), ops + op_offsets[i], n_params[i], false, &b.circuit, &b.err);
+    }, built);
+    for (int i = 0; i < n_circuits; ++i)
+        if (built[size_t(i)].rc) return fail(h, built[size_t(i)].rc, built[size_t(i)].err + " (circuit " + std::to_string(i) + ")");
+    std::lock_guard<std::mutex> lock(h->mu);
+    for (int i = 0; i < n_circuits; ++i) {
+        auto it = h->prefixes.find(prefix_ids[i]);
+        if (it == h->prefixes.end() || it->second.released) return fail(h, QSV_E_ARG, "unknown kept state " + std::to_string(prefix_ids[i]));
+    }
+    h->epoch += 1;
+    for (int i = 0; i < n_circuits; ++i) {
+        built[size_t(i)].circuit.prefix_id = prefix_ids[i];
+        h->prefixes.find(prefix_ids[i])->second.refs += 1;
+        out_circuit_ids[i] = insert_circuit(h, std::move(built[size_t(i)].circuit));
+    }
+    return QSV_OK;
+}
+
+int qsv_circuit_create_on_prefix(qsv_t* h, int prefix_id, int n_ops, const qsv_op* ops, int n_params, int* out_circuit_id) {
+    const int64_t offsets[2] = {0, n_ops};
+    return qsv_circuits_create_on_prefixes(h, 1, offsets, ops, &n_params, &prefix_id, out_circuit_id);
+}
+
+int qsv_circuit_cost(qsv_t* h, int circuit_id, qsv_circuit_cost_t* out) {
+    if (!h) return QSV_E_ARG;
+    if (!out) return fail(h, QSV_E_ARG, "out is null");
+    std::lock_guard<std::mutex> lock(h->mu);
+    auto it = h->circuits.find(circuit_id);
+    if (it == h->circuits.end()) return fail(h, QSV_E_ARG, "unknown circuit id");
+    Circuit& c = it->second;
+    *out = qsv_circuit_cost_t{};
+    // which way an expectation value of this circuit goes under the operator set now (eval_begin's rules)
+    const bool allow_split = h->n_terms == 0 || h->diagonal || factor_terms_path(h);
+    const int max_keys = (h->n_terms == 0 || factor_path(h)) ? kMaxSplitKeys : 3;
+    const double scale = std::ldexp(1.0, h->n - 20) * (h->dtype == QSV_F64 ? 1.0 : 0.5);
+    if (c.split.ok && allow_split && c.split.n_keys <= max_keys) {
+        const SplitInfo& sp = c.split;
+        const bool one_launch = sp.fused && h->fused_factor && (h->n_terms == 0 || factor_path(h));
+        out->route = one_launch ? QSV_ROUTE_SPLIT_ONE_LAUNCH : QSV_ROUTE_SPLIT;
+        out->n_keys = sp.n_keys;
+        out->n_passes = std::max(sp.stats[0].n_passes, sp.stats[1].n_passes);
+        // measured at 20 qubits (profiles/r03_split_by_depth.txt, r03_chain_stream.txt): one launch of 64 evaluations 49 us; own
+        // launches 1.2 us per evaluation up to three keys, 16 / 32 product terms 5 / 9 us; sides larger than 2^10 cost in proportion
+        const double sides = 0.5 * (std::ldexp(1.0, sp.n_virtual[0] - sp.n_keys - 10) + std::ldexp(1.0, sp.n_virtual[1] - sp.n_keys - 10));
+        const double per = one_launch ? 0.8 : (sp.n_keys <= 3 ? 1.2 : (sp.n_keys == 4 ? 5.0 : 9.0));
+        out->microseconds = per * std::max(1.0, sides) * double(out->n_passes);
+        return QSV_OK;
+    }
+    int rc = ensure_plan(h, c);
+    if (rc) return rc;
+    out->n_passes = c.plan.stats.n_passes;
+    out->on_kept_state = c.prefix_id >= 0 ? 1 : 0;
+    if (h->geo.blocks_per_state == 1) {
+        out->route = QSV_ROUTE_ONE_TILE;
+        out->microseconds = 1.0;
+        return QSV_OK;
+    }
+    out->route = QSV_ROUTE_PASSES;
+    // a pass over a 2^20 state inside a full launch, measured (profiles/r04_prefix_reuse.txt): a deep individual's whole circuit
+    // 17.1 us per evaluation at 3.13 passes = 5.5 us per pass (the synthesising, compact first pass included); on a kept state
+    // 10.5 - 11 us at 1.89 passes, 18.4 at 2.8: 5.8 - 6.6 us per pass -- few gates, but every pass reads and writes the whole state
+    // (HBM bound: 56 MiB per two-pass evaluation at 5.3 TB/s); n = 24: 16 times both
+    out->microseconds = (c.prefix_id >= 0 ? 6.0 : 5.5) * double(out->n_passes) * scale;
     return QSV_OK;
 }
 
@@ -2467,6 +2757,8 @@ static int sample_batch_locked(qsv_t* h, const std::vector<Circuit*>& circs, con
                                double* out_values, double alpha = 1.0, double* out_cvar = nullptr) {
     const size_t n_evals = circs.size();
     if (n_evals == 0 || shots == 0) return QSV_OK;
+    for (const Circuit* c : circs)
+        if (c->prefix_id >= 0) return fail(h, QSV_E_UNSUPPORTED, "circuits on kept states are not sampled (qsv_eval_* only)");
     if ((out_values || out_cvar) && !(h->has_diag_part && h->diagonal))
         return fail(h, QSV_E_STATE, "sample values need a diagonal operator (call qsv_set_operator with I/Z terms only)");
     std::vector<int64_t> np(n_evals);
@@ -2577,6 +2869,8 @@ static int exact_cvar_locked(qsv_t* h, const std::vector<Circuit*>& circs, const
                              double alpha, double* out_cvar) {
     const size_t n_evals = circs.size();
     if (n_evals == 0) return QSV_OK;
+    for (const Circuit* c : circs)
+        if (c->prefix_id >= 0) return fail(h, QSV_E_UNSUPPORTED, "circuits on kept states are not sampled (qsv_eval_* only)");
     if (!(h->has_diag_part && h->diagonal))
         return fail(h, QSV_E_STATE, "the exact CVaR needs a diagonal operator (call qsv_set_operator with I/Z terms only)");
     if (h->n > 28) return fail(h, QSV_E_UNSUPPORTED, "the exact CVaR is available up to 28 qubits");

@@ -446,6 +446,18 @@ class EVQEIndividual:
         name-sorted order over all free parameters); every other layer is bound to this individual's
         values, the k-th value going to that layer's k-th *name-sorted* parameter, exactly as
         ``assign_parameters`` with a sequence does in the reference (circuit_layer.py:233-235)."""
+        return self._lower(parameterized_layers, 0, len(self.layers))
+
+    def get_layer_search_circuits(self, layer_id: int) -> tuple[CircuitIR, CircuitIR]:
+        """``get_partially_parameterized_quantum_circuit({layer_id})`` cut in front of the searched layer: (the layers before it,
+        every angle bound; the searched layer with its free parameters followed by the later layers, bound).  The first has
+        the same final state in every evaluation of the search (mutation.py:57-59): an evaluator that can keep it
+        (``keep_states``) evaluates the second from there.  The parameter numbering of the second is the whole circuit's."""
+        layer_id %= len(self.layers)
+        return self._lower(set(), 0, layer_id), self._lower({layer_id}, layer_id, len(self.layers))
+
+    def _lower(self, parameterized_layers: set[int], first: int, last: int) -> CircuitIR:
+        """Layers [first, last) of the circuit (get_partially_parameterized_quantum_circuit: all of them)."""
         chosen = {layer_id % len(self.layers) for layer_id in parameterized_layers}
         # Fast form of the statement below (kept as _lower_by_names, which the tests hold it to): per layer a cached template
         # of its ops with the ranks of their angles among the layer's name-sorted parameters; a free layer's parameters
@@ -458,6 +470,8 @@ class EVQEIndividual:
             cursor += self.layers[i].template[1]
         rows = []
         for i, layer in enumerate(self.layers):
+            if not first <= i < last:
+                continue
             ops, _ = layer.template
             if i in chosen:
                 base = offset[i]

@@ -427,6 +427,11 @@ class EVQEMinimumEigensolverConfiguration:
     # (evqe/device_search.py; iterates agree with the host driver's to the last bits, not bit for bit; the same stopping
     # iterations).  None: where the evaluator can do it and a search has at least 16 runs; False: never; True: whenever it can.
     device_resident_search: Optional[bool] = None
+    # Layer searches of individuals whose circuits have no split form on the device (deep individuals: every evaluation is a few
+    # passes over the 2^n state) keep the state in front of the searched layer on the device and evaluate from there
+    # (mutation.py:57-59: only that layer's angles change) -- where the evaluator can (``keep_states``) and the circuit costs
+    # say it pays.  None: yes; False: never (QSV_KEPT_STATES=0 / 1 overrides).
+    kept_state_search: Optional[bool] = None
 
     def __post_init__(self):
         if self.population_size < 1:
@@ -492,10 +497,13 @@ class EVQEMinimumEigensolver:
                                                               self.configuration.optimizer)
         if os.environ.get("QSV_SHARE_CIRCUITS") == "2":  # (measurements, tests: embedded also where the host packs the points)
             embed = True
+        kept = self._kept_state_circuits(evaluator, individuals, layer_ids)
         jobs = []
-        for individual, layer_id, seed in zip(individuals, layer_ids, seeds):
+        for k, (individual, layer_id, seed) in enumerate(zip(individuals, layer_ids, seeds)):
             run = self.configuration.optimizer.new_run(individual.get_layer_parameter_values(layer_id), seed)
-            if embed:
+            if k in kept:
+                circuit = kept[k]  # (the searched layer and what follows it, on the kept state: the layer's own parameters)
+            elif embed:
                 circuit = individual.get_parameterized_quantum_circuit(shared=True)
                 # (positions and the other layers' values in the CIRCUIT's parameter order -- name-sorted blocks, which is
                 # the layer order only up to ten layers: layer10_ sorts before layer2_)
@@ -507,11 +515,46 @@ class EVQEMinimumEigensolver:
                 circuit = individual.get_partially_parameterized_quantum_circuit({layer_id})
             jobs.append((circuit, run))
         _minimize_batched(evaluator, jobs, on_device=self.configuration.device_resident_search)
+        if kept:  # (nothing may hold the search's circuits any longer: their kept states are a 2^n-amplitude buffer each)
+            evaluator.forget_circuits()
         out, nfev = [], 0
         for individual, layer_id, (_, run) in zip(individuals, layer_ids, jobs):
             out.append(EVQEIndividual.change_layer_parameter_values(individual, layer_id, tuple(run.x.tolist())))
             nfev += run.nfev
         return out, nfev
+
+    def _kept_state_circuits(self, evaluator, individuals: list[EVQEIndividual], layer_ids: list[int]) -> dict:
+        """position -> the circuit a layer search evaluates from a KEPT state: for individuals whose whole circuit takes gate
+        passes over the 2^n state on the evaluator's device (no split form: deep individuals), the state in front of the
+        searched layer is computed once, kept resident, and every evaluation of the search applies only the searched layer and
+        what follows it (reference: the layers in front are bound and never change, mutation.py:57-59).  Taken where the
+        evaluator reports fewer, cheaper passes for it (last-layer searches of deep individuals: 1.5 - 1.8 x at 20 / 24
+        qubits and eight layers, profiles/r04_prefix_reuse.txt); a search in the middle of a deep circuit keeps its whole
+        circuit (the same number of passes either way).  The values agree with the whole circuit's to rounding (1e-14), not
+        bit for bit."""
+        flag = self.configuration.kept_state_search
+        env = os.environ.get("QSV_KEPT_STATES")
+        if env == "0" or (flag is False and env != "1") or not hasattr(evaluator, "keep_states") or not hasattr(evaluator, "circuit_costs"):
+            return {}
+        candidates = [k for k, (ind, layer) in enumerate(zip(individuals, layer_ids)) if layer % len(ind.layers) > 0]
+        if not candidates:
+            return {}
+        whole = [individuals[k].get_parameterized_quantum_circuit(shared=True) for k in candidates]
+        first = evaluator.circuit_costs(whole[:1])[0]
+        if first["route"] == "one tile":  # (a register of one tile: nothing to save)
+            return {}
+        costs = [first] + evaluator.circuit_costs(whole[1:])
+        deep = [(k, c) for k, c in zip(candidates, costs) if c["route"] == "gate passes"]
+        if not deep:
+            return {}
+        pairs = [individuals[k].get_layer_search_circuits(layer_ids[k]) for k, _ in deep]
+        states = evaluator.keep_states([front for front, _ in pairs], [[] for _ in pairs])
+        circuits = [rest.continue_from(state) for (_, rest), state in zip(pairs, states)]
+        out = {}
+        for (k, cost), circuit, kept_cost in zip(deep, circuits, evaluator.circuit_costs(circuits)):
+            if kept_cost["microseconds"] < 0.9 * cost["microseconds"]:
+                out[k] = circuit
+        return out
 
     def _last_layer_search(self, evaluator, population: EVQEPopulation) -> tuple[EVQEPopulation, int]:
         chosen = self._chosen(population, self._rng_last_layer, 1.0)

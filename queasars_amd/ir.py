@@ -80,9 +80,14 @@ class CircuitIR:
         # (device key -> circuit id) cache used by the evaluator; cleared on mutation.  Process-local: a device key
         # is only meaningful in the process that created the device, so copies and pickles start without it.
         self._registered: dict[object, int] = {}
+        # A state kept on a device (StatevectorDevice.keep_states) this circuit starts from instead of |0..0>: set by
+        # continue_from.  Such a circuit belongs to that device and to this process.
+        self._kept_state = None
 
     # -- copying ----------------------------------------------------------------------------------
     def __getstate__(self) -> dict:
+        if self._kept_state is not None:
+            raise TypeError("a circuit that continues a state kept on a device cannot be pickled (the state does not travel)")
         state = self.__dict__.copy()
         state["_registered"] = {}
         state["_packed"] = None
@@ -93,6 +98,7 @@ class CircuitIR:
         out._rows = list(self._rows)  # rows are immutable tuples
         out._bytes = bytearray(self._bytes)
         out._n_parameters = self._n_parameters
+        out._kept_state = self._kept_state
         memo[id(self)] = out
         return out
 
@@ -173,7 +179,27 @@ class CircuitIR:
         out._rows = list(self._rows) + list(other._rows)
         out._bytes = self._bytes + other._bytes
         out._n_parameters = max(self._n_parameters, other._n_parameters)
+        if other._kept_state is not None:
+            raise ValueError("a circuit that continues a kept state cannot follow another circuit")
+        out._kept_state = self._kept_state
         return out
+
+    def continue_from(self, kept_state) -> "CircuitIR":
+        """This circuit applied to ``kept_state`` (one of ``StatevectorDevice.keep_states(...)``) instead of to |0..0>: what a
+        layer search evaluates again and again once everything in front of the searched layer is a state on the device
+        (reference: optimize_layer_of_individual binds the other layers into the circuit, mutation.py:57-59).  Returns self."""
+        if kept_state is not None and kept_state.n_qubits != self._n_qubits:
+            raise ValueError("the kept state has another number of qubits")
+        if self._registered:
+            CircuitIR.edits_of_registered += 1
+            self._registered = {}
+        self._kept_state = kept_state
+        self._version += 1
+        return self
+
+    @property
+    def kept_state(self):
+        return self._kept_state
 
     # -- views ----------------------------------------------------------------------------------
     @property
