@@ -324,6 +324,7 @@ struct PassScalars {
     uint32_t* factor_counters;
     uint32_t n_full;
     const void* prefix_states;
+    uint32_t dephase;
 };
 
 // XMODE selects how a tile is transposed through LDS:
@@ -807,6 +808,11 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, FIRST>::waves_per_si
     bool lds_dirty = false;      // LDS holds exchange data some wave may still be reading
     bool cross_pending = false;  // ... and that wave may be another one (the last exchange crossed waves)
 
+    if constexpr (!FIRST) {
+        // (measurement: the two workgroups of a CU start half a tile apart, so that one loads while the other computes)
+        if (a.dephase && (blockIdx.x & 1u))
+            for (uint32_t i = 0; i < a.dephase; ++i) __builtin_amdgcn_s_sleep(127);
+    }
     QSV_STAMP(0);
     for (uint32_t j = 0; j < n_tiles; ++j) {
         // what depends on the tile number comes from prepare_kernel's table: one scalar load
@@ -1254,7 +1260,7 @@ static hipError_t launch_pass_t(dim3 grid, int threads, size_t lds_bytes, hipStr
     const PassScalars sc{args.state_stride, args.wtab_stride, args.pass_index, args.mode, args.tiles_per_block,
                          args.partial_chunks, args.region_stride, args.host_evals, args.evals_out, args.host_params,
                          args.mats_out, args.result_out, args.quad, args.factor_scratch, args.factor_counters, args.n_full,
-                         args.prefix_states};
+                         args.prefix_states, args.dephase};
     cx<real>* st = reinterpret_cast<cx<real>*>(args.states);
     const bool first = args.pass_index == 0 && (args.mode & kModeSynthFirst);
     if (first)
@@ -1300,7 +1306,7 @@ static hipError_t pass_dispatch(int op, int dtype, int r, int xmode, dim3 grid, 
     const PassScalars sc{args->state_stride, args->wtab_stride, args->pass_index, args->mode, args->tiles_per_block,
                          args->partial_chunks, args->region_stride, args->host_evals, args->evals_out, args->host_params,
                          args->mats_out, args->result_out, args->quad, args->factor_scratch, args->factor_counters, args->n_full,
-                          args->prefix_states};
+                          args->prefix_states, args->dephase};
     if (args->pass_index == 0 && (args->mode & kModeSynthFirst))
         hipLaunchKernelGGL((pass_kernel<double, QSV_PROBE_R, 2, true>), grid, dim3(threads), lds_bytes, stream, args->plan,
                            args->mats, args->evals, reinterpret_cast<cx<double>*>(args->states),

@@ -103,6 +103,7 @@ struct PassArgs {
     uint32_t* factor_counters;
     uint32_t n_full;
     const void* prefix_states;  // kEvalPrefix: kept states, slot s at s * state_stride amplitudes (may be null otherwise)
+    uint32_t dephase;           // (measurement knob QSV_DEPHASE) odd workgroups of a later pass sleep this many s_sleep(127) first
 };
 // LDS bytes the fused factor tail of a pass launch needs (up to eight waves form a side's Gram matrices)
 constexpr size_t kFusedFactorLdsBytes = 8 * (18 * 64 + 64) * sizeof(double) + 64;

@@ -1049,6 +1049,10 @@ int run_group(qsv_t* h, const std::vector<Circuit*>& circs, size_t first, size_t
     a.state_stride = uint64_t(1) << h->n;
     a.mode = mode | h->stream_mode;
     a.prefix_states = h->d_prefix.ptr;
+    {
+        static const uint32_t dephase = getenv("QSV_DEPHASE") ? uint32_t(atoi(getenv("QSV_DEPHASE"))) : 0u;
+        a.dephase = dephase;
+    }
     // Pass 0 and the later passes have their own grids (tiles per workgroup): a compact pass 0 has few tiles and wants
     // them spread, a later pass sweeps all of them and amortises its set-up over more.  Which grid an evaluation's
     // LAST pass runs on depends on its own pass count only, so its partial sums are laid out (and added) the same

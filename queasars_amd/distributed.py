@@ -1,16 +1,24 @@
 """Population sharding over the GPUs of one node: one process per GPU, one fitness all-gather per evaluation.
 
 The reference farms one task per individual to a thread pool or a Dask cluster
-(queasars/minimum_eigensolvers/evqe/evolutionary_algorithm/selection.py:75-85, mutation.py:206-218).  Here the
-individuals are split into contiguous blocks by population index; each rank evaluates its block on its own GPU
-with no communication, and a single all-gather of ``P / world`` doubles per rank (``backend="nccl"`` is RCCL on
-ROCm) gives every rank all P fitness values, which is what selection needs (selection.py:85, :102).  The
-collective moves a few hundred bytes: it is latency bound, xGMI bandwidth does not matter.
+(queasars/minimum_eigensolvers/evqe/evolutionary_algorithm/selection.py:75-85, mutation.py:206-218): its pool balances
+dynamically -- a worker that drew a shallow individual takes the next one.  Here every rank evaluates a fixed share of the
+population on its own GPU with no communication, and a single all-gather of ``ceil(P / world)`` doubles per rank
+(``backend="nccl"`` is RCCL on ROCm) gives every rank all P fitness values, which is what selection needs (selection.py:85,
+:102).  The collective moves a few hundred bytes: it is latency bound, xGMI bandwidth does not matter.
+
+Shares.  Contiguous blocks by population index while the blocks are even; once the evaluator can tell what a
+circuit costs on its device (``circuit_costs``: the route a circuit takes there, ``qsv_circuit_cost``) and the blocks' costs
+differ by more than 10 %, the individuals are dealt by longest processing time first -- an eight-layer individual without
+a split form costs eighteen shallow ones, and one block of them would leave seven GPUs waiting.  The deal is a pure function
+of the costs (every rank computes the same one); results go back to population order.
 """
 
 from __future__ import annotations
 
 import os
+import time
+import weakref
 from typing import Optional, Sequence
 
 import numpy as np
@@ -26,6 +34,74 @@ def shard_bounds(n_items: int, world_size: int, rank: int) -> tuple[int, int]:
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def contiguous_shares(n_items: int, world_size: int) -> list[list[int]]:
+    return [list(range(*shard_bounds(n_items, world_size, r))) for r in range(world_size)]
+
+
+def imbalance(shares: Sequence[Sequence[int]], costs: Sequence[float]) -> float:
+    """Largest share's cost over the mean share's (1.0 = even)."""
+    totals = [sum(costs[i] for i in share) for share in shares]
+    mean = sum(totals) / max(1, len(totals))
+    return max(totals) / mean if mean > 0 else 1.0
+
+
+def partition_by_cost(costs: Sequence[float], world_size: int, tolerance: float = 0.10) -> list[list[int]]:
+    """Which items each rank takes.  Contiguous blocks while their costs are within ``tolerance`` of even ("deal
+    round-robin if imbalance > 10 %"); otherwise longest processing time first: items in order of falling cost (ties by
+    index), each to the rank with the least work so far (ties to the lowest rank), every share in ascending index order; the
+    shares may differ in length (the gather's slots are as wide as the longest).  Deterministic."""
+    n = len(costs)
+    if world_size < 1:
+        raise ValueError("bad world_size")
+    blocks = contiguous_shares(n, world_size)
+    if world_size == 1 or n == 0 or imbalance(blocks, costs) <= 1.0 + tolerance:
+        return blocks
+    order = sorted(range(n), key=lambda i: (-float(costs[i]), i))
+    load = [0.0] * world_size
+    shares: list[list[int]] = [[] for _ in range(world_size)]
+    for i in order:
+        r = min(range(world_size), key=lambda r: (load[r], r))
+        shares[r].append(i)
+        load[r] += float(costs[i])
+    for share in shares:
+        share.sort()
+    # (never worse than the blocks it replaces)
+    return shares if imbalance(shares, costs) < imbalance(blocks, costs) else blocks
+
+
+def evaluation_costs(evaluator, circuits: Sequence) -> Optional[list[float]]:
+    """Microseconds per evaluation of every circuit on the evaluator's device, or None when it cannot tell (then the shares
+    are contiguous blocks).  The same numbers on every rank: a function of the circuit, the operator and the library."""
+    tell = getattr(evaluator, "circuit_costs", None)
+    if tell is None or os.environ.get("QSV_SHARD_BALANCE", "1") == "0":
+        return None
+    return [float(c["microseconds"]) for c in tell(list(circuits))]
+
+
+_SHARES: dict = {}
+
+
+def population_shares(evaluator, circuits: Sequence, world: int) -> list[list[int]]:
+    """:func:`partition_by_cost` of a population, remembered while the same circuit objects come again (an optimiser's next
+    iteration): the costs are asked once per list of circuits."""
+    n = len(circuits)
+    if world == 1:
+        return [list(range(n))]
+    key = id(evaluator)
+    hit = _SHARES.get(key)
+    ids = tuple(map(id, circuits))
+    if hit is not None and hit[0]() is evaluator and hit[1] == (ids, world):
+        return hit[3]
+    costs = evaluation_costs(evaluator, circuits)
+    shares = contiguous_shares(n, world) if costs is None else partition_by_cost(costs, world)
+    try:
+        ref = weakref.ref(evaluator, lambda _r, k=key: _SHARES.pop(k, None))
+    except TypeError:  # (an evaluator that cannot be weakly referenced: nothing is remembered)
+        return shares
+    _SHARES[key] = (ref, (ids, world), list(circuits), shares)  # (holds the circuits: their ids cannot be recycled)
+    return shares
+
+
 def _rows(parameter_values, lo: int, hi: int):
     """Rows [lo, hi) of the population's parameter values: a list of vectors, or -- for a matrix that lives in device memory
     (a torch tensor; ``OperatorCircuitEvaluator.evaluate_circuits`` reads it where it is) -- a view of its rows."""
@@ -34,8 +110,25 @@ def _rows(parameter_values, lo: int, hi: int):
     return list(parameter_values[lo:hi])
 
 
+def _take(circuits: Sequence, parameter_values, share: Sequence[int]):
+    """The share's circuits and parameter values.  A contiguous share of a device matrix is a view of its rows; any other
+    share of one is gathered into a new matrix on the device (index_select: one small kernel)."""
+    if not share:
+        return [], []
+    lo, hi = share[0], share[-1] + 1
+    if hi - lo == len(share):
+        return list(circuits[lo:hi]), _rows(parameter_values, lo, hi)
+    picked = [circuits[i] for i in share]
+    if getattr(parameter_values, "is_cuda", False):
+        import torch
+
+        index = torch.as_tensor(list(share), dtype=torch.int64, device=parameter_values.device)
+        return picked, parameter_values.index_select(0, index).contiguous()
+    return picked, [parameter_values[i] for i in share]
+
+
 def evaluate_population_sharded(evaluator, circuits: Sequence, parameter_values: Sequence, group=None, device=None) -> list[float]:
-    """Evaluate this rank's block of the population and all-gather the fitness values.
+    """Evaluate this rank's share of the population and all-gather the fitness values.
 
     ``evaluator`` is any object with ``evaluate_circuits(circuits, parameter_values)``; every rank must pass the
     same full ``circuits`` / ``parameter_values`` lists (or, for evaluators that take it, the population's parameter matrix
@@ -49,27 +142,38 @@ def evaluate_population_sharded(evaluator, circuits: Sequence, parameter_values:
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return list(evaluator.evaluate_circuits(list(circuits), _rows(parameter_values, 0, n)))
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    lo, hi = shard_bounds(n, world, rank)
+    shares = population_shares(evaluator, circuits, world)
     if device is None and dist.get_backend(group) == "nccl" and os.environ.get("QSV_GATHER_CHAIN", "1") != "0":
         # evaluation, collective and copy back as one chain on one stream (no host round trip in between)
         chained = evaluate_block_and_gather(evaluator, circuits, parameter_values, n, world, rank, group,
-                                           torch.device("cuda", torch.cuda.current_device()))
+                                           torch.device("cuda", torch.cuda.current_device()), shares)
         if chained is not None:
             return chained
-    local = evaluator.evaluate_circuits(list(circuits[lo:hi]), _rows(parameter_values, lo, hi)) if hi > lo else []
+    mine_c, mine_p = _take(circuits, parameter_values, shares[rank])
+    local = evaluator.evaluate_circuits(mine_c, mine_p) if mine_c else []
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
     owner = id(getattr(evaluator, "statevector_device", None) or evaluator)
-    return _gather(local, n, world, rank, group, torch.device(device), owner)
+    return _gather(local, n, world, rank, group, torch.device(device), owner, shares)
 
 
-def evaluate_block_and_gather(evaluator, circuits: Sequence, parameter_values: Sequence, n: int, world: int, rank: int, group, device):
-    """This rank's block and the all-gather as ONE chain on one HIP stream, with one synchronisation at its end: the
+# a receive slot no rank has written yet: a NaN whose payload no arithmetic produces (the evaluator's own sentinel is another)
+_SENTINEL = np.frombuffer(np.uint64(0x7FF8C0DEC0DE0001).tobytes(), dtype=np.float64)[0]
+_POLL_SECONDS = 0.002
+
+
+def evaluate_block_and_gather(evaluator, circuits: Sequence, parameter_values: Sequence, n: int, world: int, rank: int, group, device,
+                              shares: Optional[list] = None):
+    """This rank's share and the all-gather as ONE chain on one HIP stream: the
     evaluator leaves its values in the collective's send buffer (``evaluate_circuits_to_device``: device memory, no wait),
-    the all-gather and the copy to the host follow on the same stream.  Measured on one MI355X (nccl group of one rank,
-    ``scripts/gatherstep.py``): the step with the gather costs 138 us the old way (evaluate, wait, stage, copy to the
-    device, gather, copy back, wait) against 91 us for the evaluation alone.  Returns None when the evaluator cannot leave
-    its values on the device (the caller then takes the old way).
+    the all-gather follows on the same stream.  Measured on one MI355X (nccl group of one rank, ``scripts/gatherstep.py``):
+    round 2, the step with the gather cost 138 us the staged way (evaluate, wait, stage, copy to the device, gather, copy
+    back, wait) against 91 us for the evaluation alone; round 3, chained with a copy back and a stream synchronisation at its
+    end, 27 + 4 us over the evaluation; round 4: the collective RECEIVES INTO HOST MEMORY the device can address (a pinned
+    buffer seen as a device tensor) and the host reads the end of the step off the slots themselves -- every slot starts as
+    a sentinel no arithmetic produces, the values are there when no sentinel is left -- as ``qsv_eval_end`` does with its
+    result buffer: no copy back, no synchronisation call (``QSV_GATHER_HOST=0``: the copy back).  Returns None when the
+    evaluator cannot leave its values on the device (the caller then takes the staged way).
 
     The chain runs on a stream of its own (the one the evaluator's device launches on).  It is ordered behind whatever the
     caller has queued on ITS current stream (one event wait), and the caller's current stream is the same after the call
@@ -87,30 +191,53 @@ def evaluate_block_and_gather(evaluator, circuits: Sequence, parameter_values: S
     state = _chain_state(evaluator, device)
     if state is None or state.get("disabled"):
         return None
-    lo, hi = shard_bounds(n, world, rank)
-    width = -(-n // world)
+    if shares is None:
+        shares = contiguous_shares(n, world)
+    mine_c, mine_p = _take(circuits, parameter_values, shares[rank])
+    width = max(len(share) for share in shares)
+    host_receive = os.environ.get("QSV_GATHER_HOST", "1") != "0" and not state.get("no_host_receive")
     _, send, recv, recv_host = _buffers(world, width, device, group, state["key"])
+    mapped = _mapped_receive(world, width, device, group, state["key"]) if host_receive else None
+    if host_receive and mapped is None:
+        state["no_host_receive"] = True
+        host_receive = False
     stream = state["stream"]
     caller = torch.cuda.current_stream(device)
     if caller != stream:
         stream.wait_stream(caller)  # (the application's earlier work on its own stream comes first)
         torch.cuda.set_stream(stream)
     try:
-        if hi - lo < width:
+        if len(mine_c) < width:
             send.fill_(float("nan"))
-        if hi > lo and not to_device(circuits[lo:hi], _rows(parameter_values, lo, hi), send.data_ptr()):
+        if host_receive:
+            mapped[1].fill(_SENTINEL)
+        if mine_c and not to_device(mine_c, mine_p, send.data_ptr()):
             return None
-        dist.all_gather_into_tensor(recv, send, group=group)
-        recv_host.copy_(recv, non_blocking=True)
-        stream.synchronize()
+        if host_receive:
+            dist.all_gather_into_tensor(mapped[0], send, group=group)
+            table = mapped[1]
+            deadline = time.perf_counter() + _POLL_SECONDS
+            flat = table.view(np.uint64)
+            marker = np.float64(_SENTINEL).view(np.uint64)
+            while (flat == marker).any():
+                if time.perf_counter() > deadline:  # (a long step: wait on the stream as before)
+                    stream.synchronize()
+                    break
+            recv_values = table
+        else:
+            dist.all_gather_into_tensor(recv, send, group=group)
+            recv_host.copy_(recv, non_blocking=True)
+            stream.synchronize()
+            recv_values = recv_host.numpy()
     finally:
         if caller != stream:
             torch.cuda.set_stream(caller)
-    values = _unpack(recv_host, n, world, width)
+    values = _unpack(recv_values, n, world, width, shares)
     verified = state["verified"]
-    if id(group) not in verified:
-        local = evaluator.evaluate_circuits(list(circuits[lo:hi]), _rows(parameter_values, lo, hi)) if hi > lo else []
-        staged = _gather(local, n, world, rank, group, device, state["key"])
+    known = any(ref() is group for ref in verified) if group is not None else bool(state.get("verified_default"))
+    if not known:
+        local = evaluator.evaluate_circuits(mine_c, mine_p) if mine_c else []
+        staged = _gather(local, n, world, rank, group, device, state["key"], shares)
         same = len(staged) == len(values) and all(a == b for a, b in zip(staged, values))
         # every rank must take the same path from now on: agree on the verdict (a collective itself, staged way)
         flag = torch.tensor([1.0 if same else 0.0], dtype=torch.float64, device=device)
@@ -118,23 +245,36 @@ def evaluate_block_and_gather(evaluator, circuits: Sequence, parameter_values: S
         if float(flag.item()) != 1.0:
             import warnings
 
+            if host_receive:  # (first suspect: the collective writing into host memory; the device receive buffer gets its turn)
+                warnings.warn("queasars_amd.distributed: the all-gather into host-mapped memory disagreed with the staged step; "
+                              "receiving on the device", RuntimeWarning)
+                state["no_host_receive"] = True
+                return staged
             warnings.warn("queasars_amd.distributed: the chained evaluate + all-gather step disagreed with the staged one; "
                           "using the staged path", RuntimeWarning)
             state["disabled"] = True
             return staged
-        verified.add(id(group))
+        if group is not None:
+            # (by the group object itself, weakly: an id() can be recycled by another group)
+            verified.append(weakref.ref(group))
+            verified[:] = [ref for ref in verified if ref() is not None]
+        else:
+            state["verified_default"] = True
     return values
 
 
-def _unpack(recv_host, n: int, world: int, width: int) -> list[float]:
+def _unpack(recv_values, n: int, world: int, width: int, shares: Optional[list] = None) -> list[float]:
     """The gathered slots (one of ``width`` values per rank, the unused tail NaN) as one list ordered by population index."""
-    table = recv_host.numpy().reshape(world, width)
-    if n == world * width:
+    table = np.asarray(recv_values).reshape(world, width)
+    if shares is None:
+        shares = contiguous_shares(n, world)
+    if n == world * width and all(share == list(range(r * width, (r + 1) * width)) for r, share in enumerate(shares)):
         return table.ravel().tolist()
-    out: list[float] = []
-    for r in range(world):
-        rlo, rhi = shard_bounds(n, world, r)
-        out.extend(table[r, : rhi - rlo].tolist())
+    out = [0.0] * n
+    for r, share in enumerate(shares):
+        row = table[r, : len(share)].tolist()
+        for i, v in zip(share, row):
+            out[i] = v
     return out
 
 
@@ -146,7 +286,6 @@ def _chain_state(evaluator, device):
     kernels, the collective and the copy back are then ordered by the stream alone), which groups the chained step has
     been verified on, and the key of its buffers.  The entry goes when the device does."""
     import torch
-    import weakref
 
     dev = getattr(evaluator, "statevector_device", None)
     if dev is None:
@@ -155,24 +294,26 @@ def _chain_state(evaluator, device):
     if hit is None or hit["ref"]() is not dev:
         key = id(dev)
 
-        def gone(_ref, key=key):
-            _CHAIN_STATE.pop(key, None)
-            for k in [k for k in _BUFFERS if k[-1] == key]:
-                _BUFFERS.pop(k, None)
+        def gone(_ref, key=key, tables=(_CHAIN_STATE, _BUFFERS, _MAPPED)):  # (bound now: at interpreter exit the globals are gone)
+            tables[0].pop(key, None)
+            for table in tables[1:]:
+                for k in [k for k in table if k[-1] == key]:
+                    table.pop(k, None)
 
         stream = torch.cuda.Stream(device=device)
         dev.set_stream(stream.cuda_stream)
-        hit = {"ref": weakref.ref(dev, gone), "stream": stream, "verified": set(), "disabled": False, "key": key}
+        hit = {"ref": weakref.ref(dev, gone), "stream": stream, "verified": [], "disabled": False, "key": key}
         _CHAIN_STATE[key] = hit
     return hit
 
 
-def _gather(local: Sequence[float], n: int, world: int, rank: int, group, device, owner=None) -> list[float]:
-    """All ranks' blocks of fitness values, ordered by population index (``local`` is this rank's block)."""
+def _gather(local: Sequence[float], n: int, world: int, rank: int, group, device, owner=None, shares: Optional[list] = None) -> list[float]:
+    """All ranks' shares of fitness values, ordered by population index (``local`` is this rank's share)."""
     import torch
     import torch.distributed as dist
 
-    width = -(-n // world)  # every rank contributes a fixed-size slot so one all_gather_into_tensor suffices
+    # every rank contributes a fixed-size slot so one all_gather_into_tensor suffices: as wide as the longest share
+    width = -(-n // world) if shares is None else max(len(share) for share in shares)
     send_host, send, recv, recv_host = _buffers(world, width, device, group, owner)
     # pinned staging buffers and device tensors are kept between calls: the collective moves a few hundred bytes and
     # is latency bound, so every allocation and every synchronous pageable copy on its path counts
@@ -184,21 +325,26 @@ def _gather(local: Sequence[float], n: int, world: int, rank: int, group, device
     recv_host.copy_(recv, non_blocking=True)
     if recv.is_cuda:
         torch.cuda.current_stream(recv.device).synchronize()
-    return _unpack(recv_host, n, world, width)
+    return _unpack(recv_host.numpy(), n, world, width, shares)
 
 
 _BUFFERS: dict = {}
+_MAPPED: dict = {}
+
+
+def _buffer_key(world: int, width: int, device, group, owner):
+    import threading
+
+    return (world, width, str(device), id(group) if group is not None else 0, threading.get_ident(), owner)
 
 
 def _buffers(world: int, width: int, device, group=None, owner=None):
     """(pinned send staging, device send, device receive, pinned receive staging) for one (world, width, device, group,
     calling thread, owner): two evaluators, groups or threads never share a send / receive buffer (``owner`` = the
     evaluator device of a chained step; its entries are dropped when it dies)."""
-    import threading
-
     import torch
 
-    key = (world, width, str(device), id(group) if group is not None else 0, threading.get_ident(), owner)
+    key = _buffer_key(world, width, device, group, owner)
     hit = _BUFFERS.get(key)
     if hit is None:
         pin = device.type == "cuda"
@@ -212,3 +358,83 @@ def _buffers(world: int, width: int, device, group=None, owner=None):
         hit = (send_host, send, recv, recv_host)
         _BUFFERS[key] = hit
     return hit
+
+
+class _DeviceView:
+    """Pinned host memory presented through ``__cuda_array_interface__``: on ROCm a pinned allocation has ONE address, valid on
+    the host and on every device, so ``torch.as_tensor(view, device=...)`` is a device tensor whose bytes live in host memory."""
+
+    def __init__(self, pinned):
+        self._keep = pinned
+        self.__cuda_array_interface__ = {"shape": tuple(pinned.shape), "typestr": "<f8", "data": (pinned.data_ptr(), False),
+                                         "version": 2, "strides": None}
+
+
+def _mapped_receive(world: int, width: int, device, group=None, owner=None):
+    """(device tensor over pinned host memory, the same memory as a NumPy array) or None where torch will not make one."""
+    import torch
+
+    key = _buffer_key(world, width, device, group, owner)
+    hit = _MAPPED.get(key)
+    if hit is None:
+        try:
+            pinned = torch.empty(world * width, dtype=torch.float64, pin_memory=True)
+            as_device = torch.as_tensor(_DeviceView(pinned), device=device)
+            if as_device.data_ptr() != pinned.data_ptr() or not as_device.is_cuda:
+                return None
+        except Exception:  # (no unified addressing, or torch refuses the interface: the device receive buffer is used)
+            return None
+        hit = (as_device, pinned.numpy(), pinned)
+        _MAPPED[key] = hit
+    return hit
+
+
+# ---- layer searches sharded by individual ---------------------------------------------------------------------------------
+
+
+def shard_searches(evaluator, jobs: Sequence, group=None) -> Optional[list[int]]:
+    """Which of a layer search's (circuit, run) jobs THIS rank runs (reference: every individual's whole optimiser run is one task
+    on the pool, mutation.py:194-235): the jobs dealt by what their circuits cost (:func:`partition_by_cost`), or None without
+    a process group of several ranks."""
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return None
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    costs = evaluation_costs(evaluator, [circuit for circuit, _ in jobs])
+    shares = contiguous_shares(len(jobs), world) if costs is None else partition_by_cost(costs, world)
+    return shares[rank]
+
+
+def gather_search_results(jobs: Sequence, mine: Sequence[int], group=None) -> None:
+    """After every rank has advanced ITS runs to completion: ONE all-gather per search hands every rank every run's final
+    iterate, iteration count and evaluation count (mutation.py:206-218: the futures' results), so that the evolution goes on
+    identically everywhere.  Rows of max(len(x)) + 3 doubles: job index, iterations, evaluations, the iterate."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    n = len(jobs)
+    width = max((run.x.size for _, run in jobs), default=0) + 3
+    rows = -(-n // world)
+    device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    send = np.full((rows, width), np.nan)
+    for slot, j in enumerate(mine):
+        run = jobs[j][1]
+        send[slot, 0], send[slot, 1], send[slot, 2] = j, run.iteration, run.nfev
+        send[slot, 3 : 3 + run.x.size] = run.x
+    send_t = torch.from_numpy(send).to(device)
+    recv_t = torch.empty((world * rows, width), dtype=torch.float64, device=device)
+    dist.all_gather_into_tensor(recv_t, send_t, group=group)
+    table = recv_t.cpu().numpy()
+    seen = set()
+    for row in table:
+        if np.isnan(row[0]):
+            continue
+        j = int(row[0])
+        run = jobs[j][1]
+        run.x = row[3 : 3 + run.x.size].copy()
+        run.iteration, run.nfev, run.done = int(row[1]), int(row[2]), True
+        seen.add(j)
+    if len(seen) != n:
+        raise RuntimeError(f"sharded search: results of {n - len(seen)} of {n} runs are missing")

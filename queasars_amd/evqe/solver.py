@@ -460,9 +460,18 @@ class EVQEResult:
 
 
 class EVQEMinimumEigensolver:
-    def __init__(self, configuration: EVQEMinimumEigensolverConfiguration, log: Optional[Callable[[str], None]] = None):
+    def __init__(self, configuration: EVQEMinimumEigensolverConfiguration, log: Optional[Callable[[str], None]] = None,
+                 on_generation: Optional[Callable[[dict], None]] = None, shard: bool = False, process_group=None):
+        """``on_generation``: called when a generation has been scored, with {"generation", "population", "values",
+        "circuit_evaluations" (so far)}.  ``shard``: one process per GPU (torch.distributed initialised), every rank running
+        this same solver with the same seed: the individuals' optimiser runs and the fitness evaluations are dealt to the ranks
+        (the reference hands each to a worker of its pool, mutation.py:194-235, selection.py:75-85) and ONE all-gather per
+        search / per scoring gives every rank all results, so that the evolution is the same everywhere."""
         self.configuration = configuration
         self._log = log or (lambda message: None)
+        self._on_generation = on_generation
+        self.shard = bool(shard)
+        self.process_group = process_group
         # (QSV_SHARE_CIRCUITS=0: a circuit per individual and search, the other layers' values bound into it, as the reference has it)
         self.share_circuits = os.environ.get("QSV_SHARE_CIRCUITS", "1") != "0"
         rng = Random(configuration.random_seed)
@@ -497,13 +506,10 @@ class EVQEMinimumEigensolver:
                                                               self.configuration.optimizer)
         if os.environ.get("QSV_SHARE_CIRCUITS") == "2":  # (measurements, tests: embedded also where the host packs the points)
             embed = True
-        kept = self._kept_state_circuits(evaluator, individuals, layer_ids)
         jobs = []
         for k, (individual, layer_id, seed) in enumerate(zip(individuals, layer_ids, seeds)):
             run = self.configuration.optimizer.new_run(individual.get_layer_parameter_values(layer_id), seed)
-            if k in kept:
-                circuit = kept[k]  # (the searched layer and what follows it, on the kept state: the layer's own parameters)
-            elif embed:
+            if embed:
                 circuit = individual.get_parameterized_quantum_circuit(shared=True)
                 # (positions and the other layers' values in the CIRCUIT's parameter order -- name-sorted blocks, which is
                 # the layer order only up to ten layers: layer10_ sorts before layer2_)
@@ -514,9 +520,24 @@ class EVQEMinimumEigensolver:
             else:
                 circuit = individual.get_partially_parameterized_quantum_circuit({layer_id})
             jobs.append((circuit, run))
-        _minimize_batched(evaluator, jobs, on_device=self.configuration.device_resident_search)
+        # several ranks: each runs the searches of ITS individuals (dealt by what their circuits cost), one all-gather at the end
+        mine = None
+        if self.shard:
+            from queasars_amd import distributed
+
+            mine = distributed.shard_searches(evaluator, jobs, self.process_group)
+        own = list(range(len(jobs))) if mine is None else list(mine)
+        # deep individuals of this rank: from a kept state (the searched layer and what follows it: the layer's own parameters)
+        kept = self._kept_state_circuits(evaluator, [individuals[j] for j in own], [layer_ids[j] for j in own])
+        for position, circuit in kept.items():
+            j = own[position]
+            jobs[j][1].embed = None
+            jobs[j] = (circuit, jobs[j][1])
+        _minimize_batched(evaluator, [jobs[j] for j in own], on_device=self.configuration.device_resident_search)
         if kept:  # (nothing may hold the search's circuits any longer: their kept states are a 2^n-amplitude buffer each)
             evaluator.forget_circuits()
+        if mine is not None:
+            distributed.gather_search_results(jobs, own, self.process_group)
         out, nfev = [], 0
         for individual, layer_id, (_, run) in zip(individuals, layer_ids, jobs):
             out.append(EVQEIndividual.change_layer_parameter_values(individual, layer_id, tuple(run.x.tolist())))
@@ -685,7 +706,13 @@ class EVQEMinimumEigensolver:
             if not budget_left(len(population.individuals)):
                 break
             circuits = [ind.get_parameterized_quantum_circuit(shared=self.share_circuits) for ind in population.individuals]
-            values = evaluator.evaluate_circuits(circuits, [list(ind.parameter_values) for ind in population.individuals])
+            if self.shard:
+                from queasars_amd.distributed import evaluate_population_sharded
+
+                values = evaluate_population_sharded(evaluator, circuits, [list(ind.parameter_values) for ind in population.individuals],
+                                                     group=self.process_group)
+            else:
+                values = evaluator.evaluate_circuits(circuits, [list(ind.parameter_values) for ind in population.individuals])
             evaluations[-1] += len(values)
             best = int(np.argmin(values))
             if values[best] < result.eigenvalue:
@@ -694,6 +721,9 @@ class EVQEMinimumEigensolver:
             result.median_expectation_values.append(median(values))
             result.mean_expectation_values.append(mean(values))
             self._log(f"generation {result.generations}: best {values[best]:.6f} median {median(values):.6f} mean {mean(values):.6f}")
+            if self._on_generation is not None:
+                self._on_generation({"generation": result.generations, "population": population, "values": list(values),
+                                     "circuit_evaluations": sum(evaluations)})
             result.generations += 1
             evaluations.append(0)
             terminate = cfg.termination_criterion is not None and cfg.termination_criterion.check_termination(values[best])

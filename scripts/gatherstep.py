@@ -31,7 +31,27 @@ t_both, got = timed(lambda: qd._gather(ev.evaluate_circuits(circuits, params), P
 assert list(got) == list(want)
 print(f"evaluation {t_eval:.1f} us; evaluation + gather path {t_both:.1f} us")
 if hasattr(qd, "evaluate_block_and_gather"):
-    t_fused, got2 = timed(lambda: qd.evaluate_block_and_gather(ev, circuits, params, P, 1, 0, None, dev))
-    assert list(got2) == list(want), (got2[:3], want[:3])
-    print(f"device-resident results + gather {t_fused:.1f} us")
+    # round 4: the collective receives into host memory the device addresses, the end is read off the slots (QSV_GATHER_HOST=0:
+    # round 3's copy back + stream synchronisation)
+    for host in ("0", "1", "0", "1"):
+        os.environ["QSV_GATHER_HOST"] = host
+        t_fused, got2 = timed(lambda: qd.evaluate_block_and_gather(ev, circuits, params, P, 1, 0, None, dev))
+        assert list(got2) == list(want), (got2[:3], want[:3])
+        state = qd._chain_state(ev, dev)
+        print(f"chained step, receive {'into host-mapped memory, polled' if host == '1' else 'on the device, copied back'}: "
+              f"{t_fused:.1f} us (+{t_fused - t_eval:.1f} over the evaluation alone; host receive refused: {bool(state.get('no_host_receive'))})")
+    # the same with the parameter values resident in device memory (what bench.py feeds)
+    import numpy as np
+    width = max(len(p) for p in params)
+    m = np.zeros((P, width))
+    for i, p in enumerate(params):
+        m[i, : len(p)] = p
+    matrix = torch.from_numpy(m).cuda()
+    torch.cuda.synchronize()
+    t_eval_dev, _ = timed(lambda: ev.evaluate_circuits(circuits, matrix))
+    for host in ("0", "1"):
+        os.environ["QSV_GATHER_HOST"] = host
+        t_fused, got3 = timed(lambda: qd.evaluate_block_and_gather(ev, circuits, matrix, P, 1, 0, None, dev))
+        assert list(got3) == list(want)
+        print(f"device-resident inputs: evaluation {t_eval_dev:.1f} us; chained step (host receive {host}) {t_fused:.1f} us (+{t_fused - t_eval_dev:.1f})")
 dist.destroy_process_group()

@@ -95,6 +95,161 @@ def test_single_process_falls_back_to_local_evaluation():
     assert ev.seen == 3 and len(values) == 3
 
 
+# ---- cost-aware shares (SURVEY.md 8(e): "sort by gate count and deal round-robin if imbalance > 10 %") --------------------
+
+
+def test_partition_by_cost():
+    from queasars_amd.distributed import contiguous_shares, imbalance, partition_by_cost
+
+    # even costs: the contiguous blocks stay
+    assert partition_by_cost([1.0] * 64, 8) == contiguous_shares(64, 8)
+    assert partition_by_cost([1.0, 1.05, 0.95, 1.0], 2) == [[0, 1], [2, 3]]
+    # one deep individual among shallow ones (17 us against 1 us): its block would be 2.4 times the mean
+    costs = [1.0] * 16
+    costs[3] = 17.0
+    blocks = contiguous_shares(16, 4)
+    assert imbalance(blocks, costs) > 2.0
+    shares = partition_by_cost(costs, 4)
+    assert sorted(i for share in shares for i in share) == list(range(16))
+    assert [3] in shares and imbalance(shares, costs) < imbalance(blocks, costs)  # (the deep one alone: it IS the longest share)
+    # a mixed-depth population: within 10 % of even
+    rng = np.random.default_rng(0)
+    costs = list(np.where(rng.random(64) < 0.3, 17.0, 1.0) * rng.uniform(0.9, 1.1, 64))
+    for world in (2, 4, 8):
+        shares = partition_by_cost(costs, world)
+        assert sorted(i for share in shares for i in share) == list(range(64))
+        assert imbalance(shares, costs) <= 1.10, (world, imbalance(shares, costs))
+        assert shares == partition_by_cost(costs, world)  # (a pure function of the costs)
+        assert all(share == sorted(share) for share in shares)
+    assert partition_by_cost([], 4) == [[], [], [], []]
+    assert partition_by_cost([3.0, 1.0], 1) == [[0, 1]]
+
+
+class _CostedOracleEvaluator(_OracleEvaluator):
+    """... that also tells what a circuit costs (as OperatorCircuitEvaluator.circuit_costs does): here by its depth."""
+
+    def __init__(self, operator):
+        super().__init__(operator)
+        self.seen_circuits = []
+
+    def evaluate_circuits(self, circuits, parameter_values):
+        self.seen_circuits.extend(circuits)
+        return super().evaluate_circuits(circuits, parameter_values)
+
+    @property
+    def n_qubits(self):
+        return self.operator.num_qubits
+
+    def circuit_costs(self, circuits):
+        return [{"microseconds": 17.0 if c.depth() >= 8 else 1.0} for c in circuits]
+
+
+def _mixed_population(n_individuals: int):
+    """Four-layer individuals with one eight-layer individual among them."""
+    import helpers
+    from queasars_amd.evqe import EVQEPopulation
+
+    shallow = EVQEPopulation.random_population(5, 4, n_individuals, True, 3).individuals
+    deep = EVQEPopulation.random_population(5, 8, 1, True, 4).individuals
+    individuals = list(shallow)
+    individuals[1] = deep[0]
+    circuits = [ind.get_parameterized_quantum_circuit() for ind in individuals]
+    params = [list(ind.parameter_values) for ind in individuals]
+    return individuals, circuits, params, helpers.random_ising_operator(5, seed=7)
+
+
+def _balanced_worker(rank: int, world: int, port: int, out_dir: str):
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+
+    from queasars_amd.distributed import evaluate_population_sharded, imbalance, population_shares
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        _, circuits, params, op = _mixed_population(20)
+        evaluator = _CostedOracleEvaluator(op)
+        values = evaluate_population_sharded(evaluator, circuits, params)
+        shares = population_shares(evaluator, circuits, world)
+        costs = [c["microseconds"] for c in evaluator.circuit_costs(circuits)]
+        assert imbalance(shares, costs) <= 1.10
+        assert [id(c) for c in evaluator.seen_circuits] == [id(circuits[i]) for i in shares[rank]], "a rank evaluates its share only"
+        again = evaluate_population_sharded(evaluator, circuits, params)  # (the shares are remembered: the same answer)
+        assert again == values
+        np.save(os.path.join(out_dir, f"rank{rank}.npy"), np.asarray(values))
+        np.save(os.path.join(out_dir, f"share{rank}.npy"), np.asarray(shares[rank]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_evaluation_with_one_deep_individual_among_shallow_ones(tmp_path):
+    """One eight-layer circuit among four-layer ones: the shares are dealt by cost (within 10 % of even, where the contiguous
+    blocks are 26 : 10, the dealt shares 18 : 18 -- the deep individual and one shallow one against eighteen shallow ones), and the values come back in population order, identical to the unsharded call."""
+    world = 2
+    mp.spawn(_balanced_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    import helpers
+
+    _, circuits, params, op = _mixed_population(20)
+    want = np.asarray([helpers.oracle_expectation(c, p, op) for c, p in zip(circuits, params)])
+    shares = [np.load(tmp_path / f"share{r}.npy").tolist() for r in range(world)]
+    assert sorted(shares[0] + shares[1]) == list(range(20)) and sorted(map(len, shares)) == [2, 18]
+    for rank in range(world):
+        assert np.array_equal(np.load(tmp_path / f"rank{rank}.npy"), want)
+
+
+def _search_worker(rank: int, world: int, port: int, out_dir: str):
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        result, seen = _run_small_evolution(shard=True)
+        np.save(os.path.join(out_dir, f"values{rank}.npy"), np.asarray(result.best_expectation_values + [result.eigenvalue]))
+        np.save(os.path.join(out_dir, f"best{rank}.npy"), np.asarray(result.best_individual.parameter_values))
+        np.save(os.path.join(out_dir, f"counts{rank}.npy"), np.asarray(result.circuit_evaluations + [seen]))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_small_evolution(shard: bool):
+    import helpers
+    from queasars_amd.evqe.solver import SPSA, EVQEMinimumEigensolver, EVQEMinimumEigensolverConfiguration
+
+    op = helpers.random_ising_operator(4, seed=5)
+    evaluator = _CostedOracleEvaluator(op)
+    cfg = EVQEMinimumEigensolverConfiguration(
+        optimizer=SPSA(maxiter=6, learning_rate=0.4, perturbation=0.3), population_size=7, max_generations=3, random_seed=1,
+        n_initial_layers=2, randomize_initial_population_parameters=True, speciation_genetic_distance_threshold=2,
+        use_tournament_selection=True, tournament_size=2, selection_alpha_penalty=0.1, selection_beta_penalty=0.1,
+        parameter_search_probability=0.5, topological_search_probability=0.5, layer_removal_probability=0.05)
+    result = EVQEMinimumEigensolver(cfg, shard=shard).compute_minimum_eigenvalue(evaluator)
+    return result, evaluator.seen
+
+
+def test_two_rank_sharded_searches_are_the_single_rank_evolution(tmp_path):
+    """Every rank runs the optimiser runs of ITS individuals and one all-gather per search hands everybody the results
+    (mutation.py:206-218): the evolution -- best values per generation, the best individual's iterate, evaluation counts -- is
+    the single-process one on every rank, and each rank has evaluated about half of it."""
+    world = 2
+    mp.spawn(_search_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    single, seen_single = _run_small_evolution(shard=False)
+    want_values = np.asarray(single.best_expectation_values + [single.eigenvalue])
+    seen = []
+    for rank in range(world):
+        assert np.array_equal(np.load(tmp_path / f"values{rank}.npy"), want_values)
+        assert np.array_equal(np.load(tmp_path / f"best{rank}.npy"), np.asarray(single.best_individual.parameter_values))
+        counts = np.load(tmp_path / f"counts{rank}.npy")
+        assert counts[:-1].tolist() == single.circuit_evaluations
+        seen.append(int(counts[-1]))
+    assert sum(seen) == seen_single == sum(single.circuit_evaluations)
+    assert max(seen) < 0.75 * seen_single
+
+
 # ---- the same path on RCCL, when the box has two GPUs ----------------------------------------------------------------
 
 
