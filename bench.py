@@ -167,6 +167,10 @@ def kernel_rooflines(device, step, profiled_steps: int, traffic: dict, n_qubits:
         avg_ms = acc["kernel_ms"][kind] / launches
         alg = acc["kernel_bytes"][kind] / launches
         moved = acc["kernel_moved_bytes"][kind] / launches
+        if kind == 0:
+            # a compact first pass writes 2^(m + k) amplitudes per state, not 2^n (plan.hpp COMPACT): the row is priced by what
+            # the pass has to move in THIS design -- pricing 16 * 2^n per state gave fractions above 1
+            alg = min(alg, moved)
         flops = acc["kernel_flops"][kind] / launches
         measured = traffic.get("kernels", {}).get(str(kind), {}).get("hbm_bytes_per_launch")
         entry = {
@@ -343,6 +347,106 @@ def search_block(operator, population, reps: int = 5):
     return out
 
 
+def trajectory_block(operator, generations: int = 8):
+    """What a user sits in: the REAL solver on the benchmark's operator (n = 20, population 64, two initial layers, the notebook's
+    optimiser and mutation probabilities, examples/evqe_jssp_optimization.ipynb: SPSA 33 iterations, parameter search 0.39,
+    topological search 0.79, layer removal 0.02), `generations` generations.  The population's layers grow every generation
+    (base/evolving_ansatz_minimum_eigensolver.py:401-433, mutation.py:347-353), so the evaluations per second drift from the
+    shallow-circuit figure of the headline to the deep-circuit one.  Per generation: wall-clock evaluations per second (the
+    last-layer search of everybody, the scoring, the previous generation's parameter searches), the layer histogram and the
+    routes the scored population's circuits take on the device."""
+    from collections import Counter
+
+    from queasars_amd.circuit_evaluation import OperatorCircuitEvaluator
+    from queasars_amd.evqe import solver as S
+
+    evaluator = OperatorCircuitEvaluator(operator)
+    checker = S.SPSATerminationChecker(minimum_relative_change=0.01, allowed_consecutive_violations=2)
+    cfg = S.EVQEMinimumEigensolverConfiguration(
+        optimizer=S.SPSA(maxiter=33, perturbation=0.35, learning_rate=0.43, trust_region=True, termination_checker=checker),
+        population_size=POP_PER_GPU, max_generations=generations, random_seed=0, n_initial_layers=2,
+        randomize_initial_population_parameters=True, speciation_genetic_distance_threshold=1, use_tournament_selection=True,
+        tournament_size=2, selection_alpha_penalty=0.15, selection_beta_penalty=0.02, parameter_search_probability=0.39,
+        topological_search_probability=0.79, layer_removal_probability=0.02)
+    rows, marks = [], {"t": time.perf_counter(), "evals": 0}
+
+    def scored(info):
+        now = time.perf_counter()
+        individuals = info["population"].individuals
+        circuits = [ind.get_parameterized_quantum_circuit(shared=True) for ind in individuals]
+        routes = Counter(c["route"] for c in evaluator.circuit_costs(circuits))
+        layers = Counter(len(ind.layers) for ind in individuals)
+        dt, de = now - marks["t"], info["circuit_evaluations"] - marks["evals"]
+        rows.append({"generation": info["generation"], "evaluations": de, "seconds": dt, "evals_per_s": de / dt,
+                     "layers": {str(k): layers[k] for k in sorted(layers)}, "mean_layers": sum(k * v for k, v in layers.items()) / len(individuals),
+                     "routes": dict(routes), "best_value": min(info["values"])})
+        marks["t"], marks["evals"] = time.perf_counter(), info["circuit_evaluations"]  # (the bookkeeping above is not the solver's time)
+
+    t0 = time.perf_counter()
+    result = S.EVQEMinimumEigensolver(cfg, on_generation=scored).compute_minimum_eigenvalue(evaluator)
+    total = time.perf_counter() - t0
+    evaluator.statevector_device.close()
+    return {"workload": f"EVQE on the {N_QUBITS}-qubit Ising operator of the headline, population {POP_PER_GPU}, from 2 layers, {generations} "
+                        "generations; the notebook's optimiser and mutation probabilities",
+            "generations": rows, "evaluations": sum(result.circuit_evaluations), "seconds": total,
+            "evals_per_s": sum(result.circuit_evaluations) / total, "eigenvalue": result.eigenvalue,
+            "kept_state_searches": os.environ.get("QSV_KEPT_STATES", "default (on where the circuit costs say it pays)"),
+            "unit": "circuit-evals/s",
+            "note": "wall clock of the whole solver (its own Python included), one process, one GPU; generation g's evaluations = "
+                    "the parameter searches of generation g - 1's survivors (every layer of 39 % of them), the last-layer search of "
+                    "everybody and the scoring"}
+
+
+def layer_search_block(reps: int = 3):
+    """The depth rows where a run lives after a few generations (n = 20, P = 64, seven and eight layers), as a LAST-LAYER search
+    evaluates them (mutation.py:57-59: the other layers bound): whole circuits (rounds 1-3) against kept states for the
+    individuals without a split form (round 4, solver._kept_state_circuits).  Whole evaluator calls, expectation included."""
+    from queasars_amd.circuit_evaluation import OperatorCircuitEvaluator
+    from queasars_amd.evqe import EVQEPopulation
+
+    out = {}
+    operator = ising_operator(N_QUBITS, 2020)
+    for layers in (6, 7, 8):
+        population = EVQEPopulation.random_population(N_QUBITS, layers, POP_PER_GPU, True, 0)
+        evaluator = OperatorCircuitEvaluator(operator)
+        whole = [ind.get_partially_parameterized_quantum_circuit({layers - 1}) for ind in population.individuals]
+        values = [list(ind.get_layer_parameter_values(layers - 1)) for ind in population.individuals]
+        costs = evaluator.circuit_costs(whole)
+        pairs = [ind.get_layer_search_circuits(layers - 1) for ind in population.individuals]
+        deep = [i for i, c in enumerate(costs) if c["route"] == "gate passes"]
+        states = evaluator.keep_states([pairs[i][0] for i in deep], [[] for _ in deep])
+        mixed = list(whole)
+        for i, state in zip(deep, states):
+            mixed[i] = pairs[i][1].continue_from(state)
+
+        def rate(circuits):
+            for _ in range(3):
+                got = evaluator.evaluate_circuits(circuits, values)
+            t0 = time.perf_counter()
+            evaluator.evaluate_circuits(circuits, values)
+            per = time.perf_counter() - t0
+            n = max(5, int(0.3 / max(per, 1e-6)))
+            best = 0.0
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    evaluator.evaluate_circuits(circuits, values)
+                best = max(best, len(circuits) * n / (time.perf_counter() - t0))
+            return best, np.asarray(got)
+
+        whole_rate, whole_values = rate(whole)
+        kept_rate, kept_values = rate(mixed)
+        out[f"L{layers}"] = {"whole_circuits_evals_per_s": whole_rate, "kept_states_evals_per_s": kept_rate, "gain": kept_rate / whole_rate,
+                            "individuals_on_kept_states": len(deep), "max_abs_diff": float(np.abs(whole_values - kept_values).max()),
+                            "routes_whole": {r: sum(c["route"] == r for c in costs) for r in sorted({c["route"] for c in costs})}}
+        del states, mixed
+        evaluator.statevector_device.close()
+    out["note"] = ("last-layer search points of the whole population per call; kept states: the individuals whose circuits take gate "
+                   "passes over the 2^n state evaluate from the state in front of the last layer (qsv_prefix_create), the others as "
+                   "before.  A kept-state evaluation moves 16 MiB read + 16 write + 16 read + the diagonal table: HBM bound")
+    return out
+
+
 # ---- the deep (unsplit) multi-pass path: the statevector sweep north_star names ----------------------------------------
 
 DEEP_ROWS = {
@@ -458,7 +562,7 @@ def agreed_count(mine: int, world: int, comm_device: str, limit: int = 5000) -> 
     return int(t.item())
 
 
-COLLECTIVE_US = 27.0  # chained all-gather + copy back on an RCCL group of ONE rank (112 us against 85)
+COLLECTIVE_US = 27.0  # chained all-gather into host-mapped memory on an RCCL group of ONE rank (profiles/r04_gatherstep.txt: 85 us against 58)
 
 
 def config3_block(world: int, rank: int, local_rank: int, steps: int = 8, layers: int = 4):
@@ -517,19 +621,33 @@ def config3_block(world: int, rank: int, local_rank: int, steps: int = 8, layers
     # collective's latency as measured on a one-rank RCCL group -- skew between ranks and the ring's hops are not in it.
     predicted = None
     if world == 1:
+        from queasars_amd.distributed import contiguous_shares, evaluation_costs, imbalance, partition_by_cost
+
         predicted = {}
         t_all = elapsed / steps
+        costs = evaluation_costs(evaluator, circuits)
         for g in (2, 4, 8):
-            blo, bhi = shard_bounds(total, g, 0)
-            bc, bp = circuits[blo:bhi], params[blo:bhi]
-            evaluator.evaluate_circuits(bc, bp)
-            t1 = time.perf_counter()
-            for _ in range(steps):
+            # every rank's share (dealt by circuit cost where the contiguous blocks are uneven, queasars_amd/distributed.py) timed
+            # on this GPU: the step is as long as the SLOWEST share
+            shares = partition_by_cost(costs, g) if costs is not None else contiguous_shares(total, g)
+            times = []
+            for share in shares:
+                bc, bp = [circuits[i] for i in share], [params[i] for i in share]
                 evaluator.evaluate_circuits(bc, bp)
-            t_block = (time.perf_counter() - t1) / steps
-            predicted[str(g)] = {"block_ms": t_block * 1e3, "speedup": t_all / (t_block + COLLECTIVE_US * 1e-6)}
-        predicted["note"] = (f"speedup at N ranks = this GPU's time for all 256 / (its time for rank 0's block of 256 / N + "
-                             f"{COLLECTIVE_US:.0f} us of collective latency, DESIGN.md section 6); a prediction, not a measurement")
+                t1 = time.perf_counter()
+                for _ in range(steps):
+                    evaluator.evaluate_circuits(bc, bp)
+                times.append((time.perf_counter() - t1) / steps)
+            slowest = max(times)
+            predicted[str(g)] = {"slowest_share_ms": slowest * 1e3, "mean_share_ms": sum(times) / len(times) * 1e3,
+                                 "imbalance_measured_max_over_mean": slowest / (sum(times) / len(times)),
+                                 "imbalance_by_cost_model_dealt": imbalance(shares, costs) if costs is not None else None,
+                                 "imbalance_by_cost_model_contiguous_blocks": imbalance(contiguous_shares(total, g), costs) if costs is not None else None,
+                                 "dealt_by_cost": shares != contiguous_shares(total, g),
+                                 "speedup": t_all / (slowest + COLLECTIVE_US * 1e-6)}
+        predicted["note"] = (f"speedup at N ranks = this GPU's time for all 256 / (its time for the SLOWEST of the N shares + "
+                             f"{COLLECTIVE_US:.0f} us of collective path, profiles/r04_gatherstep.txt); a prediction from one GPU, not a "
+                             "measurement: no multi-GPU node was available to the builder")
     evaluator.statevector_device.close()
     return {
         "workload": f"24-qubit EVQE population = 256 in total, {layers} layers, Ising 300 terms (default_rng(2024)), fp64 "
@@ -551,10 +669,15 @@ def main() -> None:
     ap.add_argument("--no-extras", action="store_true", help="only the headline measurement (profiling runs)")
     ap.add_argument("--only", default=None, help="profiling runs: just one row of the deep block (" + ", ".join(DEEP_ROWS) + ")")
     args = ap.parse_args()
+    if args.only in ("trajectory", "layer_search"):
+        torch.cuda.set_device(0)
+        block = trajectory_block(ising_operator(N_QUBITS, 2020)) if args.only == "trajectory" else layer_search_block()
+        print(json.dumps({args.only: block}), flush=True)
+        return
     if args.only is not None:
         # (rocprofv3 then sees the kernels of that row alone; N = 1)
         if args.only not in DEEP_ROWS:
-            raise SystemExit(f"--only takes one of {list(DEEP_ROWS)}")
+            raise SystemExit(f"--only takes one of {list(DEEP_ROWS) + ['trajectory', 'layer_search']}")
         torch.cuda.set_device(0)
         print(json.dumps({"deep": deep_block(0, args.only, kernels_only=True)}), flush=True)
         return
@@ -675,6 +798,34 @@ def main() -> None:
         feed["values"] = param_matrix
         inputs_agree = list(host_values) == list(values)
     elapsed_host = sorted(host_windows)[len(host_windows) // 2] if host_windows else None
+    # ... and with FRESH inputs every step: two device matrices taking turns (an optimiser never presents the same matrix twice;
+    # the evaluator recognises a matrix it has just read and skips its checks, worth about 0.5 us)
+    elapsed_fresh = None
+    if feed["values"] is param_matrix:
+        other = torch.from_numpy(host_matrix * 0.5 + 0.25).cuda()
+        torch.cuda.synchronize()
+        turn = {"k": 0}
+
+        def step_fresh():
+            turn["k"] ^= 1
+            return evaluate_population_sharded(evaluator, circuits, other if turn["k"] else param_matrix)
+
+        for _ in range(6):
+            step_fresh()
+        fresh_windows = []
+        for _ in range(max(3, min(n_windows, 32))):
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step_fresh()
+            fence()
+            dt = time.perf_counter() - t0
+            if world > 1:
+                t = torch.tensor([dt], dtype=torch.float64, device=comm_device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt = float(t.item())
+            fresh_windows.append(dt)
+        elapsed_fresh = sorted(fresh_windows)[len(fresh_windows) // 2]
 
     # ---- after the timed region: per-kernel roofline of the same step -------------------------------------
     traffic = load_traffic("headline")
@@ -748,6 +899,8 @@ def main() -> None:
             "value_host_lists": (total_evals / elapsed_host) if elapsed_host else None,
             "ms_per_step_host_lists": (elapsed_host / args.steps * 1e3) if elapsed_host else None,
             "host_lists_results_identical": inputs_agree,
+            "value_fresh_inputs": (total_evals / elapsed_fresh) if elapsed_fresh else None,
+            "ms_per_step_fresh_inputs": (elapsed_fresh / args.steps * 1e3) if elapsed_fresh else None,
             "inputs": ("`value`: circuit structures registered (plans in the device arena) and the population's parameter values "
                        "resident in HBM before the timed region (a float64 matrix in device memory, one row per individual: "
                        "qsv_eval_push_device); results to the host.  `value_host_lists`: the same steps with the parameter "
@@ -777,6 +930,8 @@ def main() -> None:
             result["config3"] = config3
             result["config3_deep"] = config3_deep
         if world == 1 and not args.no_extras:
+            result["trajectory"] = trajectory_block(operator)
+            result["layer_search"] = layer_search_block()
             result["deep"] = deep_block(local_rank)
         if world == 1 and not args.no_extras:
             result["roofline"]["microbench"] = microbench_block()

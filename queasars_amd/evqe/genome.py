@@ -187,6 +187,10 @@ class EVQECircuitLayer:
         return sum(1 for g in self.gates if g.kind is EVQEGateType.CONTROLLED_ROTATION)
 
     def is_valid(self) -> bool:
+        return self._valid
+
+    @cached_property
+    def _valid(self) -> bool:  # (an individual checks every one of its layers whenever it is made: once per layer is enough)
         if len(self.gates) != self.n_qubits:
             return False
         for position, gate in enumerate(self.gates):
@@ -455,6 +459,18 @@ class EVQEIndividual:
         (``keep_states``) evaluates the second from there.  The parameter numbering of the second is the whole circuit's."""
         layer_id %= len(self.layers)
         return self._lower(set(), 0, layer_id), self._lower({layer_id}, layer_id, len(self.layers))
+
+    def get_layer_search_state_circuit(self, layer_id: int) -> tuple[CircuitIR, tuple[float, ...]]:
+        """The circuit in front of the searched layer as (the SHARED fully parameterised circuit of those layers, its parameter
+        values): the same state as the first circuit of :meth:`get_layer_search_circuits`, from a structure that an evaluator
+        has usually registered already -- after a topological search the layers in front of the new one are the parent's whole
+        circuit, scored the generation before."""
+        layer_id %= len(self.layers)
+        if layer_id == 0:
+            raise EVQEIndividualException("there is nothing in front of the first layer")
+        count = sum(layer.n_parameters for layer in self.layers[:layer_id])
+        front = EVQEIndividual(self.n_qubits, self.layers[:layer_id], self.parameter_values[:count])
+        return front.get_parameterized_quantum_circuit(shared=True), front.parameter_values_in_circuit_order()
 
     def _lower(self, parameterized_layers: set[int], first: int, last: int) -> CircuitIR:
         """Layers [first, last) of the circuit (get_partially_parameterized_quantum_circuit: all of them)."""

@@ -557,6 +557,7 @@ class EVQEMinimumEigensolver:
         env = os.environ.get("QSV_KEPT_STATES")
         if env == "0" or (flag is False and env != "1") or not hasattr(evaluator, "keep_states") or not hasattr(evaluator, "circuit_costs"):
             return {}
+        force = env == "1" or flag is True  # (asked for: taken wherever the rest of the circuit is cheaper than the whole)
         candidates = [k for k, (ind, layer) in enumerate(zip(individuals, layer_ids)) if layer % len(ind.layers) > 0]
         if not candidates:
             return {}
@@ -565,12 +566,31 @@ class EVQEMinimumEigensolver:
         if first["route"] == "one tile":  # (a register of one tile: nothing to save)
             return {}
         costs = [first] + evaluator.circuit_costs(whole[1:])
-        deep = [(k, c) for k, c in zip(candidates, costs) if c["route"] == "gate passes"]
+        # Worth it?  A kept state costs about one and a half whole evaluations (the circuit in front run once, its state copied)
+        # plus the registration of the rest; every evaluation of the search then saves (whole - rest) microseconds.  A search
+        # makes at most n_circuit_evaluations of them -- about a third of that where a termination checker ends runs early
+        # (measured on the benchmark's trajectory: 22 of 66).  The rest's cost is estimated from its layers: the passes of the
+        # whole circuit scale with its depth, a single last layer takes two.
+        optimizer = self.configuration.optimizer
+        expected = float(optimizer.n_circuit_evaluations)
+        if getattr(optimizer, "termination_checker", None) is not None:
+            expected /= 3.0
+        deep = []
+        for k, c in zip(candidates, costs):
+            if c["route"] != "gate passes":
+                continue
+            n_layers = len(individuals[k].layers)
+            rest_layers = n_layers - layer_ids[k] % n_layers
+            rest_passes = max(2.0, c["n_passes"] * rest_layers / n_layers + 1.0)
+            per_pass = c["microseconds"] / max(1, c["n_passes"])
+            saving = c["microseconds"] - 1.1 * per_pass * rest_passes
+            if force or saving * expected > 1.5 * c["microseconds"] + 60.0:
+                deep.append((k, c))
         if not deep:
             return {}
-        pairs = [individuals[k].get_layer_search_circuits(layer_ids[k]) for k, _ in deep]
-        states = evaluator.keep_states([front for front, _ in pairs], [[] for _ in pairs])
-        circuits = [rest.continue_from(state) for (_, rest), state in zip(pairs, states)]
+        fronts = [individuals[k].get_layer_search_state_circuit(layer_ids[k]) for k, _ in deep]
+        states = evaluator.keep_states([circuit for circuit, _ in fronts], [list(values) for _, values in fronts])
+        circuits = [individuals[k].get_layer_search_circuits(layer_ids[k])[1].continue_from(state) for (k, _), state in zip(deep, states)]
         out = {}
         for (k, cost), circuit, kept_cost in zip(deep, circuits, evaluator.circuit_costs(circuits)):
             if kept_cost["microseconds"] < 0.9 * cost["microseconds"]:

@@ -35,6 +35,9 @@ def main() -> None:
 
     n, P, L = (int(x) for x in (sys.argv[2:5] + ["20", "64", "4"][len(sys.argv[2:5]):]))
     _, circuits, params = helpers.population_circuits(n, L, P, seed=0)
+    if os.environ.get("QSV_STAMP_ONLY"):  # (some circuits of the population alone: indices)
+        only = [int(x) for x in os.environ["QSV_STAMP_ONLY"].split(",")]
+        circuits, params = [circuits[i] for i in only], [params[i] for i in only]
     ev = OperatorCircuitEvaluator(helpers.random_ising_operator(n, seed=2020))
     lib = _lib.load()
     table = (C.c_ulonglong * 128)()
