@@ -447,13 +447,68 @@ def layer_search_block(reps: int = 3):
     return out
 
 
+def config5_sweep_block(sizes=(24, 26, 28)):
+    """BASELINE.json configs[4] as a sweep: one genome (four layers, seed 0), 500 random Pauli strings (default_rng(2028)), single
+    and double precision at n = 24, 26, 28: |fp32 - fp64| of the expectation value, evaluations per second on the library's
+    default route (the genome has a split form: the term kernel on two small states) and THROUGH THE 2^n STATE (splitting off:
+    gate passes over the state, then one read of it per group of strings), and the later-pass kernel's launch time and
+    fraction of the HBM roof there (HIP events; 2 * sizeof(amplitude) * 2^n bytes per pass)."""
+    from queasars_amd.circuit_evaluation import OperatorCircuitEvaluator
+    from queasars_amd.evqe import EVQEPopulation
+    from queasars_amd.workloads import random_pauli_operator
+
+    rows = {}
+    for n in sizes:
+        individual = EVQEPopulation.random_population(n, 4, 1, True, 0).individuals[0]
+        circuits, params = [individual.get_parameterized_quantum_circuit()], [list(individual.parameter_values)]
+        operator = random_pauli_operator(n, 500, seed=2028)
+        row = {}
+        for precision in ("fp64", "fp32"):
+            entry = {}
+            for route, split in (("default_route", 1), ("through_the_state", 0)):
+                evaluator = OperatorCircuitEvaluator(operator, dtype=precision)
+                device = evaluator.statevector_device
+                if not split:
+                    device.set_option("split", 0)
+                value = evaluator.evaluate_circuits(circuits, params)[0]
+                t0 = time.perf_counter()
+                evaluator.evaluate_circuits(circuits, params)
+                per = time.perf_counter() - t0
+                reps = max(2, min(50, int(0.5 / max(per, 1e-6))))
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    evaluator.evaluate_circuits(circuits, params)
+                entry[route] = {"value": value, "evals_per_s": reps / (time.perf_counter() - t0)}
+                if not split:
+                    device.set_option("streams", 1)
+                    kernels, _ = kernel_rooflines(device, lambda: evaluator.evaluate_circuits(circuits, params), 3, {}, n)
+                    later = next((k for k in kernels if "later passes" in k["kernel"]), None)
+                    if later is not None:
+                        entry[route].update({"later_pass_launch_us": later["avg_launch_us"], "later_pass_GBps": later["achieved_GBps"],
+                                             "later_pass_frac_hbm": later["frac_hbm_algorithmic"], "later_pass_launches": later["launches"]})
+                device.close()
+            row[precision] = entry
+        row["abs_diff_fp32_vs_fp64"] = abs(row["fp32"]["default_route"]["value"] - row["fp64"]["default_route"]["value"])
+        row["abs_diff_fp32_vs_fp64_through_the_state"] = abs(row["fp32"]["through_the_state"]["value"] - row["fp64"]["through_the_state"]["value"])
+        row["abs_diff_of_the_two_routes_fp64"] = abs(row["fp64"]["default_route"]["value"] - row["fp64"]["through_the_state"]["value"])
+        row["sum_abs_coefficients"] = float(np.abs(operator.coeffs).sum())
+        rows[f"n{n}"] = row
+    rows["note"] = ("fp32 tolerance of the GPU tests: 2e-6 * sum |c_k|.  later_pass_*: pass_kernel<real, R, X, false> on the genome's own "
+                    "gate passes (not a single-gate sweep), one state per launch")
+    return rows
+
+
 # ---- the deep (unsplit) multi-pass path: the statevector sweep north_star names ----------------------------------------
 
 DEEP_ROWS = {
-    # name: (qubits, layers, individuals, splitting on?)   -- reference behaviour: circuit_evaluation.py:200-215
-    "deep_n20_L8": (20, 8, 64, True),
-    "deep_n24_L4_nosplit": (24, 4, 32, False),
-    "deep_n24_L8": (24, 8, 32, True),
+    # name: (qubits, layers, individuals, splitting on?, precision)   -- reference behaviour: circuit_evaluation.py:200-215
+    "deep_n20_L8": (20, 8, 64, True, "fp64"),
+    "deep_n24_L4_nosplit": (24, 4, 32, False, "fp64"),
+    "deep_n24_L8": (24, 8, 32, True, "fp64"),
+    # the same rows in single precision (BASELINE configs[4] asks for an fp32 / fp64 sweep): the generated fp32 round loop
+    "deep_n20_L8_fp32": (20, 8, 64, True, "fp32"),
+    "deep_n24_L4_nosplit_fp32": (24, 4, 32, False, "fp32"),
+    "deep_n24_L8_fp32": (24, 8, 32, True, "fp32"),
 }
 
 
@@ -483,14 +538,14 @@ def deep_block(local_rank: int, only: str = None, kernels_only: bool = False):
     from queasars_amd.evqe import EVQEPopulation
 
     rows = {}
-    for name, (n, layers, pop, split) in DEEP_ROWS.items():
+    for name, (n, layers, pop, split, precision) in DEEP_ROWS.items():
         if only is not None and name != only:
             continue
         population = EVQEPopulation.random_population(n, layers, pop, True, 0)
         circuits = [ind.get_parameterized_quantum_circuit() for ind in population.individuals]
         params = [list(ind.parameter_values) for ind in population.individuals]
         operator = ising_operator(n, 2020 if n == 20 else 2024)
-        evaluator = OperatorCircuitEvaluator(operator, device=local_rank)
+        evaluator = OperatorCircuitEvaluator(operator, device=local_rank, dtype=precision)
         device = evaluator.statevector_device
         if not split:
             device.set_option("split", 0)
@@ -529,16 +584,21 @@ def deep_block(local_rank: int, only: str = None, kernels_only: bool = False):
         torch.cuda.synchronize()
         rate_one = pop * reps / (time.perf_counter() - t0)
         kernels, _ = kernel_rooflines(device, step, 5, load_traffic(name), n)
+        if precision == "fp32":
+            for k in kernels:  # (kernel_names() spells the fp64 instantiations; the single-precision peak is twice the fp64 one)
+                k["kernel"] = k["kernel"].replace("pass_kernel<double, 4, 2,", "pass_kernel<float, 3, 0,").replace("<double>", "<float>")
+                k["frac_fp32"] = k.pop("frac_fp64") / 2.0
+                k.pop("achieved_fp64_TFLOPs", None)
         later = next((k for k in kernels if "later passes" in k["kernel"]), None)
         rows[name] = {
-            "workload": f"{n}-qubit EVQE population={pop}, {layers} layers, Ising operator, fp64"
+            "workload": f"{n}-qubit EVQE population={pop}, {layers} layers, Ising operator, {precision}"
                         + ("" if split else ", register splitting switched off"),
             "value": rate, "unit": "circuit-evals/s", "value_one_stream": rate_one,
             "pass_launches_per_call": prof["n_pass_launches"], "state_passes_per_call": prof["n_state_passes"],
             "split_evaluations": int(prof["kernel_states"][2]),
             "kernels_one_stream": kernels,
             "later_pass_frac_hbm": later["frac_hbm_algorithmic"] if later else None,
-            "later_pass_frac_fp64": later["frac_fp64"] if later else None,
+            "later_pass_frac_fp64": later.get("frac_fp64") if later else None,
             "all_values_finite": bool(np.isfinite(values).all()),
         }
         evaluator.statevector_device.close()
@@ -669,15 +729,16 @@ def main() -> None:
     ap.add_argument("--no-extras", action="store_true", help="only the headline measurement (profiling runs)")
     ap.add_argument("--only", default=None, help="profiling runs: just one row of the deep block (" + ", ".join(DEEP_ROWS) + ")")
     args = ap.parse_args()
-    if args.only in ("trajectory", "layer_search"):
+    if args.only in ("trajectory", "layer_search", "config5_sweep"):
         torch.cuda.set_device(0)
-        block = trajectory_block(ising_operator(N_QUBITS, 2020)) if args.only == "trajectory" else layer_search_block()
+        block = (trajectory_block(ising_operator(N_QUBITS, 2020)) if args.only == "trajectory" else
+                 layer_search_block() if args.only == "layer_search" else config5_sweep_block())
         print(json.dumps({args.only: block}), flush=True)
         return
     if args.only is not None:
         # (rocprofv3 then sees the kernels of that row alone; N = 1)
         if args.only not in DEEP_ROWS:
-            raise SystemExit(f"--only takes one of {list(DEEP_ROWS) + ['trajectory', 'layer_search']}")
+            raise SystemExit(f"--only takes one of {list(DEEP_ROWS) + ['trajectory', 'layer_search', 'config5_sweep']}")
         torch.cuda.set_device(0)
         print(json.dumps({"deep": deep_block(0, args.only, kernels_only=True)}), flush=True)
         return
@@ -932,6 +993,7 @@ def main() -> None:
         if world == 1 and not args.no_extras:
             result["trajectory"] = trajectory_block(operator)
             result["layer_search"] = layer_search_block()
+            result["config5_sweep"] = config5_sweep_block()
             result["deep"] = deep_block(local_rank)
         if world == 1 and not args.no_extras:
             result["roofline"]["microbench"] = microbench_block()

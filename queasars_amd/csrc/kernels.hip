@@ -469,9 +469,11 @@ static_assert(kPrepScratchDoubles * sizeof(double) == kFusedPrepareLdsBytes, "ke
 #define QSV_PSTAMP_PARAMS
 #define QSV_PSTAMP_PARAMS_DEF
 #endif
+// float_mats: the scheduled entries' matrices are left as eight FLOATS at the start of their 64-byte records (single-precision
+// handles: the round loops read them as they are, instead of rounding eight doubles per gate, wave and tile)
 __device__ __forceinline__ void prepare_eval(const uint32_t* __restrict__ plan, const EvalDesc& ev,
                                              const double* __restrict__ params, double* __restrict__ mats,
-                                             double* scratch QSV_PSTAMP_PARAMS) {
+                                             double* scratch, bool float_mats QSV_PSTAMP_PARAMS) {
     double* sv = scratch;                   // initial factors (v0, v1) of every qubit, n <= 32
     double* sp = scratch + 4 * 32;          // the parameter vector
     double* fm = sp + kPrepMaxParams;       // matrices of the fold entries
@@ -525,8 +527,16 @@ __device__ __forceinline__ void prepare_eval(const uint32_t* __restrict__ plan, 
         else
             entry_matrix(table + size_t(n_factors + j - n_real) * kAngleEntryWords, p, m);
         double* dst = j < n_real ? out + size_t(j) * 8 : fm + size_t(j - n_real) * 8;
+        if (float_mats && j < n_real) {
+            float* dstf = reinterpret_cast<float*>(dst);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) dst[i] = m[i];
+            for (int i = 0; i < 8; ++i) dstf[i] = float(m[i]);
+#pragma unroll
+            for (int i = 8; i < 16; ++i) dstf[i] = 0.f;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dst[i] = m[i];
+        }
     }
     if (staged) __syncthreads();
     QSV_PSTAMP(4);  // matrices
@@ -691,9 +701,9 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, FIRST>::waves_per_si
         }
 #ifdef QSV_STAMPS
         QSV_STAMP(0);  // descriptor
-        prepare_eval(plan_arena, ev, a.host_params, a.mats_out, reinterpret_cast<double*>(lds_raw), st_acc, &st_last);
+        prepare_eval(plan_arena, ev, a.host_params, a.mats_out, reinterpret_cast<double*>(lds_raw), std::is_same<real, float>::value, st_acc, &st_last);
 #else
-        prepare_eval(plan_arena, ev, a.host_params, a.mats_out, reinterpret_cast<double*>(lds_raw));
+        prepare_eval(plan_arena, ev, a.host_params, a.mats_out, reinterpret_cast<double*>(lds_raw), std::is_same<real, float>::value);
 #endif
         __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
@@ -922,14 +932,21 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, FIRST>::waves_per_si
         // fp64, exchange mode 2 (the production configuration): every round of the tile is ONE generated assembly block
         // (gate_loop_gen.inc, RoundLoopF64).  The C++ loop below states the same thing and serves fp32, the other
         // exchange modes and the stamped diagnostic build.
-        constexpr bool kAsmRounds = std::is_same<real, double>::value && XMODE == 2 && R <= 4;
+        // (fp32 in exchange mode 0 likewise since round 4: RoundLoopF32, packed arithmetic)
+        constexpr bool kAsmRounds = (std::is_same<real, double>::value && XMODE == 2 && R <= 4) ||
+                                    (std::is_same<real, float>::value && XMODE == 0 && R <= 4);
 #else
         constexpr bool kAsmRounds = false;
 #endif
         if constexpr (kAsmRounds) {
-            if (n_rounds > 0)
-                RoundLoopF64<R>::run(amp, rp, mp, uint32_t(n_rounds), uint32_t(base), tid_ext, wave, active_mask,
-                                     uint32_t(uintptr_t(lds_raw)), xflags);
+            if (n_rounds > 0) {
+                if constexpr (std::is_same<real, double>::value)
+                    RoundLoopF64<R>::run(amp, rp, mp, uint32_t(n_rounds), uint32_t(base), tid_ext, wave, active_mask,
+                                         uint32_t(uintptr_t(lds_raw)), xflags);
+                else
+                    RoundLoopF32<R>::run(amp, rp, mp, uint32_t(n_rounds), uint32_t(base), tid_ext, wave, active_mask,
+                                         uint32_t(uintptr_t(lds_raw)), xflags);
+            }
             QSV_STAMP(10);
         } else
         for (int m = 0; m < n_rounds; ++m) {
@@ -1099,13 +1116,22 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, FIRST>::waves_per_si
                 }
             } else {
                 // gate stream: descriptor and matrix of gate g+1 are fetched (scalar loads) while gate g runs
+                // (single precision: the records hold eight floats, prepare_eval's float_mats)
+                auto entry = [](cf64p rec, int i) -> double {
+                    if constexpr (std::is_same<real, float>::value)
+                        return double(reinterpret_cast<const QSV_CONST_AS float*>(rec)[i]);
+                    else
+                        return rec[i];
+                };
                 uint32_t w0 = rp[0], ct = rp[1], cg = rp[2], ncg = rp[3];
-                double m0 = mp[0], mi = mp[1], m1 = mp[2], m2 = mp[3], m3 = mp[4], m4 = mp[5], m5 = mp[6], m6 = mp[7];
+                double m0 = entry(mp, 0), mi = entry(mp, 1), m1 = entry(mp, 2), m2 = entry(mp, 3), m3 = entry(mp, 4), m4 = entry(mp, 5),
+                       m5 = entry(mp, 6), m6 = entry(mp, 7);
                 for (int g = 0; g < n_gates; ++g) {
                     rp += kGateWords;
                     mp += 8;
                     const uint32_t nw0 = rp[0], nct = rp[1], nxcg = rp[2], nxncg = rp[3];
-                    const double n0 = mp[0], ni = mp[1], n1 = mp[2], n2 = mp[3], n3 = mp[4], n4 = mp[5], n5 = mp[6], n6 = mp[7];
+                    const double n0 = entry(mp, 0), ni = entry(mp, 1), n1 = entry(mp, 2), n2 = entry(mp, 3), n3 = entry(mp, 4),
+                                 n4 = entry(mp, 5), n5 = entry(mp, 6), n6 = entry(mp, 7);
                     if ((w0 & (kGateGeneral | kGateNegated)) != 0) {
                         // an entry of a multiplexed gate or a product of matrices (plan.hpp FUSION): predicates over the
                         // complemented bits too, pairs by the entry's mask, general matrix
@@ -1349,19 +1375,19 @@ __global__ void __launch_bounds__(256) prepare_kernel(const uint32_t* __restrict
                                                       const EvalDesc* __restrict__ host_evals,
                                                       EvalDesc* __restrict__ evals,
                                                       const double* __restrict__ params, double* __restrict__ mats,
-                                                      uint32_t region_stride) {
+                                                      uint32_t region_stride, uint32_t float_mats) {
     __shared__ double scratch[kPrepScratchDoubles];
     const size_t slot = size_t(blockIdx.x) + size_t(blockIdx.y) * region_stride;
     const EvalDesc ev = host_evals[slot];
     if (threadIdx.x == 0) evals[slot] = ev;
     if (ev.flags & kEvalNull) return;
-    prepare_eval(plan, ev, params, mats, scratch);
+    prepare_eval(plan, ev, params, mats, scratch, float_mats != 0);
 }
 
 hipError_t launch_prepare(const uint32_t* plan, const EvalDesc* host_evals, EvalDesc* evals, const double* params,
-                          double* mats, int n_evals, hipStream_t stream, int n_regions, uint32_t region_stride) {
+                          double* mats, int n_evals, hipStream_t stream, int n_regions, uint32_t region_stride, int dtype) {
     hipLaunchKernelGGL(prepare_kernel, dim3(n_evals, n_regions), dim3(256), 0, stream, plan, host_evals, evals, params,
-                       mats, region_stride);
+                       mats, region_stride, uint32_t(dtype != 0));
     return hipGetLastError();
 }
 

@@ -147,8 +147,9 @@ inline __host__ __device__ size_t tile_info_offset(uint32_t n_real, uint32_t n_q
 // Angles -> gate matrices, initial product-state factors and synthesis tables, one workgroup per evaluation.
 // host_evals / params are pinned host memory read by the kernel; evals receives the device copy of the descriptors.
 // n_regions = 2: also descriptors [region_stride + i] (the second descriptors of split evaluations).
+// dtype != 0 (single precision): the gate matrices are left as floats (kernels.hip prepare_eval, float_mats).
 hipError_t launch_prepare(const uint32_t* plan, const EvalDesc* host_evals, EvalDesc* evals, const double* params,
-                          double* mats, int n_evals, hipStream_t stream, int n_regions = 1, uint32_t region_stride = 0);
+                          double* mats, int n_evals, hipStream_t stream, int n_regions = 1, uint32_t region_stride = 0, int dtype = 0);
 
 // Split evaluations (split.hpp): <psi|D|psi> with psi[i] = sum_kappa A_kappa[a(i)] B_kappa[b(i)] formed on the fly from
 // the two side tables; grid and partial-sum layout as the pass kernel's fused last pass (PassArgs: plan, evals, wtab,

@@ -703,15 +703,22 @@ CircuitPlan build_plan(int n, const std::vector<GateIn>& all_gates, const std::v
                 std::swap(*in_reg, fin.thr[size_t(u)]);
             }
             if (!fix.empty()) {
-                if (fix.size() > kMaxSwaps) throw std::logic_error("too many restoring swaps");
-                pass.rounds.emplace_back();
-                pass.rounds.back().regbits = fin.reg;
-                layouts.push_back(fin);
-                swaps.push_back(fix);
-                by_swap.push_back(1);
-                intra.push_back(0);
-                wave_sets.push_back(prev_w);
-                needed.emplace_back();
+                // (more than a round's worth of transpositions -- three low lane bits of single-precision plans can need six --
+                // take several gate-less rounds, each with the layout its own swaps leave)
+                Layout cur = layouts.back();
+                for (size_t at = 0; at < fix.size(); at += kMaxSwaps) {
+                    const size_t end = std::min(fix.size(), at + size_t(kMaxSwaps));
+                    std::vector<std::pair<int, int>> part(fix.begin() + long(at), fix.begin() + long(end));
+                    for (const auto& vu : part) std::swap(cur.reg[size_t(vu.first)], cur.thr[size_t(vu.second)]);
+                    pass.rounds.emplace_back();
+                    pass.rounds.back().regbits = cur.reg;
+                    layouts.push_back(cur);
+                    swaps.push_back(part);
+                    by_swap.push_back(1);
+                    intra.push_back(0);
+                    wave_sets.push_back(prev_w);
+                    needed.emplace_back();
+                }
                 w[pass_header_at] = uint32_t(k) | uint32_t(r) << 8 | uint32_t(t) << 16 | uint32_t(pass.rounds.size()) << 24;
             }
         }

@@ -416,10 +416,22 @@ PlanConfig resolve_config(const qsv_plan_config* cfg, int dtype, int n_qubits) {
     // Tile geometry by size (fp64; measured on MI355X with the EVQE benchmark family, scripts/geometry_sweep.sh): 16 amplitudes
     // per thread halve the per-amplitude cost of decoding the plan from n = 20 on, and 13 tile qubits save a pass
     // from n = 21 on (n = 24: 3 -> 2.25 passes on average, +33 % evaluations per second).
-    if (dtype == QSV_F64 && n_qubits >= 20) {
+    // (single precision likewise since its round loop is generated assembly too, round 4: n = 20, L = 8 60 k -> 81 k evals/s with
+    // 16 amplitudes per thread, n = 24 3.0 k -> 3.8 k with 13-qubit tiles, profiles/r04_fp32.txt)
+    if (n_qubits >= 20) {
         pc.reg_bits = 4;
         pc.tile_bits = n_qubits >= 21 ? 13 : 12;
     }
+    // Runs in memory.  The load and store layouts of a multi-gate pass keep only the lowest `lane_bits` tile qubits on the low
+    // lanes (everything else goes where the first round's targets want it): a wave's access is 64 / 2^lane_bits separate runs
+    // of 2^lane_bits amplitudes.  Two bits are 64-byte runs in double precision -- half an L2 line (128 bytes on this part) --
+    // and 32-byte runs in single precision.  Measured in round 4 (profiles/r04_fp32.txt): with THREE the later pass of config
+    // 5's genome goes from 0.55 to 0.68 of 8 TB/s at n = 28 (fp64) and from 0.36 to 0.57 (fp32), whole deep evaluations at
+    // n = 26 / 28 gain 10 - 20 %; at n <= 24 in double precision the pass gains as much as the lost free qubit costs in
+    // passes (n = 24: L = 8 +5 %, L = 4 -5 %).  So: three wherever the state is beyond the Infinity Cache, and in single
+    // precision from 20 qubits on.
+    if ((size_t(1) << n_qubits) * size_t(pc.amp_bytes) > (size_t(256) << 20) || (dtype != QSV_F64 && n_qubits >= 20))
+        pc.low_bits = pc.lane_bits = 3;
     if (dtype != QSV_F64) pc.xmode = 0;  // fp32: one 8-byte complex element per LDS access
     if (const char* e = getenv("QSV_XMODE")) pc.xmode = atoi(e);
     if (const char* e = getenv("QSV_TILE_BITS")) pc.tile_bits = atoi(e);
@@ -429,9 +441,9 @@ PlanConfig resolve_config(const qsv_plan_config* cfg, int dtype, int n_qubits) {
     if (const char* e = getenv("QSV_FOLD")) pc.fold = atoi(e) != 0;
     if (const char* e = getenv("QSV_COMPACT")) pc.compact = atoi(e) != 0;
     if (const char* e = getenv("QSV_SWAPS")) pc.swaps = atoi(e) != 0;
-    // multiplexed gates (plan.hpp FUSION): fp64's assembly gate loop takes their entries at full speed; fp32's C++ loop
-    // takes them correctly but through a generic butterfly, so they stay off there unless asked for
-    pc.fuse = dtype == QSV_F64;
+    // multiplexed gates (plan.hpp FUSION): the assembly round loops of both precisions take their entries at full speed (fp32
+    // since round 4: RoundLoopF32's one body serves products of matrices as well)
+    pc.fuse = true;
     if (const char* e = getenv("QSV_FUSE")) pc.fuse = atoi(e) != 0;
     if (const char* e = getenv("QSV_RETRIES")) pc.retries = atoi(e);
     if (cfg) {
@@ -477,8 +489,13 @@ int build_circuit(qsv_t* h, int n_ops, const qsv_op* ops, int n_params, bool fol
             const int side_tile = std::max(h->geo.k, std::min(h->geo.r + 9, int(kMaxTileBits)));
             std::vector<int> limits{h->geo.k};
             if (side_tile > h->geo.k && side_tile < h->n) limits.push_back(side_tile);
-            limits.push_back(std::min(h->geo.k + 2, h->n - 1));
-            limits.push_back(std::min(h->geo.k + kSideExtraBits, h->n - 1));
+            // (every size up to tile + 4 is a stage of its own since round 4: the first limit that has a partition wins, and with
+            // the stages two qubits apart config 5's genome -- 14 + 14 qubits and two keys under limit 16 -- was taken as 13 + 15
+            // under limit 17 on handles with 13-qubit tiles, a quarter more rows for the term kernel)
+            for (int extra = 1; extra <= kSideExtraBits; ++extra) {
+                const int limit = std::min(h->geo.k + extra, h->n - 1);
+                if (limit > limits.back()) limits.push_back(limit);
+            }
             SplitCircuits sc = find_split(h->n, gates, angles, limits, h->split_max_keys);
             if (sc.ok && std::max(sc.n_side[0], sc.n_side[1]) > kSideMaxOwnBits) sc.ok = false;
             if (sc.ok) {
@@ -969,7 +986,7 @@ int batch_ship(qsv_t* h, size_t first, size_t count, const double* values, size_
     if (count > n_fused)
         QSV_HIP(h, launch_prepare(static_cast<const uint32_t*>(h->d_arena.ptr), host_evals + first + n_fused,
                                   static_cast<EvalDesc*>(h->d_batch.ptr) + first + n_fused, ship_params,
-                                  static_cast<double*>(h->d_mats.ptr), int(count - n_fused), ws(h)));
+                                  static_cast<double*>(h->d_mats.ptr), int(count - n_fused), ws(h), 1, 0, h->dtype));
     return QSV_OK;
 }
 

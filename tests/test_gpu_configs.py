@@ -1136,9 +1136,9 @@ def test_multiplexed_gates_agree_with_separate_gates(n, layers, count, c_oracle)
             assert np.abs(a - helpers.oracle_state(c, p)).max() < 1e-12
 
 
-def test_multiplexed_gates_in_fp32_take_the_generic_butterfly():
-    """fp32 plans are not fused by default (their gate loop is the C++ one); with QSV_FUSE=1 its flagged entries -- negated
-    predicates, products with a complex m00 -- go through the generic butterfly: the same values as without, to fp32."""
+def test_multiplexed_gates_in_fp32():
+    """fp32 plans carry multiplexed gates like fp64 plans since round 4 (the generated fp32 round loop has one packed-arithmetic
+    body for u-type matrices and products with a complex m00); QSV_FUSE=0 switches them off: the same values, to fp32."""
     n = 16
     _, circuits, params = helpers.population_circuits(n, 7, 8, seed=9)
     op = helpers.random_ising_operator(n, seed=n)
@@ -1148,6 +1148,34 @@ def test_multiplexed_gates_in_fp32_take_the_generic_butterfly():
         dev = _device_with_env(n, "fp32", QSV_FUSE=fuse, QSV_SPLIT=0)
         got = np.asarray(OperatorCircuitEvaluator(op, statevector_device=dev).evaluate_circuits(circuits, params))
         assert np.abs(got - want).max() < bound, fuse
+
+
+@pytest.mark.parametrize("tile_bits,reg_bits", [(0, 0), (13, 4), (12, 4), (11, 3), (10, 2), (9, 1)])
+def test_fp32_round_loop_geometries(tile_bits, reg_bits):
+    """The generated fp32 round loop (RoundLoopF32: packed butterflies, lane swaps, LDS exchanges of whole elements) in every
+    register width, on deep unsplit circuits whose plans have all three kinds of round: amplitudes within 2e-5 of the oracle,
+    expectation values within FP32_REL * sum |c_k| of fp64, and the same bits whatever the batch."""
+    n = 15
+    _, circuits, params = helpers.population_circuits(n, 7, 6, seed=21)
+    op = helpers.random_ising_operator(n, seed=n)
+    want = np.asarray([helpers.oracle_expectation(c, p, op) for c, p in zip(circuits, params)])
+    bound = FP32_REL * float(np.abs(op.coeffs).sum())
+    env = dict(QSV_SPLIT=0)
+    if tile_bits:
+        env.update(QSV_TILE_BITS=tile_bits, QSV_REG_BITS=reg_bits)
+    dev = _device_with_env(n, "fp32", **env)
+    ev = OperatorCircuitEvaluator(op, statevector_device=dev)
+    got = np.asarray(ev.evaluate_circuits(circuits, params))
+    assert np.abs(got - want).max() < bound
+    for c, p in zip(circuits[:2], params[:2]):
+        assert np.abs(dev.statevector(c, p) - helpers.oracle_state(c, p)).max() < 2e-5
+    assert np.array_equal(np.asarray(ev.evaluate_circuits(circuits[::-1], params[::-1]))[::-1], got)
+    assert ev.evaluate_circuits([circuits[3]], [params[3]])[0] == got[3]
+    # a general operator: the state is stored and read back by the grouped expectation kernel
+    general = helpers.random_pauli_operator(n, 10, seed=2)
+    got = np.asarray(OperatorCircuitEvaluator(general, statevector_device=dev).evaluate_circuits(circuits, params))
+    want = np.asarray([helpers.oracle_expectation(c, p, general) for c, p in zip(circuits, params)])
+    assert np.abs(got - want).max() < FP32_REL * float(np.abs(general.coeffs).sum())
 
 
 def test_chain_stream_and_result_polling_change_no_bit():

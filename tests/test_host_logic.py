@@ -283,7 +283,7 @@ class TestProcessLocalRegistrations:
         dev = object.__new__(StatevectorDevice)  # no GPU here: only the bookkeeping is exercised
         from queasars_amd.circuit_evaluation.circuit_evaluation import _make_gone
 
-        dev._dead, dev._watched, dev._handle, dev._lib = [], {}, 1, FakeLib()
+        dev._dead, dev._dead_states, dev._watched, dev._handle, dev._lib = [], [], {}, 1, FakeLib()
         dev._gone = _make_gone(dev._dead, dev._watched)
         c = CircuitIR(2).u(0.1, 0.2, 0.3, 0)
         dev._watch(c, 17)
