@@ -457,6 +457,25 @@ PlanConfig resolve_config(const qsv_plan_config* cfg, int dtype, int n_qubits) {
     return pc;
 }
 
+// The ordinary (multi-pass) plan of a circuit.  With THREE low lane bits instead of two a pass over a state runs faster (128-byte
+// runs, resolve_config) but has one free tile qubit fewer, which costs some circuits a pass: where the handle's default is two
+// (double precision up to 24 qubits) the circuit is scheduled both ways and takes three when that costs no pass -- three in four
+// deep individuals (n = 24, L = 8: 24 of 32; L = 4: 31 of 32).  QSV_LOW_BITS / QSV_LANE_BITS / QSV_AUTO_LANE=0 switch it off.
+CircuitPlan build_ordinary_plan(const qsv_t* h, const std::vector<GateIn>& gates, const std::vector<AngleSource>& angles, const PlanConfig& pc) {
+    CircuitPlan two = build_plan(h->n, gates, angles, pc);
+    static const bool automatic = !getenv("QSV_LOW_BITS") && !getenv("QSV_LANE_BITS") && !(getenv("QSV_AUTO_LANE") && atoi(getenv("QSV_AUTO_LANE")) == 0);
+    if (!automatic || pc.low_bits != 2 || pc.lane_bits != 2 || h->geo.blocks_per_state < 2 || two.stats.n_passes < 1) return two;
+    PlanConfig wide = pc;
+    wide.low_bits = wide.lane_bits = 3;
+    try {
+        CircuitPlan three = build_plan(h->n, gates, angles, wide);
+        if (three.stats.n_passes <= two.stats.n_passes) return three;
+    } catch (const std::exception&) {
+        // (the narrower plan stands)
+    }
+    return two;
+}
+
 // Validate an op list and schedule it.  Touches only immutable parts of the handle (n, cfg), so it needs no lock and
 // several threads may build plans at the same time.
 int build_circuit(qsv_t* h, int n_ops, const qsv_op* ops, int n_params, bool fold, Circuit* out, std::string* err) {
@@ -604,7 +623,7 @@ int build_circuit(qsv_t* h, int n_ops, const qsv_op* ops, int n_params, bool fol
             out->gates = std::move(gates);
             out->angles = std::move(angles);
         } else {
-            const CircuitPlan p = build_plan(h->n, gates, angles, pc);
+            const CircuitPlan p = build_ordinary_plan(h, gates, angles, pc);
             out->off_plan = uint32_t(out->plan.words.size());
             out->plan.words.insert(out->plan.words.end(), p.words.begin(), p.words.end());
             out->plan.stats = p.stats;
@@ -623,7 +642,7 @@ int ensure_plan(qsv_t* h, Circuit& c) {
     try {
         PlanConfig pc = h->cfg;
         pc.fold = pc.fold && c.fold;
-        const CircuitPlan p = build_plan(h->n, c.gates, c.angles, pc);
+        const CircuitPlan p = build_ordinary_plan(h, c.gates, c.angles, pc);
         c.off_plan = uint32_t(c.plan.words.size());
         c.plan.words.insert(c.plan.words.end(), p.words.begin(), p.words.end());
         c.plan.stats = p.stats;
@@ -863,7 +882,7 @@ int batch_layout(qsv_t* h, const std::vector<Circuit*>& circs, const std::vector
                 try {
                     PlanConfig pc = h->cfg;
                     pc.fold = pc.fold && c.fold;
-                    out.circuit.plan = build_plan(h->n, c.gates, c.angles, pc);
+                    out.circuit.plan = build_ordinary_plan(h, c.gates, c.angles, pc);
                 } catch (const std::exception& e) {
                     out.rc = QSV_E_ARG;
                     out.err = std::string("plan: ") + e.what();
