@@ -513,9 +513,9 @@ DEEP_ROWS = {
 
 
 def load_traffic(row: str) -> dict:
-    """HBM traffic per launch of a bench row from the committed profile (profiles/r03_traffic.json: separate rocprofv3
+    """HBM traffic per launch of a bench row from the committed profile (profiles/r04_traffic.json: separate rocprofv3
     --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --only <row>`); not measured inside this run."""
-    for name in ("r03_traffic.json", "traffic.json"):
+    for name in ("r04_traffic.json", "r03_traffic.json", "traffic.json"):
         f = ROOT / "profiles" / name
         if f.exists():
             try:
@@ -606,7 +606,7 @@ def deep_block(local_rank: int, only: str = None, kernels_only: bool = False):
                     "kernels_one_stream: HIP events around every launch with the handle on ONE stream (a launch then has the "
                     "chip to itself; with the default two streams launches overlap and stretch each other), bytes per SURVEY "
                     "8(d): 16 * 2^n per state and direction a pass has to move; traffic_bytes_per_launch from the committed "
-                    "rocprofv3 PMC passes of `bench.py --only <row>` (profiles/r03_traffic.json), not measured in this run")
+                    "rocprofv3 PMC passes of `bench.py --only <row>` (profiles/r04_traffic.json), not measured in this run")
     return rows
 
 

@@ -675,6 +675,10 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, FIRST>::waves_per_si
     extern __shared__ __align__(16) unsigned char lds_raw[];
 
     QSV_STAMP_DECL
+    // (kModeTileMajor: the two grid dimensions trade places)
+    const bool tile_major = !FIRST && (a.mode & kModeTileMajor);
+    const uint32_t block_x = tile_major ? blockIdx.y : blockIdx.x, grid_x = tile_major ? gridDim.y : gridDim.x;
+    const uint32_t block_y = tile_major ? blockIdx.x : blockIdx.y;
     EvalDesc ev;
     const double* mats_base = mats_all;
     bool prepared_here = false;
@@ -685,10 +689,10 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, FIRST>::waves_per_si
         // memory, matrices and tables into the evaluation's region -- which this workgroup then reads back through the
         // scalar cache: its stores must have landed, stale lines must go, and no load below may be moved above this
         // point (the pointer the loads use is only known to the compiler from here on).
-        const size_t slot = size_t(blockIdx.y) + size_t(blockIdx.z) * a.region_stride;
+        const size_t slot = size_t(block_y) + size_t(blockIdx.z) * a.region_stride;
         ev = a.host_evals[slot];
         // (the device copy first, also of a null descriptor: a repeated batch reads its descriptors from that copy)
-        if (threadIdx.x == 0 && blockIdx.x == 0) a.evals_out[slot] = ev;
+        if (threadIdx.x == 0 && block_x == 0) a.evals_out[slot] = ev;
         if (ev.flags & kEvalNull) return;
         {
             // a launch's grid is as wide as its largest evaluation: a workgroup beyond THIS evaluation's tiles leaves before
@@ -697,7 +701,7 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, FIRST>::waves_per_si
             const uint32_t* p0 = c0 + c0[kCircuitHeaderWords];
             const uint32_t f0 = p0[2];
             const uint32_t tiles0 = (f0 & kPassCompactStore) ? 1u << ((f0 >> 8) & 0xffu) : 1u << (c0[2] - (p0[0] & 0xffu));
-            if (blockIdx.x >= tiles0) return;
+            if (block_x >= tiles0) return;
         }
 #ifdef QSV_STAMPS
         QSV_STAMP(0);  // descriptor
@@ -712,7 +716,7 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, FIRST>::waves_per_si
         asm volatile("" : "+s"(mats_base)::"memory");
         QSV_STAMP(13);
     } else {
-        cu32p e = as_constant(reinterpret_cast<const uint32_t*>(evals + blockIdx.y + size_t(blockIdx.z) * a.region_stride));
+        cu32p e = as_constant(reinterpret_cast<const uint32_t*>(evals + block_y + size_t(blockIdx.z) * a.region_stride));
         ev.plan_base = e[0];
         ev.mat_base = e[1];
         ev.state_slot = e[2];
@@ -800,7 +804,7 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, FIRST>::waves_per_si
     // Workgroup b sweeps tiles b, b + gridDim.x, b + 2 gridDim.x, ..: neighbouring workgroups (which run at the same
     // time) work on neighbouring tiles, and a compact pass 0 -- fewer tiles than the grid -- gives each working
     // workgroup a single tile instead of leaving half of them idle.
-    const uint32_t tile0 = blockIdx.x, tile_step = gridDim.x;
+    const uint32_t tile0 = block_x, tile_step = grid_x;
     if (tile0 >= total_tiles) return;  // (uniform, before any barrier)
     const uint32_t n_tiles = (total_tiles - tile0 + tile_step - 1) / tile_step < a.tiles_per_block
                                  ? (total_tiles - tile0 + tile_step - 1) / tile_step
@@ -820,7 +824,7 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, FIRST>::waves_per_si
 
     if constexpr (!FIRST) {
         // (measurement: the two workgroups of a CU start half a tile apart, so that one loads while the other computes)
-        if (a.dephase && (blockIdx.x & 1u))
+        if (a.dephase && (block_x & 1u))
             for (uint32_t i = 0; i < a.dephase; ++i) __builtin_amdgcn_s_sleep(127);
     }
     QSV_STAMP(0);
@@ -1266,11 +1270,11 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, FIRST>::waves_per_si
             return;
         }
         // a launch with fewer workgroups than the reducer's shape also clears the slots nobody owns
-        const uint32_t slots = a.partial_chunks ? a.partial_chunks : gridDim.x;
+        const uint32_t slots = a.partial_chunks ? a.partial_chunks : grid_x;
         if ((tid & 63u) == 0) {
             double* mine = partials + size_t(ev.out_index) * slots * n_waves + wave;
-            mine[size_t(blockIdx.x) * n_waves] = acc;
-            for (uint32_t b2 = blockIdx.x + gridDim.x; b2 < slots; b2 += gridDim.x) mine[size_t(b2) * n_waves] = 0.0;
+            mine[size_t(block_x) * n_waves] = acc;
+            for (uint32_t b2 = block_x + grid_x; b2 < slots; b2 += grid_x) mine[size_t(b2) * n_waves] = 0.0;
         }
     }
 #ifdef QSV_STAMPS

@@ -69,6 +69,9 @@ enum PassMode : uint32_t {
     kModeFusedLdsTable = 512u, // (with kModeFusedFactor, fp64) the launch has the LDS for it (kFusedLdsTableEnd) and at most one
                                // workgroup per CU anyway: sides of up to kFusedLdsTableBits qubits hand their state to the
                                // Gram matrices through LDS.  Same values, same order of every sum: a launch may choose.
+    kModeTileMajor = 1024u,  // (later passes) grid = (evaluations, tile chunks) instead of (tile chunks, evaluations): the workgroups
+                             // of ONE tile of every state are dispatched together (the last pass's reads of the diagonal table then
+                             // meet in the memory-side cache); measurement knob QSV_TILE_MAJOR
     kModeFusedPrepare = 8u,  // (pass 0 only) every workgroup first does prepare_kernel's work for its evaluation, reading
                              // the descriptor from host_evals (PassArgs below); no prepare launch ran for these evaluations
 };

@@ -1224,6 +1224,12 @@ int run_group(qsv_t* h, const std::vector<Circuit*>& circs, size_t first, size_t
         a.tiles_per_block = (h->geo.blocks_per_state + chunks_p - 1) / chunks_p;
         dim3 grid(chunks_p, unsigned(n_plain));
         a.pass_index = uint32_t(p);
+        {
+            static const bool tile_major = getenv("QSV_TILE_MAJOR") && atoi(getenv("QSV_TILE_MAJOR")) != 0;
+            const bool swap = tile_major && !(p == 0 && (mode & kModeSynthFirst)) && n_plain > 1;
+            a.mode = swap ? (a.mode | kModeTileMajor) : (a.mode & ~uint32_t(kModeTileMajor));
+            if (swap) grid = dim3(unsigned(n_plain), chunks_p);
+        }
         const int kind = (p == 0 && (mode & kModeSynthFirst)) ? 0 : 1;  // which instantiation of the kernel runs
         if (h->stamping) QSV_HIP(h, stamp(h, h->batch.launch_events[kind], true));
         QSV_HIP(h, launch_pass(h->dtype, h->geo.r, h->cfg.xmode, grid, h->geo.threads_launch,

@@ -14,6 +14,7 @@ Round 2's version of this script timed one unbatched cached pass without its exp
     python scripts/prefix_cache_experiment.py [n:layers:population ...]     (default 20:8:64 20:7:64 20:6:64 24:8:32)
 """
 import json
+import os
 import sys
 import time
 from pathlib import Path
@@ -48,7 +49,18 @@ def main():
         n, layers, pop = (int(x) for x in spec.split(":"))
         population = EVQEPopulation.random_population(n, layers, pop, True, 0)
         evaluator = OperatorCircuitEvaluator(workloads.random_ising_operator(n, seed=2020 if n == 20 else 2024))
-        for layer in sorted({layers - 1, layers // 2}, reverse=True):
+        only_kept = os.environ.get("QSV_EXP_ONLY") == "kept"  # (profiling runs: the last-layer search's kept-state evaluations alone)
+        for layer in ([layers - 1] if only_kept else sorted({layers - 1, layers // 2}, reverse=True)):
+            if only_kept:
+                pairs = [ind.get_layer_search_circuits(layer) for ind in population.individuals]
+                values = [list(ind.get_layer_parameter_values(layer)) for ind in population.individuals]
+                states = evaluator.keep_states([p for p, _ in pairs], [[] for _ in pairs])
+                kept = [s.continue_from(state) for (_, s), state in zip(pairs, states)]
+                kept_rate, _ = rate(evaluator, kept, values, seconds=0.1)
+                costs = evaluator.circuit_costs(kept)
+                print(json.dumps({"n": n, "layers": layers, "population": pop, "kept_evals_per_s": round(kept_rate),
+                                  "passes": [c["n_passes"] for c in costs]}), flush=True)
+                continue
             full = [ind.get_partially_parameterized_quantum_circuit({layer}) for ind in population.individuals]
             values = [list(ind.get_layer_parameter_values(layer)) for ind in population.individuals]
             costs_full = evaluator.circuit_costs(full)

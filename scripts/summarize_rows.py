@@ -43,7 +43,7 @@ for row in rows:
             kind = "0" if ", true>" in k["kernel"] else "1"
             hbm = kernels.get(kind, {}).get("hbm_bytes_per_launch")
             print(f"    {k['kernel'][:44]:44s} launches={k['launches']:5d} states/launch={k['states_per_launch']:5.1f} HIP-event avg_us={k['avg_launch_us']:8.1f} "
-                  f"alg_MB={k['algorithmic_bytes_per_launch'] / 1e6:8.1f} frac_hbm={k['frac_hbm_algorithmic']:.3f} frac_fp64={k['frac_fp64']:.3f} "
+                  f"alg_MB={k['algorithmic_bytes_per_launch'] / 1e6:8.1f} frac_hbm={k['frac_hbm_algorithmic']:.3f} frac_fp={k.get('frac_fp64', k.get('frac_fp32', 0.0)):.3f} "
                   f"PMC traffic_MB={(hbm or 0) / 1e6:8.1f}" + (f" -> {hbm / (k['avg_launch_us'] * 1e-6) / 1e12:.2f} TB/s moved" if hbm else ""))
 with open(f"{root}/traffic.json", "w") as f:
     json.dump(traffic, f, indent=1)
