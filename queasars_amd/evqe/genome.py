@@ -315,6 +315,8 @@ class EVQEIndividual:
     def parameter_values_in_circuit_order(self) -> tuple[float, ...]:
         """This individual's values laid out so that the fully parameterised circuit gives every layer ITS values (what
         binding layer by layer does, individual.py:288-322); equal to ``parameter_values`` up to ten layers."""
+        if len(self.layers) <= 10:  # (layer0_ .. layer9_ sort as they are numbered)
+            return self.parameter_values
         out = [0.0] * len(self.parameter_values)
         for i in range(len(self.layers)):
             start = self.circuit_parameter_offsets[i]

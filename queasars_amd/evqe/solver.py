@@ -654,14 +654,31 @@ class EVQEMinimumEigensolver:
         threshold = self.configuration.speciation_genetic_distance_threshold
         representatives = list(population.species_representatives or [])
         members: dict[EVQEIndividual, list[int]] = {rep: [] for rep in representatives}
-        for i, individual in enumerate(population.individuals):
+        if 0 < threshold <= 1:
+            # A genetic distance below one is zero: the same number of layers and every layer equal (individual.py:217-237), and
+            # an equal individual has equal layers too -- the first representative with the individual's layers, found by
+            # hashing instead of by comparing with every representative in turn (36 k distance calls per run of the
+            # benchmark's trajectory, a sixth of the driver's time; the notebooks' threshold is 1).
+            first = {}
             for rep in representatives:
-                if EVQEIndividual.get_genetic_distance(individual, rep) < threshold or individual == rep:
+                first.setdefault(rep.layers, rep)
+            for i, individual in enumerate(population.individuals):
+                rep = first.get(individual.layers)
+                if rep is None:
+                    representatives.append(individual)
+                    members[individual] = [i]
+                    first[individual.layers] = individual
+                else:
                     members[rep].append(i)
-                    break
-            else:
-                representatives.append(individual)
-                members[individual] = [i]
+        else:
+            for i, individual in enumerate(population.individuals):
+                for rep in representatives:
+                    if EVQEIndividual.get_genetic_distance(individual, rep) < threshold or individual == rep:
+                        members[rep].append(i)
+                        break
+                else:
+                    representatives.append(individual)
+                    members[individual] = [i]
         new_members: dict[EVQEIndividual, list[int]] = {}
         for group in members.values():
             if not group:

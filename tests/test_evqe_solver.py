@@ -303,6 +303,42 @@ def test_reference_speciation_keeps_members_within_the_genetic_distance():
     assert seen == set(range(10))
 
 
+def test_speciation_at_threshold_one_is_the_general_rule():
+    """At a genetic-distance threshold of one (the notebooks') the driver finds an individual's species by hashing its layers
+    (a distance below one is zero: the same layers); the result must be what the reference's rule gives compared individual by
+    individual (speciation.py:34-90) -- the same representatives in the same order, the same members -- also across
+    generations, where the previous generation's representatives come first."""
+    from queasars_amd.evqe.genome import EVQEIndividual
+
+    def by_the_rule(solver, population, threshold):
+        representatives = list(population.species_representatives or [])
+        members = {rep: [] for rep in representatives}
+        for i, individual in enumerate(population.individuals):
+            for rep in representatives:
+                if EVQEIndividual.get_genetic_distance(individual, rep) < threshold or individual == rep:
+                    members[rep].append(i)
+                    break
+            else:
+                representatives.append(individual)
+                members[individual] = [i]
+        return representatives, members
+
+    ev = OracleEvaluator(xy_hamiltonian())
+    solver = EVQEMinimumEigensolver(make_config(population_size=12, speciation_genetic_distance_threshold=1, topological_search_probability=0.6,
+                                                layer_removal_probability=0.2, optimizer=SPSA(maxiter=4, learning_rate=0.4, perturbation=0.3)))
+    population = EVQEPopulation.random_population(4, 2, 12, True, random_seed=3)
+    for _ in range(4):
+        want_reps, want_members = by_the_rule(solver, population, 1)
+        # (the driver then draws a new representative per species: compare the grouping, which is what the rule decides)
+        groups_want = sorted(sorted(m) for m in want_members.values() if m)
+        speciated = solver._speciation(population)
+        groups_got = sorted(sorted(m) for m in speciated.species_members.values())
+        assert groups_got == groups_want
+        population = solver._selection(speciated, _population_values(ev, speciated))
+        population = solver._topological_search(population)
+        population = solver._layer_removal(population)
+
+
 def test_reference_selection_lowers_the_expectation_values():
     """test_evqe_operators.py:184-209: three rounds of speciation and selection, the population's sum falls every round."""
     ev = OracleEvaluator(xy_hamiltonian())
