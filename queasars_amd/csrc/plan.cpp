@@ -368,7 +368,10 @@ CircuitPlan build_plan(int n, const std::vector<GateIn>& all_gates, const std::v
     // attempt), which reaches tile sets the greedy rule cannot.  build_plan keeps the attempt with the fewest passes:
     // a pass is a full sweep of the state, and at n = 24 one circuit in six needs three passes under the greedy rule
     // where two suffice.
-    auto attempt_schedule = [&](int try_no) {
+    // tiles_only: just the choice of tiles and the gates each pass takes (what decides the NUMBER of passes): the rounds of the
+    // best attempt are laid out afterwards, once -- an attempt then costs a tenth, and build_plan can afford many more of them
+    // (round 4: n = 24, L = 8 3.94 -> 3.5 passes per circuit with 256 attempts, n = 20, L = 6 2.44 -> 2.16).
+    auto attempt_schedule = [&](int try_no, bool tiles_only) {
     uint32_t lcg = 0x2545F491u * uint32_t(try_no + 1);
     auto decline = [&]() {
         if (try_no == 0) return false;
@@ -410,6 +413,15 @@ CircuitPlan build_plan(int n, const std::vector<GateIn>& all_gates, const std::v
                 else
                     blk.defer(g);
             }
+        }
+        if (tiles_only) {
+            for (int s2 : selected) {
+                done[size_t(s2)] = 1;
+                ++n_done;
+            }
+            if (selected.empty() && n_done < gates.size()) return std::vector<PassPlan>();
+            passes.emplace_back();
+            continue;
         }
         for (int q = 0; q < n && tile_count < k; ++q)
             if (!in_tile[q]) {
@@ -484,12 +496,24 @@ CircuitPlan build_plan(int n, const std::vector<GateIn>& all_gates, const std::v
     }
     return passes;
     };
-    std::vector<PassPlan> passes = attempt_schedule(0);
-    if (cfg.retries > 0 && n > k && passes.size() > 2)
-        for (int attempt = 1; attempt <= cfg.retries && passes.size() > 2; ++attempt) {
-            std::vector<PassPlan> other = attempt_schedule(attempt);
-            if (!other.empty() && other.size() < passes.size()) passes = std::move(other);
+    std::vector<PassPlan> passes = attempt_schedule(0, false);
+    if (cfg.retries > 0 && n > k && passes.size() > 2) {
+        size_t best = passes.size();
+        int best_try = 0, last_gain = 0;
+        // (patience: a circuit whose attempts stop improving is not tried to the end -- most eight-layer circuits at 20 qubits
+        // stay at three passes whatever is tried, and their plans are built while a generation waits)
+        // (from 22 qubits on an evaluation is hundreds of microseconds and a pass a tenth of it: every attempt is worth its 8 us)
+        const int patience = n >= 22 ? cfg.retries : std::max(16, cfg.retries / 4);
+        for (int attempt = 1; attempt <= cfg.retries && best > 2 && attempt - last_gain <= patience; ++attempt) {
+            const size_t count = attempt_schedule(attempt, true).size();
+            if (count > 0 && count < best) {
+                best = count;
+                best_try = attempt;
+                last_gain = attempt;
+            }
         }
+        if (best_try != 0) passes = attempt_schedule(best_try, false);
+    }
 
     // ---- 3. encode ---------------------------------------------------------------------------------------
     std::vector<uint32_t>& w = out.words;
