@@ -51,7 +51,8 @@ struct PlanConfig {
     int xmode = 2;       // LDS exchange mode (kernels.hip): 0 whole element, 1 two resident planes, 2 one plane buffer
     bool fold = true;    // absorb leading gates into the synthesised initial product state
     bool compact = true; // (needs fold) pass 0 computes one tile per pattern of its outer control qubits, see below
-    int retries = 256;   // randomised scheduling attempts when the first-come rule needs more than two passes (tiles only: cheap)
+    int retries = 32;    // randomised scheduling attempts (tiles only: cheap) when the first-come rule AND the local search over
+                         // the tiles (plan.cpp) need more than two passes; > 0 also switches the local search on
     bool swaps = true;   // relayouts that only trade register bits for lane bits 2..5 run as in-register lane swaps
                          // (v_permlane16/32_swap, DPP row shifts) instead of an LDS exchange, see "round" below
     bool fuse = true;    // FUSION (below): u gates next to a cu3 on the same target become part of it
