@@ -196,6 +196,36 @@ def test_swap_rounds_bring_the_low_tile_bits_home():
             assert ps["store_cols"][:cl] == ps["load_cols"][:cl], "low tile bits must end on the lanes they started on"
 
 
+def test_the_tile_search_keeps_its_pass_counts():
+    """A pass is a full sweep of the state: what the scheduler's local search over the tiles buys (round 4) is held as a bound
+    on the mean number of passes of fixed populations -- first-come tiles gave 3.94 (n = 24, eight layers), 2.44 (n = 20, six),
+    3.09 (n = 20, eight); 256 random attempts 3.5 / 2.16 / 3.0 -- and every plan still reproduces its circuit at a size the
+    interpreter can run."""
+    for n, layers, count, tile, reg, bound in ((24, 8, 8, 13, 4, 3.2), (20, 6, 16, 12, 4, 2.2), (20, 8, 16, 12, 4, 3.05)):
+        _, circuits, _ = helpers.population_circuits(n, layers, count, seed=0)
+        passes = [pi.decode(build_plan_words(c, tile_bits=tile, reg_bits=reg))["n_passes"] for c in circuits]
+        assert sum(passes) / count <= bound, (n, layers, sum(passes) / count)
+    # (executed: registers of 14 - 16 qubits with 8- and 9-qubit tiles need the search as a 24-qubit one with 13-qubit tiles does;
+    # QSV_RETRIES=0 is the first-come rule alone)
+    import os
+
+    improved = 0
+    for n, layers, tile, reg in ((15, 8, 8, 3), (14, 8, 8, 2), (16, 8, 9, 3)):
+        _, circuits, params = helpers.population_circuits(n, layers, 4, seed=5)
+        for c, p in zip(circuits, params):
+            os.environ["QSV_RETRIES"] = "0"
+            try:
+                plain = pi.decode(build_plan_words(c, tile_bits=tile, reg_bits=reg))["n_passes"]
+            finally:
+                del os.environ["QSV_RETRIES"]
+            words = build_plan_words(c, tile_bits=tile, reg_bits=reg)
+            searched = pi.decode(words)["n_passes"]
+            assert searched <= plain
+            improved += searched < plain
+            assert np.abs(pi.run(words, n, p) - helpers.oracle_state(c, p)).max() < 1e-13
+    assert improved >= 6, improved
+
+
 def test_three_low_lane_bits_restored_in_several_swap_rounds(monkeypatch):
     """With three low tile bits pinned to lanes (64-byte runs of 8-byte single-precision amplitudes) bringing them home can take
     six transpositions: more than one swap round holds.  The scheduler then emits several gate-less rounds (round 4; it used
