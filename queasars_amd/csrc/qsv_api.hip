@@ -2366,7 +2366,16 @@ int qsv_circuit_cost(qsv_t* h, int circuit_id, qsv_circuit_cost_t* out) {
     // 17.1 us per evaluation at 3.13 passes = 5.5 us per pass (the synthesising, compact first pass included); on a kept state
     // 10.5 - 11 us at 1.89 passes, 18.4 at 2.8: 5.8 - 6.6 us per pass -- few gates, but every pass reads and writes the whole state
     // (HBM bound: 56 MiB per two-pass evaluation at 5.3 TB/s); n = 24: 16 times both
-    out->microseconds = (c.prefix_id >= 0 ? 6.0 : 5.5) * double(out->n_passes) * scale;
+    // ... refitted at the end of round 4 (scripts/prefix_cache_experiment.py after the scheduler's tile search): a pass that
+    // moves the state costs 4.2 us at 20 qubits, a scheduled gate entry 0.09 us on top, a synthesising first pass 1 us and no
+    // state traffic: whole eight-layer circuit 2.98 passes, 78 entries -> 15 us (14.6 measured); seven layers 13.4 (13.5); a last
+    // layer on a kept state 1.89 passes, 15 entries -> 9.3 (9.6); the upper four of eight layers 2.02 passes, 70 entries -> 14.8
+    // (14.8: as dear as the whole circuit, which is why a search in the middle keeps it)
+    {
+        const bool synth = c.prefix_id < 0;
+        const double moving = double(out->n_passes) - (synth ? 1.0 : 0.0);
+        out->microseconds = (4.2 * std::max(0.0, moving) + 0.09 * double(c.plan.stats.n_real_gates) + (synth ? 1.0 : 0.0)) * scale;
+    }
     return QSV_OK;
 }
 

@@ -24,6 +24,9 @@ from __future__ import annotations
 import numpy as np
 
 
+_MAX_SIGN_BYTES = 256 << 20
+
+
 def supported(evaluator, jobs) -> bool:
     """Can :func:`minimize_spsa_on_device` take these jobs?  An exact estimator on a GPU, fresh SPSA runs of one configuration."""
     if len(jobs) < 2 or not hasattr(evaluator, "evaluate_device_to_device"):
@@ -33,6 +36,12 @@ def supported(evaluator, jobs) -> bool:
     runs = [run for _, run in jobs]
     cfg = runs[0].config
     if any(run.config is not cfg or run.iteration != 0 or run.nfev != 0 or run.done for run in runs):
+        return False
+    # (the sign vectors of every iteration are drawn ahead, as float64 rows of the widest run's width -- on the host and again on
+    # the device: long optimisations of many deep individuals with embedded parameter vectors would be hundreds of megabytes;
+    # beyond a quarter of a gigabyte the host driver, which draws them iteration by iteration, takes the search)
+    width = max(run.embed[0].size if run.embed is not None else run.x.size for run in runs)
+    if int(cfg.maxiter) * len(runs) * width * 8 > _MAX_SIGN_BYTES:
         return False
     checker = cfg.termination_checker
     return cfg.maxiter > 0 and (checker is None or type(checker).__name__ == "SPSATerminationChecker")

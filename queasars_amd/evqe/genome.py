@@ -238,7 +238,8 @@ class EVQECircuitLayer:
             target, control = rng.sample(to_pair, 2)
             candidate = ControlledRotationGate(target, control)
             marker = ControlGate(control, target)
-            if previous_layer is None or (candidate not in previous_layer.gates and marker not in previous_layer.gates):
+            # (a valid layer keeps the gate of qubit q at position q: "not in previous_layer.gates" is a look at two positions)
+            if previous_layer is None or (previous_layer.gates[target] != candidate and previous_layer.gates[control] != marker):
                 slots[target], slots[control] = candidate, marker
                 to_pair.remove(target)
                 to_pair.remove(control)
