@@ -41,7 +41,7 @@ def supported(evaluator, jobs) -> bool:
     # the device: long optimisations of many deep individuals with embedded parameter vectors would be hundreds of megabytes;
     # beyond a quarter of a gigabyte the host driver, which draws them iteration by iteration, takes the search)
     width = max(run.embed[0].size if run.embed is not None else run.x.size for run in runs)
-    if int(cfg.maxiter) * len(runs) * width * 8 > _MAX_SIGN_BYTES:
+    if int(cfg.maxiter) * len(runs) * width * 8 > _MAX_SIGN_BYTES:  # (as doubles on the device; bytes on the host)
         return False
     checker = cfg.termination_checker
     return cfg.maxiter > 0 and (checker is None or type(checker).__name__ == "SPSATerminationChecker")
@@ -71,7 +71,8 @@ def minimize_spsa_on_device(evaluator, jobs, look_every: int = 8) -> None:
     lengths = np.array([run.embed[0].size if run.embed is not None else run.x.size for run in runs])
     width, n_runs = int(lengths.max()), len(runs)
     x_host = np.zeros((n_runs, width))
-    signs_host = np.zeros((n_iter, n_runs, width))
+    # (the signs travel as bytes -- an eighth of the transfer, which was a tenth of a short search -- and become doubles on the device)
+    signs_host = np.zeros((n_iter, n_runs, width), dtype=np.int8)
     for i, run in enumerate(runs):
         if run.embed is not None:
             x_host[i, : lengths[i]] = run.embed[0]
@@ -89,7 +90,7 @@ def minimize_spsa_on_device(evaluator, jobs, look_every: int = 8) -> None:
     lib, handle = dev._lib, dev._handle
     with torch.cuda.stream(stream):
         x = torch.from_numpy(x_host).to(device)
-        signs = torch.from_numpy(signs_host).to(device)
+        signs = torch.from_numpy(signs_host).to(device).to(torch.float64)
         points = torch.empty((2 * n_runs, width), dtype=torch.float64, device=device)
         values = torch.empty(2 * n_runs, dtype=torch.float64, device=device)
         active = torch.ones(n_runs, dtype=torch.uint8, device=device)
@@ -138,7 +139,7 @@ def _minimize_with_torch_operations(evaluator, jobs, look_every: int = 8) -> Non
     lengths = np.array([run.embed[0].size if run.embed is not None else run.x.size for run in runs])
     width, n_runs = int(lengths.max()), len(runs)
     x_host = np.zeros((n_runs, width))
-    signs_host = np.zeros((n_iter, n_runs, width))
+    signs_host = np.zeros((n_iter, n_runs, width), dtype=np.int8)
     for i, run in enumerate(runs):
         if run.embed is not None:
             x_host[i, : lengths[i]] = run.embed[0]
@@ -156,7 +157,7 @@ def _minimize_with_torch_operations(evaluator, jobs, look_every: int = 8) -> Non
     stream.wait_stream(caller)
     with torch.cuda.stream(stream):
         x = torch.from_numpy(x_host).to(device)
-        signs = torch.from_numpy(signs_host).to(device)
+        signs = torch.from_numpy(signs_host).to(device).to(torch.float64)
         points = torch.empty((2 * n_runs, width), dtype=torch.float64, device=device)
         values = torch.empty(2 * n_runs, dtype=torch.float64, device=device)
         active = torch.ones(n_runs, dtype=torch.bool, device=device)

@@ -18,3 +18,4 @@ print(round(out["evals_per_s"]), "evals/s", out["evaluations"], "evaluations", r
 for g in out["generations"]:
     print("  gen", g["generation"], g["evaluations"], "evals", round(g["seconds"] * 1e3, 1), "ms", round(g["evals_per_s"]), "evals/s", g["routes"])
 pstats.Stats(prof).sort_stats("cumulative").print_stats(top)
+pstats.Stats(prof).sort_stats("tottime").print_stats(25)
