@@ -214,7 +214,16 @@ def evaluate_block_and_gather(evaluator, circuits: Sequence, parameter_values: S
         if mine_c and not to_device(mine_c, mine_p, send.data_ptr()):
             return None
         if host_receive:
-            dist.all_gather_into_tensor(mapped[0], send, group=group)
+            try:
+                dist.all_gather_into_tensor(mapped[0], send, group=group)
+            except Exception as exc:  # (a collective library that refuses host-mapped memory refuses it on every rank alike)
+                import warnings
+
+                warnings.warn(f"queasars_amd.distributed: all-gather into host-mapped memory refused ({exc}); receiving on the device",
+                              RuntimeWarning)
+                state["no_host_receive"] = True
+                host_receive = False
+        if host_receive:
             table = mapped[1]
             deadline = time.perf_counter() + _POLL_SECONDS
             flat = table.view(np.uint64)
@@ -224,7 +233,7 @@ def evaluate_block_and_gather(evaluator, circuits: Sequence, parameter_values: S
                     stream.synchronize()
                     break
             recv_values = table
-        else:
+        if not host_receive:
             dist.all_gather_into_tensor(recv, send, group=group)
             recv_host.copy_(recv, non_blocking=True)
             stream.synchronize()

@@ -30,7 +30,7 @@ def search_circuits(population, layer):
     return out
 
 
-@pytest.mark.parametrize("n,layers,layer", [(14, 6, 5), (14, 6, 2), (16, 5, 4), (13, 4, 1)])
+@pytest.mark.parametrize("n,layers,layer", [(14, 6, 5), (14, 6, 2), (16, 5, 4), (13, 4, 1), (10, 4, 3), (12, 5, 2)])
 def test_circuits_on_kept_states_against_the_oracle(n, layers, layer):
     """Values and amplitudes of circuits that continue a kept state: the NumPy oracle's for the whole circuit."""
     population = EVQEPopulation.random_population(n, layers, 8, True, 3)
