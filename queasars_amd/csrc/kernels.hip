@@ -462,10 +462,12 @@ static_assert(kPrepScratchDoubles * sizeof(double) == kFusedPrepareLdsBytes, "ke
 
 #ifdef QSV_STAMPS  // (diagnostic build: phases 2 .. 8 of the stamp table take prepare_eval's steps)
 #define QSV_PSTAMP(ph) do { if (st_acc) { const unsigned long long st_t = qsv_stamp_now(); st_acc[ph] += st_t - *st_last; *st_last = st_t; } } while (0)
+#define QSV_PSTAMP_ARGS , st_acc, st_last
 #define QSV_PSTAMP_PARAMS , unsigned long long* st_acc = nullptr, unsigned long long* st_last = nullptr
 #define QSV_PSTAMP_PARAMS_DEF , unsigned long long* st_acc, unsigned long long* st_last
 #else
 #define QSV_PSTAMP(ph)
+#define QSV_PSTAMP_ARGS
 #define QSV_PSTAMP_PARAMS
 #define QSV_PSTAMP_PARAMS_DEF
 #endif
@@ -659,7 +661,7 @@ template <typename real>
 __device__ __forceinline__ void fused_factor_tail(const uint32_t* __restrict__ plan_arena, const EvalDesc& ev,
                                                   const cx<real>* __restrict__ slot_tables, uint64_t side_stride,
                                                   const double* __restrict__ diag, const PassScalars& a, unsigned char* lds,
-                                                  uint32_t gram_waves, bool table_in_lds QSV_PSTAMP_PARAMS);
+                                                  uint32_t gram_waves, uint32_t lds_table QSV_PSTAMP_PARAMS);
 
 // FIRST = the pass synthesises its input (pass 0 of an evaluation from |0..0>): two instantiations, so that neither
 // carries the other's load path through register allocation.
@@ -779,12 +781,21 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, FIRST>::waves_per_si
     // A side whose Gram matrices this workgroup forms itself (fused_factor_tail) stores its state WRITE-THROUGH: nobody but
     // this workgroup reads it, and left dirty in L2 the side tables of a launch (12 MB at 64 evaluations) are written back
     // when the kernel ends -- ten microseconds between the last workgroup and the host seeing the results.
+#ifdef QSV_ABL_NO_THROUGH  // (measurement: the fused sides' states stored like any other)
+    const bool through = false;
+#else
     const bool through = FIRST && R == 4 && side && (ev.flags & kEvalFused) && (a.mode & kModeFusedFactor);
+#endif
     // ... and a small enough side does not go to memory at all where the launch has the LDS for it (kModeFusedLdsTable): the
     // table is laid out in LDS exactly as it would be in its slot (a fused side is one tile: offsets inside the tile ARE table
     // indices), behind everything else this kernel keeps there
     const bool table_in_lds = through && std::is_same<real, double>::value && (a.mode & kModeFusedLdsTable) &&
                               n_qubits <= uint32_t(kFusedLdsTableBits);
+    // ... or, a three-key side of thirteen virtual qubits, as padded rows from offset 0 (kernels.hpp, kFusedLdsRowsBits)
+    bool table_lds_rows = false;
+    if constexpr (FIRST && R == 4 && std::is_same<real, double>::value)
+        table_lds_rows = through && (a.mode & kModeFusedLdsTable) && n_qubits == uint32_t(kFusedLdsRowsBits) &&
+                         plan_arena[ev.split_base] == uint32_t(kFusedLdsRowsKeys);
 
     const uint32_t tg = xor_columns(pp + kPassLoadColsOffset, tid, wave);
     const uint32_t sg = xor_columns(pp + kPassStoreColsOffset, tid, wave);
@@ -1163,6 +1174,8 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, FIRST>::waves_per_si
             QSV_STAMP(10);
         }
 
+        // (rows in LDS from offset 0: over whatever the last exchange left there for a slower wave to read)
+        if (table_lds_rows) __syncthreads();
         if (active && (do_store || do_diag || do_probs)) {
             if (!wide || cstore) {
                 unsigned char* tile = reinterpret_cast<unsigned char*>(cstore ? wt0 + (uint64_t(tile0 + j * tile_step) << k) : st0 + base);
@@ -1189,6 +1202,10 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, FIRST>::waves_per_si
                             __builtin_nontemporal_store(v, reinterpret_cast<vec2*>(tile + ob));
                         } else if (table_in_lds) {
                             *reinterpret_cast<cxr*>(lds_raw + kFusedLdsTableOffset + ob) = amp[gray_index(i)];
+                        } else if (table_lds_rows) {
+                            // (one amplitude of padding after every row of 2^10)
+                            constexpr uint32_t row_shift = uint32_t(kFusedLdsRowsBits - kFusedLdsRowsKeys) + ASH;
+                            *reinterpret_cast<cxr*>(lds_raw + ob + ((ob >> row_shift) << ASH)) = amp[gray_index(i)];
                         } else if (through) {
                             store_through(tile + ob, amp[gray_index(i)]);
                         } else {
@@ -1240,11 +1257,11 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, FIRST>::waves_per_si
             QSV_STAMP_FLUSH(0u);
             for (int ph = 0; ph < kStampPhases; ++ph) st_acc[ph] = 0;
             st_last = qsv_stamp_now();
-            fused_factor_tail<real>(plan_arena, ev, wt0, a.wtab_stride, diag, a, lds_raw, t >= 9 ? 8u : 4u, table_in_lds, st_acc, &st_last);
+            fused_factor_tail<real>(plan_arena, ev, wt0, a.wtab_stride, diag, a, lds_raw, t >= 9 ? 8u : 4u, table_in_lds ? 1u : table_lds_rows ? 2u : 0u, st_acc, &st_last);
             QSV_STAMP_FLUSH(7u);
 #else
             // (Gram waves: by the virtual circuit's own geometry, never by the launch's block size)
-            fused_factor_tail<real>(plan_arena, ev, wt0, a.wtab_stride, diag, a, lds_raw, t >= 9 ? 8u : 4u, table_in_lds);
+            fused_factor_tail<real>(plan_arena, ev, wt0, a.wtab_stride, diag, a, lds_raw, t >= 9 ? 8u : 4u, table_in_lds ? 1u : table_lds_rows ? 2u : 0u);
 #endif
             return;
         }
@@ -2524,9 +2541,30 @@ constexpr uint32_t kFactorPitch = 65;    // doubles per row of a Gram table in L
 // out (LDS, [weight][64]) may overlap other waves' staging regions: it is written after a workgroup barrier.
 // AHEAD: the next block's rows are fetched while this one is added up (32 more registers at eight terms; the tail of the pass
 // kernel, which has none to spare, fetches each block when it needs it).
+// The values of D for a wave's first kFactorDAhead blocks (first, first + step, ..; below `end`): scattered reads of a table
+// the size of the state -- the longest latency of the whole Gram phase and independent of the side's state, so the callers
+// ask for them BEFORE they wait for the side's stores; the bodies keep the queue kFactorDAhead blocks ahead.
+constexpr int kFactorDAhead = 4;
+__device__ __forceinline__ double factor_d_of_block(const double* __restrict__ diag, uint32_t bits, uint32_t mask, uint32_t blk, uint32_t end) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t n_local = bits < 6u ? 1u << bits : 64u;
+    double d = 0.0;
+    if (lane < n_local && blk < end) d = diag[deposit_bits(blk * 64u + lane, mask)];
+    return d;
+}
+template <int DA>
+__device__ __forceinline__ void factor_prefetch_d(double (&dq)[DA], const double* __restrict__ diag, uint32_t bits, uint32_t mask,
+                                                  uint32_t first_block, uint32_t block_step, uint32_t end) {
+#pragma unroll
+    for (int k = 0; k < DA; ++k) dq[k] = factor_d_of_block(diag, bits, mask, first_block + uint32_t(k) * block_step, end);
+}
+constexpr int kFactorDAheadPairs = 2;  // (the eight-term body has no registers to spare)
+__device__ __forceinline__ uint32_t factor_block_count(uint32_t bits) { return bits < 6u ? 1u : 1u << (bits - 6u); }
+
 template <typename real, int J, bool AHEAD = true>
 __device__ __forceinline__ void factor_side_body(const cx<real>* __restrict__ tab, uint32_t bits, uint32_t mask, const double* __restrict__ diag,
-                                 uint32_t first_block, uint32_t block_step, cx<real>* stage, double* dstage, double* out) {
+                                 uint32_t first_block, uint32_t block_step, cx<real>* stage, double* dstage, double* out,
+                                 double (&dq)[kFactorDAhead] QSV_PSTAMP_PARAMS) {
     constexpr uint32_t NQ = J * J;
     constexpr uint32_t LQ = J == 1 ? 0 : J == 2 ? 2 : J == 4 ? 4 : 6;  // log2(NQ)
     constexpr uint32_t PITCH = J + 1;
@@ -2539,22 +2577,27 @@ __device__ __forceinline__ void factor_side_body(const cx<real>* __restrict__ ta
 #pragma unroll
     for (int q = 0; q < 10; ++q) acc_high[q] = 0.0;
     cx<real> rows[J];
-    double d_next = 0.0;
     auto fetch = [&](uint32_t blk) {
         const bool live = lane < n_local && blk < n_blocks;
 #pragma unroll
         for (int j = 0; j < J; ++j) {
             rows[j] = cx<real>{real(0), real(0)};
-            if (live) rows[j] = tab[(size_t(j) << bits) + size_t(blk) * 64 + lane];
+            // (a 32-bit byte offset from the uniform base: one address register per row instead of a 64-bit pointer each)
+            const uint32_t off = ((uint32_t(j) << bits) + blk * 64u + lane) * uint32_t(sizeof(cx<real>));
+            if (live) rows[j] = *reinterpret_cast<const cx<real>*>(reinterpret_cast<const char*>(tab) + off);
         }
-        d_next = live ? diag[deposit_bits(blk * 64u + lane, mask)] : 0.0;
     };
     if constexpr (AHEAD) fetch(first_block);
+    QSV_PSTAMP(4);  // (diagnostic build: the first block's rows)
     for (uint32_t blk = first_block; blk < n_blocks; blk += block_step) {
         if constexpr (!AHEAD) fetch(blk);
 #pragma unroll
         for (int j = 0; j < J; ++j) stage[lane * PITCH + uint32_t(j)] = rows[j];
-        dstage[lane] = d_next;
+        dstage[lane] = dq[0];
+        // (the queue moves up; the block kFactorDAhead steps on is asked for AFTER this block's rows: loads return in order)
+#pragma unroll
+        for (int k = 0; k + 1 < kFactorDAhead; ++k) dq[k] = dq[k + 1];
+        dq[kFactorDAhead - 1] = factor_d_of_block(diag, bits, mask, blk + uint32_t(kFactorDAhead) * block_step, n_blocks);
         if constexpr (AHEAD) fetch(blk + block_step);
         double s_one = 0.0, s_d = 0.0;
 #pragma unroll
@@ -2577,9 +2620,16 @@ __device__ __forceinline__ void factor_side_body(const cx<real>* __restrict__ ta
         for (int q = 0; q < 10; ++q)  // (bits 6 and up are the block number's)
             if (blk >> q & 1u) acc_high[q] += s_one;
     }
-    // the runs of one entry, added across lanes; the lanes of the first run write
+    QSV_PSTAMP(5);  // the blocks
+    // The runs of one entry are added INSIDE each row of 16 lanes only (rotations by DPP: no LDS traffic); the four rows leave
+    // as four partial sums which whoever adds the waves' partials adds as well (factor_sum_partials).  The butterflies over
+    // all 64 lanes this replaces were 18 accumulators x 6 steps x 2 ds_bpermute per wave: the largest piece of a zero-key
+    // side's Gram phase (5.4 k of 9.5 k cycles), every wave of the CU queueing at the same LDS crossbar.
     auto across = [&](double v) {
-        for (uint32_t off = NQ; off < 64; off <<= 1) v += __shfl_xor(v, int(off));
+        if constexpr (NQ < 2) v += dpp_f64<0x121, 0xf>(v);   // row_ror:1
+        if constexpr (NQ < 4) v += dpp_f64<0x122, 0xf>(v);   // row_ror:2
+        if constexpr (NQ < 8) v += dpp_f64<0x124, 0xf>(v);   // row_ror:4
+        if constexpr (NQ < 16) v += dpp_f64<0x128, 0xf>(v);  // row_ror:8
         return v;
     };
     acc_one = across(acc_one);
@@ -2588,25 +2638,218 @@ __device__ __forceinline__ void factor_side_body(const cx<real>* __restrict__ ta
     for (int q = 0; q < 6; ++q) acc_low[q] = across(acc_low[q]);
 #pragma unroll
     for (int q = 0; q < 10; ++q) acc_high[q] = across(acc_high[q]);
+    QSV_PSTAMP(6);  // sums across lanes
     __syncthreads();  // (every wave of the workgroup is here: nobody reads a staging region any more)
-    if (lane < NQ && out) {  // (out = null: a wave that only keeps the others company at the barrier)
-        out[0 * 64 + pi] = acc_one;
-        out[1 * 64 + pi] = acc_d;
+    if ((lane & 15u) < NQ && out) {  // (out = null: a wave that only keeps the others company at the barrier)
+        // slot row * 16 + pi of every weight: the row's partial sum of entry pi
+        out[0 * 64 + lane] = acc_one;
+        out[1 * 64 + lane] = acc_d;
 #pragma unroll
-        for (int q = 0; q < 6; ++q) out[(2 + q) * 64 + pi] = acc_low[q];
+        for (int q = 0; q < 6; ++q) out[(2 + q) * 64 + lane] = acc_low[q];
 #pragma unroll
-        for (int q = 0; q < 10; ++q) out[(8 + q) * 64 + pi] = acc_high[q];
+        for (int q = 0; q < 10; ++q) out[(8 + q) * 64 + lane] = acc_high[q];
+    }
+}
+
+// Entry pi of weight w, added over the partial matrices [wave][weight][64] the bodies above leave in LDS: the waves in
+// order, and for up to four product terms each wave's four row partials in order (eight terms: one value per wave).
+__device__ __forceinline__ double factor_sum_partials(const double* partial, uint32_t n_waves, uint32_t w, uint32_t pi, uint32_t n_keys) {
+    double v = 0.0;
+    if (n_keys < 3) {
+        for (uint32_t g = 0; g < n_waves; ++g)
+#pragma unroll
+            for (uint32_t row = 0; row < 4; ++row) v += partial[(size_t(g) * kFactorWeights + w) * 64 + row * 16 + pi];
+    } else {
+        for (uint32_t g = 0; g < n_waves; ++g) v += partial[(size_t(g) * kFactorWeights + w) * 64 + pi];
+    }
+    return v;
+}
+
+// EIGHT product terms (three cut keys): with a lane per entry every (entry, x) reads its two amplitudes from LDS -- 2 KiB per x
+// and wave, and eight waves of a workgroup doing that was most of a three-key side's Gram phase (the longest workgroup of the
+// benchmark's launch).  Here a lane owns TWO entries that share their amplitudes -- the real and the imaginary part of one
+// pair (28 lanes), or two diagonal entries (4 lanes) -- so 32 lanes cover the 64 entries and the wave's halves take two x
+// at a time: half the LDS traffic per x.  x = 64 blk + 2 i + half: the weight of bit 0 comes from the half, bits 1 .. 5 from the
+// step number (three of them known inside an unrolled group of eight steps).  Worker `worker` of `n_workers` (a power of two) takes the CONTIGUOUS blocks [worker m, (worker + 1) m),
+// m = n_blocks / n_workers, so only the low log2(m) <= HB bits of the block number need accumulators of their own (two entries
+// per lane doubled the accumulators; ten more pairs of them for the block number did not fit the pass kernel's registers):
+// the bits above are the worker's.  Sums ascend in x per lane, the two halves are added last, in every batch alike.
+// (the contiguous blocks of a worker of the eight-term body: [begin, end))
+__device__ __forceinline__ void factor_pairs_blocks(uint32_t bits, uint32_t worker, uint32_t n_workers, uint32_t* begin, uint32_t* end) {
+    const uint32_t n_blocks = factor_block_count(bits);
+    const uint32_t per_worker = n_blocks > n_workers ? n_blocks / n_workers : 1u;
+    *begin = worker * per_worker;
+    *end = worker < n_blocks ? *begin + per_worker : *begin;
+    if (worker >= n_workers) *end = *begin;
+}
+template <typename real, int HB, bool LDS_ROWS>
+__device__ __forceinline__ void factor_side_body_pairs(const cx<real>* __restrict__ tab, uint32_t bits, uint32_t mask, const double* __restrict__ diag,
+                                 uint32_t worker, uint32_t n_workers, cx<real>* stage, double* dstage, double* out,
+                                 double (&dq)[kFactorDAheadPairs] QSV_PSTAMP_PARAMS) {
+    constexpr int J = 8;
+    constexpr uint32_t PITCH = J + 1;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t half = lane >> 5, L = lane & 31u;
+    const bool diagonal = L < uint32_t(J / 2);
+    uint32_t ja = 2 * L, jb = 2 * L + 1, pi0 = 2 * L;
+    if (!diagonal) {
+        uint32_t part;
+        pi0 = uint32_t(J) + 2 * (L - uint32_t(J / 2));
+        split_entry_of<J>(pi0, &ja, &jb, &part);
+    }
+    const uint32_t n_local = bits < 6u ? 1u << bits : 64u, n_blocks = bits < 6u ? 1u : 1u << (bits - 6u);
+    const uint32_t per_worker = n_blocks > n_workers ? n_blocks / n_workers : 1u;  // m
+    const uint32_t lm = uint32_t(__builtin_ctz(per_worker));
+    if (lm > uint32_t(HB)) __builtin_trap();  // (the callers' sides are smaller: kernels.hpp)
+    uint32_t blk_begin, blk_end;
+    factor_pairs_blocks(bits, worker, n_workers, &blk_begin, &blk_end);
+    double acc_one[2] = {0.0, 0.0}, acc_d[2] = {0.0, 0.0}, acc_low[2][6], acc_high[2][HB];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) acc_low[e][q] = 0.0;
+#pragma unroll
+        for (int q = 0; q < HB; ++q) acc_high[e][q] = 0.0;
+    }
+    for (uint32_t blk = blk_begin; blk < blk_end; ++blk) {
+        if constexpr (!LDS_ROWS) {
+            const bool live = lane < n_local;
+#pragma unroll
+            for (int j = 0; j < J; ++j) {  // (a table of fewer than 64 x: the other lanes read lane 0's entry and stage zeros)
+                const uint32_t off = ((uint32_t(j) << bits) + blk * 64u + (live ? lane : 0u)) * uint32_t(sizeof(cx<real>));
+                cx<real> v = *reinterpret_cast<const cx<real>*>(reinterpret_cast<const char*>(tab) + off);
+                v.re = live ? v.re : real(0);
+                v.im = live ? v.im : real(0);
+                stage[lane * PITCH + uint32_t(j)] = v;
+            }
+        }
+        dstage[lane] = dq[0];
+#pragma unroll
+        for (int k = 0; k + 1 < kFactorDAheadPairs; ++k) dq[k] = dq[k + 1];
+        dq[kFactorDAheadPairs - 1] = factor_d_of_block(diag, bits, mask, blk + uint32_t(kFactorDAheadPairs), blk_end);
+        QSV_PSTAMP(4);  // (diagnostic build: a block's rows fetched and staged)
+        double s_one[2] = {0.0, 0.0}, s_d[2] = {0.0, 0.0};
+        // Four groups of eight steps: bits 1 .. 3 of x are known inside the unrolled group, bits 4 and 5 are the group's.  The
+        // reads of step i + 1 are ISSUED before step i is added up (and kept there: the compiler's own order waited for every
+        // pair of reads right after asking for it -- two waves per SIMD do not hide an LDS round trip per step).
+        // (LDS_ROWS: `tab` IS the side's state in LDS, rows of 2^bits amplitudes one amplitude apart: read in place)
+        const uint32_t row_pitch = (1u << bits) + 1u;
+        constexpr uint32_t XS = LDS_ROWS ? 1u : PITCH;  // amplitudes from one x to the next
+        const cx<real>* pa = LDS_ROWS ? tab + ja * row_pitch + blk * 64u + half : stage + half * PITCH + ja;
+        const cx<real>* pb = LDS_ROWS ? tab + jb * row_pitch + blk * 64u + half : stage + half * PITCH + jb;
+        const double* pd = dstage + half;
+        real ar_next = pa[0].re, ai_next = pa[0].im, br_next = pb[0].re, bi_next = pb[0].im;
+        double d_next = pd[0];
+#pragma unroll 1
+        for (uint32_t g = 0; g < 4; ++g) {
+            double t_one[2] = {0.0, 0.0};
+#pragma unroll
+            for (uint32_t ii = 0; ii < 8; ++ii) {
+                const double ar = double(ar_next), ai = double(ai_next), br = double(br_next), bi = double(bi_next);
+                const double d = d_next;
+                {
+                    // (the step after the block's last one reads the last rows again: never used)
+                    const uint32_t nxt = 8 * g + ii + 1 < 32 ? 8 * g + ii + 1 : 31;
+                    const cx<real> an = pa[2 * nxt * XS], bn = pb[2 * nxt * XS];
+                    ar_next = an.re;
+                    ai_next = an.im;
+                    br_next = bn.re;
+                    bi_next = bn.im;
+                    d_next = pd[2 * nxt];
+                }
+                if constexpr (sizeof(real) == 8) __builtin_amdgcn_sched_barrier(0);  // (single precision: the fence costs the kernel a stack slot)
+                // a pair: Re, Im of a conj(b) as split_entry_value has them; two diagonal entries: |a|^2, |b|^2
+                const double p0 = diagonal ? fma(ar, ar, ai * ai) : fma(ar, br, ai * bi);
+                const double p1 = diagonal ? fma(br, br, bi * bi) : fma(ai, br, -ar * bi);
+                t_one[0] += p0;
+                t_one[1] += p1;
+                s_d[0] = fma(d, p0, s_d[0]);
+                s_d[1] = fma(d, p1, s_d[1]);
+#pragma unroll
+                for (uint32_t q = 1; q < 4; ++q)
+                    if (ii >> (q - 1) & 1u) {
+                        acc_low[0][q] += p0;
+                        acc_low[1][q] += p1;
+                    }
+                if constexpr (sizeof(real) == 8) __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                acc_low[e][4] += (g & 1u) ? t_one[e] : 0.0;
+                acc_low[e][5] += (g & 2u) ? t_one[e] : 0.0;
+                s_one[e] += t_one[e];
+            }
+        }
+        QSV_PSTAMP(7);  // (diagnostic build: a block's steps)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            acc_low[e][0] += half ? s_one[e] : 0.0;
+            acc_one[e] += s_one[e];
+            acc_d[e] += s_d[e];
+#pragma unroll
+            for (int q = 0; q < HB; ++q)
+                if (blk >> q & 1u) acc_high[e][q] += s_one[e];
+        }
+    }
+    QSV_PSTAMP(5);  // the blocks' sums
+    // (the two halves: v_permlane32_swap of the value with a copy of itself leaves (low, low) and (high, high) -- no LDS)
+    auto across = [&](double v) {
+        uint32_t lo0 = uint32_t(__double2loint(v)), lo1 = lo0, hi0 = uint32_t(__double2hiint(v)), hi1 = hi0;
+        swap_words<5>(lo0, lo1);
+        swap_words<5>(hi0, hi1);
+        return __hiloint2double(int(hi0), int(lo0)) + __hiloint2double(int(hi1), int(lo1));
+    };
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        acc_one[e] = across(acc_one[e]);
+        acc_d[e] = across(acc_d[e]);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) acc_low[e][q] = across(acc_low[e][q]);
+#pragma unroll
+        for (int q = 0; q < HB; ++q) acc_high[e][q] = across(acc_high[e][q]);
+    }
+    QSV_PSTAMP(6);  // the halves added
+    __syncthreads();  // (every wave of the workgroup is here: nobody reads a staging region any more)
+    if (lane < 32 && out) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const uint32_t pi = pi0 + uint32_t(e);
+            out[0 * 64 + pi] = acc_one[e];
+            out[1 * 64 + pi] = acc_d[e];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) out[(2 + q) * 64 + pi] = acc_low[e][q];
+#pragma unroll
+            for (uint32_t q = 0; q < 10; ++q) {  // (block-number bit q: one of this worker's own, or the same for all its blocks)
+                double v = 0.0;
+                if (q < uint32_t(HB) && q < lm) v = acc_high[e][q < uint32_t(HB) ? q : 0];
+                if (q >= lm && (worker >> (q - lm) & 1u)) v = acc_one[e];
+                out[(8 + q) * 64 + pi] = v;
+            }
+        }
     }
 }
 
 // sum_{j'j} A[j'j] B[j'j] for two Hermitian matrices in the entry representation (split_entry_of): the diagonal entries,
 // and for every pair twice the real part of the product
-__device__ __forceinline__ double factor_pairing(const double* a, const double* b, uint32_t n_keys) {
-    const uint32_t J = 1u << n_keys, NQ = J * J;
+// (unrolled per J: the reads of a table row go out together instead of one dependent LDS round trip per entry -- at eight
+// terms the loop form was 36 round trips, most of the three-key combination; the order of the additions is the loop's)
+template <uint32_t J>
+__device__ __forceinline__ double factor_pairing_unrolled(const double* a, const double* b) {
+    constexpr uint32_t NQ = J * J;
     double t = 0.0;
+#pragma unroll
     for (uint32_t j = 0; j < J; ++j) t = fma(a[j], b[j], t);
+#pragma unroll
     for (uint32_t e = J; e < NQ; e += 2) t += 2.0 * fma(a[e], b[e], -a[e + 1] * b[e + 1]);
     return t;
+}
+__device__ __forceinline__ double factor_pairing(const double* a, const double* b, uint32_t n_keys) {
+    switch (n_keys) {
+        case 0: return factor_pairing_unrolled<1>(a, b);
+        case 1: return factor_pairing_unrolled<2>(a, b);
+        case 2: return factor_pairing_unrolled<4>(a, b);
+        default: return factor_pairing_unrolled<8>(a, b);
+    }
 }
 
 constexpr unsigned kFactorParts = 8;
@@ -2830,22 +3073,28 @@ __global__ void __launch_bounds__(256, 2) factor_moments_kernel(const uint32_t* 
     double* partial = reinterpret_cast<double*>(raw);  // [wave][weight][64]
     double* out = partial + size_t(wave) * kFactorWeights * 64;
     const uint32_t first = slice * kWaves + wave, step = kFactorSlices * kWaves;
+    double dq[kFactorDAhead], dq_pairs[kFactorDAheadPairs];
+    if (n_keys < 3) {
+        factor_prefetch_d(dq, diag, bits, mask, first, step, factor_block_count(bits));
+    } else {
+        uint32_t b0, b1;
+        factor_pairs_blocks(bits, first, step, &b0, &b1);
+        factor_prefetch_d(dq_pairs, diag, bits, mask, b0, 1u, b1);
+    }
     if (n_keys == 0)
-        factor_side_body<real, 1>(tab, bits, mask, diag, first, step, stage, dstage + wave * 64, out);
+        factor_side_body<real, 1>(tab, bits, mask, diag, first, step, stage, dstage + wave * 64, out, dq);
     else if (n_keys == 1)
-        factor_side_body<real, 2>(tab, bits, mask, diag, first, step, stage, dstage + wave * 64, out);
+        factor_side_body<real, 2>(tab, bits, mask, diag, first, step, stage, dstage + wave * 64, out, dq);
     else if (n_keys == 2)
-        factor_side_body<real, 4>(tab, bits, mask, diag, first, step, stage, dstage + wave * 64, out);
+        factor_side_body<real, 4>(tab, bits, mask, diag, first, step, stage, dstage + wave * 64, out, dq);
     else
-        factor_side_body<real, 8>(tab, bits, mask, diag, first, step, stage, dstage + wave * 64, out);
+        factor_side_body_pairs<real, 6, false>(tab, bits, mask, diag, first, step, stage, dstage + wave * 64, out, dq_pairs);
     __syncthreads();
     double* mine = scratch + size_t(ev.state_slot) * factor_slot_doubles() +
                    (size_t(side) * kFactorSlices + slice) * kFactorWeights * 64;
     for (uint32_t idx = tid; idx < (2u + bits) * NQ; idx += blockDim.x) {
         const uint32_t w = idx / NQ, pi = idx % NQ;
-        double v = 0.0;
-        for (uint32_t g = 0; g < kWaves; ++g) v += partial[size_t(g) * kFactorWeights * 64 + w * 64 + pi];
-        mine[w * 64 + pi] = v;
+        mine[w * 64 + pi] = factor_sum_partials(partial, kWaves, w, pi, n_keys);
     }
 }
 
@@ -2925,8 +3174,11 @@ template <typename real>
 __device__ __forceinline__ void fused_factor_tail(const uint32_t* __restrict__ plan_arena, const EvalDesc& ev,
                                                   const cx<real>* __restrict__ slot_tables, uint64_t side_stride,
                                                   const double* __restrict__ diag, const PassScalars& a, unsigned char* lds,
-                                                  uint32_t gram_waves, bool table_in_lds QSV_PSTAMP_PARAMS_DEF) {
+                                                  uint32_t gram_waves, uint32_t lds_table QSV_PSTAMP_PARAMS_DEF) {
     constexpr uint32_t kMaxWaves = 8;
+    // (lds_table: 0 the side's state is in its slot; 1 in LDS behind the tail's scratch, laid out like the slot; 2 in LDS from
+    // offset 0 as padded rows, kernels.hpp)
+    const bool table_in_lds = lds_table == 1u, table_lds_rows = lds_table == 2u;
     const uint32_t kWaves = gram_waves;
     const uint32_t* sp = plan_arena + ev.split_base;
     const uint32_t n_keys = sp[0], NQ = 1u << (2 * n_keys);
@@ -2936,12 +3188,26 @@ __device__ __forceinline__ void fused_factor_tail(const uint32_t* __restrict__ p
     const uint32_t tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // (the side's state: in its half of the slot -- or still in LDS, where the pass left it for this tail alone)
     const cx<real>* tab = table_in_lds ? reinterpret_cast<const cx<real>*>(lds + kFusedLdsTableOffset) : slot_tables + (is_b ? side_stride >> 1 : 0);
-    // the side's state was stored by this workgroup: its waves' stores have to be in L2 before anybody reads them back
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // (the values of D this wave's blocks will want: asked for before the wait below, whose stores they do not depend on)
+    double dq[kFactorDAhead], dq_pairs[kFactorDAheadPairs];
+    {
+        const uint32_t worker = wave < kWaves ? wave : 0xffffffu;
+        if (n_keys < 3) {
+            factor_prefetch_d(dq, diag, bits, mask, worker, kWaves, factor_block_count(bits));
+        } else {
+            uint32_t b0, b1;
+            factor_pairs_blocks(bits, worker, kWaves, &b0, &b1);
+            factor_prefetch_d(dq_pairs, diag, bits, mask, b0, 1u, b1);
+        }
+    }
+    // the side's state was stored by this workgroup: its waves' stores have to be in L2 before anybody reads them back (a state
+    // left in LDS has no stores to wait for -- and the wait would be for the values of D just asked for)
+    if (lds_table == 0u) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     QSV_PSTAMP(0);  // the side's stores drained
     double* partial = reinterpret_cast<double*>(lds);                              // [wave][weight][64]
-    double* dstage_all = partial + size_t(kMaxWaves) * kFactorWeights * 64;        // [wave][64]
+    // [wave][64]; (rows in LDS: behind them -- the partial matrices lie over the rows, and are written when nobody reads those any more)
+    double* dstage_all = table_lds_rows ? reinterpret_cast<double*>(lds + kFusedLdsRowsDstage) : partial + size_t(kMaxWaves) * kFactorWeights * 64;
     uint32_t* flag = reinterpret_cast<uint32_t*>(dstage_all + size_t(kMaxWaves) * 64);
     {
         // (waves beyond the fourth take no blocks -- first block past the end -- but join the body's barrier)
@@ -2951,13 +3217,16 @@ __device__ __forceinline__ void fused_factor_tail(const uint32_t* __restrict__ p
         const uint32_t first = wave < kWaves ? wave : 0xffffffu, step = kWaves;
         double* sink = wave < kWaves ? out : nullptr;
         if (n_keys == 0)
-            factor_side_body<real, 1, true>(tab, bits, mask, diag, first, step, stage, dstage_all + w * 64, sink);
+            factor_side_body<real, 1, true>(tab, bits, mask, diag, first, step, stage, dstage_all + w * 64, sink, dq QSV_PSTAMP_ARGS);
         else if (n_keys == 1)
-            factor_side_body<real, 2, true>(tab, bits, mask, diag, first, step, stage, dstage_all + w * 64, sink);
+            factor_side_body<real, 2, true>(tab, bits, mask, diag, first, step, stage, dstage_all + w * 64, sink, dq QSV_PSTAMP_ARGS);
         else if (n_keys == 2)
-            factor_side_body<real, 4, false>(tab, bits, mask, diag, first, step, stage, dstage_all + w * 64, sink);
+            factor_side_body<real, 4, false>(tab, bits, mask, diag, first, step, stage, dstage_all + w * 64, sink, dq QSV_PSTAMP_ARGS);
+        else if (table_lds_rows)
+            factor_side_body_pairs<real, 2, true>(reinterpret_cast<const cx<real>*>(lds), bits, mask, diag, wave < kWaves ? wave : 0xffffffu, step, stage,
+                                                  dstage_all + w * 64, sink, dq_pairs QSV_PSTAMP_ARGS);
         else
-            factor_side_body<real, 8, false>(tab, bits, mask, diag, first, step, stage, dstage_all + w * 64, sink);
+            factor_side_body_pairs<real, 2, false>(tab, bits, mask, diag, wave < kWaves ? wave : 0xffffffu, step, stage, dstage_all + w * 64, sink, dq_pairs QSV_PSTAMP_ARGS);
     }
     __syncthreads();
     QSV_PSTAMP(1);  // Gram matrices
@@ -2967,9 +3236,7 @@ __device__ __forceinline__ void fused_factor_tail(const uint32_t* __restrict__ p
     // this XCD's L2 holds dirty -- the side tables of sixteen workgroups; an agent-scope release did that: 46 us per launch)
     for (uint32_t idx = tid; idx < (2u + bits) * NQ; idx += blockDim.x) {
         const uint32_t w = idx / NQ, pi = idx % NQ;
-        double v = 0.0;
-        for (uint32_t g = 0; g < kWaves; ++g) v += partial[size_t(g) * kFactorWeights * 64 + w * 64 + pi];
-        __hip_atomic_store(mine + w * 64 + pi, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(mine + w * 64 + pi, factor_sum_partials(partial, kWaves, w, pi, n_keys), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave, before the barrier the signalling lane joins
     __syncthreads();
@@ -2998,12 +3265,30 @@ __device__ __forceinline__ void fused_factor_tail(const uint32_t* __restrict__ p
     const double d00 = diag[0];
     double* gram = reinterpret_cast<double*>(lds);  // [side][weight][kFactorPitch] (the partial matrices are no longer needed)
     const uint32_t side_bits[2] = {bx, by};
-    for (uint32_t s2 = 0; s2 < 2; ++s2)
-        for (uint32_t idx = tid; idx < (2u + side_bits[s2]) * NQ; idx += blockDim.x) {
-            const uint32_t w = idx / NQ, pi = idx % NQ;
-            gram[size_t(s2) * kFactorWeights * kFactorPitch + w * kFactorPitch + pi] = __hip_atomic_load(
-                slot + size_t(s2) * kFactorSlices * kFactorWeights * 64 + w * 64 + pi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+    {
+        // (all of a thread's loads first, then its LDS writes: at eight terms a thread has up to five values per side to fetch,
+        // and a loop that stored each before asking for the next paid a memory round trip per value)
+        constexpr uint32_t kMaxPerThread = (kFactorWeights * 64 + 255) / 256;
+        double fetched[2][kMaxPerThread];
+#pragma unroll
+        for (uint32_t s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (uint32_t it = 0; it < kMaxPerThread; ++it) {
+                const uint32_t idx = tid + it * blockDim.x;
+                fetched[s2][it] = 0.0;
+                if (idx < (2u + side_bits[s2]) * NQ)
+                    fetched[s2][it] = __hip_atomic_load(slot + size_t(s2) * kFactorSlices * kFactorWeights * 64 + (idx / NQ) * 64 + idx % NQ,
+                                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+        for (uint32_t s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (uint32_t it = 0; it < kMaxPerThread; ++it) {
+                const uint32_t idx = tid + it * blockDim.x;
+                if (idx < (2u + side_bits[s2]) * NQ)
+                    gram[size_t(s2) * kFactorWeights * kFactorPitch + (idx / NQ) * kFactorPitch + idx % NQ] = fetched[s2][it];
+            }
+    }
     __syncthreads();
     const double* g0 = gram;
     const double* g1 = gram + size_t(kFactorWeights) * kFactorPitch;

@@ -115,6 +115,15 @@ constexpr size_t kFusedFactorLdsBytes = 8 * (18 * 64 + 64) * sizeof(double) + 64
 constexpr int kFusedLdsTableBits = 12;
 constexpr size_t kFusedLdsTableOffset = ((kFusedFactorLdsBytes + 1023) / 1024) * 1024;
 constexpr size_t kFusedLdsTableEnd = kFusedLdsTableOffset + (size_t(16) << kFusedLdsTableBits);  // 141 KiB
+// ... and a THREE-KEY side of kFusedLdsRowsBits virtual qubits (eight product terms of 2^10 amplitudes: the largest side the
+// one-launch route takes) keeps its state in LDS too, FROM OFFSET 0 -- under the tail's scratch, which is only written once
+// the Gram sums are done -- as eight rows with one amplitude of padding between them, so that the lanes of the eight-term
+// Gram body read their two rows' amplitudes straight from it without bank conflicts: no staging, nothing stored or fetched.
+constexpr int kFusedLdsRowsBits = 13, kFusedLdsRowsKeys = 3;
+constexpr size_t kFusedLdsRowPitch = (size_t(1) << (kFusedLdsRowsBits - kFusedLdsRowsKeys)) + 1;  // amplitudes
+constexpr size_t kFusedLdsRowsDstage = ((kFusedLdsRowPitch * 8 * 16 + 127) / 128) * 128;      // [wave][64] values of D
+constexpr size_t kFusedLdsRowsEnd = kFusedLdsRowsDstage + 8 * 64 * sizeof(double) + 64;
+static_assert(kFusedLdsRowsEnd <= kFusedLdsTableEnd, "a launch with kModeFusedLdsTable has the LDS for either form");
 
 // Diagnostic stamps (only in a -DQSV_STAMPS build): [pass][phase] shader cycles summed over WAVES; the last phase
 // slot counts waves.  Phases: 0 setup, 1 load / synthesis, 2 xor-column setup + wait for the previous exchange's

@@ -64,7 +64,9 @@ def main() -> None:
         per = t[p, :NP] / wgs
         if p == 7:  # (the tail of the one-launch route of split evaluations: its own phases)
             names = ["stores drained", "Gram matrices", "hand-off", "combination (second side only)"]
-            print(f"tail  {wgs / reps:11.0f}   " + "   ".join(f"{nm} {c:.0f}" for nm, c in zip(names, per)) + f"   total {per[:4].sum():.0f}")
+            print(f"tail  {wgs / reps:11.0f}   " + "   ".join(f"{nm} {c:.0f}" for nm, c in zip(names, per)) + f"   total {per[:8].sum():.0f}")
+            # (inside the Gram phase, sides of up to four product terms: stamped separately, the phase's own column holds the rest)
+            print("      Gram phase: " + "   ".join(f"{nm} {c:.0f}" for nm, c in zip(["rows staged (eight terms: all that is not the steps)", "blocks (eight terms: the tail of the last)", "sums across lanes", "eight terms: the blocks' steps"], per[4:8])))
             continue
         grand += t[p, :NP]
         print(f"{p:4d}  {wgs / reps:11.0f} " + " ".join(f"{c:10.0f}" for c in per) + f" {per.sum():10.0f}")
