@@ -324,6 +324,9 @@ int qsv_exact_cvar_batch(qsv_t* h, int n_evals, const int* circuit_ids, const in
  *                        created with splitting on.  Applies to circuits registered afterwards.
  *   "factor" 0|1         split evaluations use the factorised expectation kernels instead of the contraction sweep
  *   "fused_factor" 0|1   ... inside the launch that runs their virtual circuits, where a circuit qualifies (one launch per push)
+ *   "fused_lds_table" 0|1 ... and there a side hands its state to its Gram matrices through LDS where it fits (up to twelve
+ *                        virtual qubits as the state would lie in memory; three-key sides of thirteen as padded rows read in
+ *                        place) instead of through its slot: the same sums in the same order, the same bits
  *   "split_max_keys" 0..5 most cut keys of a split form (default 5; four and five: quadratic operators only).  Applies to
  *                        circuits registered afterwards.
  *   "chain_stream" 0|1   in a push that holds split evaluations of both kinds (finished by the launch that runs their

@@ -3091,6 +3091,8 @@ int qsv_set_option(qsv_t* h, const char* name, int value) {
         h->split_max_keys = value;
     } else if (key == "split_sampling") {
         h->split_sampling = value != 0;
+    } else if (key == "fused_lds_table") {  // one-launch route: sides' states handed to their Gram matrices through LDS (same bits either way)
+        h->fused_lds_table = value != 0;
     } else if (key == "streams") {
         if (value < 1 || value > h->n_lane_streams + 1) return fail(h, QSV_E_ARG, "streams must be between 1 and the number the handle was created with");
         h->n_streams = value;

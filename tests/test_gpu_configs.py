@@ -687,6 +687,11 @@ def test_one_launch_route_of_split_evaluations(c_oracle):
         assert ev.evaluate_circuits(big_c, big_p) == one * 5
     dev.set_option("streams", 1)
     assert ev.evaluate_circuits(circuits, params) == one
+    # the sides' states handed over in LDS (small sides as they would lie in their slots, three-key sides of thirteen qubits as
+    # padded rows read in place) or through their slots: the same sums in the same order
+    dev.set_option("fused_lds_table", 0)
+    assert ev.evaluate_circuits(circuits, params) == one
+    dev.set_option("fused_lds_table", 1)
     got32 = np.asarray(OperatorCircuitEvaluator(op, dtype="fp32").evaluate_circuits(circuits, params))
     assert np.abs(got32 - np.asarray(one)).max() < FP32_REL * float(np.abs(op.coeffs).sum())
 
