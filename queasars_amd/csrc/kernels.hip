@@ -255,6 +255,11 @@ struct SwapDispatch<real, R, -1> {
 // Diagnostic build only (-DQSV_STAMPS, scripts/stamps.sh): per-phase shader-cycle counters of the pass kernel,
 // summed over waves.  The shipped library compiles every QSV_STAMP to nothing.
 #ifdef QSV_STAMPS
+#ifdef QSV_STAMPS_WAVE0  // (only the first wave of every workgroup is counted: the critical path where the others wait at barriers)
+#define QSV_STAMP_WAVE_OK (tid < 64u)
+#else
+#define QSV_STAMP_WAVE_OK true
+#endif
 __device__ unsigned long long qsv_stamp_table[kStampPasses * kStampPhases];
 #define QSV_STAMP_DECL unsigned long long st_acc[kStampPhases] = {}; unsigned long long st_last = qsv_stamp_now();
 // the waves' counters summed in LDS first: one global atomic per phase per workgroup (row `row` of the table)
@@ -263,7 +268,7 @@ __device__ unsigned long long qsv_stamp_table[kStampPasses * kStampPhases];
         __syncthreads(); \
         if (tid < kStampPhases) tab[tid] = 0; \
         __syncthreads(); \
-        if ((tid & 63u) == 0) { \
+        if ((tid & 63u) == 0 && QSV_STAMP_WAVE_OK) { \
             for (int ph = 0; ph < kStampPhases - 1; ++ph) atomicAdd(&tab[ph], st_acc[ph]); \
             atomicAdd(&tab[kStampPhases - 1], 1ull); \
         } \
@@ -574,60 +579,88 @@ __device__ __forceinline__ void prepare_eval(const uint32_t* __restrict__ plan, 
     //   thread_factor[tid] = product over the tile qubits that pass 0's load layout keeps on thread bits
     //   tile_factor[tile]  = product over the qubits outside the tile
     // The pass kernel multiplies the two and expands the register-held qubits itself.
-    // pass 0's header block, copied to LDS with one load per thread: the loops below index it with run-time subscripts,
-    // and straight from memory every such access was a dependent load of its own (4 of the kernel's 10 microseconds)
-    uint32_t* pp = reinterpret_cast<uint32_t*>(fm);  // (the fold matrices are no longer needed)
-    {
-        const uint32_t* __restrict__ src = cp + cp[kCircuitHeaderWords];
-        for (uint32_t i = threadIdx.x; i < kPassLoadColsOffset + kColumnWords; i += blockDim.x) pp[i] = src[i];
-        __syncthreads();
-    }
-    const uint32_t hdr = pp[0];
+    // Pass 0's header block comes into SCALAR registers with wide loads (every use below has a compile-time subscript), and a
+    // thread's factor is the product of ITS t factors, read from LDS all at once: the version before this one copied the block
+    // to LDS behind a barrier and walked every qubit of the register per thread with run-time subscripts -- one dependent LDS
+    // round trip after the other, 2.7 us of a one-launch evaluation's 36 (measured by leaving the tables out).
+    uint32_t hw[kPassLoadColsOffset + kMaxThreadBits + 2];  // header, tile positions, thread columns of the load layout
+    load_words<int(kPassLoadColsOffset + kMaxThreadBits + 2)>(as_constant(cp) + cp[kCircuitHeaderWords], hw);
+    const uint32_t hdr = hw[0];
     const int k = hdr & 0xff, t = (hdr >> 16) & 0xff;
-    const uint32_t* pos = pp + kPassHeaderWords;
-    const uint32_t* cols = pp + kPassLoadColsOffset;
-    uint32_t thread_mask = 0, tile_mask = 0;
-    for (int u = 0; u < t; ++u) thread_mask |= cols[u];
-    for (int j = 0; j < k; ++j) tile_mask |= 1u << pos[j];
+    uint32_t tile_mask = 0;
+#pragma unroll
+    for (int j = 0; j < int(kMaxTileBits); ++j)
+        if (j < k) tile_mask |= 1u << hw[kPassHeaderWords + j];
     double* thread_factor = pad + kMatPadDoubles;
     double* tile_factor = thread_factor + (size_t(2) << t);
-    auto product = [&](uint64_t index, uint32_t qubits) {
+#ifndef QSV_ABL_PREP_TABLES  // (measurement: the launch without the synthesis tables -- wrong results, the time they cost)
+    for (uint32_t i = threadIdx.x; i < (1u << t); i += blockDim.x) {
+        // (a thread column is one bit: the position of the qubit thread bit u holds; ascending u, in every launch alike)
+        double vr[kMaxThreadBits], vi[kMaxThreadBits];
+#pragma unroll
+        for (int u = 0; u < int(kMaxThreadBits); ++u) {
+            vr[u] = 1.0;
+            vi[u] = 0.0;
+            if (u < t) {
+                const double* v = sv + 4 * uint32_t(__builtin_ctz(hw[kPassLoadColsOffset + u])) + 2 * ((i >> u) & 1u);
+                vr[u] = v[0];
+                vi[u] = v[1];
+            }
+        }
         double fr = 1.0, fi = 0.0;
-        for (uint32_t q = 0; q < n_qubits; ++q) {
-            if (!((qubits >> q) & 1u)) continue;
-            const double* v = sv + 4 * q + 2 * ((index >> q) & 1u);
-            const double nr = fr * v[0] - fi * v[1];
-            fi = fr * v[1] + fi * v[0];
+#pragma unroll
+        for (int u = 0; u < int(kMaxThreadBits); ++u) {
+            const double nr = fr * vr[u] - fi * vi[u];
+            fi = fr * vi[u] + fi * vr[u];
             fr = nr;
         }
-        return make_double2(fr, fi);
-    };
-    for (uint32_t i = threadIdx.x; i < (1u << t); i += blockDim.x) {
-        uint32_t off = 0;
-        for (int u = 0; u < t; ++u) off ^= (0u - ((i >> u) & 1u)) & cols[u];
-        const double2 f = product(off, thread_mask);
-        thread_factor[2 * size_t(i)] = f.x;
-        thread_factor[2 * size_t(i) + 1] = f.y;
+        thread_factor[2 * size_t(i)] = fr;
+        thread_factor[2 * size_t(i) + 1] = fi;
     }
+#endif
     const uint32_t all_qubits = n_qubits >= 32 ? 0xffffffffu : ((1u << n_qubits) - 1u);
     const uint32_t n_tiles = 1u << (n_qubits - uint32_t(k));
+    // tile number -> the index with the tile's own bits clear (a zero inserted at every tile position, ascending)
+    auto tile_base = [&](uint64_t base, const uint32_t (&w)[kPassLoadColsOffset + kMaxThreadBits + 2]) {
+#pragma unroll
+        for (int j = 0; j < int(kMaxTileBits); ++j)
+            if (j < k) {
+                const uint32_t ps = w[kPassHeaderWords + j];
+                base = ((base >> ps) << (ps + 1)) | (base & ((uint64_t(1) << ps) - 1));
+            }
+        return base;
+    };
+#ifndef QSV_ABL_PREP_TABLES
+    const uint32_t outside = all_qubits & ~tile_mask;
     for (uint32_t tile = threadIdx.x; tile < n_tiles; tile += blockDim.x) {
-        uint64_t base = tile;
-        for (int j = 0; j < k; ++j) {
-            const uint32_t ps = pos[j];
-            base = ((base >> ps) << (ps + 1)) | (base & ((uint64_t(1) << ps) - 1));
+        double fr = 1.0, fi = 0.0;
+        if (outside) {  // (a register of one tile has nothing outside it: its one factor is 1)
+            const uint64_t base = tile_base(tile, hw);
+            for (uint32_t m = outside; m; m &= m - 1u) {  // ascending qubits
+                const uint32_t q = uint32_t(__builtin_ctz(m));
+                const double* v = sv + 4 * q + 2 * ((base >> q) & 1u);
+                const double nr = fr * v[0] - fi * v[1];
+                fi = fr * v[1] + fi * v[0];
+                fr = nr;
+            }
         }
-        const double2 f = product(base, all_qubits & ~tile_mask);
-        tile_factor[2 * size_t(tile)] = f.x;
-        tile_factor[2 * size_t(tile) + 1] = f.y;
+        tile_factor[2 * size_t(tile)] = fr;
+        tile_factor[2 * size_t(tile) + 1] = fi;
     }
+#endif
     QSV_PSTAMP(6);  // synthesis tables
     // Per pass and tile: what the pass kernel needs to know about its tile number (kernels.hpp TileInfo).
     TileInfo* info_all = reinterpret_cast<TileInfo*>(tile_factor + (size_t(2) << (n_qubits - uint32_t(k))));
     for (uint32_t p = 0; p < n_passes; ++p) {
         const uint32_t* __restrict__ ph = cp + cp[kCircuitHeaderWords + p];
-        const uint32_t* __restrict__ ppos = ph + kPassHeaderWords;
-        const uint32_t flags = ph[2];
+        uint32_t pw[kPassLoadColsOffset + kMaxThreadBits + 2];  // (the pass's header and tile positions: scalar registers again)
+        if (p == 0) {
+#pragma unroll
+            for (int i = 0; i < int(kPassLoadColsOffset + kMaxThreadBits + 2); ++i) pw[i] = hw[i];
+        } else {
+            load_words<int(kPassLoadColsOffset + kMaxThreadBits + 2)>(as_constant(ph), pw);
+        }
+        const uint32_t flags = pw[2];
         const bool cstore = flags & kPassCompactStore, cload = flags & kPassCompactLoad;
         const uint32_t count = cstore ? 1u << ((flags >> 8) & 0xffu) : n_tiles;
         TileInfo* info = info_all + size_t(p) * n_tiles;
@@ -637,11 +670,7 @@ __device__ __forceinline__ void prepare_eval(const uint32_t* __restrict__ plan, 
                 base = 0;
                 for (uint32_t b = 0; b < kMaxCompactBits; ++b) base |= uint64_t((tile >> b) & 1u) << ph[kPassCompactOffset + b];
             } else {
-                base = tile;
-                for (int j = 0; j < k; ++j) {
-                    const uint32_t ps = ppos[j];
-                    base = ((base >> ps) << (ps + 1)) | (base & ((uint64_t(1) << ps) - 1));
-                }
+                base = tile_base(tile, pw);
             }
             uint32_t wbase = 0, fbase = 0;
             if (cload)

@@ -25,6 +25,8 @@ def main() -> None:
 
         # "build asm": stamps around the production assembly round loop (all of it charged to "gates")
         defines = ("QSV_STAMPS", "QSV_STAMPS_ASM") if "asm" in sys.argv[2:] else ("QSV_STAMPS",)
+        if "wave0" in sys.argv[2:]:  # only the first wave of every workgroup is counted
+            defines += ("QSV_STAMPS_WAVE0",)
         print(_build.build(force=True, defines=defines, lib_path=STAMP_LIB))
         return
     os.environ["QSV_LIBRARY"] = str(STAMP_LIB)
