@@ -519,7 +519,11 @@ __device__ __forceinline__ void prepare_eval(const uint32_t* __restrict__ plan, 
             double angle = pidx >= 0 ? p[pidx] : __hiloint2double(int(e[4 + 2 * which]), int(e[3 + 2 * which]));
             if (which == 0) angle *= 0.5;
             double sn, cs;
+#ifndef QSV_ABL_PREP_TRIG
             sincos(angle, &sn, &cs);
+#else
+            sn = angle, cs = 1.0 - angle;  // (measurement: what the sines and cosines cost)
+#endif
             trig[size_t(f) * 6 + 2 * which] = sn;
             trig[size_t(f) * 6 + 2 * which + 1] = cs;
         }
@@ -3245,8 +3249,16 @@ __device__ __forceinline__ void fused_factor_tail(const uint32_t* __restrict__ p
         double* out = partial + size_t(w) * kFactorWeights * 64;
         const uint32_t first = wave < kWaves ? wave : 0xffffffu, step = kWaves;
         double* sink = wave < kWaves ? out : nullptr;
+#ifdef QSV_ABL_TAIL_GRAM  // (measurement: the tail without its Gram sums)
+        if (sink)
+            for (uint32_t i = tid & 63u; i < kFactorWeights * 64; i += 64) sink[i] = 0.0;
+        __syncthreads();
+        if (n_keys > 99)
+#else
         if (n_keys == 0)
+#endif
             factor_side_body<real, 1, true>(tab, bits, mask, diag, first, step, stage, dstage_all + w * 64, sink, dq QSV_PSTAMP_ARGS);
+#ifndef QSV_ABL_TAIL_GRAM
         else if (n_keys == 1)
             factor_side_body<real, 2, true>(tab, bits, mask, diag, first, step, stage, dstage_all + w * 64, sink, dq QSV_PSTAMP_ARGS);
         else if (n_keys == 2)
@@ -3256,6 +3268,7 @@ __device__ __forceinline__ void fused_factor_tail(const uint32_t* __restrict__ p
                                                   dstage_all + w * 64, sink, dq_pairs QSV_PSTAMP_ARGS);
         else
             factor_side_body_pairs<real, 2, false>(tab, bits, mask, diag, wave < kWaves ? wave : 0xffffffu, step, stage, dstage_all + w * 64, sink, dq_pairs QSV_PSTAMP_ARGS);
+#endif
     }
     __syncthreads();
     QSV_PSTAMP(1);  // Gram matrices
