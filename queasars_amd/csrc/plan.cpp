@@ -805,6 +805,15 @@ CircuitPlan build_plan(int n, const std::vector<GateIn>& all_gates, const std::v
             std::sort(regs.begin(), regs.end());
             rd.regbits = regs;
             layouts.push_back(make_layout(k, regs, wset));
+            // A pass whose first layout faces nothing (cl = 0: a synthesised one-tile side) may seat its lane bits anywhere: a
+            // transposition with lane bit 4 or 5 is 32 vector instructions at 16 amplitudes per thread, with bit 2 or 3 64, with
+            // bit 0 or 1 128 -- the qubits the rounds will want soonest go to the cheap end, those nobody targets to lanes 0, 1.
+            if (m == 0 && cl == 0 && cfg.swaps) {
+                Layout& l0 = layouts.back();
+                const size_t n_lanes = std::min<size_t>(6, l0.thr.size() - std::min(l0.thr.size(), wset.size()));
+                std::stable_sort(l0.thr.begin(), l0.thr.begin() + long(n_lanes),
+                                 [&](int x, int y) { return next_use(x, 0) > next_use(y, 0); });
+            }
             // a workgroup of one wave (t <= 6) never needs a barrier
             intra[m] = m > 0 && (nw == 0 || (int(wset.size()) == nw && wset == prev_w));
             wave_sets[m] = wset;
