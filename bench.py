@@ -5,7 +5,9 @@ Workload of the headline number (BASELINE.json configs[1], SURVEY.md 8(d) "Confi
 individuals per GPU, L = 4 layers, genomes from the restated ``EVQEPopulation.random_population(..., random_seed=0)``,
 random Ising Hamiltonian (190 ZZ + 20 Z terms, J, h ~ N(0,1), default_rng(2020)), fp64.  One "step" = one fitness
 evaluation of the whole population through the product's ``evaluate_population_sharded`` (each rank evaluates its
-block, then one RCCL all-gather of the fitness values).
+block and every rank ends up with all fitness values: on one node through a table in shared host memory that the kernels
+store into, no collective in the step; the RCCL all-gather is the way across nodes, the fallback, and what the first step is
+checked against).
 
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
@@ -622,7 +624,10 @@ def agreed_count(mine: int, world: int, comm_device: str, limit: int = 5000) -> 
     return int(t.item())
 
 
-COLLECTIVE_US = 27.0  # chained all-gather into host-mapped memory on an RCCL group of ONE rank (profiles/r04_gatherstep.txt: 85 us against 58)
+# what the exchange of the fitness values adds to a rank's step on one node: through the node's shared table (no collective: the
+# kernels store into the rank's slot, queasars_amd/distributed.py) 9.6 us over the evaluation alone on a group of ONE rank
+# (profiles/r04_gatherstep.txt: 61.6 us against 52.0); the RCCL all-gather into host-mapped memory it replaced there: 21 - 27
+COLLECTIVE_US = 10.0
 
 
 def config3_block(world: int, rank: int, local_rank: int, steps: int = 8, layers: int = 4):
@@ -706,12 +711,12 @@ def config3_block(world: int, rank: int, local_rank: int, steps: int = 8, layers
                                  "dealt_by_cost": shares != contiguous_shares(total, g),
                                  "speedup": t_all / (slowest + COLLECTIVE_US * 1e-6)}
         predicted["note"] = (f"speedup at N ranks = this GPU's time for all 256 / (its time for the SLOWEST of the N shares + "
-                             f"{COLLECTIVE_US:.0f} us of collective path, profiles/r04_gatherstep.txt); a prediction from one GPU, not a "
+                             f"{COLLECTIVE_US:.0f} us for the exchange through the node's shared table, profiles/r04_gatherstep.txt); a prediction from one GPU, not a "
                              "measurement: no multi-GPU node was available to the builder")
     evaluator.statevector_device.close()
     return {
         "workload": f"24-qubit EVQE population = 256 in total, {layers} layers, Ising 300 terms (default_rng(2024)), fp64 "
-        "(BASELINE.json configs[2]); strong scaling: rank r evaluates its contiguous block, one RCCL all-gather",
+        "(BASELINE.json configs[2]); strong scaling: rank r evaluates its share, the fitness values exchanged through the node's shared table (RCCL all-gather as fallback)",
         "predicted_speedup": predicted,
         "value": total * steps / elapsed, "unit": "circuit-evals/s", "n_gpus": world, "steps": steps,
         "ms_per_step": elapsed / steps * 1e3, "scaling": "strong", "individuals_per_rank": hi - lo,
@@ -980,7 +985,8 @@ def main() -> None:
                 "population_per_gpu": POP_PER_GPU,
                 "layers": N_LAYERS,
                 "pauli_terms": len(operator),
-                "parallelism": f"population sharded over {world} GPU(s), RCCL all-gather of fitness" if world > 1 else "1 GPU",
+                "parallelism": (f"population sharded over {world} GPU(s); fitness values exchanged through a table in shared host memory the "
+                                "kernels store into (one node; RCCL all-gather: fallback and first-step check)") if world > 1 else "1 GPU",
                 "path": "library defaults (DESIGN.md 4.2 / 5): register splitting with up to five cut keys, one launch per push "
                         "where both virtual circuits are one tile, factorised Ising expectation, multiplexed gates, chain "
                         "stream, end of a batch read off the pinned result buffer, a repeated batch keeps its layout",

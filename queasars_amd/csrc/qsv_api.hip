@@ -1680,13 +1680,14 @@ int eval_end(qsv_t* h, double* out) {
                 QSV_HIP(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
             }
         if (!h->diagonal)
-            QSV_HIP(h, hipMemcpyAsync(h->out_target, h->d_out.ptr, n_evals * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+            // (hipMemcpyDefault: the caller's buffer may be host memory the device can address -- a node's shared fitness table)
+            QSV_HIP(h, hipMemcpyAsync(h->out_target, h->d_out.ptr, n_evals * sizeof(double), hipMemcpyDefault, h->stream));
         h->async_pending = true;
         return QSV_OK;
     }
     if (!h->diagonal)
         QSV_HIP(h, hipMemcpyAsync(h->out_target ? h->out_target : h->h_out, h->d_out.ptr, n_evals * sizeof(double),
-                                  h->out_target ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, h->stream));
+                                  h->out_target ? hipMemcpyDefault : hipMemcpyDeviceToHost, h->stream));
     // The results themselves say when they are there: every evaluation's is one store to the pinned buffer, visible to the host
     // about 5 us before the stream's completion signal is (scripts/ubench/flag_vs_sync.hip).  Watched for at most kPollMicros
     // -- a step of a shallow population; longer batches wait on the streams as before.  Results that have all arrived ARE the
@@ -1716,7 +1717,7 @@ int eval_end(qsv_t* h, double* out) {
             if (used_mask >> i & 1u) QSV_HIP(h, hipStreamSynchronize(h->side_streams[i]));
     }
     if (h->out_target) {  // (a waiting end of a batch with a device output: the caller also gets a host copy)
-        if (out) QSV_HIP(h, hipMemcpy(out, h->out_target, n_evals * sizeof(double), hipMemcpyDeviceToHost));
+        if (out) QSV_HIP(h, hipMemcpy(out, h->out_target, n_evals * sizeof(double), hipMemcpyDefault));
     } else {
         std::memcpy(out, h->h_out, n_evals * sizeof(double));
     }

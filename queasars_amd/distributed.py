@@ -7,6 +7,12 @@ population on its own GPU with no communication, and a single all-gather of ``ce
 (``backend="nccl"`` is RCCL on ROCm) gives every rank all P fitness values, which is what selection needs (selection.py:85,
 :102).  The collective moves a few hundred bytes: it is latency bound, xGMI bandwidth does not matter.
 
+On ONE node the all-gather does not need a collective at all (round 4): the ranks share a table of fitness slots in POSIX
+shared memory that every GPU can write (``_NodeTable``); a rank's evaluation leaves its values in the rank's slot straight
+from the kernel that computed them, and every rank reads the end of the step off the table -- each slot starts as a sentinel
+no arithmetic produces.  The RCCL all-gather stays as the path for groups that span nodes and as the fallback
+(``QSV_GATHER_NODE=0``), and the first step on a group is run both ways and compared.
+
 Shares.  Contiguous blocks by population index while the blocks are even; once the evaluator can tell what a
 circuit costs on its device (``circuit_costs``: the route a circuit takes there, ``qsv_circuit_cost``) and the blocks' costs
 differ by more than 10 %, the individuals are dealt by longest processing time first -- an eight-layer individual without
@@ -149,6 +155,17 @@ def evaluate_population_sharded(evaluator, circuits: Sequence, parameter_values:
                                            torch.device("cuda", torch.cuda.current_device()), shares)
         if chained is not None:
             return chained
+    if device is None and dist.get_backend(group) != "nccl":
+        # (a CPU group -- rehearsals, tests: the node's shared table serves it too, the host writing the slots)
+        # (an evaluator with a GPU of its own under a CPU group -- a gloo rehearsal on a GPU box: the table is registered with
+        # that GPU and its kernels store into it, exactly as under RCCL)
+        on_gpu = getattr(evaluator, "statevector_device", None) is not None and torch.cuda.is_available()
+        table = _node_table(group, world, rank, torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu"))
+        if table is not None:
+            through_table = evaluate_block_through_node_table(evaluator, circuits, parameter_values, n, world, rank, table, shares,
+                                                              torch.cuda.synchronize if on_gpu else None)
+            if through_table is not None:
+                return through_table
     mine_c, mine_p = _take(circuits, parameter_values, shares[rank])
     local = evaluator.evaluate_circuits(mine_c, mine_p) if mine_c else []
     if device is None:
@@ -160,6 +177,187 @@ def evaluate_population_sharded(evaluator, circuits: Sequence, parameter_values:
 # a receive slot no rank has written yet: a NaN whose payload no arithmetic produces (the evaluator's own sentinel is another)
 _SENTINEL = np.frombuffer(np.uint64(0x7FF8C0DEC0DE0001).tobytes(), dtype=np.float64)[0]
 _POLL_SECONDS = 0.002
+
+
+class _NodeTable:
+    """Two tables of ``world`` slots of ``capacity`` doubles in POSIX shared memory, mapped by every rank of a group whose ranks
+    all run on one host and registered with HIP, so that each rank's GPU can store into them (``pointer``: the address the
+    device uses), behind one step counter per rank (a cache line each).
+
+    A step: the rank marks ITS slot of table s & 1 with sentinels, starts its evaluation (whose kernels store the values into
+    the slot), watches its own slot until no sentinel is left, and only then publishes ``done[rank] = s + 1``; it reads the
+    other slots once every rank's counter says s + 1.  (Readers cannot go by the sentinels of somebody else's slot: the
+    owner may not have marked it yet, and the values of step s - 2 would pass for this step's.)  Two tables are enough: a
+    rank that marks its slot for step s + 2 has seen every counter at s + 2, and a rank publishes that only after it has read
+    all of step s.  Created collectively (``create``); rank 0 unlinks the name as soon as everybody has it open."""
+
+    capacity = 4096
+    _header = 8  # doubles per rank in front of the tables: the step counter, padded to a cache line
+
+    def __init__(self, mm, world: int, rank: int, device_address: int, host_address: int, registered: bool):
+        self.mm, self.world, self.rank = mm, world, rank
+        self.device_address, self.host_address, self.registered = device_address, host_address, registered
+        self.step = 0
+        self.done = np.frombuffer(mm, dtype=np.int64, count=world * self._header)[:: self._header]
+        flat = np.frombuffer(mm, dtype=np.float64, count=2 * world * self.capacity, offset=8 * world * self._header)
+        self.tables = flat.reshape(2, world, self.capacity)
+        self.words = flat.view(np.uint64).reshape(2, world, self.capacity)
+
+    @classmethod
+    def bytes_for(cls, world: int) -> int:
+        return 8 * (world * cls._header + 2 * world * cls.capacity)
+
+    def pointer(self, table: int, rank: int) -> int:
+        return self.device_address + 8 * (self.world * self._header + (table * self.world + rank) * self.capacity)
+
+    @classmethod
+    def create(cls, group, world: int, rank: int, device) -> Optional["_NodeTable"]:
+        import mmap
+        import socket
+
+        import torch
+        import torch.distributed as dist
+
+        try:
+            boot = open("/proc/sys/kernel/random/boot_id").read().strip()
+        except OSError:
+            boot = ""
+        hosts = [None] * world
+        dist.all_gather_object(hosts, (socket.gethostname(), boot), group=group)
+        if len(set(hosts)) != 1:
+            return None  # (a group that spans nodes: the collective)
+        size = cls.bytes_for(world)
+        name = [None]
+        fd = -1
+        if rank == 0:
+            path = f"/dev/shm/qsv_fitness_{os.getpid()}_{int.from_bytes(os.urandom(6), 'little'):x}"
+            try:
+                fd = os.open(path, os.O_CREAT | os.O_EXCL | os.O_RDWR, 0o600)
+                os.ftruncate(fd, size)
+                name[0] = path
+            except OSError:
+                name[0] = None
+        dist.broadcast_object_list(name, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        ok = name[0] is not None
+        mm = None
+        if ok:
+            try:
+                if rank != 0:
+                    fd = os.open(name[0], os.O_RDWR)
+                mm = mmap.mmap(fd, size)
+            except OSError:
+                ok = False
+        if fd >= 0:
+            os.close(fd)
+        host_address = 0
+        device_address = 0
+        registered = False
+        if ok:
+            import ctypes
+
+            host_address = ctypes.addressof(ctypes.c_char.from_buffer(mm))
+            device_address = host_address
+            if device.type == "cuda":
+                try:
+                    hip = ctypes.CDLL("libamdhip64.so")
+                    hip.hipHostRegister.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint]
+                    hip.hipHostGetDevicePointer.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, ctypes.c_uint]
+                    torch.cuda.set_device(device)
+                    if hip.hipHostRegister(host_address, size, 3) != 0:  # portable | mapped
+                        ok = False
+                    else:
+                        registered = True
+                        seen = ctypes.c_void_p()
+                        if hip.hipHostGetDevicePointer(ctypes.byref(seen), host_address, 0) != 0 or not seen.value:
+                            ok = False
+                        else:
+                            device_address = int(seen.value)
+                except OSError:
+                    ok = False
+        # every rank takes the same path: one failure anywhere and nobody uses the table
+        flags = [None] * world
+        dist.all_gather_object(flags, bool(ok), group=group)
+        if rank == 0 and name[0] is not None:
+            try:
+                os.unlink(name[0])
+            except OSError:
+                pass
+        if not all(flags):
+            return None
+        table = cls(mm, world, rank, device_address, host_address, registered)
+        table.tables[:, rank] = np.nan  # (a fresh file is zeros: the counters start at 0)
+        dist.barrier(group=group)
+        return table
+
+
+_NODE_TABLES: dict = {}
+
+
+def _node_table(group, world: int, rank: int, device):
+    """The group's table (created on first use, collectively), or None: switched off, a group over several nodes, no shared
+    memory, or memory the device cannot be given."""
+    if os.environ.get("QSV_GATHER_NODE", "1") == "0":
+        return None
+    key = (id(group) if group is not None else 0, world, str(device))
+    hit = _NODE_TABLES.get(key)
+    if hit is None:
+        made = _NodeTable.create(group, world, rank, device)
+        hit = (made, weakref.ref(group) if group is not None else None)
+        _NODE_TABLES[key] = hit
+    table, ref = hit
+    if ref is not None and ref() is not group:  # (an id() recycled by another group)
+        _NODE_TABLES.pop(key, None)
+        return _node_table(group, world, rank, device)
+    return table
+
+
+_NODE_WAIT_SECONDS = 120.0
+
+
+def evaluate_block_through_node_table(evaluator, circuits: Sequence, parameter_values: Sequence, n: int, world: int, rank: int,
+                                      table: "_NodeTable", shares: list, synchronize=None) -> Optional[list[float]]:
+    """One step through the node's shared table: this rank's share evaluated with the kernels' results going straight into
+    the rank's slot (an evaluator that cannot do that evaluates the ordinary way and the host writes the slot), then every
+    rank's values read off the table.  No collective call.  ``synchronize``: waits for this rank's own device work (called when
+    the table has not filled after a couple of milliseconds: a long step needs no busy host).  None: the shares do not fit."""
+    width = max(len(share) for share in shares)
+    if width > table.capacity:
+        return None
+    mine_c, mine_p = _take(circuits, parameter_values, shares[rank])
+    which = table.step & 1
+    table.step += 1
+    slot = table.tables[which, rank]
+    slot[: len(mine_c)] = _SENTINEL
+    if len(mine_c) < width:
+        slot[len(mine_c): width] = np.nan
+    to_device = getattr(evaluator, "evaluate_circuits_to_device", None)
+    if not table.registered and getattr(evaluator, "statevector_device", None) is not None:
+        to_device = None  # (memory the evaluator's GPU has not been given: the host writes the slot)
+    if mine_c and not (to_device is not None and to_device(mine_c, mine_p, table.pointer(which, rank))):
+        slot[: len(mine_c)] = evaluator.evaluate_circuits(mine_c, mine_p)
+    marker = np.float64(_SENTINEL).view(np.uint64)
+    mine = table.words[which, rank, : len(mine_c)]
+    t0 = time.perf_counter()
+    waited = False
+
+    def patience(what: str) -> None:
+        nonlocal waited
+        elapsed = time.perf_counter() - t0
+        if elapsed > _POLL_SECONDS and not waited:
+            waited = True
+            if synchronize is not None:
+                synchronize()
+        elif elapsed > _NODE_WAIT_SECONDS:
+            raise RuntimeError(f"queasars_amd.distributed: {what} within {_NODE_WAIT_SECONDS:.0f} s")
+        elif waited:
+            time.sleep(0)
+
+    while (mine == marker).any():  # this rank's own values, from its own kernels
+        patience("this rank's fitness values did not reach the node's shared table")
+    table.done[rank] = table.step
+    while (table.done < table.step).any():
+        patience("another rank's fitness values did not arrive in the node's shared table")
+    return _unpack(table.tables[which, :, :width], n, world, width, shares)
 
 
 def evaluate_block_and_gather(evaluator, circuits: Sequence, parameter_values: Sequence, n: int, world: int, rank: int, group, device,
@@ -193,6 +391,26 @@ def evaluate_block_and_gather(evaluator, circuits: Sequence, parameter_values: S
         return None
     if shares is None:
         shares = contiguous_shares(n, world)
+    stream = state["stream"]
+    if not state.get("no_node_table"):
+        # One node: no collective -- the kernels' results go straight into this rank's slot of the shared table.  Nothing of the
+        # collective's apparatus is touched on this path (buffers, the current-stream switch: the evaluator launches on its own
+        # stream anyway); the caller's stream is waited for only if it has work queued.
+        node_table = _node_table(group, world, rank, device)
+        if node_table is not None:
+            caller = torch.cuda.current_stream(device)
+            if caller != stream and not caller.query():
+                stream.wait_stream(caller)
+            values = evaluate_block_through_node_table(evaluator, circuits, parameter_values, n, world, rank, node_table, shares,
+                                                       stream.synchronize)
+            if values is not None:
+                if state.get("node_verified") is node_table:
+                    return values
+                mine_c, mine_p = _take(circuits, parameter_values, shares[rank])
+                checked = _verified_or_staged(evaluator, values, mine_c, mine_p, n, world, rank, group, device, state, shares, "node")
+                if not state.get("no_node_table"):
+                    state["node_verified"] = node_table
+                return checked
     mine_c, mine_p = _take(circuits, parameter_values, shares[rank])
     width = max(len(share) for share in shares)
     host_receive = os.environ.get("QSV_GATHER_HOST", "1") != "0" and not state.get("no_host_receive")
@@ -201,7 +419,6 @@ def evaluate_block_and_gather(evaluator, circuits: Sequence, parameter_values: S
     if host_receive and mapped is None:
         state["no_host_receive"] = True
         host_receive = False
-    stream = state["stream"]
     caller = torch.cuda.current_stream(device)
     if caller != stream:
         stream.wait_stream(caller)  # (the application's earlier work on its own stream comes first)
@@ -209,41 +426,63 @@ def evaluate_block_and_gather(evaluator, circuits: Sequence, parameter_values: S
     try:
         if len(mine_c) < width:
             send.fill_(float("nan"))
-        if host_receive:
-            mapped[1].fill(_SENTINEL)
-        if mine_c and not to_device(mine_c, mine_p, send.data_ptr()):
+        recv_values = _collective_step(to_device, mine_c, mine_p, send, recv, recv_host, mapped, host_receive, state, group, stream)
+        if recv_values is None:
             return None
-        if host_receive:
-            try:
-                dist.all_gather_into_tensor(mapped[0], send, group=group)
-            except Exception as exc:  # (a collective library that refuses host-mapped memory refuses it on every rank alike)
-                import warnings
-
-                warnings.warn(f"queasars_amd.distributed: all-gather into host-mapped memory refused ({exc}); receiving on the device",
-                              RuntimeWarning)
-                state["no_host_receive"] = True
-                host_receive = False
-        if host_receive:
-            table = mapped[1]
-            deadline = time.perf_counter() + _POLL_SECONDS
-            flat = table.view(np.uint64)
-            marker = np.float64(_SENTINEL).view(np.uint64)
-            while (flat == marker).any():
-                if time.perf_counter() > deadline:  # (a long step: wait on the stream as before)
-                    stream.synchronize()
-                    break
-            recv_values = table
-        if not host_receive:
-            dist.all_gather_into_tensor(recv, send, group=group)
-            recv_host.copy_(recv, non_blocking=True)
-            stream.synchronize()
-            recv_values = recv_host.numpy()
+        values = _unpack(recv_values, n, world, width, shares)
+        way = "host" if host_receive and not state.get("no_host_receive") else "device"
     finally:
         if caller != stream:
             torch.cuda.set_stream(caller)
-    values = _unpack(recv_values, n, world, width, shares)
-    verified = state["verified"]
-    known = any(ref() is group for ref in verified) if group is not None else bool(state.get("verified_default"))
+    return _verified_or_staged(evaluator, values, mine_c, mine_p, n, world, rank, group, device, state, shares, way)
+
+
+def _collective_step(to_device, mine_c, mine_p, send, recv, recv_host, mapped, host_receive, state, group, stream):
+    """The RCCL way of :func:`evaluate_block_and_gather`: the evaluation's values into the send buffer, the all-gather behind it
+    on the same stream -- into host-mapped memory read off its sentinels, or into device memory and copied back.  The
+    gathered slots, or None where the evaluator cannot leave its values on the device."""
+    import torch.distributed as dist
+
+    if host_receive:
+        mapped[1].fill(_SENTINEL)
+    if mine_c and not to_device(mine_c, mine_p, send.data_ptr()):
+        return None
+    if host_receive:
+        try:
+            dist.all_gather_into_tensor(mapped[0], send, group=group)
+        except Exception as exc:  # (a collective library that refuses host-mapped memory refuses it on every rank alike)
+            import warnings
+
+            warnings.warn(f"queasars_amd.distributed: all-gather into host-mapped memory refused ({exc}); receiving on the device",
+                          RuntimeWarning)
+            state["no_host_receive"] = True
+            host_receive = False
+    if host_receive:
+        table = mapped[1]
+        deadline = time.perf_counter() + _POLL_SECONDS
+        flat = table.view(np.uint64)
+        marker = np.float64(_SENTINEL).view(np.uint64)
+        while (flat == marker).any():
+            if time.perf_counter() > deadline:  # (a long step: wait on the stream as before)
+                stream.synchronize()
+                break
+        return table
+    dist.all_gather_into_tensor(recv, send, group=group)
+    recv_host.copy_(recv, non_blocking=True)
+    stream.synchronize()
+    return recv_host.numpy()
+
+
+def _verified_or_staged(evaluator, values, mine_c, mine_p, n, world, rank, group, device, state, shares, way: str):
+    """The first chained step of an evaluator on a group, run the staged way as well and compared (every rank agrees on the
+    verdict); a way that disagrees is switched off for that evaluator, with a warning, and the staged values are returned."""
+    import torch
+    import torch.distributed as dist
+
+    host_receive = way == "host"
+    verified = state["verified"]  # (group, way) pairs this evaluator's chained step has been checked on
+    known = (any(ref() is group and w == way for ref, w in verified) if group is not None
+             else way in state.setdefault("verified_default", set()))
     if not known:
         local = evaluator.evaluate_circuits(mine_c, mine_p) if mine_c else []
         staged = _gather(local, n, world, rank, group, device, state["key"], shares)
@@ -254,6 +493,11 @@ def evaluate_block_and_gather(evaluator, circuits: Sequence, parameter_values: S
         if float(flag.item()) != 1.0:
             import warnings
 
+            if way == "node":
+                warnings.warn("queasars_amd.distributed: the step through the node's shared table disagreed with the staged step; "
+                              "using the collective", RuntimeWarning)
+                state["no_node_table"] = True
+                return staged
             if host_receive:  # (first suspect: the collective writing into host memory; the device receive buffer gets its turn)
                 warnings.warn("queasars_amd.distributed: the all-gather into host-mapped memory disagreed with the staged step; "
                               "receiving on the device", RuntimeWarning)
@@ -265,10 +509,10 @@ def evaluate_block_and_gather(evaluator, circuits: Sequence, parameter_values: S
             return staged
         if group is not None:
             # (by the group object itself, weakly: an id() can be recycled by another group)
-            verified.append(weakref.ref(group))
-            verified[:] = [ref for ref in verified if ref() is not None]
+            verified.append((weakref.ref(group), way))
+            verified[:] = [(ref, w) for ref, w in verified if ref() is not None]
         else:
-            state["verified_default"] = True
+            state["verified_default"].add(way)
     return values
 
 

@@ -30,6 +30,7 @@ t_eval, want = timed(lambda: ev.evaluate_circuits(circuits, params))
 t_both, got = timed(lambda: qd._gather(ev.evaluate_circuits(circuits, params), P, 1, 0, None, dev))
 assert list(got) == list(want)
 print(f"evaluation {t_eval:.1f} us; evaluation + gather path {t_both:.1f} us")
+os.environ["QSV_GATHER_NODE"] = "0"  # (first the collective's ways; the node's shared table at the end)
 if hasattr(qd, "evaluate_block_and_gather"):
     # round 4: the collective receives into host memory the device addresses, the end is read off the slots (QSV_GATHER_HOST=0:
     # round 3's copy back + stream synchronisation)
@@ -54,4 +55,12 @@ if hasattr(qd, "evaluate_block_and_gather"):
         t_fused, got3 = timed(lambda: qd.evaluate_block_and_gather(ev, circuits, matrix, P, 1, 0, None, dev))
         assert list(got3) == list(want)
         print(f"device-resident inputs: evaluation {t_eval_dev:.1f} us; chained step (host receive {host}) {t_fused:.1f} us (+{t_fused - t_eval_dev:.1f})")
+    # the node's shared table (no collective: the kernels store into the rank's slot, the host reads the table)
+    os.environ["QSV_GATHER_NODE"] = "1"
+    for values, name, base in ((params, "host lists", t_eval), (matrix, "device-resident inputs", t_eval_dev)):
+        t_node, got4 = timed(lambda: qd.evaluate_block_and_gather(ev, circuits, values, P, 1, 0, None, dev))
+        assert list(got4) == list(want)
+        table = qd._node_table(None, 1, 0, dev)
+        print(f"{name}: step through the node's shared table {t_node:.1f} us (+{t_node - base:.1f} over the evaluation alone; "
+              f"table registered with the GPU: {bool(table is not None and table.registered)}, steps through it: {table.step if table else 0})")
 dist.destroy_process_group()

@@ -320,3 +320,133 @@ def test_gather_buffers_are_not_shared_between_evaluators_groups_or_threads():
     assert other[0][0] is not a[0]
     for key in [k for k in _BUFFERS if k[-1] in (101, 202)]:
         _BUFFERS.pop(key)
+
+
+class _PointerEvaluator(_OracleEvaluator):
+    """An evaluator that can leave its values where the caller says (``evaluate_circuits_to_device``): here the "device"
+    is the host, the pointer a host address -- what the node's shared table hands a CPU rank."""
+
+    def __init__(self, operator):
+        super().__init__(operator)
+        self.to_pointer = 0
+
+    def evaluate_circuits_to_device(self, circuits, parameter_values, pointer):
+        import ctypes
+
+        values = np.asarray(self.evaluate_circuits(circuits, parameter_values), dtype=np.float64)
+        ctypes.memmove(pointer, values.ctypes.data, values.nbytes)
+        self.to_pointer += 1
+        return True
+
+
+def _node_table_worker(rank: int, world: int, port: int, out_dir: str):
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+
+    import helpers
+    from queasars_amd import distributed
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        op = helpers.random_ising_operator(5, seed=7)
+        table = distributed._node_table(None, world, rank, torch.device("cpu"))
+        assert table is not None, "two ranks on one host share a table"
+        assert not [f for f in os.listdir("/dev/shm") if f.startswith("qsv_fitness_")], "the name is gone once everybody has it open"
+        got = []
+        for step, n_individuals in enumerate([8, 7, 1, 8, 8, 3, 8]):  # (uneven and empty shares, both tables several times over)
+            _, circuits, params = helpers.population_circuits(5, 2, n_individuals, seed=40 + step)
+            evaluator = _PointerEvaluator(op) if step % 2 == 0 else _OracleEvaluator(op)
+            values = distributed.evaluate_population_sharded(evaluator, circuits, params)
+            lo, hi = distributed.shard_bounds(n_individuals, world, rank)
+            assert evaluator.seen == hi - lo
+            if step % 2 == 0 and hi > lo:
+                assert evaluator.to_pointer == 1, "the values went straight into the rank's slot"
+            got.append(values)
+        assert table.step == 7
+        # shares wider than a slot: the collective takes over, same values
+        distributed._NodeTable.capacity, keep = 2, distributed._NodeTable.capacity
+        _, circuits, params = helpers.population_circuits(5, 2, 8, seed=40)
+        assert distributed.evaluate_population_sharded(_OracleEvaluator(op), circuits, params) == got[0]
+        distributed._NodeTable.capacity = keep
+        os.environ["QSV_GATHER_NODE"] = "0"
+        assert distributed.evaluate_population_sharded(_OracleEvaluator(op), circuits, params) == got[0]
+        np.save(os.path.join(out_dir, f"rank{rank}.npy"), np.concatenate([np.asarray(v) for v in got]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_through_the_nodes_shared_table(tmp_path):
+    """The all-gather without a collective: both ranks map one table in POSIX shared memory, each leaves its values in its
+    slot, everybody reads the table (queasars_amd.distributed._NodeTable)."""
+    world = 2
+    mp.spawn(_node_table_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    import helpers
+
+    op = helpers.random_ising_operator(5, seed=7)
+    want = []
+    for step, n_individuals in enumerate([8, 7, 1, 8, 8, 3, 8]):
+        _, circuits, params = helpers.population_circuits(5, 2, n_individuals, seed=40 + step)
+        want += [helpers.oracle_expectation(c, p, op) for c, p in zip(circuits, params)]
+    for rank in range(world):
+        got = np.load(tmp_path / f"rank{rank}.npy")
+        assert got.shape == (len(want),) and np.array_equal(got, np.asarray(want)), np.abs(got - np.asarray(want)).max()
+
+
+def _gpu_node_table_worker(rank: int, world: int, port: int, out_dir: str):
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+
+    import helpers
+    from queasars_amd import distributed
+    from queasars_amd.circuit_evaluation import OperatorCircuitEvaluator
+
+    torch.cuda.set_device(0)  # (both ranks on the one GPU of the box: the table is host memory, every GPU is given it alike)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n = 14
+        op = helpers.random_ising_operator(n, seed=7)
+        evaluator = OperatorCircuitEvaluator(op, device=0)
+        got = []
+        for step, count in enumerate([8, 7, 1, 12, 8, 3]):
+            _, circuits, params = helpers.population_circuits(n, 3, count, seed=40 + step)
+            got.append(distributed.evaluate_population_sharded(evaluator, circuits, params))
+        table = distributed._node_table(None, world, rank, torch.device("cuda", 0))
+        assert table is not None and table.registered and table.step == 6, "the GPUs stored into the node's shared table"
+        # the parameter values in the rank's own device memory, and the same population again: the same bits
+        _, circuits, params = helpers.population_circuits(n, 3, 12, seed=43)
+        host_matrix = np.zeros((len(params), max(len(p) for p in params)))
+        for row, p in zip(host_matrix, params):
+            row[: len(p)] = p
+        matrix = torch.from_numpy(host_matrix).cuda()
+        assert distributed.evaluate_population_sharded(evaluator, circuits, matrix) == got[3]
+        os.environ["QSV_GATHER_NODE"] = "0"
+        assert distributed.evaluate_population_sharded(evaluator, circuits, params) == got[3], "the collective's values, bit for bit"
+        np.save(os.path.join(out_dir, f"rank{rank}.npy"), np.concatenate([np.asarray(v) for v in got]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_gpu_kernels_store_into_the_nodes_shared_table(tmp_path):
+    """Two ranks (gloo for the set-up, both on GPU 0) with real evaluators: each rank's kernels store its values straight into
+    its slot of the node's shared table, registered with HIP; values against the oracle, and the collective's bits."""
+    world = 2
+    mp.spawn(_gpu_node_table_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    import helpers
+
+    op = helpers.random_ising_operator(14, seed=7)
+    want = []
+    for step, count in enumerate([8, 7, 1, 12, 8, 3]):
+        _, circuits, params = helpers.population_circuits(14, 3, count, seed=40 + step)
+        want += [helpers.oracle_expectation(c, p, op) for c, p in zip(circuits, params)]
+    got0, got1 = (np.load(tmp_path / f"rank{r}.npy") for r in range(world))
+    assert np.array_equal(got0, got1)
+    assert np.abs(got0 - np.asarray(want)).max() < 1e-10
