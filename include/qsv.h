@@ -316,6 +316,21 @@ int qsv_sample_cvar_batch(qsv_t* h, int n_evals, const int* circuit_ids, const i
 int qsv_exact_cvar_batch(qsv_t* h, int n_evals, const int* circuit_ids, const int64_t* param_offsets, const double* params,
                          double alpha, double* out_cvar);
 
+/* ---- sharded populations on one node ------------------------------------------------------------- */
+
+/*
+ * The waiting part of one step through a node's shared fitness table (queasars_amd/distributed.py, _NodeTable; reference:
+ * the executor's futures of selection.py:75-85 -- here every rank's values land in a table all ranks map).  `own`: this rank's
+ * slot (count doubles that the rank marked with QSV_TABLE_SENTINEL before it started its evaluation, whose kernels store
+ * the values there); `done`: the ranks' step counters, `stride` 64-bit words apart.  Spins until no sentinel is left in the
+ * slot, publishes done[rank * stride] = step, spins until every rank's counter has reached `step`.  Needs no handle and no
+ * GPU.  Returns 0; 1 / 2 when the slot / the counters were not there after budget_us microseconds (nothing published in
+ * case 1): the caller decides how to go on waiting.
+ */
+#define QSV_TABLE_SENTINEL 0x7FF8C0DEC0DE0001ull
+int qsv_fitness_table_wait(const volatile uint64_t* own, int count, volatile int64_t* done, int stride, int world, int rank,
+                           int64_t step, int budget_us);
+
 /* ---- measurement support ----------------------------------------------------------------------- */
 
 /*

@@ -142,6 +142,7 @@ SIGNATURES = {
     "qsv_sample_cvar_batch": (C.c_int, [_P, C.c_int, _P, _P, _P, C.c_int, C.c_uint64, C.c_double, _P]),
     "qsv_exact_cvar_batch": (C.c_int, [_P, C.c_int, _P, _P, _P, C.c_double, _P]),
     "qsv_set_option": (C.c_int, [_P, C.c_char_p, C.c_int]),
+    "qsv_fitness_table_wait": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int]),
     "qsv_set_profiling": (C.c_int, [_P, C.c_int]),
     "qsv_get_profile": (C.c_int, [_P, C.POINTER(QsvProfile)]),
     "qsv_bench_gate": (C.c_int, [_P, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.POINTER(C.c_double)]),

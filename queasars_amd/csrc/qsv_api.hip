@@ -3071,6 +3071,32 @@ int qsv_sample(qsv_t* h, int circuit_id, const double* params, int n_params, int
     return sample_batch_locked(h, circs, offsets, params ? params : &dummy, shots, seed, out_states, nullptr);
 }
 
+int qsv_fitness_table_wait(const volatile uint64_t* own, int count, volatile int64_t* done, int stride, int world, int rank,
+                           int64_t step, int budget_us) {
+    if (!own || !done || count < 0 || world < 1 || rank < 0 || rank >= world || stride < 1) return QSV_E_ARG;
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(budget_us);
+    auto expired = [&](unsigned& spins) {
+        __builtin_ia32_pause();
+        return (++spins & 255u) == 0 && std::chrono::steady_clock::now() > deadline;
+    };
+    unsigned spins = 0;
+    for (int i = 0; i < count;) {  // (values arrive in any order: every word is looked at until it is no sentinel)
+        if (own[i] != QSV_TABLE_SENTINEL)
+            ++i;
+        else if (expired(spins))
+            return 1;
+    }
+    // (the values were seen by this core before the counter is published: whoever sees the counter sees them)
+    __atomic_store_n(&done[size_t(rank) * size_t(stride)], step, __ATOMIC_RELEASE);
+    for (int r = 0; r < world;) {
+        if (__atomic_load_n(&done[size_t(r) * size_t(stride)], __ATOMIC_ACQUIRE) >= step)
+            ++r;
+        else if (expired(spins))
+            return 2;
+    }
+    return 0;
+}
+
 int qsv_set_option(qsv_t* h, const char* name, int value) {
     if (!h) return QSV_E_ARG;
     if (!name) return fail(h, QSV_E_ARG, "option name is null");

@@ -95,8 +95,15 @@ def population_shares(evaluator, circuits: Sequence, world: int) -> list[list[in
         return [list(range(n))]
     key = id(evaluator)
     hit = _SHARES.get(key)
+    if hit is not None and hit[0]() is evaluator and hit[4] is circuits and len(hit[2]) == n and hit[1][1] == world and (
+            n == 0 or (hit[2][0] is circuits[0] and hit[2][n // 2] is circuits[n // 2] and hit[2][-1] is circuits[-1])):
+        # (the very list of the last call, a few of its members looked at: walking 64 N ids per step is microseconds per rank
+        # that grow with N.  Whatever the list has become in between, the remembered shares are still a partition of its indices:
+        # every rank evaluates and returns the right values, at worst less evenly dealt.)
+        return hit[3]
     ids = tuple(map(id, circuits))
     if hit is not None and hit[0]() is evaluator and hit[1] == (ids, world):
+        _SHARES[key] = hit[:4] + (circuits,)
         return hit[3]
     costs = evaluation_costs(evaluator, circuits)
     shares = contiguous_shares(n, world) if costs is None else partition_by_cost(costs, world)
@@ -104,7 +111,7 @@ def population_shares(evaluator, circuits: Sequence, world: int) -> list[list[in
         ref = weakref.ref(evaluator, lambda _r, k=key: _SHARES.pop(k, None))
     except TypeError:  # (an evaluator that cannot be weakly referenced: nothing is remembered)
         return shares
-    _SHARES[key] = (ref, (ids, world), list(circuits), shares)  # (holds the circuits: their ids cannot be recycled)
+    _SHARES[key] = (ref, (ids, world), list(circuits), shares, circuits)  # (holds the circuits: their ids cannot be recycled)
     return shares
 
 
@@ -133,6 +140,24 @@ def _take(circuits: Sequence, parameter_values, share: Sequence[int]):
     return picked, [parameter_values[i] for i in share]
 
 
+_GROUP_FACTS: dict = {}
+
+
+def _group_facts(group):
+    """(world size, rank, backend) of a process group, asked once per group object: torch's own accessors walk their registries on
+    every call -- tens of microseconds per step on a path whose whole point is a few."""
+    import torch.distributed as dist
+
+    g = group if group is not None else dist.group.WORLD
+    hit = _GROUP_FACTS.get(id(g))
+    if hit is None or hit[0]() is not g:
+        hit = (weakref.ref(g), dist.get_world_size(group), dist.get_rank(group), dist.get_backend(group))
+        if len(_GROUP_FACTS) > 64:
+            _GROUP_FACTS.clear()
+        _GROUP_FACTS[id(g)] = hit
+    return hit[1], hit[2], hit[3]
+
+
 def evaluate_population_sharded(evaluator, circuits: Sequence, parameter_values: Sequence, group=None, device=None) -> list[float]:
     """Evaluate this rank's share of the population and all-gather the fitness values.
 
@@ -145,17 +170,19 @@ def evaluate_population_sharded(evaluator, circuits: Sequence, parameter_values:
     import torch.distributed as dist
 
     n = len(circuits)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return list(evaluator.evaluate_circuits(list(circuits), _rows(parameter_values, 0, n)))
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    world, rank, backend = _group_facts(group)
+    if world == 1:
+        return list(evaluator.evaluate_circuits(list(circuits), _rows(parameter_values, 0, n)))
     shares = population_shares(evaluator, circuits, world)
-    if device is None and dist.get_backend(group) == "nccl" and os.environ.get("QSV_GATHER_CHAIN", "1") != "0":
+    if device is None and backend == "nccl" and os.environ.get("QSV_GATHER_CHAIN", "1") != "0":
         # evaluation, collective and copy back as one chain on one stream (no host round trip in between)
         chained = evaluate_block_and_gather(evaluator, circuits, parameter_values, n, world, rank, group,
                                            torch.device("cuda", torch.cuda.current_device()), shares)
         if chained is not None:
             return chained
-    if device is None and dist.get_backend(group) != "nccl":
+    if device is None and backend != "nccl":
         # (a CPU group -- rehearsals, tests: the node's shared table serves it too, the host writing the slots)
         # (an evaluator with a GPU of its own under a CPU group -- a gloo rehearsal on a GPU box: the table is registered with
         # that GPU and its kernels store into it, exactly as under RCCL)
@@ -169,13 +196,14 @@ def evaluate_population_sharded(evaluator, circuits: Sequence, parameter_values:
     mine_c, mine_p = _take(circuits, parameter_values, shares[rank])
     local = evaluator.evaluate_circuits(mine_c, mine_p) if mine_c else []
     if device is None:
-        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+        device = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
     owner = id(getattr(evaluator, "statevector_device", None) or evaluator)
     return _gather(local, n, world, rank, group, torch.device(device), owner, shares)
 
 
 # a receive slot no rank has written yet: a NaN whose payload no arithmetic produces (the evaluator's own sentinel is another)
 _SENTINEL = np.frombuffer(np.uint64(0x7FF8C0DEC0DE0001).tobytes(), dtype=np.float64)[0]
+_MARKER = _SENTINEL.view(np.uint64)
 _POLL_SECONDS = 0.002
 
 
@@ -209,6 +237,9 @@ class _NodeTable:
 
     def pointer(self, table: int, rank: int) -> int:
         return self.device_address + 8 * (self.world * self._header + (table * self.world + rank) * self.capacity)
+
+    def host_pointer(self, table: int, rank: int) -> int:
+        return self.host_address + 8 * (self.world * self._header + (table * self.world + rank) * self.capacity)
 
     @classmethod
     def create(cls, group, world: int, rank: int, device) -> Optional["_NodeTable"]:
@@ -312,6 +343,23 @@ def _node_table(group, world: int, rank: int, device):
 
 
 _NODE_WAIT_SECONDS = 120.0
+_WAITER: list = []
+
+
+def _table_waiter():
+    """``qsv_fitness_table_wait`` of the library (a spin in C without the interpreter lock: own slot, publish, the other ranks'
+    counters), or None where the library is not there (it is never built for this: a CPU rank with a foreign evaluator)."""
+    if not _WAITER:
+        fn = None
+        if os.environ.get("QSV_GATHER_NODE_SPIN", "1") != "0":
+            try:
+                from . import _lib
+
+                fn = getattr(_lib.load(build_if_missing=False), "qsv_fitness_table_wait", None)
+            except Exception:  # (no library, or one from before this entry point)
+                fn = None
+        _WAITER.append(fn)
+    return _WAITER[0]
 
 
 def evaluate_block_through_node_table(evaluator, circuits: Sequence, parameter_values: Sequence, n: int, world: int, rank: int,
@@ -324,39 +372,47 @@ def evaluate_block_through_node_table(evaluator, circuits: Sequence, parameter_v
     if width > table.capacity:
         return None
     mine_c, mine_p = _take(circuits, parameter_values, shares[rank])
+    count = len(mine_c)
     which = table.step & 1
     table.step += 1
+    step = table.step
     slot = table.tables[which, rank]
-    slot[: len(mine_c)] = _SENTINEL
-    if len(mine_c) < width:
-        slot[len(mine_c): width] = np.nan
+    slot[:count] = _SENTINEL
+    if count < width:
+        slot[count:width] = np.nan
     to_device = getattr(evaluator, "evaluate_circuits_to_device", None)
     if not table.registered and getattr(evaluator, "statevector_device", None) is not None:
         to_device = None  # (memory the evaluator's GPU has not been given: the host writes the slot)
-    if mine_c and not (to_device is not None and to_device(mine_c, mine_p, table.pointer(which, rank))):
-        slot[: len(mine_c)] = evaluator.evaluate_circuits(mine_c, mine_p)
-    marker = np.float64(_SENTINEL).view(np.uint64)
-    mine = table.words[which, rank, : len(mine_c)]
-    t0 = time.perf_counter()
+    if count and not (to_device is not None and to_device(mine_c, mine_p, table.pointer(which, rank))):
+        slot[:count] = evaluator.evaluate_circuits(mine_c, mine_p)
+    waiter = _table_waiter()
+    if waiter is not None and waiter(table.host_pointer(which, rank), count, table.host_address, table._header, world, rank, step,
+                                     int(_POLL_SECONDS * 1e6)) == 0:
+        return _unpack(table.tables[which, :, :width], n, world, width, shares)
+    # (without the library -- a CPU rank whose evaluator is not ours -- or past the spinning budget: the same in NumPy, with
+    # this rank's own device work waited for once and a deadline)
+    mine = table.words[which, rank, :count]
+    done = table.done
+    t0 = None
     waited = False
-
-    def patience(what: str) -> None:
-        nonlocal waited
-        elapsed = time.perf_counter() - t0
-        if elapsed > _POLL_SECONDS and not waited:
-            waited = True
-            if synchronize is not None:
-                synchronize()
-        elif elapsed > _NODE_WAIT_SECONDS:
-            raise RuntimeError(f"queasars_amd.distributed: {what} within {_NODE_WAIT_SECONDS:.0f} s")
-        elif waited:
-            time.sleep(0)
-
-    while (mine == marker).any():  # this rank's own values, from its own kernels
-        patience("this rank's fitness values did not reach the node's shared table")
-    table.done[rank] = table.step
-    while (table.done < table.step).any():
-        patience("another rank's fitness values did not arrive in the node's shared table")
+    # this rank's own values (from its own kernels), then every rank's counter
+    for own in (True, False):
+        while (mine == _MARKER).any() if own else (done < step).any():
+            if t0 is None:
+                t0 = time.perf_counter()
+                continue
+            elapsed = time.perf_counter() - t0
+            if elapsed > _POLL_SECONDS and not waited:
+                waited = True  # (a long step needs no busy host: wait for this rank's own device work once)
+                if synchronize is not None:
+                    synchronize()
+            elif elapsed > _NODE_WAIT_SECONDS:
+                raise RuntimeError("queasars_amd.distributed: " + ("this rank's" if own else "another rank's") +
+                                   f" fitness values did not reach the node's shared table within {_NODE_WAIT_SECONDS:.0f} s")
+            elif waited:
+                time.sleep(0)
+        if own:
+            done[rank] = step
     return _unpack(table.tables[which, :, :width], n, world, width, shares)
 
 
@@ -521,8 +577,15 @@ def _unpack(recv_values, n: int, world: int, width: int, shares: Optional[list] 
     table = np.asarray(recv_values).reshape(world, width)
     if shares is None:
         shares = contiguous_shares(n, world)
-    if n == world * width and all(share == list(range(r * width, (r + 1) * width)) for r, share in enumerate(shares)):
-        return table.ravel().tolist()
+    if n == world * width:
+        even = _EVEN_BLOCKS.get(id(shares))
+        if even is None or even[0] is not shares:  # (asked once per shares object: N lists of 64 N indices compared per step otherwise)
+            even = (shares, all(share == list(range(r * width, (r + 1) * width)) for r, share in enumerate(shares)))
+            if len(_EVEN_BLOCKS) > 64:
+                _EVEN_BLOCKS.clear()
+            _EVEN_BLOCKS[id(shares)] = even
+        if even[1]:
+            return table.ravel().tolist()
     out = [0.0] * n
     for r, share in enumerate(shares):
         row = table[r, : len(share)].tolist()
@@ -531,6 +594,7 @@ def _unpack(recv_values, n: int, world: int, width: int, shares: Optional[list] 
     return out
 
 
+_EVEN_BLOCKS: dict = {}
 _CHAIN_STATE: dict = {}
 
 
