@@ -2624,15 +2624,24 @@ __device__ __forceinline__ void factor_side_body(const cx<real>* __restrict__ ta
     QSV_PSTAMP(4);  // (diagnostic build: the first block's rows)
     for (uint32_t blk = first_block; blk < n_blocks; blk += block_step) {
         if constexpr (!AHEAD) fetch(blk);
+        // (ONE product term: a lane's only entry is |its own amplitude|^2 times its own value of D -- nothing goes through LDS)
+        const double own_re = double(rows[0].re), own_im = double(rows[0].im), own_d = dq[0];
+        if constexpr (J > 1) {
 #pragma unroll
-        for (int j = 0; j < J; ++j) stage[lane * PITCH + uint32_t(j)] = rows[j];
-        dstage[lane] = dq[0];
+            for (int j = 0; j < J; ++j) stage[lane * PITCH + uint32_t(j)] = rows[j];
+            dstage[lane] = dq[0];
+        }
         // (the queue moves up; the block kFactorDAhead steps on is asked for AFTER this block's rows: loads return in order)
 #pragma unroll
         for (int k = 0; k + 1 < kFactorDAhead; ++k) dq[k] = dq[k + 1];
         dq[kFactorDAhead - 1] = factor_d_of_block(diag, bits, mask, blk + uint32_t(kFactorDAhead) * block_step, n_blocks);
         if constexpr (AHEAD) fetch(blk + block_step);
         double s_one = 0.0, s_d = 0.0;
+        if constexpr (J == 1) {
+            const double p = split_entry_value(0u, own_re, own_im, own_re, own_im);
+            s_one += p;
+            s_d = fma(own_d, p, s_d);
+        } else
 #pragma unroll
         for (uint32_t i = 0; i < NQ; ++i) {
             const uint32_t xl = sub * NQ + i;
