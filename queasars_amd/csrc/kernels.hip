@@ -350,12 +350,14 @@ struct PassScalars {
 #ifndef QSV_WAVES_R4_FIRST
 #define QSV_WAVES_R4_FIRST 4
 #endif
-template <int R, int XMODE, bool FIRST>
+template <int R, int XMODE, bool FIRST, bool FUSED = false>
 struct Occupancy {
     // 2^R amplitudes = 4 * 2^R VGPRs: R = 3 fits the 80-VGPR budget of 6 waves per SIMD, R = 4 needs the 128 of 4 --
     // (the synthesising pass 0 has no load phase and would fit the 96 of 5 waves; measured: no faster)
+    // (FUSED: the one-launch route's instantiation -- two workgroups per evaluation on a chip of 256 CUs, one workgroup per CU
+    // by its LDS anyway: its tail, the sides' Gram sums, may take the registers of two waves per SIMD)
     static constexpr int waves_per_simd =
-        R >= 4 ? (FIRST && XMODE == 2 ? QSV_WAVES_R4_FIRST : QSV_WAVES_R4) : (XMODE == 2 ? QSV_WAVES_PER_SIMD : 4);
+        FUSED ? 2 : R >= 4 ? (FIRST && XMODE == 2 ? QSV_WAVES_R4_FIRST : QSV_WAVES_R4) : (XMODE == 2 ? QSV_WAVES_PER_SIMD : 4);
 };
 
 template <typename T>
@@ -698,8 +700,11 @@ __device__ __forceinline__ void fused_factor_tail(const uint32_t* __restrict__ p
 
 // FIRST = the pass synthesises its input (pass 0 of an evaluation from |0..0>): two instantiations, so that neither
 // carries the other's load path through register allocation.
-template <typename real, int R, int XMODE, bool FIRST>
-__global__ void __launch_bounds__(512, (Occupancy<R, XMODE, FIRST>::waves_per_simd))
+// FUSED (only with FIRST and R = 4): the instantiation the one-launch route of split evaluations runs (kModeFusedFactor) -- the
+// only one that carries the sides' Gram sums and the combination behind the virtual circuits (fused_factor_tail): the other
+// first-pass kernels are the leaner for it (a third fewer scalar spills), this one has registers to spare.
+template <typename real, int R, int XMODE, bool FIRST, bool FUSED = false>
+__global__ void __launch_bounds__(512, (Occupancy<R, XMODE, FIRST, FUSED>::waves_per_simd))
     pass_kernel(const uint32_t* __restrict__ plan_arena, const double* __restrict__ mats_all,
                 const EvalDesc* __restrict__ evals, cx<real>* __restrict__ states, cx<real>* __restrict__ wtabs,
                 const double* __restrict__ diag, double* __restrict__ partials, const PassScalars a) {
@@ -817,7 +822,7 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, FIRST>::waves_per_si
 #ifdef QSV_ABL_NO_THROUGH  // (measurement: the fused sides' states stored like any other)
     const bool through = false;
 #else
-    const bool through = FIRST && R == 4 && side && (ev.flags & kEvalFused) && (a.mode & kModeFusedFactor);
+    const bool through = FUSED && side && (ev.flags & kEvalFused) && (a.mode & kModeFusedFactor);
 #endif
     // ... and a small enough side does not go to memory at all where the launch has the LDS for it (kModeFusedLdsTable): the
     // table is laid out in LDS exactly as it would be in its slot (a fused side is one tile: offsets inside the tile ARE table
@@ -826,7 +831,7 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, FIRST>::waves_per_si
                               n_qubits <= uint32_t(kFusedLdsTableBits);
     // ... or, a three-key side of thirteen virtual qubits, as padded rows from offset 0 (kernels.hpp, kFusedLdsRowsBits)
     bool table_lds_rows = false;
-    if constexpr (FIRST && R == 4 && std::is_same<real, double>::value)
+    if constexpr (FUSED && std::is_same<real, double>::value)
         table_lds_rows = through && (a.mode & kModeFusedLdsTable) && n_qubits == uint32_t(kFusedLdsRowsBits) &&
                          plan_arena[ev.split_base] == uint32_t(kFusedLdsRowsKeys);
 
@@ -1282,7 +1287,7 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, FIRST>::waves_per_si
         QSV_STAMP(11);
     }
 
-    if constexpr (FIRST && R == 4) {
+    if constexpr (FUSED) {
         // split evaluations whose virtual circuits are one tile and one pass each, under a quadratic operator: this side's
         // workgroup goes straight on to its weighted Gram matrices, and the side that finishes second combines
         if (side && (ev.flags & kEvalFused) && (a.mode & kModeFusedFactor)) {
@@ -1343,6 +1348,13 @@ static hipError_t launch_pass_t(dim3 grid, int threads, size_t lds_bytes, hipStr
                          args.prefix_states, args.dephase};
     cx<real>* st = reinterpret_cast<cx<real>*>(args.states);
     const bool first = args.pass_index == 0 && (args.mode & kModeSynthFirst);
+    if constexpr (R == 4) {
+        if (first && (args.mode & kModeFusedFactor)) {
+            hipLaunchKernelGGL((pass_kernel<real, R, XMODE, true, true>), grid, dim3(threads), lds, stream, args.plan, args.mats,
+                               args.evals, st, reinterpret_cast<cx<real>*>(args.wtab), args.diag, args.partials, sc);
+            return hipGetLastError();
+        }
+    }
     if (first)
         hipLaunchKernelGGL((pass_kernel<real, R, XMODE, true>), grid, dim3(threads), lds, stream, args.plan, args.mats,
                            args.evals, st, reinterpret_cast<cx<real>*>(args.wtab), args.diag, args.partials, sc);
@@ -1358,6 +1370,11 @@ static hipError_t configure_t(size_t lds_bytes) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pass_kernel<real, R, XMODE, true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e != hipSuccess) return e;
+    if constexpr (R == 4) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pass_kernel<real, R, XMODE, true, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) return e;
+    }
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&pass_kernel<real, R, XMODE, false>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
