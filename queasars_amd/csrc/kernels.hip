@@ -715,6 +715,9 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, FIRST, FUSED>::waves
     extern __shared__ __align__(16) unsigned char lds_raw[];
 
     QSV_STAMP_DECL
+#ifdef QSV_ABL_EMPTY  // (measurement: what a launch of the one-launch route costs with nothing in it)
+    if constexpr (FUSED) return;
+#endif
     // (kModeTileMajor: the two grid dimensions trade places)
     const bool tile_major = !FIRST && (a.mode & kModeTileMajor);
     const uint32_t block_x = tile_major ? blockIdx.y : blockIdx.x, grid_x = tile_major ? gridDim.y : gridDim.x;
@@ -755,6 +758,9 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, FIRST, FUSED>::waves
         __builtin_amdgcn_s_waitcnt(0);
         asm volatile("" : "+s"(mats_base)::"memory");
         QSV_STAMP(13);
+#ifdef QSV_ABL_AFTER_PREP  // (measurement: descriptor + preparation alone)
+        if constexpr (FUSED) return;
+#endif
     } else {
         cu32p e = as_constant(reinterpret_cast<const uint32_t*>(evals + block_y + size_t(blockIdx.z) * a.region_stride));
         ev.plan_base = e[0];
@@ -3298,6 +3304,9 @@ __device__ __forceinline__ void fused_factor_tail(const uint32_t* __restrict__ p
     }
     __syncthreads();
     QSV_PSTAMP(1);  // Gram matrices
+#ifdef QSV_ABL_NO_HANDOFF  // (measurement: no hand-off between the sides, no combination)
+    return;
+#endif
     double* slot = a.factor_scratch + size_t(ev.state_slot) * factor_slot_doubles();
     double* mine = slot + size_t(xy) * kFactorSlices * kFactorWeights * 64;
     // (write-through stores: the few hundred bytes the other side will read must not wait for a write-back of everything

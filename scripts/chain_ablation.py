@@ -16,6 +16,9 @@ DEFINES = {
     "no_sincos": ("QSV_ABL_PREP_TRIG",),
     "no_tables": ("QSV_ABL_PREP_TABLES",),
     "no_gram": ("QSV_ABL_TAIL_GRAM",),
+    "no_handoff_no_combination": ("QSV_ABL_NO_HANDOFF",),
+    "preparation_only": ("QSV_ABL_AFTER_PREP",),
+    "empty_kernel": ("QSV_ABL_EMPTY",),
     "plain_stores": ("QSV_ABL_NO_THROUGH",),
 }
 ASM = {"no_gates": "gateloop", "no_swaps": "swapvalu", "no_gates_no_swaps": "gateloop,swapvalu"}
