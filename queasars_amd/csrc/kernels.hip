@@ -2805,8 +2805,13 @@ __device__ __forceinline__ void factor_side_body_pairs(const cx<real>* __restric
         const double* pd = dstage + half;
         real ar_next = pa[0].re, ai_next = pa[0].im, br_next = pb[0].re, bi_next = pb[0].im;
         double d_next = pd[0];
+#ifdef QSV_ABL_PAIR_STEPS  // (measurement: the eight-term body without its steps)
+#define QSV_PAIR_GROUPS 0
+#else
+#define QSV_PAIR_GROUPS 4
+#endif
 #pragma unroll 1
-        for (uint32_t g = 0; g < 4; ++g) {
+        for (uint32_t g = 0; g < QSV_PAIR_GROUPS; ++g) {
             double t_one[2] = {0.0, 0.0};
 #pragma unroll
             for (uint32_t ii = 0; ii < 8; ++ii) {
@@ -2824,8 +2829,13 @@ __device__ __forceinline__ void factor_side_body_pairs(const cx<real>* __restric
                 }
                 if constexpr (sizeof(real) == 8) __builtin_amdgcn_sched_barrier(0);  // (single precision: the fence costs the kernel a stack slot)
                 // a pair: Re, Im of a conj(b) as split_entry_value has them; two diagonal entries: |a|^2, |b|^2
+#ifdef QSV_ABL_PAIR_NODIAG  // (measurement: the steps without the diagonal entries' second form and the selects)
+                const double p0 = fma(ar, br, ai * bi);
+                const double p1 = fma(ai, br, -ar * bi);
+#else
                 const double p0 = diagonal ? fma(ar, ar, ai * ai) : fma(ar, br, ai * bi);
                 const double p1 = diagonal ? fma(br, br, bi * bi) : fma(ai, br, -ar * bi);
+#endif
                 t_one[0] += p0;
                 t_one[1] += p1;
                 s_d[0] = fma(d, p0, s_d[0]);

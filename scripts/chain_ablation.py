@@ -16,6 +16,8 @@ DEFINES = {
     "no_sincos": ("QSV_ABL_PREP_TRIG",),
     "no_tables": ("QSV_ABL_PREP_TABLES",),
     "no_gram": ("QSV_ABL_TAIL_GRAM",),
+    "no_pair_steps": ("QSV_ABL_PAIR_STEPS",),
+    "pair_steps_without_diagonals": ("QSV_ABL_PAIR_NODIAG",),
     "no_handoff_no_combination": ("QSV_ABL_NO_HANDOFF",),
     "preparation_only": ("QSV_ABL_AFTER_PREP",),
     "empty_kernel": ("QSV_ABL_EMPTY",),
