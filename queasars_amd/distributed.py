@@ -225,6 +225,7 @@ class _NodeTable:
     def __init__(self, mm, world: int, rank: int, device_address: int, host_address: int, registered: bool):
         self.mm, self.world, self.rank = mm, world, rank
         self.device_address, self.host_address, self.registered = device_address, host_address, registered
+        self.capacity = type(self).capacity  # (this table's layout, whatever becomes of the class's default)
         self.step = 0
         self.done = np.frombuffer(mm, dtype=np.int64, count=world * self._header)[:: self._header]
         flat = np.frombuffer(mm, dtype=np.float64, count=2 * world * self.capacity, offset=8 * world * self._header)

@@ -368,10 +368,10 @@ def _node_table_worker(rank: int, world: int, port: int, out_dir: str):
             got.append(values)
         assert table.step == 7
         # shares wider than a slot: the collective takes over, same values
-        distributed._NodeTable.capacity, keep = 2, distributed._NodeTable.capacity
+        table.capacity, keep = 2, table.capacity
         _, circuits, params = helpers.population_circuits(5, 2, 8, seed=40)
         assert distributed.evaluate_population_sharded(_OracleEvaluator(op), circuits, params) == got[0]
-        distributed._NodeTable.capacity = keep
+        table.capacity = keep
         os.environ["QSV_GATHER_NODE"] = "0"
         assert distributed.evaluate_population_sharded(_OracleEvaluator(op), circuits, params) == got[0]
         np.save(os.path.join(out_dir, f"rank{rank}.npy"), np.concatenate([np.asarray(v) for v in got]))
