@@ -625,9 +625,10 @@ def agreed_count(mine: int, world: int, comm_device: str, limit: int = 5000) -> 
 
 
 # what the exchange of the fitness values adds to a rank's step on one node: through the node's shared table (no collective: the
-# kernels store into the rank's slot, queasars_amd/distributed.py) 9.6 us over the evaluation alone on a group of ONE rank
-# (profiles/r04_gatherstep.txt: 61.6 us against 52.0); the RCCL all-gather into host-mapped memory it replaced there: 21 - 27
-COLLECTIVE_US = 10.0
+# kernels store into the rank's slot, queasars_amd/distributed.py) 2 - 7 us over the evaluation alone on a group of ONE rank
+# (profiles/r04_gatherstep.txt: 57.2 us against 54.9 at the end of the round); the RCCL all-gather into host-mapped memory it
+# replaced there: 21 - 27.  The prediction takes 7.
+COLLECTIVE_US = 7.0
 
 
 def config3_block(world: int, rank: int, local_rank: int, steps: int = 8, layers: int = 4):

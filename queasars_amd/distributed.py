@@ -455,9 +455,16 @@ def evaluate_block_and_gather(evaluator, circuits: Sequence, parameter_values: S
         # stream anyway); the caller's stream is waited for only if it has work queued.
         node_table = _node_table(group, world, rank, device)
         if node_table is not None:
-            caller = torch.cuda.current_stream(device)
-            if caller != stream and not caller.query():
-                stream.wait_stream(caller)
+            # (the caller's current stream by its raw handle first: building the Stream object costs more than the table look-ups)
+            raw = torch._C._cuda_getCurrentRawStream(device.index if device.index is not None else torch.cuda.current_device())
+            if raw != stream.cuda_stream:
+                caller = state.get("default_stream") if raw == 0 else None
+                if caller is None:
+                    caller = torch.cuda.current_stream(device)
+                    if raw == 0:
+                        state["default_stream"] = caller
+                if not caller.query():
+                    stream.wait_stream(caller)
             values = evaluate_block_through_node_table(evaluator, circuits, parameter_values, n, world, rank, node_table, shares,
                                                        stream.synchronize)
             if values is not None:
