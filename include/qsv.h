@@ -224,6 +224,14 @@ int qsv_eval_end(qsv_t* h, double* out_expectations);
  */
 int qsv_eval_set_output(qsv_t* h, double* device_out);
 /*
+ * The caller has SEEN every result of the last batch that ended without waiting (qsv_eval_set_output into memory the host can
+ * read -- a node's shared fitness table: a result is an evaluation's last store): nothing of that batch is still running,
+ * and the next call on the handle need not wait for the streams before it reuses the staging buffers (20 us per step of a
+ * caller that hands its parameter values over as host arrays).  Saying so about results that have not all arrived is the
+ * caller's error.
+ */
+int qsv_eval_results_seen(qsv_t* h);
+/*
  * The optimiser's share of one iteration of R lock-step SPSA runs as ONE launch on the handle's stream, for a parameter search
  * whose state lives in device memory (evqe/device_search.py; the reference runs one qiskit_algorithms SPSA per individual on a
  * worker thread, mutation.py:28-89): with qsv_eval_push_device and qsv_eval_set_output an iteration is this launch plus the

@@ -132,6 +132,7 @@ SIGNATURES = {
     "qsv_spsa_step": (C.c_int, [_P, _P]),
     "qsv_eval_end": (C.c_int, [_P, _P]),
     "qsv_eval_set_output": (C.c_int, [_P, _P]),
+    "qsv_eval_results_seen": (C.c_int, [_P]),
     "qsv_eval_suggested_pushes": (C.c_int, [_P]),
     "qsv_group_size": (C.c_int, [_P]),
     "qsv_eval_batch": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P]),

@@ -484,6 +484,11 @@ class StatevectorDevice:
         self._last_batch = ((CircuitIR.edits_of_registered, *map(id, circuits)), list(circuits), ids, need, total)
         return ids, need, total
 
+    def results_seen(self) -> None:
+        """The caller has seen every result of the last batch that ended without waiting (``qsv_eval_results_seen``): the next
+        call need not wait for the streams before it reuses the staging buffers."""
+        self._check(self._lib.qsv_eval_results_seen(self._handle))
+
     def expectation_values_to_device(
         self, circuits: Sequence[CircuitIR], parameter_values: Sequence[Sequence[float]], device_pointer: int
     ) -> None:

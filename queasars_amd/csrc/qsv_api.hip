@@ -2680,6 +2680,15 @@ int qsv_eval_set_output(qsv_t* h, double* device_out) {
     return QSV_OK;
 }
 
+int qsv_eval_results_seen(qsv_t* h) {
+    if (!h) return QSV_E_ARG;
+    if (h->batch_owner.load() == std::this_thread::get_id()) return fail(h, QSV_E_STATE, "a batch is open");
+    std::lock_guard<std::mutex> lock(h->mu);
+    if (h->batch.open) return fail(h, QSV_E_STATE, "a batch is open");
+    h->async_pending = false;
+    return QSV_OK;
+}
+
 int qsv_eval_end(qsv_t* h, double* out_expectations) {
     if (!h) return QSV_E_ARG;
     if (!h->batch.open) return fail(h, QSV_E_STATE, "no open batch (call qsv_eval_begin first)");

@@ -384,11 +384,15 @@ def evaluate_block_through_node_table(evaluator, circuits: Sequence, parameter_v
     to_device = getattr(evaluator, "evaluate_circuits_to_device", None)
     if not table.registered and getattr(evaluator, "statevector_device", None) is not None:
         to_device = None  # (memory the evaluator's GPU has not been given: the host writes the slot)
-    if count and not (to_device is not None and to_device(mine_c, mine_p, table.pointer(which, rank))):
+    launched = bool(count) and to_device is not None and to_device(mine_c, mine_p, table.pointer(which, rank))
+    if count and not launched:
         slot[:count] = evaluator.evaluate_circuits(mine_c, mine_p)
+    seen = getattr(getattr(evaluator, "statevector_device", None), "results_seen", None) if launched else None
     waiter = _table_waiter()
     if waiter is not None and waiter(table.host_pointer(which, rank), count, table.host_address, table._header, world, rank, step,
                                      int(_POLL_SECONDS * 1e6)) == 0:
+        if seen is not None:
+            seen()  # (every value of this rank's batch has arrived: the library need not wait for it before its next batch)
         return _unpack(table.tables[which, :, :width], n, world, width, shares)
     # (without the library -- a CPU rank whose evaluator is not ours -- or past the spinning budget: the same in NumPy, with
     # this rank's own device work waited for once and a deadline)
@@ -414,6 +418,8 @@ def evaluate_block_through_node_table(evaluator, circuits: Sequence, parameter_v
                 time.sleep(0)
         if own:
             done[rank] = step
+            if seen is not None:
+                seen()
     return _unpack(table.tables[which, :, :width], n, world, width, shares)
 
 
