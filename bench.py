@@ -408,9 +408,10 @@ def layer_search_block(reps: int = 3):
 
     out = {}
     operator = ising_operator(N_QUBITS, 2020)
-    for layers in (6, 7, 8):
+    reference = {}
+    for layers, precision in ((6, "fp64"), (7, "fp64"), (8, "fp64"), (7, "fp32"), (8, "fp32")):
         population = EVQEPopulation.random_population(N_QUBITS, layers, POP_PER_GPU, True, 0)
-        evaluator = OperatorCircuitEvaluator(operator)
+        evaluator = OperatorCircuitEvaluator(operator, dtype=precision)
         whole = [ind.get_partially_parameterized_quantum_circuit({layers - 1}) for ind in population.individuals]
         values = [list(ind.get_layer_parameter_values(layers - 1)) for ind in population.individuals]
         costs = evaluator.circuit_costs(whole)
@@ -438,14 +439,22 @@ def layer_search_block(reps: int = 3):
 
         whole_rate, whole_values = rate(whole)
         kept_rate, kept_values = rate(mixed)
-        out[f"L{layers}"] = {"whole_circuits_evals_per_s": whole_rate, "kept_states_evals_per_s": kept_rate, "gain": kept_rate / whole_rate,
-                            "individuals_on_kept_states": len(deep), "max_abs_diff": float(np.abs(whole_values - kept_values).max()),
-                            "routes_whole": {r: sum(c["route"] == r for c in costs) for r in sorted({c["route"] for c in costs})}}
+        row = {"whole_circuits_evals_per_s": whole_rate, "kept_states_evals_per_s": kept_rate, "gain": kept_rate / whole_rate,
+               "individuals_on_kept_states": len(deep), "max_abs_diff": float(np.abs(whole_values - kept_values).max()),
+               "routes_whole": {r: sum(c["route"] == r for c in costs) for r in sorted({c["route"] for c in costs})}}
+        if precision == "fp64":
+            reference[layers] = whole_values
+        else:  # (a search tolerates single precision; the fitness behind it stays fp64: the error against the fp64 values)
+            row["max_abs_diff_vs_fp64"] = float(np.abs(kept_values - reference[layers]).max())
+            row["sum_abs_coefficients"] = float(np.abs(operator.coeffs).sum())
+        out[f"L{layers}" + ("" if precision == "fp64" else "_fp32")] = row
         del states, mixed
         evaluator.statevector_device.close()
     out["note"] = ("last-layer search points of the whole population per call; kept states: the individuals whose circuits take gate "
                    "passes over the 2^n state evaluate from the state in front of the last layer (qsv_prefix_create), the others as "
-                   "before.  A kept-state evaluation moves 16 MiB read + 16 write + 16 read + the diagonal table: HBM bound")
+                   "before.  A kept-state evaluation moves 16 MiB read + 16 write + 16 read + the diagonal table: HBM bound; "
+                   "the _fp32 rows: the same on a single-precision handle (half the bytes; the solver does not switch precision "
+                   "by itself)")
     return out
 
 

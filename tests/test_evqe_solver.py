@@ -459,3 +459,29 @@ def test_embedded_search_of_an_individual_with_more_than_ten_layers(monkeypatch)
     assert solver_results["2"][1] == solver_results["0"][1]
     for a, b in zip(solver_results["2"][0], solver_results["0"][0]):
         assert a == b
+
+
+class _RoundedEvaluator(OracleEvaluator):
+    """An evaluator whose values carry single-precision error: what a search evaluator is allowed to be."""
+
+    def evaluate_circuits(self, circuits, parameter_values):
+        return [float(np.float32(v)) for v in super().evaluate_circuits(circuits, parameter_values)]
+
+
+def test_a_search_evaluator_serves_the_searches_and_only_them():
+    """``compute_minimum_eigenvalue(evaluator, search_evaluator)``: the optimiser runs evaluate on the second evaluator (a
+    single-precision handle), every fitness value -- what selection compares and the result reports -- comes from the first."""
+    op = xy_hamiltonian()
+    fitness, search = OracleEvaluator(op), _RoundedEvaluator(op)
+    result = EVQEMinimumEigensolver(make_config()).compute_minimum_eigenvalue(fitness, search)
+    assert result.eigenvalue < -8.5 and result.generations == 6
+    # one fitness call per generation, the whole population each (possibly shrunk by speciation); everything else on the searcher
+    assert fitness.calls == 6 and fitness.evaluations <= 6 * 8
+    assert search.evaluations + fitness.evaluations == sum(result.circuit_evaluations)
+    assert search.evaluations > 10 * fitness.evaluations
+    exact = helpers.oracle_expectation(result.best_individual.get_parameterized_quantum_circuit(),
+                                       list(result.best_individual.parameter_values), op)
+    assert result.eigenvalue == exact  # (not a rounded value)
+    with pytest.raises(ValueError):
+        EVQEMinimumEigensolver(make_config()).compute_minimum_eigenvalue(
+            fitness, OracleEvaluator(PauliOperator.from_sparse_list([("Z", [0], 1.0)], 5)))

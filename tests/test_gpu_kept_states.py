@@ -269,3 +269,33 @@ def test_layer_searches_on_kept_states_are_the_searches_on_whole_circuits(monkey
         assert whole[1] == with_kept[1]
         assert np.abs(whole[0] - with_kept[0]).max() < 1e-8
     assert n_kept >= 4, n_kept
+
+
+def test_a_single_precision_search_evaluator_under_a_double_precision_fitness(monkeypatch):
+    """``compute_minimum_eigenvalue(evaluator, search_evaluator)``: the layer searches -- kept states included -- on an fp32
+    handle, the generation's fitness on the fp64 one: the reported eigenvalue is the fp64 handle's value of the best
+    individual (the oracle's to 1e-10), and the run lowers the energy as the all-fp64 run does."""
+    from queasars_amd.evqe.solver import SPSA, EVQEMinimumEigensolver, EVQEMinimumEigensolverConfiguration
+
+    n = 14
+    op = helpers.random_ising_operator(n, seed=21)
+    monkeypatch.setenv("QSV_KEPT_STATES", "1")
+
+    def run(search_dtype):
+        cfg = EVQEMinimumEigensolverConfiguration(
+            optimizer=SPSA(maxiter=10, learning_rate=0.2, perturbation=0.1), population_size=16, max_generations=3, random_seed=3,
+            n_initial_layers=5, randomize_initial_population_parameters=True, speciation_genetic_distance_threshold=2,
+            use_tournament_selection=True, tournament_size=2, selection_alpha_penalty=0.1, selection_beta_penalty=0.1,
+            parameter_search_probability=0.3, topological_search_probability=0.4, layer_removal_probability=0.05)
+        fitness = OperatorCircuitEvaluator(op)
+        search = OperatorCircuitEvaluator(op, dtype=search_dtype) if search_dtype else None
+        return EVQEMinimumEigensolver(cfg).compute_minimum_eigenvalue(fitness, search)
+
+    mixed, double = run("fp32"), run(None)
+    best = mixed.best_individual
+    exact = helpers.oracle_expectation(best.get_parameterized_quantum_circuit(), list(best.parameter_values), op)
+    assert abs(mixed.eigenvalue - exact) < 1e-10
+    assert mixed.generations == double.generations == 3
+    assert mixed.best_expectation_values[-1] < mixed.best_expectation_values[0] + 1e-9
+    # the two runs see values that differ by 1e-6 and may part ways; they end in the same neighbourhood
+    assert abs(mixed.eigenvalue - double.eigenvalue) < 0.25 * abs(double.eigenvalue)
