@@ -349,7 +349,7 @@ def search_block(operator, population, reps: int = 5):
     return out
 
 
-def trajectory_block(operator, generations: int = 8):
+def trajectory_block(operator, generations: int = 8, search_precision: str = None):
     """What a user sits in: the REAL solver on the benchmark's operator (n = 20, population 64, two initial layers, the notebook's
     optimiser and mutation probabilities, examples/evqe_jssp_optimization.ipynb: SPSA 33 iterations, parameter search 0.39,
     topological search 0.79, layer removal 0.02), `generations` generations.  The population's layers grow every generation
@@ -363,6 +363,8 @@ def trajectory_block(operator, generations: int = 8):
     from queasars_amd.evqe import solver as S
 
     evaluator = OperatorCircuitEvaluator(operator)
+    # (search_precision = "fp32": the parameter searches on a single-precision handle of the same operator, the fitness as ever)
+    searcher = OperatorCircuitEvaluator(operator, dtype=search_precision) if search_precision else None
     checker = S.SPSATerminationChecker(minimum_relative_change=0.01, allowed_consecutive_violations=2)
     cfg = S.EVQEMinimumEigensolverConfiguration(
         optimizer=S.SPSA(maxiter=33, perturbation=0.35, learning_rate=0.43, trust_region=True, termination_checker=checker),
@@ -385,14 +387,17 @@ def trajectory_block(operator, generations: int = 8):
         marks["t"], marks["evals"] = time.perf_counter(), info["circuit_evaluations"]  # (the bookkeeping above is not the solver's time)
 
     t0 = time.perf_counter()
-    result = S.EVQEMinimumEigensolver(cfg, on_generation=scored).compute_minimum_eigenvalue(evaluator)
+    result = S.EVQEMinimumEigensolver(cfg, on_generation=scored).compute_minimum_eigenvalue(evaluator, searcher)
     total = time.perf_counter() - t0
     evaluator.statevector_device.close()
+    if searcher is not None:
+        searcher.statevector_device.close()
     return {"workload": f"EVQE on the {N_QUBITS}-qubit Ising operator of the headline, population {POP_PER_GPU}, from 2 layers, {generations} "
                         "generations; the notebook's optimiser and mutation probabilities",
             "generations": rows, "evaluations": sum(result.circuit_evaluations), "seconds": total,
             "evals_per_s": sum(result.circuit_evaluations) / total, "eigenvalue": result.eigenvalue,
             "kept_state_searches": os.environ.get("QSV_KEPT_STATES", "default (on where the circuit costs say it pays)"),
+            "search_precision": search_precision or "fp64",
             "unit": "circuit-evals/s",
             "note": "wall clock of the whole solver (its own Python included), one process, one GPU; generation g's evaluations = "
                     "the parameter searches of generation g - 1's survivors (every layer of 39 % of them), the last-layer search of "
@@ -746,7 +751,7 @@ def main() -> None:
     args = ap.parse_args()
     if args.only in ("trajectory", "layer_search", "config5_sweep"):
         torch.cuda.set_device(0)
-        block = (trajectory_block(ising_operator(N_QUBITS, 2020)) if args.only == "trajectory" else
+        block = (trajectory_block(ising_operator(N_QUBITS, 2020), search_precision=os.environ.get("QSV_BENCH_SEARCH_PRECISION")) if args.only == "trajectory" else
                  layer_search_block() if args.only == "layer_search" else config5_sweep_block())
         print(json.dumps({args.only: block}), flush=True)
         return
@@ -1008,6 +1013,8 @@ def main() -> None:
             result["config3_deep"] = config3_deep
         if world == 1 and not args.no_extras:
             result["trajectory"] = trajectory_block(operator)
+            fp32_search = trajectory_block(operator, search_precision="fp32")
+            result["trajectory"]["with_fp32_search_evaluator"] = {k: fp32_search[k] for k in ("evaluations", "seconds", "evals_per_s", "eigenvalue")}
             result["layer_search"] = layer_search_block()
             result["config5_sweep"] = config5_sweep_block()
             result["deep"] = deep_block(local_rank)
