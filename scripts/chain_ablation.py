@@ -71,6 +71,10 @@ def main():
             dev.set_profiling(False)
             return acc / launches * 1e3
 
+        if os.environ.get("QSV_CHAIN_CIRCUITS"):  # (other circuits of the population, alone: indices)
+            picked = [int(x) for x in os.environ["QSV_CHAIN_CIRCUITS"].split(",")]
+            print(f"{sys.argv[2]:20s} " + "   ".join(f"circuit {i} alone {launch_us([i]):6.1f} us" for i in picked), flush=True)
+            return
         print(f"{sys.argv[2]:20s} circuit 8 alone {launch_us([8]):6.1f} us   circuit 41 alone {launch_us([41]):6.1f} us   all 64 {launch_us(list(range(P))):6.1f} us", flush=True)
         return
     for name in ["base"] + [v for v in list(DEFINES) + list(ASM) if lib_of(v).exists()]:
