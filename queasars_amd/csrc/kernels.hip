@@ -289,6 +289,32 @@ static __device__ __forceinline__ unsigned long long qsv_stamp_now() {
 #define QSV_STAMP(ph)
 #endif
 
+// Diagnostic build only (-DQSV_TIMELINE, scripts/timeline.py): the first wave of every workgroup of a LATER pass writes down
+// WHEN each of its tiles' phases began (s_memtime, nothing drained: the waits the production kernel has are the only ones) and
+// on which compute unit it ran -- so that the phases of the workgroups sharing a compute unit can be laid side by side.
+// Record of a workgroup: [0] HW_ID | XCC_ID << 32, [1] block | pass << 32, [2] tiles, [3] s_memrealtime at its start (100 MHz),
+// [4] s_memrealtime at its end, [5] s_memtime at its end, then per tile: loads issued from, loads back at, rounds done at,
+// stores issued at.
+#ifdef QSV_TIMELINE
+__device__ unsigned long long qsv_timeline[kTimelineWgs * kTimelineWords];
+__device__ unsigned int qsv_timeline_count;
+static __device__ __forceinline__ unsigned long long qsv_time_now() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+static __device__ __forceinline__ unsigned long long qsv_realtime_now() {
+    unsigned long long t;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+#define QSV_TL(slot) do { if (tl_rec && j < kTimelineTiles && threadIdx.x == 0) tl_rec[6 + 4 * j + (slot)] = qsv_time_now(); } while (0)
+#else
+#define QSV_TL(slot)
+#endif
+
 // 16-byte (8-byte) store that leaves no dirty line in L2 (sc1: write-through); the compiler does not count it, the caller
 // waits for it with s_waitcnt vmcnt(0).
 __device__ __forceinline__ void store_through(void* p, const cx<double>& v) {
@@ -882,8 +908,27 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, FIRST, FUSED>::waves
         if (a.dephase && (block_x & 1u))
             for (uint32_t i = 0; i < a.dephase; ++i) __builtin_amdgcn_s_sleep(127);
     }
+#ifdef QSV_TIMELINE
+    unsigned long long* tl_rec = nullptr;
+    if constexpr (!FIRST) {
+        uint32_t slot = 0;
+        if (threadIdx.x == 0) slot = atomicAdd(&qsv_timeline_count, 1u);
+        slot = __builtin_amdgcn_readfirstlane(slot);
+        if (threadIdx.x < 64 && slot < kTimelineWgs) {
+            tl_rec = qsv_timeline + size_t(slot) * kTimelineWords;
+            if (threadIdx.x == 0) {
+                const uint32_t hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);
+                tl_rec[0] = uint64_t(hw) | uint64_t(xcc) << 32;
+                tl_rec[1] = uint64_t(block_x) | uint64_t(a.pass_index) << 32 | uint64_t(block_y) << 40;
+                tl_rec[2] = n_tiles;
+                tl_rec[3] = qsv_realtime_now();
+            }
+        }
+    }
+#endif
     QSV_STAMP(0);
     for (uint32_t j = 0; j < n_tiles; ++j) {
+        QSV_TL(0);
         // what depends on the tile number comes from prepare_kernel's table: one scalar load
         uint32_t ti[4];
         load_words<4>(tile_info + 4 * size_t(tile0 + j * tile_step), ti);
@@ -985,6 +1030,7 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, FIRST, FUSED>::waves
         }
 
         QSV_STAMP(1);
+        QSV_TL(1);
         cu32p rp = rounds0;
         cf64p mp = mats0;
 #if !defined(QSV_STAMPS) || defined(QSV_STAMPS_ASM)  // (QSV_STAMPS_ASM: stamps around the production block)
@@ -1219,6 +1265,7 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, FIRST, FUSED>::waves
         }
 
         // (rows in LDS from offset 0: over whatever the last exchange left there for a slower wave to read)
+        QSV_TL(2);
         if (table_lds_rows) __syncthreads();
         if (active && (do_store || do_diag || do_probs)) {
             if (!wide || cstore) {
@@ -1291,7 +1338,14 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, FIRST, FUSED>::waves
             }
         }
         QSV_STAMP(11);
+        QSV_TL(3);
     }
+#ifdef QSV_TIMELINE
+    if (tl_rec && threadIdx.x == 0) {
+        tl_rec[4] = qsv_realtime_now();
+        tl_rec[5] = qsv_time_now();
+    }
+#endif
 
     if constexpr (FUSED) {
         // split evaluations whose virtual circuits are one tile and one pass each, under a quadratic operator: this side's
@@ -3833,6 +3887,32 @@ hipError_t read_stamps(unsigned long long* out, int reset) {
     return hipMemcpyToSymbol(HIP_SYMBOL(qsv_stamp_table), zeros, sizeof(zeros));
 #else
     (void)out;
+    (void)reset;
+    return hipErrorNotSupported;
+#endif
+}
+
+hipError_t read_timeline(unsigned long long* out, size_t max_words, unsigned int* n_records, int reset) {
+#ifdef QSV_TIMELINE
+    hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) return e;
+    unsigned int count = 0;
+    e = hipMemcpyFromSymbol(&count, HIP_SYMBOL(qsv_timeline_count), sizeof(count));
+    if (e != hipSuccess) return e;
+    if (count > kTimelineWgs) count = kTimelineWgs;
+    if (size_t(count) * kTimelineWords > max_words) count = unsigned(max_words / kTimelineWords);
+    *n_records = count;
+    if (count) {
+        e = hipMemcpyFromSymbol(out, HIP_SYMBOL(qsv_timeline), sizeof(unsigned long long) * size_t(count) * kTimelineWords);
+        if (e != hipSuccess) return e;
+    }
+    if (!reset) return hipSuccess;
+    const unsigned int zero = 0;
+    return hipMemcpyToSymbol(HIP_SYMBOL(qsv_timeline_count), &zero, sizeof(zero));
+#else
+    (void)out;
+    (void)max_words;
+    (void)n_records;
     (void)reset;
     return hipErrorNotSupported;
 #endif

@@ -131,6 +131,9 @@ static_assert(kFusedLdsRowsEnd <= kFusedLdsTableEnd, "a launch with kModeFusedLd
 // 10 gates, 11 store / reduce, 12 epilogue.
 constexpr int kStampPasses = 8, kStampPhases = 16;
 hipError_t read_stamps(unsigned long long* out, int reset);  // hipErrorNotSupported in the shipped build
+// (-DQSV_TIMELINE builds: when each tile's phases began, per workgroup of a later pass)
+constexpr unsigned kTimelineWgs = 16384, kTimelineTiles = 14, kTimelineWords = 6 + 4 * kTimelineTiles + 2;
+hipError_t read_timeline(unsigned long long* out, size_t max_words, unsigned int* n_records, int reset);
 
 // doubles an evaluation's matrix region occupies for a circuit with n_real scheduled gates in n_passes passes on n qubits
 // (gate matrices | 4 doubles per qubit: initial factors | kMatPadDoubles | thread factors: 2 * 2^t | tile factors:

@@ -1822,6 +1822,11 @@ int qsv_debug_stamps(unsigned long long* out, int reset) {
     return qsv::read_stamps(out, reset) == hipSuccess ? QSV_OK : QSV_E_UNSUPPORTED;
 }
 
+// Likewise not part of include/qsv.h: the phase timeline of a -DQSV_TIMELINE build (scripts/timeline.py).
+int qsv_debug_timeline(unsigned long long* out, size_t max_words, unsigned int* n_records, int reset) {
+    return qsv::read_timeline(out, max_words, n_records, reset) == hipSuccess ? QSV_OK : QSV_E_UNSUPPORTED;
+}
+
 int qsv_create(int n_qubits, int dtype, int device, const qsv_plan_config* cfg, qsv_t** out) {
     if (!out) return fail(nullptr, QSV_E_ARG, "out is null");
     *out = nullptr;
