@@ -350,6 +350,9 @@ int qsv_fitness_table_wait(const volatile uint64_t* own, int count, volatile int
  *   "fused_lds_table" 0|1 ... and there a side hands its state to its Gram matrices through LDS where it fits (up to twelve
  *                        virtual qubits as the state would lie in memory; three-key sides of thirteen as padded rows read in
  *                        place) instead of through its slot: the same sums in the same order, the same bits
+ *   "side_diag" 0|1      ... and reads its values of D from a table of its own -- entry x of a side = D[x deposited in the side's
+ *                        qubits], one run, filled when the circuit's plan is uploaded -- instead of gathering them from D, one
+ *                        cache line per value: the same values, the same bits
  *   "split_max_keys" 0..5 most cut keys of a split form (default 5; four and five: quadratic operators only).  Applies to
  *                        circuits registered afterwards.
  *   "chain_stream" 0|1   in a push that holds split evaluations of both kinds (finished by the launch that runs their

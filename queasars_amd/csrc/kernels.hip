@@ -356,6 +356,7 @@ struct PassScalars {
     uint32_t n_full;
     const void* prefix_states;
     uint32_t dephase;
+    const double* side_diag;
 };
 
 // XMODE selects how a tile is transposed through LDS:
@@ -1405,7 +1406,7 @@ static hipError_t launch_pass_t(dim3 grid, int threads, size_t lds_bytes, hipStr
     const PassScalars sc{args.state_stride, args.wtab_stride, args.pass_index, args.mode, args.tiles_per_block,
                          args.partial_chunks, args.region_stride, args.host_evals, args.evals_out, args.host_params,
                          args.mats_out, args.result_out, args.quad, args.factor_scratch, args.factor_counters, args.n_full,
-                         args.prefix_states, args.dephase};
+                         args.prefix_states, args.dephase, args.side_diag};
     cx<real>* st = reinterpret_cast<cx<real>*>(args.states);
     const bool first = args.pass_index == 0 && (args.mode & kModeSynthFirst);
     if constexpr (R == 4) {
@@ -1463,7 +1464,7 @@ static hipError_t pass_dispatch(int op, int dtype, int r, int xmode, dim3 grid, 
     const PassScalars sc{args->state_stride, args->wtab_stride, args->pass_index, args->mode, args->tiles_per_block,
                          args->partial_chunks, args->region_stride, args->host_evals, args->evals_out, args->host_params,
                          args->mats_out, args->result_out, args->quad, args->factor_scratch, args->factor_counters, args->n_full,
-                          args->prefix_states, args->dephase};
+                          args->prefix_states, args->dephase, args->side_diag};
     if (args->pass_index == 0 && (args->mode & kModeSynthFirst))
         hipLaunchKernelGGL((pass_kernel<double, QSV_PROBE_R, 2, true>), grid, dim3(threads), lds_bytes, stream, args->plan,
                            args->mats, args->evals, reinterpret_cast<cx<double>*>(args->states),
@@ -2659,7 +2660,10 @@ __device__ __forceinline__ double factor_d_of_block(const double* __restrict__ d
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_local = bits < 6u ? 1u << bits : 64u;
     double d = 0.0;
-    if (lane < n_local && blk < end) d = diag[deposit_bits(blk * 64u + lane, mask)];
+    // (a side's own table -- mask = its low `bits` bits -- is read in place: the deposit's loop over the mask's bits, taken by every
+    // block of every wave, was 5 of a 12-qubit side's 39 us)
+    const uint32_t x = blk * 64u + lane;
+    if (lane < n_local && blk < end) d = diag[mask == (1u << bits) - 1u ? x : deposit_bits(x, mask)];
     return d;
 }
 template <int DA>
@@ -3313,7 +3317,12 @@ __device__ __forceinline__ void fused_factor_tail(const uint32_t* __restrict__ p
     const uint32_t n_keys = sp[0], NQ = 1u << (2 * n_keys);
     const bool swap = sp[3] & 1u, is_b = ev.flags & kEvalSideB;
     const uint32_t xy = (is_b == swap) ? 0u : 1u;  // this side's name in the contraction's terms (X is B's half when swapped)
-    const uint32_t bits = sp[1 + xy], mask = sp[kSplitMaskX + xy];
+    const uint32_t bits = sp[1 + xy];
+    // (the side's own table of D where the block names one -- entry x, one run -- else D itself, entry x deposited in the side's qubits)
+    const uint32_t own_d = sp[kSplitSideDiag + xy];
+    const uint32_t mask = own_d != kNoSideDiag ? (1u << bits) - 1u : sp[kSplitMaskX + xy];
+    const double* whole_diag = diag;  // (the combination's D(0, 0))
+    diag = own_d != kNoSideDiag ? a.side_diag + own_d : diag;
     const uint32_t tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // (the side's state: in its half of the slot -- or still in LDS, where the pass left it for this tail alone)
     const cx<real>* tab = table_in_lds ? reinterpret_cast<const cx<real>*>(lds + kFusedLdsTableOffset) : slot_tables + (is_b ? side_stride >> 1 : 0);
@@ -3403,7 +3412,7 @@ __device__ __forceinline__ void fused_factor_tail(const uint32_t* __restrict__ p
             if (k == qb_i) qb = uint32_t(__builtin_ctz(m));
         coupling = a.quad[qa * a.n_full + qb];
     }
-    const double d00 = diag[0];
+    const double d00 = whole_diag[0];
     double* gram = reinterpret_cast<double*>(lds);  // [side][weight][kFactorPitch] (the partial matrices are no longer needed)
     const uint32_t side_bits[2] = {bx, by};
     {
@@ -3874,6 +3883,22 @@ hipError_t launch_state_to_f64(int dtype, const void* state, uint64_t dim, doubl
     else
         hipLaunchKernelGGL(state_to_f64_kernel<float>, dim3(stream_blocks(dim)), dim3(256), 0, stream,
                            reinterpret_cast<const cx<float>*>(state), dim, out_re_im);
+    return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256) side_diag_kernel(const double* __restrict__ diag, double* __restrict__ side_diag, const SideDiagJobs jobs) {
+    const SideDiagJob j = jobs.job[blockIdx.y];
+    const uint32_t count = 1u << j.bits;
+    for (uint32_t x = blockIdx.x * blockDim.x + threadIdx.x; x < count; x += gridDim.x * blockDim.x)
+        side_diag[size_t(j.base) + x] = diag[deposit_bits(x, j.mask)];
+}
+
+hipError_t launch_side_diag(const double* diag, double* side_diag, const SideDiagJobs& jobs, int n_jobs, hipStream_t stream) {
+    if (n_jobs <= 0) return hipSuccess;
+    uint32_t most = 0;
+    for (int i = 0; i < n_jobs; ++i) most = jobs.job[i].bits > most ? jobs.job[i].bits : most;
+    const uint32_t blocks = most <= 8 ? 1u : 1u << (most - 8);
+    hipLaunchKernelGGL(side_diag_kernel, dim3(blocks < 16u ? blocks : 16u, unsigned(n_jobs)), dim3(256), 0, stream, diag, side_diag, jobs);
     return hipGetLastError();
 }
 

@@ -48,8 +48,14 @@ constexpr int kSideMaxOwnBits = 16;  // ... and a side's own qubits (launch_fact
 //   [16 .. 144)  lane l -> (x piece, y piece) of index bits 0 .. 5 = l
 //   [144 .. 160) wave w -> pieces of the wave-index bits
 //   [160 .. 416) chunk & 127 -> pieces of the low seven chunk bits      [416 .. 672) chunk >> 7 -> pieces of the rest
+//   [672] where side X's OWN values of D start in PassArgs::side_diag (in doubles; kNoSideDiag: none) [673] side Y's.  Entry x of
+//       such a table is D[x deposited in the side's qubits]: what a side's Gram sums read.  Gathered from D they are one cache line
+//       per value -- a 12-qubit side's 4096 lines, times the sixteen sides an XCD serves, do not fit its L2 (measured: a zero-key
+//       circuit split 8 + 12 took 39 us where one split 10 + 10 took 31; with the values as one run 34).  Written by the host when
+//       the plan is uploaded (qsv_api.hip upload_plans), filled by side_diag_kernel right behind the copy.
+constexpr uint32_t kNoSideDiag = 0xffffffffu;
 constexpr uint32_t kSplitLoopCols = 4, kSplitLoopPos = 9, kSplitMaskX = 14, kSplitMaskY = 15, kSplitLaneTable = 16, kSplitWaveTable = 144,
-                   kSplitChunkLow = 160, kSplitChunkHigh = 416, kSplitBlockWords = 672;
+                   kSplitChunkLow = 160, kSplitChunkHigh = 416, kSplitSideDiag = 672, kSplitBlockWords = 674;
 constexpr int kSplitLoopBits = 5, kSplitMaxLoopX = 2;
 
 enum PassMode : uint32_t {
@@ -107,6 +113,7 @@ struct PassArgs {
     uint32_t n_full;
     const void* prefix_states;  // kEvalPrefix: kept states, slot s at s * state_stride amplitudes (may be null otherwise)
     uint32_t dephase;           // (measurement knob QSV_DEPHASE) odd workgroups of a later pass sleep this many s_sleep(127) first
+    const double* side_diag;    // the sides' own values of D (split block word kSplitSideDiag; may be null when no block names one)
 };
 // LDS bytes the fused factor tail of a pass launch needs (up to eight waves form a side's Gram matrices)
 constexpr size_t kFusedFactorLdsBytes = 8 * (18 * 64 + 64) * sizeof(double) + 64;
@@ -130,6 +137,15 @@ static_assert(kFusedLdsRowsEnd <= kFusedLdsTableEnd, "a launch with kModeFusedLd
 // readers, 3 write re, 4 barrier, 5 read re, 6 barrier, 7 write im, 8 barrier, 9 read im (exchange mode 2 only),
 // 10 gates, 11 store / reduce, 12 epilogue.
 constexpr int kStampPasses = 8, kStampPhases = 16;
+// A batch of sides' own tables of D: out[base + x] = diag[x deposited in mask], x < 2^bits (upload_plans)
+struct SideDiagJob {
+    uint32_t base, mask, bits;
+};
+constexpr int kSideDiagJobsPerLaunch = 128;
+struct SideDiagJobs {
+    SideDiagJob job[kSideDiagJobsPerLaunch];
+};
+hipError_t launch_side_diag(const double* diag, double* side_diag, const SideDiagJobs& jobs, int n_jobs, hipStream_t stream);
 hipError_t read_stamps(unsigned long long* out, int reset);  // hipErrorNotSupported in the shipped build
 // (-DQSV_TIMELINE builds: when each tile's phases began, per workgroup of a later pass)
 constexpr unsigned kTimelineWgs = 16384, kTimelineTiles = 14, kTimelineWords = 6 + 4 * kTimelineTiles + 2;

@@ -227,6 +227,10 @@ struct qsv_handle {
     std::unordered_map<int, PrefixState> prefixes;
     int next_prefix_id = 1;
     DeviceBuffer d_prefix;
+    // the sides' own tables of D (kernels.hpp kSplitSideDiag): filled when a split circuit's plan is uploaded, gone with the arena
+    DeviceBuffer d_sdiag;
+    size_t sdiag_used = 0;             // doubles handed out
+    bool side_diag = true;             // (QSV_SIDE_DIAG=0: the sums gather from D itself, as before round 4)
     size_t prefix_slots = 0;           // capacity
     std::vector<uint32_t> prefix_free; // recycled slots
     size_t prefix_used = 0;            // slots handed out so far (below capacity)
@@ -577,6 +581,7 @@ int build_circuit(qsv_t* h, int n_ops, const qsv_op* ops, int n_params, bool fol
                     blk[3] = (swap_xy ? 1u : 0u) | uint32_t(loop_x) << 8;
                     blk[kSplitMaskX] = uint32_t(sc.mask[sx]);
                     blk[kSplitMaskY] = uint32_t(sc.mask[1 - sx]);
+                    blk[kSplitSideDiag] = blk[kSplitSideDiag + 1] = kNoSideDiag;  // (upload_plans names the tables)
                     {
                         int at = 0;
                         for (int which = 0; which < 2; ++which)
@@ -725,31 +730,47 @@ int register_circuit(qsv_t* h, int n_ops, const qsv_op* ops, int n_params, int* 
 // space of destroyed circuits is reclaimed, and the arena only grows when the live plans really need more room.
 int upload_plans(qsv_t* h, const std::vector<Circuit*>& circs) {
     std::vector<Circuit*> fresh;
-    size_t need = 0;
+    size_t need = 0, need_d = 0;
+    // (doubles of the two sides' own tables of D: circuits on the one-launch route under a diagonal operator)
+    auto side_diag_doubles = [&](const Circuit* c) -> size_t {
+        if (!h->side_diag || !h->d_diag.ptr || !c->split.ok || !c->split.fused) return 0;
+        const uint32_t* blk = c->plan.words.data() + c->split.off_block;
+        return (size_t(1) << blk[1]) + (size_t(1) << blk[2]);
+    };
     for (Circuit* c : circs)
         if (!c->uploaded && !c->staged) {
             c->staged = true;
             fresh.push_back(c);
             need += c->plan.words.size();
+            need_d += side_diag_doubles(c);
         }
     for (Circuit* c : fresh) c->staged = false;
     if (fresh.empty()) return QSV_OK;
     const size_t cap = h->d_arena.bytes / 4;
-    if (h->arena_used_words + need > cap) {
+    if (h->arena_used_words + need > cap || h->sdiag_used + need_d > h->d_sdiag.bytes / 8) {
         // rebuild: everything still registered that is part of this batch goes in again; plans of other live circuits
         // are re-uploaded when they are next used
         QSV_HIP(h, sync_streams(h));
         for (auto& kv : h->circuits) kv.second.uploaded = false;
         fresh.clear();
-        need = 0;
+        need = need_d = 0;
         for (Circuit* c : circs)
             if (!c->staged) {
                 c->staged = true;
                 fresh.push_back(c);
                 need += c->plan.words.size();
+                need_d += side_diag_doubles(c);
             }
         for (Circuit* c : fresh) c->staged = false;
         h->arena_used_words = 0;
+        h->sdiag_used = 0;
+        if (need_d > h->d_sdiag.bytes / 8) {
+            const size_t new_doubles = std::max(need_d * 2, size_t(1) << 19);
+            if (h->d_sdiag.ptr) QSV_HIP(h, hipFree(h->d_sdiag.ptr));
+            h->d_sdiag = DeviceBuffer{};
+            QSV_HIP(h, hipMalloc(&h->d_sdiag.ptr, new_doubles * 8));
+            h->d_sdiag.bytes = new_doubles * 8;
+        }
         if (getenv("QSV_ARENA_DEBUG"))
             fprintf(stderr, "plan arena: rebuilt for a batch of %zu plans, %zu words of %zu%s\n", fresh.size(), need, cap, need > cap ? " (grows)" : "");
         if (need > cap) {
@@ -775,7 +796,19 @@ int upload_plans(qsv_t* h, const std::vector<Circuit*>& circs) {
         QSV_HIP(h, hipStreamSynchronize(h->stream));
     }
     size_t cur = 0;
+    std::vector<SideDiagJob> jobs;
     for (Circuit* c : fresh) {
+        if (c->split.ok) {
+            // the sides' own tables of D: named in the split block, filled behind the copy below
+            uint32_t* blk = c->plan.words.data() + c->split.off_block;
+            blk[kSplitSideDiag] = blk[kSplitSideDiag + 1] = kNoSideDiag;
+            if (side_diag_doubles(c))
+                for (uint32_t xy = 0; xy < 2; ++xy) {
+                    blk[kSplitSideDiag + xy] = uint32_t(h->sdiag_used);
+                    jobs.push_back(SideDiagJob{uint32_t(h->sdiag_used), blk[kSplitMaskX + xy], blk[1 + xy]});
+                    h->sdiag_used += size_t(1) << blk[1 + xy];
+                }
+        }
         std::memcpy(h->h_stage + cur, c->plan.words.data(), c->plan.words.size() * 4);
         c->plan_base = uint32_t(h->arena_used_words + cur);
         cur += c->plan.words.size();
@@ -784,6 +817,15 @@ int upload_plans(qsv_t* h, const std::vector<Circuit*>& circs) {
     QSV_HIP(h, hipMemcpyAsync(static_cast<uint32_t*>(h->d_arena.ptr) + h->arena_used_words, h->h_stage, need * 4,
                               hipMemcpyHostToDevice, h->stream));
     h->arena_used_words += need;
+    if (getenv("QSV_ARENA_DEBUG"))
+        fprintf(stderr, "plan arena: %zu fresh plans, %zu side tables of D (%zu doubles used of %zu), diag %p\n", fresh.size(), jobs.size(), h->sdiag_used,
+                h->d_sdiag.bytes / 8, h->d_diag.ptr);
+    for (size_t first = 0; first < jobs.size(); first += size_t(kSideDiagJobsPerLaunch)) {
+        SideDiagJobs batch{};
+        const int n_jobs = int(std::min(jobs.size() - first, size_t(kSideDiagJobsPerLaunch)));
+        std::copy(jobs.begin() + long(first), jobs.begin() + long(first) + n_jobs, batch.job);
+        QSV_HIP(h, launch_side_diag(static_cast<const double*>(h->d_diag.ptr), static_cast<double*>(h->d_sdiag.ptr), batch, n_jobs, h->stream));
+    }
     // launches on the second stream read the arena too: they wait for this copy
     if (!h->side_streams.empty()) {
         QSV_HIP(h, hipEventRecord(h->ev_join, h->stream));
@@ -1091,6 +1133,7 @@ int run_group(qsv_t* h, const std::vector<Circuit*>& circs, size_t first, size_t
     a.state_stride = uint64_t(1) << h->n;
     a.mode = mode | h->stream_mode;
     a.prefix_states = h->d_prefix.ptr;
+    a.side_diag = static_cast<const double*>(h->d_sdiag.ptr);
     {
         static const uint32_t dephase = getenv("QSV_DEPHASE") ? uint32_t(atoi(getenv("QSV_DEPHASE"))) : 0u;
         a.dephase = dephase;
@@ -1891,6 +1934,7 @@ int qsv_create(int n_qubits, int dtype, int device, const qsv_plan_config* cfg, 
     if (const char* env = getenv("QSV_REPEAT")) h->repeat_enabled = atoi(env) != 0;
     if (const char* env = getenv("QSV_REPEAT_DESCS")) h->repeat_device_descs = atoi(env) != 0;
     if (const char* env = getenv("QSV_FUSED_LDS")) h->fused_lds_table = atoi(env) != 0;
+    if (const char* env = getenv("QSV_SIDE_DIAG")) h->side_diag = atoi(env) != 0;
     {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) h->n_cus = cus;
@@ -1966,7 +2010,7 @@ void qsv_destroy(qsv_t* h) {
     }
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     for (DeviceBuffer* b : {&h->d_z, &h->d_cre, &h->d_diag, &h->d_order, &h->d_sorted, &h->d_term_partials, &h->d_groups, &h->d_term_odd, &h->d_arena,
-                            &h->d_states, &h->d_wtab, &h->d_side, &h->d_factor, &h->d_factor_count, &h->d_factor_big, &h->d_factor_big_count, &h->d_quad, &h->d_fterms, &h->d_fpart, &h->d_batch, &h->d_mats, &h->d_partials, &h->d_out, &h->d_scratch, &h->d_prefix})
+                            &h->d_states, &h->d_wtab, &h->d_side, &h->d_factor, &h->d_factor_count, &h->d_factor_big, &h->d_factor_big_count, &h->d_quad, &h->d_fterms, &h->d_fpart, &h->d_batch, &h->d_mats, &h->d_partials, &h->d_out, &h->d_scratch, &h->d_prefix, &h->d_sdiag})
         if (b->ptr) (void)hipFree(b->ptr);
     if (h->h_batch) (void)hipHostFree(h->h_batch);
     if (h->d_ship) (void)hipFree(h->d_ship);
@@ -2110,6 +2154,10 @@ int qsv_set_operator(qsv_t* h, int n_terms, const uint64_t* x_mask, const uint64
         QSV_HIP(h, hipStreamSynchronize(h->stream));
         h->n_fterms = uint32_t(n_terms);
     }
+    // (plans in the arena name tables of the OLD operator's D: everything is uploaded again when it is next used)
+    QSV_HIP(h, sync_streams(h));
+    for (auto& kv : h->circuits) kv.second.uploaded = false;
+    h->sdiag_used = 0;
     h->n_terms = n_terms;
     h->order_valid = false;
     h->diagonal = all_diag;
@@ -3140,6 +3188,14 @@ int qsv_set_option(qsv_t* h, const char* name, int value) {
         h->split_sampling = value != 0;
     } else if (key == "fused_lds_table") {  // one-launch route: sides' states handed to their Gram matrices through LDS (same bits either way)
         h->fused_lds_table = value != 0;
+    } else if (key == "side_diag") {  // one-launch route: a side's values of D from a table of its own (one run) instead of gathered from D
+        // (same values either way; the plans name the tables: everything is uploaded again when it is next used)
+        if (h->side_diag != (value != 0)) {
+            QSV_HIP(h, sync_streams(h));
+            for (auto& kv : h->circuits) kv.second.uploaded = false;
+            h->sdiag_used = 0;
+        }
+        h->side_diag = value != 0;
     } else if (key == "streams") {
         if (value < 1 || value > h->n_lane_streams + 1) return fail(h, QSV_E_ARG, "streams must be between 1 and the number the handle was created with");
         h->n_streams = value;

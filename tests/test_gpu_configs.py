@@ -692,6 +692,19 @@ def test_one_launch_route_of_split_evaluations(c_oracle):
     dev.set_option("fused_lds_table", 0)
     assert ev.evaluate_circuits(circuits, params) == one
     dev.set_option("fused_lds_table", 1)
+    # a side's values of D from a table of its own (filled when the plan is uploaded) or gathered from D: the same values
+    dev.set_option("side_diag", 0)
+    assert ev.evaluate_circuits(circuits, params) == one
+    dev.set_option("side_diag", 1)
+    assert ev.evaluate_circuits(circuits, params) == one
+    # ... and they follow the operator: the same circuits, registered already, under another one and back
+    other = helpers.random_ising_operator(n, seed=7)
+    fresh = OperatorCircuitEvaluator(other).evaluate_circuits(circuits, params)
+    assert max(abs(a - b) for a, b in zip(fresh, one)) > 1e-3
+    shared = OperatorCircuitEvaluator(other, statevector_device=dev)  # (evaluators that share a device set their operator per call)
+    assert shared.evaluate_circuits(circuits, params) == fresh
+    assert ev.evaluate_circuits(circuits, params) == one
+    assert shared.evaluate_circuits(circuits, params) == fresh
     got32 = np.asarray(OperatorCircuitEvaluator(op, dtype="fp32").evaluate_circuits(circuits, params))
     assert np.abs(got32 - np.asarray(one)).max() < FP32_REL * float(np.abs(op.coeffs).sum())
 
