@@ -3012,13 +3012,17 @@ size_t factor_big_slot_counters() { return kFactorBigCounters; }
 template <typename real, int J>
 __device__ __forceinline__ void factor_moments_big_body(const EvalDesc& ev, const uint32_t* __restrict__ sp,
                                                         const cx<real>* __restrict__ sides, uint64_t side_stride,
-                                                        const double* __restrict__ diag, double* __restrict__ scratch,
-                                                        uint32_t* __restrict__ counters, cx<real>* stage, double* dstage) {
+                                                        const double* __restrict__ diag, const double* __restrict__ side_diag,
+                                                        double* __restrict__ scratch, uint32_t* __restrict__ counters, cx<real>* stage, double* dstage) {
     constexpr uint32_t NQ = J * J, PITCH = J + 1, PER = uint32_t(J) * 64u / 256u;  // amplitudes a thread stages per block
     const bool swap = sp[3] & 1u;
     const uint32_t side = blockIdx.x & 1u, slice = (blockIdx.x >> 1) & (kFactorBigSlices - 1), group = blockIdx.x / (2 * kFactorBigSlices);
     if (group * 256u >= NQ) return;  // (uniform: before any barrier)
-    const uint32_t bits = sp[1 + side], mask = sp[kSplitMaskX + side];
+    const uint32_t bits = sp[1 + side];
+    const uint32_t own_d = sp[kSplitSideDiag + side];  // (the side's own table of D, read in place)
+    const bool in_place = own_d != kNoSideDiag;
+    const uint32_t mask = sp[kSplitMaskX + side];
+    diag = in_place ? side_diag + own_d : diag;
     const uint32_t tid = threadIdx.x;
     const cx<real>* ta = sides + uint64_t(ev.state_slot) * side_stride;
     const cx<real>* tab = ta + ((side == 0) == swap ? side_stride >> 1 : 0);  // X is side B's half when swapped
@@ -3038,7 +3042,7 @@ __device__ __forceinline__ void factor_moments_big_body(const EvalDesc& ev, cons
             next[i] = cx<real>{real(0), real(0)};
             if (blk < n_blocks && xl < n_local) next[i] = tab[(size_t(j) << bits) + size_t(blk) * 64 + xl];
         }
-        d_next = (tid < 64 && blk < n_blocks && tid < n_local) ? diag[deposit_bits(blk * 64u + tid, mask)] : 0.0;
+        d_next = (tid < 64 && blk < n_blocks && tid < n_local) ? diag[in_place ? blk * 64u + tid : deposit_bits(blk * 64u + tid, mask)] : 0.0;
     };
     fetch(slice);
     for (uint32_t blk = slice; blk < n_blocks; blk += kFactorBigSlices) {
@@ -3177,7 +3181,8 @@ template <typename real>
 __global__ void __launch_bounds__(256, 2) factor_moments_kernel(const uint32_t* __restrict__ plan_arena, const EvalDesc* __restrict__ evals,
                                                                 const cx<real>* __restrict__ sides, uint64_t side_stride,
                                                                 const double* __restrict__ diag, double* __restrict__ scratch,
-                                                                double* __restrict__ scratch_big, uint32_t* __restrict__ big_counters) {
+                                                                double* __restrict__ scratch_big, uint32_t* __restrict__ big_counters,
+                                                                const double* __restrict__ side_diag) {
     constexpr uint32_t kWaves = 4;
     // the waves' staging regions (9 x 64 amplitudes each) and, afterwards, their partial matrices (18 x 64 doubles each)
     __shared__ __align__(16) unsigned char raw[kWaves * kFactorWeights * 64 * sizeof(double)];
@@ -3190,15 +3195,19 @@ __global__ void __launch_bounds__(256, 2) factor_moments_kernel(const uint32_t* 
     const uint32_t n_keys = sp[0], NQ = 1u << (2 * n_keys);
     if (n_keys > 3) {  // sixteen / thirty-two product terms: a thread per entry (grid: up to four entry groups)
         if (n_keys == 4)
-            factor_moments_big_body<real, 16>(ev, sp, sides, side_stride, diag, scratch_big, big_counters, reinterpret_cast<cx<real>*>(raw), dstage);
+            factor_moments_big_body<real, 16>(ev, sp, sides, side_stride, diag, side_diag, scratch_big, big_counters, reinterpret_cast<cx<real>*>(raw), dstage);
         else
-            factor_moments_big_body<real, 32>(ev, sp, sides, side_stride, diag, scratch_big, big_counters, reinterpret_cast<cx<real>*>(raw), dstage);
+            factor_moments_big_body<real, 32>(ev, sp, sides, side_stride, diag, side_diag, scratch_big, big_counters, reinterpret_cast<cx<real>*>(raw), dstage);
         return;
     }
     if (blockIdx.x >= kFactorParts) return;  // (a grid widened for an evaluation of 32 terms)
     const bool swap = sp[3] & 1u;
     const uint32_t side = blockIdx.x & 1u, slice = blockIdx.x >> 1;
-    const uint32_t bits = sp[1 + side], mask = sp[kSplitMaskX + side];
+    const uint32_t bits = sp[1 + side];
+    // (the side's own table of D where the block names one, read in place: kernels.hpp kSplitSideDiag)
+    const uint32_t own_d = sp[kSplitSideDiag + side];
+    const uint32_t mask = own_d != kNoSideDiag ? (1u << bits) - 1u : sp[kSplitMaskX + side];
+    diag = own_d != kNoSideDiag ? side_diag + own_d : diag;
     const uint32_t tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const cx<real>* ta = sides + uint64_t(ev.state_slot) * side_stride;
     const cx<real>* tab = ta + ((side == 0) == swap ? side_stride >> 1 : 0);  // X is side B's half when swapped
@@ -3470,10 +3479,10 @@ hipError_t launch_factor(int dtype, unsigned n_evals, double* scratch, const dou
     const dim3 grid(most_keys >= 5 ? 2 * kFactorBigSlices * 4 : most_keys == 4 ? 2 * kFactorBigSlices : kFactorParts, n_evals);
     if (dtype == 0)
         hipLaunchKernelGGL(factor_moments_kernel<double>, grid, dim3(256), 0, stream, a.plan, a.evals,
-                           static_cast<const cx<double>*>(a.wtab), a.wtab_stride, a.diag, scratch, scratch_big, big_counters);
+                           static_cast<const cx<double>*>(a.wtab), a.wtab_stride, a.diag, scratch, scratch_big, big_counters, a.side_diag);
     else
         hipLaunchKernelGGL(factor_moments_kernel<float>, grid, dim3(256), 0, stream, a.plan, a.evals,
-                           static_cast<const cx<float>*>(a.wtab), a.wtab_stride, a.diag, scratch, scratch_big, big_counters);
+                           static_cast<const cx<float>*>(a.wtab), a.wtab_stride, a.diag, scratch, scratch_big, big_counters, a.side_diag);
     hipLaunchKernelGGL(factor_combine_kernel, dim3(n_evals), dim3(most_keys > 3 ? 1024 : 256), 0, stream, a.plan, a.evals, scratch,
                        scratch_big, quad, uint32_t(n_qubits), a.diag, a.result_out);
     return hipGetLastError();

@@ -731,9 +731,9 @@ int register_circuit(qsv_t* h, int n_ops, const qsv_op* ops, int n_params, int* 
 int upload_plans(qsv_t* h, const std::vector<Circuit*>& circs) {
     std::vector<Circuit*> fresh;
     size_t need = 0, need_d = 0;
-    // (doubles of the two sides' own tables of D: circuits on the one-launch route under a diagonal operator)
+    // (doubles of the two sides' own tables of D: split circuits whose expectation comes from Gram sums -- a quadratic diagonal operator)
     auto side_diag_doubles = [&](const Circuit* c) -> size_t {
-        if (!h->side_diag || !h->d_diag.ptr || !c->split.ok || !c->split.fused) return 0;
+        if (!h->side_diag || !h->d_diag.ptr || !c->split.ok || !(h->diagonal && h->quadratic && h->d_quad.ptr)) return 0;
         const uint32_t* blk = c->plan.words.data() + c->split.off_block;
         return (size_t(1) << blk[1]) + (size_t(1) << blk[2]);
     };
