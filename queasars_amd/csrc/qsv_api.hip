@@ -747,7 +747,8 @@ int upload_plans(qsv_t* h, const std::vector<Circuit*>& circs) {
     for (Circuit* c : fresh) c->staged = false;
     if (fresh.empty()) return QSV_OK;
     const size_t cap = h->d_arena.bytes / 4;
-    if (h->arena_used_words + need > cap || h->sdiag_used + need_d > h->d_sdiag.bytes / 8) {
+    const bool tables_full = h->sdiag_used + need_d > h->d_sdiag.bytes / 8;
+    if (h->arena_used_words + need > cap || tables_full) {
         // rebuild: everything still registered that is part of this batch goes in again; plans of other live circuits
         // are re-uploaded when they are next used
         QSV_HIP(h, sync_streams(h));
@@ -764,8 +765,10 @@ int upload_plans(qsv_t* h, const std::vector<Circuit*>& circs) {
         for (Circuit* c : fresh) c->staged = false;
         h->arena_used_words = 0;
         h->sdiag_used = 0;
-        if (need_d > h->d_sdiag.bytes / 8) {
-            const size_t new_doubles = std::max(need_d * 2, size_t(1) << 19);
+        if (need_d > h->d_sdiag.bytes / 8 || (tables_full && h->d_sdiag.bytes < (size_t(256) << 20))) {
+            // (it was full, or never there: twice the room up to 256 MiB, so that a run that keeps registering structures -- an
+            // EVQE run does, every generation -- comes here, and uploads everything again, ever more rarely)
+            const size_t new_doubles = std::max(std::max(need_d * 2, h->d_sdiag.bytes / 4), size_t(1) << 19);
             if (h->d_sdiag.ptr) QSV_HIP(h, hipFree(h->d_sdiag.ptr));
             h->d_sdiag = DeviceBuffer{};
             QSV_HIP(h, hipMalloc(&h->d_sdiag.ptr, new_doubles * 8));
