@@ -709,6 +709,24 @@ def test_one_launch_route_of_split_evaluations(c_oracle):
     assert np.abs(got32 - np.asarray(one)).max() < FP32_REL * float(np.abs(op.coeffs).sum())
 
 
+def test_sides_tables_of_d_survive_their_buffer_filling_up():
+    """The sides' own tables of D (kSplitSideDiag) live in a buffer that is emptied and filled again when it is full (every
+    plan is then uploaded anew, with new tables): a population evaluated before, between and after enough other structures
+    to fill it several times over gives the same bits every time, and the others agree with an evaluator of their own."""
+    n = 20
+    op = helpers.random_ising_operator(n, seed=2020)
+    ev = OperatorCircuitEvaluator(op)
+    _, first_c, first_p = helpers.population_circuits(n, 4, 64, seed=0)
+    first = ev.evaluate_circuits(first_c, first_p)
+    for seed in range(1, 13):  # (64 structures x 2 tables of up to 2^13 doubles each: the 4 MiB the buffer starts with hold four such populations)
+        _, circuits, params = helpers.population_circuits(n, 3 + seed % 3, 64, seed=seed)
+        got = ev.evaluate_circuits(circuits, params)
+        if seed % 4 == 0:
+            assert got == OperatorCircuitEvaluator(op).evaluate_circuits(circuits, params)
+            assert ev.evaluate_circuits(first_c, first_p) == first
+    assert ev.evaluate_circuits(first_c, first_p) == first
+
+
 def test_split_fp32_and_general_operators():
     """fp32 tables through the split path (within the fp32 bound of the fp64 value); a general operator on split circuits
     (the term kernel) against the same device with splitting off."""
