@@ -723,7 +723,7 @@ template <typename real>
 __device__ __forceinline__ void fused_factor_tail(const uint32_t* __restrict__ plan_arena, const EvalDesc& ev,
                                                   const cx<real>* __restrict__ slot_tables, uint64_t side_stride,
                                                   const double* __restrict__ diag, const PassScalars& a, unsigned char* lds,
-                                                  uint32_t gram_waves, uint32_t lds_table QSV_PSTAMP_PARAMS);
+                                                  uint32_t gram_waves, uint32_t lds_table, uint32_t halves_tile QSV_PSTAMP_PARAMS);
 
 // FIRST = the pass synthesises its input (pass 0 of an evaluation from |0..0>): two instantiations, so that neither
 // carries the other's load path through register allocation.
@@ -1349,6 +1349,12 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, FIRST, FUSED>::waves
 #endif
 
     if constexpr (FUSED) {
+        const bool halves_side = (ev.flags & kEvalHalves) && table_lds_rows;  // (its two workgroups: tile0 = 0, 1; R = 3: t = 9, eight waves)
+        if (side && (ev.flags & kEvalHalves) && (ev.flags & kEvalFused) && (a.mode & kModeFusedFactor) && !table_lds_rows) {
+            // (a launch without the LDS for it: the host never makes one -- no value rather than a wrong one)
+            if (threadIdx.x == 0) a.result_out[ev.out_index] = __builtin_nan("");
+            return;
+        }
         // split evaluations whose virtual circuits are one tile and one pass each, under a quadratic operator: this side's
         // workgroup goes straight on to its weighted Gram matrices, and the side that finishes second combines
         if (side && (ev.flags & kEvalFused) && (a.mode & kModeFusedFactor)) {
@@ -1356,11 +1362,11 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, FIRST, FUSED>::waves
             QSV_STAMP_FLUSH(0u);
             for (int ph = 0; ph < kStampPhases; ++ph) st_acc[ph] = 0;
             st_last = qsv_stamp_now();
-            fused_factor_tail<real>(plan_arena, ev, wt0, a.wtab_stride, diag, a, lds_raw, t >= 9 ? 8u : 4u, table_in_lds ? 1u : table_lds_rows ? 2u : 0u, st_acc, &st_last);
+            fused_factor_tail<real>(plan_arena, ev, wt0, a.wtab_stride, diag, a, lds_raw, t >= 9 ? 8u : 4u, table_in_lds ? 1u : table_lds_rows ? 2u : 0u, halves_side ? tile0 : 0xffffffffu, st_acc, &st_last);
             QSV_STAMP_FLUSH(7u);
 #else
             // (Gram waves: by the virtual circuit's own geometry, never by the launch's block size)
-            fused_factor_tail<real>(plan_arena, ev, wt0, a.wtab_stride, diag, a, lds_raw, t >= 9 ? 8u : 4u, table_in_lds ? 1u : table_lds_rows ? 2u : 0u);
+            fused_factor_tail<real>(plan_arena, ev, wt0, a.wtab_stride, diag, a, lds_raw, t >= 9 ? 8u : 4u, table_in_lds ? 1u : table_lds_rows ? 2u : 0u, halves_side ? tile0 : 0xffffffffu);
 #endif
             return;
         }
@@ -1409,7 +1415,7 @@ static hipError_t launch_pass_t(dim3 grid, int threads, size_t lds_bytes, hipStr
                          args.prefix_states, args.dephase, args.side_diag};
     cx<real>* st = reinterpret_cast<cx<real>*>(args.states);
     const bool first = args.pass_index == 0 && (args.mode & kModeSynthFirst);
-    if constexpr (R == 4) {
+    if constexpr (R == 4 || R == 3) {
         if (first && (args.mode & kModeFusedFactor)) {
             hipLaunchKernelGGL((pass_kernel<real, R, XMODE, true, true>), grid, dim3(threads), lds, stream, args.plan, args.mats,
                                args.evals, st, reinterpret_cast<cx<real>*>(args.wtab), args.diag, args.partials, sc);
@@ -1431,7 +1437,7 @@ static hipError_t configure_t(size_t lds_bytes) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pass_kernel<real, R, XMODE, true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e != hipSuccess) return e;
-    if constexpr (R == 4) {
+    if constexpr (R == 4 || R == 3) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pass_kernel<real, R, XMODE, true, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         if (e != hipSuccess) return e;
@@ -2805,10 +2811,15 @@ __device__ __forceinline__ void factor_pairs_blocks(uint32_t bits, uint32_t work
     *end = worker < n_blocks ? *begin + per_worker : *begin;
     if (worker >= n_workers) *end = *begin;
 }
-template <typename real, int HB, bool LDS_ROWS>
+// (LDS_ROWS: where row j of the side's state starts -- rows one amplitude apart by default; a half side's own and imported rows)
+struct RowsOnePitch {
+    template <typename real>
+    __device__ __forceinline__ const cx<real>* operator()(const cx<real>* tab, uint32_t j, uint32_t row_pitch) const { return tab + j * row_pitch; }
+};
+template <typename real, int HB, bool LDS_ROWS, class RowOf = RowsOnePitch>
 __device__ __forceinline__ void factor_side_body_pairs(const cx<real>* __restrict__ tab, uint32_t bits, uint32_t mask, const double* __restrict__ diag,
                                  uint32_t worker, uint32_t n_workers, cx<real>* stage, double* dstage, double* out,
-                                 double (&dq)[kFactorDAheadPairs] QSV_PSTAMP_PARAMS) {
+                                 double (&dq)[kFactorDAheadPairs] QSV_PSTAMP_PARAMS, RowOf row_of = RowOf{}) {
     constexpr int J = 8;
     constexpr uint32_t PITCH = J + 1;
     const uint32_t lane = threadIdx.x & 63u;
@@ -2858,8 +2869,8 @@ __device__ __forceinline__ void factor_side_body_pairs(const cx<real>* __restric
         // (LDS_ROWS: `tab` IS the side's state in LDS, rows of 2^bits amplitudes one amplitude apart: read in place)
         const uint32_t row_pitch = (1u << bits) + 1u;
         constexpr uint32_t XS = LDS_ROWS ? 1u : PITCH;  // amplitudes from one x to the next
-        const cx<real>* pa = LDS_ROWS ? tab + ja * row_pitch + blk * 64u + half : stage + half * PITCH + ja;
-        const cx<real>* pb = LDS_ROWS ? tab + jb * row_pitch + blk * 64u + half : stage + half * PITCH + jb;
+        const cx<real>* pa = LDS_ROWS ? row_of(tab, ja, row_pitch) + blk * 64u + half : stage + half * PITCH + ja;
+        const cx<real>* pb = LDS_ROWS ? row_of(tab, jb, row_pitch) + blk * 64u + half : stage + half * PITCH + jb;
         const double* pd = dstage + half;
         real ar_next = pa[0].re, ai_next = pa[0].im, br_next = pb[0].re, bi_next = pb[0].im;
         double d_next = pd[0];
@@ -3316,11 +3327,13 @@ template <typename real>
 __device__ __forceinline__ void fused_factor_tail(const uint32_t* __restrict__ plan_arena, const EvalDesc& ev,
                                                   const cx<real>* __restrict__ slot_tables, uint64_t side_stride,
                                                   const double* __restrict__ diag, const PassScalars& a, unsigned char* lds,
-                                                  uint32_t gram_waves, uint32_t lds_table QSV_PSTAMP_PARAMS_DEF) {
+                                                  uint32_t gram_waves, uint32_t lds_table, uint32_t halves_tile QSV_PSTAMP_PARAMS_DEF) {
     constexpr uint32_t kMaxWaves = 8;
     // (lds_table: 0 the side's state is in its slot; 1 in LDS behind the tail's scratch, laid out like the slot; 2 in LDS from
     // offset 0 as padded rows, kernels.hpp)
     const bool table_in_lds = lds_table == 1u, table_lds_rows = lds_table == 2u;
+    const bool halves = halves_tile != 0xffffffffu;  // (kEvalHalves: this workgroup has the rows whose third key bit is halves_tile)
+    const uint32_t hh = halves ? halves_tile : 0u;
     const uint32_t kWaves = gram_waves;
     const uint32_t* sp = plan_arena + ev.split_base;
     const uint32_t n_keys = sp[0], NQ = 1u << (2 * n_keys);
@@ -3343,7 +3356,10 @@ __device__ __forceinline__ void fused_factor_tail(const uint32_t* __restrict__ p
             factor_prefetch_d(dq, diag, bits, mask, worker, kWaves, factor_block_count(bits));
         } else {
             uint32_t b0, b1;
-            factor_pairs_blocks(bits, worker, kWaves, &b0, &b1);
+            if (halves)  // (a half side: this workgroup's waves are workers 8 h .. 8 h + 7 of the side's sixteen)
+                factor_pairs_blocks(bits, wave < kWaves ? kWaves * hh + wave : 0xffffffu, 2u * kWaves, &b0, &b1);
+            else
+                factor_pairs_blocks(bits, worker, kWaves, &b0, &b1);
             factor_prefetch_d(dq_pairs, diag, bits, mask, b0, 1u, b1);
         }
     }
@@ -3352,6 +3368,51 @@ __device__ __forceinline__ void fused_factor_tail(const uint32_t* __restrict__ p
     if (lds_table == 0u) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     QSV_PSTAMP(0);  // the side's stores drained
+    if (halves) {
+        // The two halves of a side trade half rows through the side's half of the slot (rows of 2^10 as they would lie there):
+        // mine for the OTHER half of x go out by write-through stores, every wave drains them, barrier, one lane adds to the
+        // exchange counter (it grows by two per launch: the first to add waits for the next even value, bounded), barrier; the
+        // partner's rows for MY half of x come in by agent-scope loads (the partner may sit on another XCD) and lie behind mine.
+        constexpr uint32_t kRow = 1u << (kFusedLdsRowsBits - kFusedLdsRowsKeys), kHalf = kRow / 2;
+        cx<real>* gtab = const_cast<cx<real>*>(slot_tables) + (is_b ? side_stride >> 1 : 0);
+        const cx<real>* own = reinterpret_cast<const cx<real>*>(lds);
+        for (uint32_t i = tid; i < 4u * kHalf; i += blockDim.x) {
+            const uint32_t r = i / kHalf, x = (1u - hh) * kHalf + i % kHalf;
+            store_through(gtab + (size_t(4u * hh + r) << (kFusedLdsRowsBits - kFusedLdsRowsKeys)) + x, own[r * uint32_t(kFusedLdsRowPitch) + x]);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t* exchange = a.factor_counters + size_t(kFactorCountersPerSlot) * ev.state_slot + 1u + (is_b ? 1u : 0u);
+            const uint32_t before = __hip_atomic_fetch_add(exchange, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t want = (before | 1u) + 1u;
+            for (uint32_t spins = 0; spins < (1u << 18); ++spins) {  // (bounded: a partner that never comes costs a wrong value, not a hang)
+                if (int32_t(__hip_atomic_load(exchange, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) >= 0) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        __syncthreads();
+        cx<real>* imported = reinterpret_cast<cx<real>*>(lds + kFusedHalvesImport);
+        // (all of a thread's loads first -- they are trips to memory --, then its LDS writes)
+        constexpr uint32_t kMost = 4u * kHalf / 256u;  // (a workgroup of at least four waves)
+        double got[kMost][2];
+#pragma unroll
+        for (uint32_t it = 0; it < kMost; ++it) {
+            const uint32_t i = tid + it * blockDim.x, r = i / kHalf, xl = i % kHalf;
+            got[it][0] = got[it][1] = 0.0;
+            if (i < 4u * kHalf) {
+                const double* src = reinterpret_cast<const double*>(gtab + (size_t(4u * (1u - hh) + r) << (kFusedLdsRowsBits - kFusedLdsRowsKeys)) + hh * kHalf + xl);
+                got[it][0] = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                got[it][1] = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+#pragma unroll
+        for (uint32_t it = 0; it < kMost; ++it) {
+            const uint32_t i = tid + it * blockDim.x, r = i / kHalf, xl = i % kHalf;
+            if (i < 4u * kHalf) imported[r * uint32_t(kFusedHalvesImportPitch) + xl] = cx<real>{real(got[it][0]), real(got[it][1])};
+        }
+        __syncthreads();
+    }
     double* partial = reinterpret_cast<double*>(lds);                              // [wave][weight][64]
     // [wave][64]; (rows in LDS: behind them -- the partial matrices lie over the rows, and are written when nobody reads those any more)
     double* dstage_all = table_lds_rows ? reinterpret_cast<double*>(lds + kFusedLdsRowsDstage) : partial + size_t(kMaxWaves) * kFactorWeights * 64;
@@ -3377,7 +3438,17 @@ __device__ __forceinline__ void fused_factor_tail(const uint32_t* __restrict__ p
             factor_side_body<real, 2, true>(tab, bits, mask, diag, first, step, stage, dstage_all + w * 64, sink, dq QSV_PSTAMP_ARGS);
         else if (n_keys == 2)
             factor_side_body<real, 4, false>(tab, bits, mask, diag, first, step, stage, dstage_all + w * 64, sink, dq QSV_PSTAMP_ARGS);
-        else if (table_lds_rows)
+        else if (halves) {
+            // rows 4 h .. 4 h + 3 are mine (pitch kFusedLdsRowPitch, every x), the others the partner's (this half of x only, so that
+            // its x = 2^9 h lies at the row's start); blocks 8 h .. 8 h + 7 of the side's sixteen, one per wave
+            const uint32_t mine_first = 4u * hh, x0 = hh << (kFusedLdsRowsBits - kFusedLdsRowsKeys - 1);
+            auto row_of = [=](const cx<real>* base, uint32_t j, uint32_t) -> const cx<real>* {
+                return (j >> 2) == (mine_first >> 2) ? base + (j & 3u) * uint32_t(kFusedLdsRowPitch)
+                                                    : base + uint32_t(kFusedHalvesImport / sizeof(cx<real>)) + (j & 3u) * uint32_t(kFusedHalvesImportPitch) - x0;
+            };
+            factor_side_body_pairs<real, 2, true>(reinterpret_cast<const cx<real>*>(lds), bits, mask, diag, wave < kWaves ? kWaves * hh + wave : 0xffffffu, 2u * kWaves, stage,
+                                                  dstage_all + w * 64, sink, dq_pairs QSV_PSTAMP_ARGS, row_of);
+        } else if (table_lds_rows)
             factor_side_body_pairs<real, 2, true>(reinterpret_cast<const cx<real>*>(lds), bits, mask, diag, wave < kWaves ? wave : 0xffffffu, step, stage,
                                                   dstage_all + w * 64, sink, dq_pairs QSV_PSTAMP_ARGS);
         else
@@ -3390,7 +3461,7 @@ __device__ __forceinline__ void fused_factor_tail(const uint32_t* __restrict__ p
     return;
 #endif
     double* slot = a.factor_scratch + size_t(ev.state_slot) * factor_slot_doubles();
-    double* mine = slot + size_t(xy) * kFactorSlices * kFactorWeights * 64;
+    double* mine = slot + (size_t(xy) * kFactorSlices + hh) * kFactorWeights * 64;  // (a half side: slice h)
     // (write-through stores: the few hundred bytes the other side will read must not wait for a write-back of everything
     // this XCD's L2 holds dirty -- the side tables of sixteen workgroups; an agent-scope release did that: 46 us per launch)
     for (uint32_t idx = tid; idx < (2u + bits) * NQ; idx += blockDim.x) {
@@ -3400,8 +3471,10 @@ __device__ __forceinline__ void fused_factor_tail(const uint32_t* __restrict__ p
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave, before the barrier the signalling lane joins
     __syncthreads();
     if (tid == 0) {
-        const uint32_t before = __hip_atomic_fetch_add(a.factor_counters + ev.state_slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *flag = before & 1u;  // (the add has returned: its value is used)
+        // (four per evaluation: a side's one workgroup adds two, a half side's one -- whoever completes the four combines)
+        const uint32_t add = halves ? 1u : 2u;
+        const uint32_t before = __hip_atomic_fetch_add(a.factor_counters + size_t(kFactorCountersPerSlot) * ev.state_slot, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *flag = ((before + add) & 3u) == 0u;  // (the add has returned: its value is used)
     }
     __syncthreads();
     QSV_PSTAMP(2);  // partial matrices out, counter
@@ -3435,9 +3508,12 @@ __device__ __forceinline__ void fused_factor_tail(const uint32_t* __restrict__ p
             for (uint32_t it = 0; it < kMaxPerThread; ++it) {
                 const uint32_t idx = tid + it * blockDim.x;
                 fetched[s2][it] = 0.0;
-                if (idx < (2u + side_bits[s2]) * NQ)
-                    fetched[s2][it] = __hip_atomic_load(slot + size_t(s2) * kFactorSlices * kFactorWeights * 64 + (idx / NQ) * 64 + idx % NQ,
-                                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (idx < (2u + side_bits[s2]) * NQ) {
+                    const double* entry = slot + size_t(s2) * kFactorSlices * kFactorWeights * 64 + (idx / NQ) * 64 + idx % NQ;
+                    fetched[s2][it] = __hip_atomic_load(entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    // (half sides: the sums over the two halves of x, the lower first)
+                    if (halves) fetched[s2][it] += __hip_atomic_load(entry + kFactorWeights * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
 #pragma unroll
         for (uint32_t s2 = 0; s2 < 2; ++s2)

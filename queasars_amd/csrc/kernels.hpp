@@ -30,6 +30,12 @@ constexpr uint32_t kEvalFused = 8u;
 // reference mutation.py:57-59): its plan is unfolded, its first pass runs the later-pass instantiation and reads slot
 // `split_base` of PassArgs::prefix_states instead of the evaluation's own state slot (which it then writes as usual).
 constexpr uint32_t kEvalPrefix = 16u;
+// (with kEvalFused) a three-key side of thirteen virtual qubits runs as TWO workgroups, one per value of its third key qubit --
+// the plan's one qubit outside its 12-qubit tile, never a target -- four product terms (rows) each; each exports the other half of x
+// of its rows through memory, imports the partner's rows for its own half of x and forms ALL Gram sums over that half; four partial
+// tables meet at the hand-off (kernels.hip fused_factor_tail).  Worth it only with eight amplitudes per thread (R = 3): a gate
+// phase is one wave's issue time over its own amplitudes, and a half side of 4096 is then eight waves of eight.
+constexpr uint32_t kEvalHalves = 32u;
 // A virtual circuit (a side's own qubits + one per key) may be this many qubits larger than a tile: it then takes the pass
 // kernel a few passes over up to 16 tiles -- nothing next to what a split evaluation saves.  (With + 2 only, populations of
 // 26 and 28 qubits mostly found no split form: 21 k and 2 k evaluations per second against 550 k at 24 qubits.)
@@ -130,6 +136,13 @@ constexpr int kFusedLdsRowsBits = 13, kFusedLdsRowsKeys = 3;
 constexpr size_t kFusedLdsRowPitch = (size_t(1) << (kFusedLdsRowsBits - kFusedLdsRowsKeys)) + 1;  // amplitudes
 constexpr size_t kFusedLdsRowsDstage = ((kFusedLdsRowPitch * 8 * 16 + 127) / 128) * 128;      // [wave][64] values of D
 constexpr size_t kFusedLdsRowsEnd = kFusedLdsRowsDstage + 8 * 64 * sizeof(double) + 64;
+// (kEvalHalves: four own rows from offset 0, pitch kFusedLdsRowPitch; behind them the partner's four half rows, one amplitude apart)
+constexpr size_t kFusedHalvesImport = kFusedLdsRowPitch * 4 * 16;
+constexpr size_t kFusedHalvesImportPitch = (size_t(1) << (kFusedLdsRowsBits - kFusedLdsRowsKeys - 1)) + 1;  // amplitudes
+static_assert(kFusedHalvesImport + kFusedHalvesImportPitch * 4 * 16 <= kFusedLdsRowsDstage, "the imported rows end before the staged values of D");
+// hand-off counters per side-table slot: [0] the evaluation's (it grows by four per evaluation: a side's one workgroup adds two, a
+// half side's one), [1 + side] the exchange of a side's two halves (each adds one when its rows are out)
+constexpr uint32_t kFactorCountersPerSlot = 4;
 static_assert(kFusedLdsRowsEnd <= kFusedLdsTableEnd, "a launch with kModeFusedLdsTable has the LDS for either form");
 
 // Diagnostic stamps (only in a -DQSV_STAMPS build): [pass][phase] shader cycles summed over WAVES; the last phase

@@ -51,6 +51,8 @@ struct SplitInfo {
     uint32_t off_block = 0;         // ... and of the split block (kernels.hpp)
     int tile_bits[2] = {0, 0};      // tile of the two plans (a side's tile may be larger than the handle's, see build_circuit)
     bool fused = false;             // both virtual circuits are one pass (kernels.hpp kEvalFused)
+    bool halves = false;            // ... three keys, thirteen virtual qubits a side: two workgroups per side (kernels.hpp kEvalHalves)
+    int side_r = 0;                 // amplitudes per thread of the side plans, as log2 (the handle's, or 3: build_circuit)
 };
 
 struct Circuit {
@@ -231,6 +233,9 @@ struct qsv_handle {
     DeviceBuffer d_sdiag;
     size_t sdiag_used = 0;             // doubles handed out
     bool side_diag = true;             // (QSV_SIDE_DIAG=0: the sums gather from D itself, as before round 4)
+    bool sides_r3 = true;              // one-launch route at 20 qubits: sides of up to twelve virtual qubits planned with EIGHT amplitudes per thread
+                                       // (a gate phase is one wave's issue time over its own amplitudes: twice the waves, half the time),
+                                       // three-key sides of thirteen as two workgroups each (kEvalHalves); circuits registered afterwards
     size_t prefix_slots = 0;           // capacity
     std::vector<uint32_t> prefix_free; // recycled slots
     size_t prefix_used = 0;            // slots handed out so far (below capacity)
@@ -525,6 +530,18 @@ int build_circuit(qsv_t* h, int n_ops, const qsv_op* ops, int n_params, bool fol
                 SplitInfo& sp = out->split;
                 std::vector<uint32_t>& w = out->plan.words;
                 bool fits = true;
+                // The one-launch route's sides at 20 qubits, where a gate phase is what ONE WAVE takes to issue a gate over its own
+                // amplitudes (HISTORY round 4, item 14): planned with eight amplitudes per thread instead of sixteen -- twice the waves
+                // -- if both are at most twelve virtual qubits (one tile of 512 threads) and stay one pass; three keys and thirteen
+                // virtual qubits a side: over 12-qubit tiles the scheduler leaves a qubit that is never a target outside the tile --
+                // a key qubit; if that is the LAST one on both sides and one pass does, each side runs as two workgroups
+                // (kEvalHalves).  Each form is tried and kept only if it holds; else the handle's own geometry, as before.
+                const bool r3_handle = h->sides_r3 && h->dtype == QSV_F64 && h->geo.k == 12 && h->geo.r == 4 && sc.n_keys <= 3;
+                bool try_halves = r3_handle && sc.n_keys == kFusedLdsRowsKeys && sc.n_side[0] + sc.n_keys == kFusedLdsRowsBits &&
+                                  sc.n_side[1] + sc.n_keys == kFusedLdsRowsBits;
+                bool try_r3 = try_halves || (r3_handle && std::max(sc.n_side[0], sc.n_side[1]) + sc.n_keys <= 12);
+                const size_t words_before = w.size();
+              plan_sides:
                 for (int s = 0; s < 2 && fits; ++s) {
                     PlanConfig side = pc;
                     sp.n_virtual[s] = sc.n_side[s] + sc.n_keys;
@@ -532,7 +549,7 @@ int build_circuit(qsv_t* h, int n_ops, const qsv_op* ops, int n_params, bool fol
                     // 512 threads: n = 20 keeps 12-qubit tiles of 256 threads for its states, but a three-key circuit's
                     // 13-qubit sides then stay one tile and one pass -- and with that in the one-launch path, kEvalFused)
                     side.tile_bits = std::min(sp.n_virtual[s], side_tile);
-                    side.reg_bits = h->geo.r;
+                    side.reg_bits = try_r3 ? 3 : h->geo.r;
                     side.compact = false;  // (the compact-table buffer is where a side's state lives)
                     fits = side.tile_bits > side.reg_bits;
                     if (!fits) break;
@@ -541,6 +558,10 @@ int build_circuit(qsv_t* h, int n_ops, const qsv_op* ops, int n_params, bool fol
                     // may target them, and the swaps that brought them home at the end (up to four of a side's ten) are not made
                     // (a zero-key circuit of the benchmark alone: 34.1 -> 32.5 us).
                     if (sp.n_virtual[s] <= side.tile_bits) side.lane_bits = 0;
+                    if (try_halves) {  // (the same goes for a half side: its state stays in LDS)
+                        side.tile_bits = 12;
+                        side.lane_bits = 0;
+                    }
                     if (const char* env = getenv("QSV_SIDE_LANE_BITS")) side.lane_bits = atoi(env);  // (measurements)
                     const CircuitPlan p = build_plan(sp.n_virtual[s], sc.gates[s], sc.angles[s], side);
                     sp.stats[s] = p.stats;
@@ -549,7 +570,22 @@ int build_circuit(qsv_t* h, int n_ops, const qsv_op* ops, int n_params, bool fol
                     sp.tile_bits[s] = side.tile_bits;
                     sp.off_side[s] = uint32_t(w.size());
                     w.insert(w.end(), p.words.begin(), p.words.end());
+                    if (try_r3) {
+                        bool ok = p.stats.n_passes == 1;
+                        if (try_halves) {  // (the tile's qubits are 0 .. 11: the third key qubit, 12, is the tile number)
+                            const uint32_t* c0 = p.words.data();
+                            const uint32_t* p0 = c0 + c0[kCircuitHeaderWords];
+                            for (uint32_t j = 0; j < 12 && ok; ++j) ok = p0[kPassHeaderWords + j] != uint32_t(kFusedLdsRowsBits - 1);
+                        }
+                        if (!ok) {  // (as before: the handle's geometry, one tile)
+                            try_halves = try_r3 = false;
+                            w.resize(words_before);
+                            goto plan_sides;
+                        }
+                    }
                 }
+                sp.halves = fits && try_halves;
+                sp.side_r = try_r3 ? 3 : h->geo.r;
                 // the contraction kernel's view of the circuit (kernels.hpp, split block): ready-made pieces of the two
                 // table indices for the lanes, the wave index, a thread's own five bits and the chunk number
                 const int wave_bits = h->geo.t > 6 ? h->geo.t - 6 : 0;
@@ -617,7 +653,7 @@ int build_circuit(qsv_t* h, int n_ops, const qsv_op* ops, int n_params, bool fol
                     // Measured (profiles/r03_fused_factor.txt): the one-launch route wins where a side's Gram matrices are a
                     // few blocks per wave -- 20-qubit registers, every population size -- and loses from 22 qubits on, where
                     // a side's table is 2^11 .. 2^13 rows for the four to eight waves of its one workgroup.
-                    sp.fused = h->geo.r == 4 && h->geo.k == 12 && sp.n_keys <= 3 && sp.outer[0] == 0 && sp.outer[1] == 0 &&
+                    sp.fused = h->geo.r == 4 && h->geo.k == 12 && sp.n_keys <= 3 && ((sp.outer[0] == 0 && sp.outer[1] == 0) || sp.halves) &&
                                sp.stats[0].n_passes == 1 && sp.stats[1].n_passes == 1;
                     if (const char* env = getenv("QSV_FUSED_MAX_KEYS")) sp.fused = sp.fused && sp.n_keys <= atoi(env);  // (measurements)
                     if (getenv("QSV_SPLIT_DEBUG"))
@@ -1003,7 +1039,7 @@ int batch_layout(qsv_t* h, const std::vector<Circuit*>& circs, const std::vector
             for (int s = 0; s < 2; ++s) {
                 hd[size_t(s) * n_evals + i] =
                     EvalDesc{c.plan_base + c.split.off_side[s], uint32_t(mcur), slot, uint32_t(i), uint32_t(pcur),
-                             uint32_t(n_params[i]), kEvalSide | (s ? kEvalSideB : 0u) | (c.split.fused ? kEvalFused : 0u),
+                             uint32_t(n_params[i]), kEvalSide | (s ? kEvalSideB : 0u) | (c.split.fused ? kEvalFused : 0u) | (c.split.fused && c.split.halves ? kEvalHalves : 0u),
                              c.plan_base + c.split.off_block};
                 mcur += mat_doubles_of(h, c, true, s);
             }
@@ -1193,15 +1229,18 @@ int run_group(qsv_t* h, const std::vector<Circuit*>& circs, size_t first, size_t
             *lds = (size_t(1) << tile) * h->amp_bytes / (h->cfg.xmode == 2 ? 2 : 1);
         };
         auto at_least_four_waves = [](int threads) { return std::max(256, threads); };  // (the fused factor tail's Gram waves)
-        auto launch_sides = [&](size_t lo, size_t hi, uint32_t extra_mode) -> int {
+        auto launch_sides = [&](size_t lo, size_t hi, uint32_t extra_mode, int r) -> int {
             int threads, passes;
             size_t lds;
             unsigned tiles;
             shape_of(lo, hi, &threads, &lds, &passes, &tiles);
             if (extra_mode & kModeFusedFactor) threads = at_least_four_waves(threads);
-            // (fused: ONE workgroup per side sweeps all its tiles, then goes on to the side's Gram matrices)
-            a.tiles_per_block = (extra_mode & kModeFusedFactor) ? tiles : 1u;
-            const unsigned grid_x = (extra_mode & kModeFusedFactor) ? 1u : tiles;
+            // (fused: ONE workgroup per side, one tile -- or, a half side, one of its two tiles -- then on to the side's Gram matrices)
+            bool any_halves = false;
+            if (extra_mode & kModeFusedFactor)
+                for (size_t i = lo; i < hi; ++i) any_halves |= circs[eval_of(first + i)]->split.halves;
+            a.tiles_per_block = 1u;
+            const unsigned grid_x = tiles;
             // (pass 0 prepares the virtual circuits' matrices and tables itself: no prepare launch ran for them)
             a.evals = batch_evals(h) + first + lo;
             a.host_evals = descs_base(h) + first + lo;
@@ -1214,12 +1253,12 @@ int run_group(qsv_t* h, const std::vector<Circuit*>& circs, size_t first, size_t
                 if (p == 0) need = std::max(need, kFusedPrepareLdsBytes);
                 if (p == 0 && (extra_mode & kModeFusedFactor)) need = std::max(need, kFusedFactorLdsBytes);
                 // at most one workgroup per CU in flight anyway (two per evaluation): room for the sides' states in LDS
-                if (p == 0 && (extra_mode & kModeFusedFactor) && h->dtype == QSV_F64 && h->fused_lds_table && 2 * (hi - lo) <= size_t(h->n_cus)) {
+                if (p == 0 && (extra_mode & kModeFusedFactor) && h->dtype == QSV_F64 && (h->fused_lds_table || any_halves) && 2 * size_t(grid_x) * (hi - lo) <= size_t(h->n_cus)) {
                     a.mode |= kModeFusedLdsTable;
                     need = std::max(need, kFusedLdsTableEnd);
                 }
                 if (h->stamping) QSV_HIP(h, stamp(h, h->batch.launch_events[kind], true));
-                QSV_HIP(h, launch_pass(h->dtype, h->geo.r, h->cfg.xmode, dim3(grid_x, unsigned(hi - lo), 2), threads, need, ws(h), a));
+                QSV_HIP(h, launch_pass(h->dtype, r, h->cfg.xmode, dim3(grid_x, unsigned(hi - lo), 2), threads, need, ws(h), a));
                 if (h->stamping) QSV_HIP(h, stamp(h, h->batch.launch_events[kind], false));
                 h->prof.n_pass_launches += 1;
                 h->prof.kernel_launches[kind] += 1;
@@ -1231,9 +1270,26 @@ int run_group(qsv_t* h, const std::vector<Circuit*>& circs, size_t first, size_t
         // has one -- theirs is the longer chain)
         hipStream_t const lane_of_group = h->work;
         if (two_chains) h->work = chain_st;
-        if (n_unfused > 0 && (rc2 = launch_sides(0, n_unfused, 0u))) return rc2;
+        // (a launch is one instantiation of the kernel: within each kind the sides with eight amplitudes per thread come first,
+        // order_split_first; half sides need their states in LDS, i.e. at most one workgroup per compute unit: four per evaluation)
+        auto launch_sides_by_r = [&](size_t lo, size_t hi, uint32_t extra_mode) -> int {
+            size_t mid = lo;
+            while (mid < hi && circs[eval_of(first + mid)]->split.side_r == 3) ++mid;
+            const size_t edge[3] = {lo, mid, hi};
+            for (int part = 0; part < 2; ++part) {
+                bool halves_here = false;
+                for (size_t i = edge[part]; i < edge[part + 1]; ++i) halves_here |= circs[eval_of(first + i)]->split.halves;
+                const size_t most = (halves_here && (extra_mode & kModeFusedFactor)) ? std::max(size_t(1), size_t(h->n_cus) / 4) : hi - lo;
+                for (size_t at = edge[part]; at < edge[part + 1]; at += most) {
+                    const int rc3 = launch_sides(at, std::min(edge[part + 1], at + most), extra_mode, part == 0 ? 3 : h->geo.r);
+                    if (rc3) return rc3;
+                }
+            }
+            return QSV_OK;
+        };
+        if (n_unfused > 0 && (rc2 = launch_sides_by_r(0, n_unfused, 0u))) return rc2;
         h->work = lane_of_group;
-        if (n_split > n_unfused && (rc2 = launch_sides(n_unfused, n_split, kModeFusedFactor))) return rc2;
+        if (n_split > n_unfused && (rc2 = launch_sides_by_r(n_unfused, n_split, kModeFusedFactor))) return rc2;
         a.mode = mode | h->stream_mode;
         // what the side circuits move: they synthesise their input and write their final states
         for (size_t i = 0; i < n_split; ++i) {
@@ -1497,12 +1553,15 @@ size_t order_split_first(qsv_t* h, size_t first, size_t count, size_t* n_cont = 
     }
     // (among the split ones first those that need launches of their own after the virtual circuits -- kEvalFused ones are
     // finished by the launch that runs theirs --, so that each kind is one contiguous range of every launch group)
+    // (... and among the kEvalFused ones first those whose sides have eight amplitudes per thread: a launch is ONE instantiation of
+    // the kernel)
     for (int fused = 0; fused <= 1; ++fused)
+      for (int r = 3; r <= 4; ++r)
         for (int cls = kMaxSplitKeys; cls >= 0; --cls)
             for (size_t j = 0; j < count; ++j) {
                 if (!b.split[first + j]) continue;
                 const SplitInfo& sp = b.circs[first + j]->split;
-                if (sp.n_keys != cls || int(sp.fused) != fused) continue;
+                if (sp.n_keys != cls || int(sp.fused) != fused || ((sp.side_r == 3) != (r == 3))) continue;
                 hd[at] = tmp[j];
                 hd[P + at] = tmp2[j];
                 b.eval_at[at] = uint32_t(first + j);
@@ -1938,6 +1997,7 @@ int qsv_create(int n_qubits, int dtype, int device, const qsv_plan_config* cfg, 
     if (const char* env = getenv("QSV_REPEAT_DESCS")) h->repeat_device_descs = atoi(env) != 0;
     if (const char* env = getenv("QSV_FUSED_LDS")) h->fused_lds_table = atoi(env) != 0;
     if (const char* env = getenv("QSV_SIDE_DIAG")) h->side_diag = atoi(env) != 0;
+    if (const char* env = getenv("QSV_SIDES_R3")) h->sides_r3 = atoi(env) != 0;
     {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) h->n_cus = cus;
@@ -1983,7 +2043,7 @@ int qsv_create(int n_qubits, int dtype, int device, const qsv_plan_config* cfg, 
             const size_t bytes = factor_slot_doubles() * sizeof(double) * size_t(h->side_slots);
             if ((e = hipMalloc(&h->d_factor.ptr, bytes)) != hipSuccess) return bail(e, "hipMalloc(partial Gram matrices)");
             h->d_factor.bytes = bytes;
-            const size_t cbytes = sizeof(uint32_t) * size_t(h->side_slots);
+            const size_t cbytes = sizeof(uint32_t) * size_t(kFactorCountersPerSlot) * size_t(h->side_slots);
             if ((e = hipMalloc(&h->d_factor_count.ptr, cbytes)) != hipSuccess) return bail(e, "hipMalloc(hand-off counters)");
             h->d_factor_count.bytes = cbytes;
             if ((e = hipMemset(h->d_factor_count.ptr, 0, cbytes)) != hipSuccess) return bail(e, "hipMemset(hand-off counters)");
@@ -1996,6 +2056,8 @@ int qsv_create(int n_qubits, int dtype, int device, const qsv_plan_config* cfg, 
         const size_t plane = (size_t(1) << side_tile) * h->amp_bytes / (pc.xmode == 2 ? 2 : 1);
         const size_t most = std::max({geo.lds_bytes, plane, kFusedPrepareLdsBytes, kFusedFactorLdsBytes, kFusedLdsTableEnd});
         if ((e = configure_pass_kernels(dtype, geo.r, pc.xmode, most)) != hipSuccess) return bail(e, "hipFuncSetAttribute");
+        // (sides of split circuits may run with eight amplitudes per thread whatever the handle's own geometry: build_circuit)
+        if (geo.r != 3 && (e = configure_pass_kernels(dtype, 3, pc.xmode, most)) != hipSuccess) return bail(e, "hipFuncSetAttribute");
     }
     *out = h;
     return QSV_OK;
@@ -3191,6 +3253,8 @@ int qsv_set_option(qsv_t* h, const char* name, int value) {
         h->split_sampling = value != 0;
     } else if (key == "fused_lds_table") {  // one-launch route: sides' states handed to their Gram matrices through LDS (same bits either way)
         h->fused_lds_table = value != 0;
+    } else if (key == "sides_r3") {  // one-launch route: sides with eight amplitudes per thread, three-key sides on two workgroups.  Circuits registered afterwards.
+        h->sides_r3 = value != 0;
     } else if (key == "side_diag") {  // one-launch route: a side's values of D from a table of its own (one run) instead of gathered from D
         // (same values either way; the plans name the tables: everything is uploaded again when it is next used)
         if (h->side_diag != (value != 0)) {
