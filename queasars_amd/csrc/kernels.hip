@@ -772,6 +772,8 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, FIRST, FUSED>::waves
             const uint32_t f0 = p0[2];
             const uint32_t tiles0 = (f0 & kPassCompactStore) ? 1u << ((f0 >> 8) & 0xffu) : 1u << (c0[2] - (p0[0] & 0xffu));
             if (block_x >= tiles0) return;
+            // (the one-launch route: a side's ONE workgroup sweeps all its tiles -- only a half side, kEvalHalves, has one per tile)
+            if (FUSED && block_x > 0 && (ev.flags & kEvalFused) && !(ev.flags & kEvalHalves) && (a.mode & kModeFusedFactor)) return;
         }
 #ifdef QSV_STAMPS
         QSV_STAMP(0);  // descriptor
@@ -886,9 +888,12 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, FIRST, FUSED>::waves
     // Workgroup b sweeps tiles b, b + gridDim.x, b + 2 gridDim.x, ..: neighbouring workgroups (which run at the same
     // time) work on neighbouring tiles, and a compact pass 0 -- fewer tiles than the grid -- gives each working
     // workgroup a single tile instead of leaving half of them idle.
-    const uint32_t tile0 = block_x, tile_step = grid_x;
+    // (the one-launch route's sides, half sides apart: workgroup 0 of the side takes every tile, whatever the grid's width)
+    const bool sweeps = FUSED && side && (ev.flags & kEvalFused) && !(ev.flags & kEvalHalves) && (a.mode & kModeFusedFactor);
+    const uint32_t tile0 = block_x, tile_step = sweeps ? 1u : grid_x;
     if (tile0 >= total_tiles) return;  // (uniform, before any barrier)
-    const uint32_t n_tiles = (total_tiles - tile0 + tile_step - 1) / tile_step < a.tiles_per_block
+    const uint32_t n_tiles = sweeps ? total_tiles
+                             : (total_tiles - tile0 + tile_step - 1) / tile_step < a.tiles_per_block
                                  ? (total_tiles - tile0 + tile_step - 1) / tile_step
                                  : a.tiles_per_block;
     // compact load: this thread's part of the W index and of the tile-factor index, the same for every tile

@@ -539,7 +539,10 @@ int build_circuit(qsv_t* h, int n_ops, const qsv_op* ops, int n_params, bool fol
                 const bool r3_handle = h->sides_r3 && h->dtype == QSV_F64 && h->geo.k == 12 && h->geo.r == 4 && sc.n_keys <= 3;
                 bool try_halves = r3_handle && sc.n_keys == kFusedLdsRowsKeys && sc.n_side[0] + sc.n_keys == kFusedLdsRowsBits &&
                                   sc.n_side[1] + sc.n_keys == kFusedLdsRowsBits;
-                bool try_r3 = try_halves || (r3_handle && std::max(sc.n_side[0], sc.n_side[1]) + sc.n_keys <= 12);
+                // (thirteen virtual qubits otherwise: two 12-qubit tiles swept by the side's one workgroup -- as long as there is a key
+                // qubit to leave outside the tile and one pass does)
+                const int most_virtual = std::max(sc.n_side[0], sc.n_side[1]) + sc.n_keys;
+                bool try_r3 = try_halves || (r3_handle && (most_virtual <= 12 || (most_virtual == 13 && sc.n_keys >= 1)));
                 const size_t words_before = w.size();
               plan_sides:
                 for (int s = 0; s < 2 && fits; ++s) {
@@ -561,6 +564,8 @@ int build_circuit(qsv_t* h, int n_ops, const qsv_op* ops, int n_params, bool fol
                     if (try_halves) {  // (the same goes for a half side: its state stays in LDS)
                         side.tile_bits = 12;
                         side.lane_bits = 0;
+                    } else if (try_r3) {
+                        side.tile_bits = std::min(sp.n_virtual[s], 12);
                     }
                     if (const char* env = getenv("QSV_SIDE_LANE_BITS")) side.lane_bits = atoi(env);  // (measurements)
                     const CircuitPlan p = build_plan(sp.n_virtual[s], sc.gates[s], sc.angles[s], side);
@@ -653,7 +658,7 @@ int build_circuit(qsv_t* h, int n_ops, const qsv_op* ops, int n_params, bool fol
                     // Measured (profiles/r03_fused_factor.txt): the one-launch route wins where a side's Gram matrices are a
                     // few blocks per wave -- 20-qubit registers, every population size -- and loses from 22 qubits on, where
                     // a side's table is 2^11 .. 2^13 rows for the four to eight waves of its one workgroup.
-                    sp.fused = h->geo.r == 4 && h->geo.k == 12 && sp.n_keys <= 3 && ((sp.outer[0] == 0 && sp.outer[1] == 0) || sp.halves) &&
+                    sp.fused = h->geo.r == 4 && h->geo.k == 12 && sp.n_keys <= 3 && ((sp.outer[0] == 0 && sp.outer[1] == 0) || sp.halves || (sp.side_r == 3 && sp.outer[0] <= 1 && sp.outer[1] <= 1)) &&
                                sp.stats[0].n_passes == 1 && sp.stats[1].n_passes == 1;
                     if (const char* env = getenv("QSV_FUSED_MAX_KEYS")) sp.fused = sp.fused && sp.n_keys <= atoi(env);  // (measurements)
                     if (getenv("QSV_SPLIT_DEBUG"))
@@ -1239,8 +1244,9 @@ int run_group(qsv_t* h, const std::vector<Circuit*>& circs, size_t first, size_t
             bool any_halves = false;
             if (extra_mode & kModeFusedFactor)
                 for (size_t i = lo; i < hi; ++i) any_halves |= circs[eval_of(first + i)]->split.halves;
-            a.tiles_per_block = 1u;
-            const unsigned grid_x = tiles;
+            // (a side's one workgroup sweeps its tiles itself, whatever the grid's width: pass_kernel)
+            a.tiles_per_block = (extra_mode & kModeFusedFactor) ? tiles : 1u;
+            const unsigned grid_x = (extra_mode & kModeFusedFactor) ? (any_halves ? 2u : 1u) : tiles;
             // (pass 0 prepares the virtual circuits' matrices and tables itself: no prepare launch ran for them)
             a.evals = batch_evals(h) + first + lo;
             a.host_evals = descs_base(h) + first + lo;
