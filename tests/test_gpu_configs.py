@@ -709,6 +709,40 @@ def test_one_launch_route_of_split_evaluations(c_oracle):
     assert np.abs(got32 - np.asarray(one)).max() < FP32_REL * float(np.abs(op.coeffs).sum())
 
 
+@pytest.mark.parametrize("layers", [4, 5])
+def test_sides_of_eight_amplitudes_per_thread_and_half_sides(c_oracle, layers):
+    """The one-launch route at 20 qubits plans its sides with eight amplitudes per thread (option "sides_r3", the default):
+    sides of up to twelve virtual qubits as one tile, thirteen with one or two keys as two tiles swept by the side's one
+    workgroup, three-key sides of thirteen as TWO workgroups each that trade half rows through memory (kEvalHalves) -- the
+    benchmark's population has one of those, the five-layer one eighteen.  Against the same circuits on sixteen amplitudes
+    per thread and one workgroup per side (other orders of the sums: 1e-10), against the C oracle for a circuit of every
+    form, and the same bits on every repetition, alone or in company, in any order: a half side that read its partner's rows
+    too early, or a stale line of them, would show as a repetition that differs."""
+    n = 20
+    _, circuits, params = helpers.population_circuits(n, layers, 64, seed=0)
+    op = helpers.random_ising_operator(n, seed=2020)
+    ev = OperatorCircuitEvaluator(op)
+    got = ev.evaluate_circuits(circuits, params)
+    wide = OperatorCircuitEvaluator(op)
+    wide.statevector_device.set_option("sides_r3", 0)  # (applies to circuits registered afterwards: none yet)
+    want = wide.evaluate_circuits(circuits, params)
+    assert np.abs(np.asarray(got) - np.asarray(want)).max() < EXP_TOL
+    assert got != want  # (the two forms add in different orders: were they the same bits, the option would not be doing anything)
+    keys = [_keys_like_the_library(c, n) for c in circuits]
+    assert 3 in keys
+    table = c_oracle.diagonal_table(op)
+    scratch = np.zeros(2 << n)
+    picked = sorted({keys.index(k) for k in set(keys) if k >= 0} | {0, 63})
+    for i in picked:
+        assert abs(got[i] - c_oracle.evaluate(circuits[i], params[i], op, table, scratch)) < EXP_TOL, (i, keys[i])
+    for rep in range(200):
+        assert ev.evaluate_circuits(circuits, params) == got, rep
+    assert ev.evaluate_circuits(circuits[::-1], params[::-1]) == got[::-1]
+    three = [i for i, k in enumerate(keys) if k == 3][:4]
+    assert [ev.evaluate_circuits([circuits[i]], [params[i]])[0] for i in three] == [got[i] for i in three]
+    assert ev.evaluate_circuits(circuits * 3, params * 3) == got * 3  # (more half sides than one launch takes: several launches)
+
+
 def test_sides_tables_of_d_survive_their_buffer_filling_up():
     """The sides' own tables of D (kSplitSideDiag) live in a buffer that is emptied and filled again when it is full (every
     plan is then uploaded anew, with new tables): a population evaluated before, between and after enough other structures
