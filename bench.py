@@ -54,7 +54,9 @@ def kernel_names(n_qubits: int, factor: bool = True):
     qsv_profile's per-kernel arrays."""
     r = 4 if n_qubits >= 20 else 3
     return (f"qsv::pass_kernel<double, {r}, 2, true> (pass 0: synthesises a product state, writes only; for a split "
-            "evaluation the two small virtual circuits, one workgroup each)",
+            "evaluation the two small virtual circuits, one workgroup each -- at 20 qubits and below in the one-launch "
+            "instantiation pass_kernel<double, 3, 2, true, true>: sides of eight amplitudes per thread, a three-key side of "
+            "thirteen qubits on two workgroups)",
             f"qsv::pass_kernel<double, {r}, 2, false> (later passes; the last one fuses the diagonal expectation and only reads)",
             "qsv::factor_moments_kernel<double> + qsv::factor_combine_kernel, timed as one (split evaluations under a "
             "quadratic diagonal operator: weighted Gram matrices of the two side tables, combined per evaluation; nothing of "
