@@ -1303,6 +1303,9 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, FIRST, FUSED>::waves
                             // (one amplitude of padding after every row of 2^10)
                             constexpr uint32_t row_shift = uint32_t(kFusedLdsRowsBits - kFusedLdsRowsKeys) + ASH;
                             *reinterpret_cast<cxr*>(lds_raw + ob + ((ob >> row_shift) << ASH)) = amp[gray_index(i)];
+                            // (a half side: what the partner will want of this row -- the other half of x -- goes to the side's slot
+                            // as well, where it would lie there; fused_factor_tail drains these stores)
+                            if ((ev.flags & kEvalHalves) && ((ob >> (row_shift - 1)) & 1u) != tile0) store_through(tile + ob, amp[gray_index(i)]);
                         } else if (through) {
                             store_through(tile + ob, amp[gray_index(i)]);
                         } else {
@@ -3370,23 +3373,17 @@ __device__ __forceinline__ void fused_factor_tail(const uint32_t* __restrict__ p
     }
     // the side's state was stored by this workgroup: its waves' stores have to be in L2 before anybody reads them back (a state
     // left in LDS has no stores to wait for -- and the wait would be for the values of D just asked for)
-    if (lds_table == 0u) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lds_table == 0u || halves) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     QSV_PSTAMP(0);  // the side's stores drained
     if (halves) {
         // The two halves of a side trade half rows through the side's half of the slot (rows of 2^10 as they would lie there):
-        // mine for the OTHER half of x go out by write-through stores, every wave drains them, barrier, one lane adds to the
-        // exchange counter (it grows by two per launch: the first to add waits for the next even value, bounded), barrier; the
-        // partner's rows for MY half of x come in by agent-scope loads (the partner may sit on another XCD) and lie behind mine.
+        // mine for the OTHER half of x went out with the pass's own stores (write-through, drained above, by every wave, before the
+        // barrier), one lane adds to the exchange counter (it grows by two per launch: the first to add waits for the next even
+        // value, bounded), barrier; the partner's rows for MY half of x come in by agent-scope loads (the partner may sit on
+        // another XCD) and lie behind mine.
         constexpr uint32_t kRow = 1u << (kFusedLdsRowsBits - kFusedLdsRowsKeys), kHalf = kRow / 2;
-        cx<real>* gtab = const_cast<cx<real>*>(slot_tables) + (is_b ? side_stride >> 1 : 0);
-        const cx<real>* own = reinterpret_cast<const cx<real>*>(lds);
-        for (uint32_t i = tid; i < 4u * kHalf; i += blockDim.x) {
-            const uint32_t r = i / kHalf, x = (1u - hh) * kHalf + i % kHalf;
-            store_through(gtab + (size_t(4u * hh + r) << (kFusedLdsRowsBits - kFusedLdsRowsKeys)) + x, own[r * uint32_t(kFusedLdsRowPitch) + x]);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        const cx<real>* gtab = slot_tables + (is_b ? side_stride >> 1 : 0);
         if (tid == 0) {
             uint32_t* exchange = a.factor_counters + size_t(kFactorCountersPerSlot) * ev.state_slot + 1u + (is_b ? 1u : 0u);
             const uint32_t before = __hip_atomic_fetch_add(exchange, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
