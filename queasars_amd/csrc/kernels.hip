@@ -773,7 +773,7 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, FIRST, FUSED>::waves
             const uint32_t tiles0 = (f0 & kPassCompactStore) ? 1u << ((f0 >> 8) & 0xffu) : 1u << (c0[2] - (p0[0] & 0xffu));
             if (block_x >= tiles0) return;
             // (the one-launch route: a side's ONE workgroup sweeps all its tiles -- only a half side, kEvalHalves, has one per tile)
-            if (FUSED && block_x > 0 && (ev.flags & kEvalFused) && !(ev.flags & kEvalHalves) && (a.mode & kModeFusedFactor)) return;
+            if (FUSED && block_x > 0 && (ev.flags & kEvalFused) && !((ev.flags & kEvalHalves) && c0[2] == uint32_t(kFusedLdsRowsBits)) && (a.mode & kModeFusedFactor)) return;
         }
 #ifdef QSV_STAMPS
         QSV_STAMP(0);  // descriptor
@@ -862,8 +862,10 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, FIRST, FUSED>::waves
     // ... and a small enough side does not go to memory at all where the launch has the LDS for it (kModeFusedLdsTable): the
     // table is laid out in LDS exactly as it would be in its slot (a fused side is one tile: offsets inside the tile ARE table
     // indices), behind everything else this kernel keeps there
+    // (a half side, kEvalHalves: a thirteen-qubit side of a circuit so flagged; each of its two workgroups holds a 12-qubit tile of it)
+    const bool half_side = FUSED && through && (ev.flags & kEvalHalves) && n_qubits == uint32_t(kFusedLdsRowsBits);
     const bool table_in_lds = through && std::is_same<real, double>::value && (a.mode & kModeFusedLdsTable) &&
-                              n_qubits <= uint32_t(kFusedLdsTableBits);
+                              (n_qubits <= uint32_t(kFusedLdsTableBits) || (half_side && plan_arena[ev.split_base] < uint32_t(kFusedLdsRowsKeys)));
     // ... or, a three-key side of thirteen virtual qubits, as padded rows from offset 0 (kernels.hpp, kFusedLdsRowsBits)
     bool table_lds_rows = false;
     if constexpr (FUSED && std::is_same<real, double>::value)
@@ -889,7 +891,7 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, FIRST, FUSED>::waves
     // time) work on neighbouring tiles, and a compact pass 0 -- fewer tiles than the grid -- gives each working
     // workgroup a single tile instead of leaving half of them idle.
     // (the one-launch route's sides, half sides apart: workgroup 0 of the side takes every tile, whatever the grid's width)
-    const bool sweeps = FUSED && side && (ev.flags & kEvalFused) && !(ev.flags & kEvalHalves) && (a.mode & kModeFusedFactor);
+    const bool sweeps = FUSED && side && (ev.flags & kEvalFused) && !half_side && (a.mode & kModeFusedFactor);
     const uint32_t tile0 = block_x, tile_step = sweeps ? 1u : grid_x;
     if (tile0 >= total_tiles) return;  // (uniform, before any barrier)
     const uint32_t n_tiles = sweeps ? total_tiles
@@ -1299,13 +1301,15 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, FIRST, FUSED>::waves
                             __builtin_nontemporal_store(v, reinterpret_cast<vec2*>(tile + ob));
                         } else if (table_in_lds) {
                             *reinterpret_cast<cxr*>(lds_raw + kFusedLdsTableOffset + ob) = amp[gray_index(i)];
+                            // (a half side: the other half of x of this row goes to the side's slot as well, for the partner)
+                            if (half_side && ((ob >> (uint32_t(kFusedLdsRowsBits) - 1u - plan_arena[ev.split_base] + ASH)) & 1u) != tile0) store_through(tile + ob, amp[gray_index(i)]);
                         } else if (table_lds_rows) {
                             // (one amplitude of padding after every row of 2^10)
                             constexpr uint32_t row_shift = uint32_t(kFusedLdsRowsBits - kFusedLdsRowsKeys) + ASH;
                             *reinterpret_cast<cxr*>(lds_raw + ob + ((ob >> row_shift) << ASH)) = amp[gray_index(i)];
                             // (a half side: what the partner will want of this row -- the other half of x -- goes to the side's slot
                             // as well, where it would lie there; fused_factor_tail drains these stores)
-                            if ((ev.flags & kEvalHalves) && ((ob >> (row_shift - 1)) & 1u) != tile0) store_through(tile + ob, amp[gray_index(i)]);
+                            if (half_side && ((ob >> (row_shift - 1)) & 1u) != tile0) store_through(tile + ob, amp[gray_index(i)]);
                         } else if (through) {
                             store_through(tile + ob, amp[gray_index(i)]);
                         } else {
@@ -1357,8 +1361,8 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, FIRST, FUSED>::waves
 #endif
 
     if constexpr (FUSED) {
-        const bool halves_side = (ev.flags & kEvalHalves) && table_lds_rows;  // (its two workgroups: tile0 = 0, 1; R = 3: t = 9, eight waves)
-        if (side && (ev.flags & kEvalHalves) && (ev.flags & kEvalFused) && (a.mode & kModeFusedFactor) && !table_lds_rows) {
+        const bool halves_side = half_side && (table_lds_rows || table_in_lds);  // (its two workgroups: tile0 = 0, 1; R = 3: t = 9, eight waves)
+        if (half_side && !halves_side) {
             // (a launch without the LDS for it: the host never makes one -- no value rather than a wrong one)
             if (threadIdx.x == 0) a.result_out[ev.out_index] = __builtin_nan("");
             return;
@@ -2689,10 +2693,16 @@ __device__ __forceinline__ void factor_prefetch_d(double (&dq)[DA], const double
 constexpr int kFactorDAheadPairs = 2;  // (the eight-term body has no registers to spare)
 __device__ __forceinline__ uint32_t factor_block_count(uint32_t bits) { return bits < 6u ? 1u : 1u << (bits - 6u); }
 
+// (a half side's rows: where each starts, in bytes from the table, so that its entry x lies at x; by value: registers)
+struct HalfRows {
+    int32_t at[4] = {0, 0, 0, 0};
+    bool on = false;
+};
 template <typename real, int J, bool AHEAD = true>
 __device__ __forceinline__ void factor_side_body(const cx<real>* __restrict__ tab, uint32_t bits, uint32_t mask, const double* __restrict__ diag,
                                  uint32_t first_block, uint32_t block_step, cx<real>* stage, double* dstage, double* out,
-                                 double (&dq)[kFactorDAhead] QSV_PSTAMP_PARAMS) {
+                                 double (&dq)[kFactorDAhead] QSV_PSTAMP_PARAMS, HalfRows row_bytes = HalfRows{}, uint32_t end_block = 0xffffffffu) {
+    // (row_bytes / end_block: a half side -- where each row starts, in bytes from `tab`, so that its entry x lies at x; the blocks end early)
     constexpr uint32_t NQ = J * J;
     constexpr uint32_t LQ = J == 1 ? 0 : J == 2 ? 2 : J == 4 ? 4 : 6;  // log2(NQ)
     constexpr uint32_t PITCH = J + 1;
@@ -2700,7 +2710,8 @@ __device__ __forceinline__ void factor_side_body(const cx<real>* __restrict__ ta
     const uint32_t pi = lane % NQ, sub = lane / NQ;
     uint32_t ja, jb, part;
     split_entry_of<J>(pi, &ja, &jb, &part);
-    const uint32_t n_local = bits < 6u ? 1u << bits : 64u, n_blocks = bits < 6u ? 1u : 1u << (bits - 6u);
+    const uint32_t n_local = bits < 6u ? 1u << bits : 64u, all_blocks = bits < 6u ? 1u : 1u << (bits - 6u);
+    const uint32_t n_blocks = end_block < all_blocks ? end_block : all_blocks;
     double acc_one = 0.0, acc_d = 0.0, acc_low[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, acc_high[10];
 #pragma unroll
     for (int q = 0; q < 10; ++q) acc_high[q] = 0.0;
@@ -2711,7 +2722,8 @@ __device__ __forceinline__ void factor_side_body(const cx<real>* __restrict__ ta
         for (int j = 0; j < J; ++j) {
             rows[j] = cx<real>{real(0), real(0)};
             // (a 32-bit byte offset from the uniform base: one address register per row instead of a 64-bit pointer each)
-            const uint32_t off = ((uint32_t(j) << bits) + blk * 64u + lane) * uint32_t(sizeof(cx<real>));
+            const int32_t row = row_bytes.on ? row_bytes.at[j < 4 ? j : 0] : int32_t((uint32_t(j) << bits) * uint32_t(sizeof(cx<real>)));
+            const int32_t off = row + int32_t((blk * 64u + lane) * uint32_t(sizeof(cx<real>)));
             if (live) rows[j] = *reinterpret_cast<const cx<real>*>(reinterpret_cast<const char*>(tab) + off);
         }
     };
@@ -3361,7 +3373,10 @@ __device__ __forceinline__ void fused_factor_tail(const uint32_t* __restrict__ p
     {
         const uint32_t worker = wave < kWaves ? wave : 0xffffffu;
         if (n_keys < 3) {
-            factor_prefetch_d(dq, diag, bits, mask, worker, kWaves, factor_block_count(bits));
+            if (halves)  // (a half side: the blocks of its half of x)
+                factor_prefetch_d(dq, diag, bits, mask, wave < kWaves ? (factor_block_count(bits) >> 1) * hh + wave : 0xffffffu, kWaves, (factor_block_count(bits) >> 1) * (hh + 1u));
+            else
+                factor_prefetch_d(dq, diag, bits, mask, worker, kWaves, factor_block_count(bits));
         } else {
             uint32_t b0, b1;
             if (halves)  // (a half side: this workgroup's waves are workers 8 h .. 8 h + 7 of the side's sixteen)
@@ -3382,7 +3397,9 @@ __device__ __forceinline__ void fused_factor_tail(const uint32_t* __restrict__ p
         // barrier), one lane adds to the exchange counter (it grows by two per launch: the first to add waits for the next even
         // value, bounded), barrier; the partner's rows for MY half of x come in by agent-scope loads (the partner may sit on
         // another XCD) and lie behind mine.
-        constexpr uint32_t kRow = 1u << (kFusedLdsRowsBits - kFusedLdsRowsKeys), kHalf = kRow / 2;
+        // (three keys: four rows of 2^10 a workgroup, the partner's half rows behind mine, one amplitude apart; fewer: 2^(keys - 1)
+        // rows of 2^bits as they lie in the tile, the partner's half of each row where my own other half was -- that went out)
+        const uint32_t own_rows = (1u << n_keys) >> 1, row_bits = bits, half_x = 1u << (bits - 1u);
         const cx<real>* gtab = slot_tables + (is_b ? side_stride >> 1 : 0);
         if (tid == 0) {
             uint32_t* exchange = a.factor_counters + size_t(kFactorCountersPerSlot) * ev.state_slot + 1u + (is_b ? 1u : 0u);
@@ -3395,23 +3412,30 @@ __device__ __forceinline__ void fused_factor_tail(const uint32_t* __restrict__ p
         }
         __syncthreads();
         cx<real>* imported = reinterpret_cast<cx<real>*>(lds + kFusedHalvesImport);
-        // (all of a thread's loads first -- they are trips to memory --, then its LDS writes)
-        constexpr uint32_t kMost = 4u * kHalf / 256u;  // (a workgroup of at least four waves)
+        cx<real>* table = reinterpret_cast<cx<real>*>(lds + kFusedLdsTableOffset);
+        // (all of a thread's loads first -- they are trips to memory --, then its LDS writes; 2^11 amplitudes whatever the keys)
+        constexpr uint32_t kCount = 1u << (kFusedLdsRowsBits - 2), kMost = kCount / 256u;  // (a workgroup of at least four waves)
         double got[kMost][2];
 #pragma unroll
         for (uint32_t it = 0; it < kMost; ++it) {
-            const uint32_t i = tid + it * blockDim.x, r = i / kHalf, xl = i % kHalf;
+            const uint32_t i = tid + it * blockDim.x, r = i >> (row_bits - 1u), xl = i & (half_x - 1u);
             got[it][0] = got[it][1] = 0.0;
-            if (i < 4u * kHalf) {
-                const double* src = reinterpret_cast<const double*>(gtab + (size_t(4u * (1u - hh) + r) << (kFusedLdsRowsBits - kFusedLdsRowsKeys)) + hh * kHalf + xl);
+            if (i < kCount) {
+                const double* src = reinterpret_cast<const double*>(gtab + (size_t(own_rows * (1u - hh) + r) << row_bits) + hh * half_x + xl);
                 got[it][0] = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 got[it][1] = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
 #pragma unroll
         for (uint32_t it = 0; it < kMost; ++it) {
-            const uint32_t i = tid + it * blockDim.x, r = i / kHalf, xl = i % kHalf;
-            if (i < 4u * kHalf) imported[r * uint32_t(kFusedHalvesImportPitch) + xl] = cx<real>{real(got[it][0]), real(got[it][1])};
+            const uint32_t i = tid + it * blockDim.x, r = i >> (row_bits - 1u), xl = i & (half_x - 1u);
+            if (i < kCount) {
+                const cx<real> v{real(got[it][0]), real(got[it][1])};
+                if (table_lds_rows)
+                    imported[r * uint32_t(kFusedHalvesImportPitch) + xl] = v;
+                else
+                    table[(size_t(r) << row_bits) + (1u - hh) * half_x + xl] = v;
+            }
         }
         __syncthreads();
     }
@@ -3432,14 +3456,32 @@ __device__ __forceinline__ void fused_factor_tail(const uint32_t* __restrict__ p
         __syncthreads();
         if (n_keys > 99)
 #else
+        // (a half side of one or two keys: row j = (its last key bit, the others): mine where they lie in the tile, the partner's in my
+        // rows' other halves of x, so that entry x of each lies at x; blocks of my half of x only)
+        HalfRows half_rows;
+        uint32_t half_first = first, half_end = 0xffffffffu;
+        if (halves && n_keys < 3) {
+            const uint32_t own_rows = (1u << n_keys) >> 1, half_x = 1u << (bits - 1u), blocks = factor_block_count(bits) >> 1;
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) {  // (unrolled: the array stays in registers)
+                const int32_t local = int32_t(((j & (own_rows - 1u)) << bits) * uint32_t(sizeof(cx<real>)));
+                const int32_t shift = int32_t(half_x * uint32_t(sizeof(cx<real>)));
+                half_rows.at[j] = (j >> (n_keys - 1u)) == hh ? local : local + (hh ? -shift : shift);
+            }
+            half_rows.on = true;
+            half_first = wave < kWaves ? blocks * hh + wave : 0xffffffu;
+            half_end = blocks * (hh + 1u);
+        }
         if (n_keys == 0)
 #endif
             factor_side_body<real, 1, true>(tab, bits, mask, diag, first, step, stage, dstage_all + w * 64, sink, dq QSV_PSTAMP_ARGS);
 #ifndef QSV_ABL_TAIL_GRAM
         else if (n_keys == 1)
-            factor_side_body<real, 2, true>(tab, bits, mask, diag, first, step, stage, dstage_all + w * 64, sink, dq QSV_PSTAMP_ARGS);
+            factor_side_body<real, 2, true>(tab, bits, mask, diag, half_first, step, stage, dstage_all + w * 64, sink, dq QSV_PSTAMP_ARGS,
+                                            half_rows, half_end);
         else if (n_keys == 2)
-            factor_side_body<real, 4, false>(tab, bits, mask, diag, first, step, stage, dstage_all + w * 64, sink, dq QSV_PSTAMP_ARGS);
+            factor_side_body<real, 4, false>(tab, bits, mask, diag, half_first, step, stage, dstage_all + w * 64, sink, dq QSV_PSTAMP_ARGS,
+                                             half_rows, half_end);
         else if (halves) {
             // rows 4 h .. 4 h + 3 are mine (pitch kFusedLdsRowPitch, every x), the others the partner's (this half of x only, so that
             // its x = 2^9 h lies at the row's start); blocks 8 h .. 8 h + 7 of the side's sixteen, one per wave
@@ -3514,7 +3556,8 @@ __device__ __forceinline__ void fused_factor_tail(const uint32_t* __restrict__ p
                     const double* entry = slot + size_t(s2) * kFactorSlices * kFactorWeights * 64 + (idx / NQ) * 64 + idx % NQ;
                     fetched[s2][it] = __hip_atomic_load(entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     // (half sides: the sums over the two halves of x, the lower first)
-                    if (halves) fetched[s2][it] += __hip_atomic_load(entry + kFactorWeights * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((ev.flags & kEvalHalves) && side_bits[s2] + n_keys == uint32_t(kFusedLdsRowsBits))
+                        fetched[s2][it] += __hip_atomic_load(entry + kFactorWeights * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
 #pragma unroll

@@ -537,8 +537,8 @@ int build_circuit(qsv_t* h, int n_ops, const qsv_op* ops, int n_params, bool fol
                 // a key qubit; if that is the LAST one on both sides and one pass does, each side runs as two workgroups
                 // (kEvalHalves).  Each form is tried and kept only if it holds; else the handle's own geometry, as before.
                 const bool r3_handle = h->sides_r3 && h->dtype == QSV_F64 && h->geo.k == 12 && h->geo.r == 4 && sc.n_keys <= 3;
-                bool try_halves = r3_handle && sc.n_keys == kFusedLdsRowsKeys && sc.n_side[0] + sc.n_keys == kFusedLdsRowsBits &&
-                                  sc.n_side[1] + sc.n_keys == kFusedLdsRowsBits;
+                // (half sides: every thirteen-qubit side of the circuit, if each leaves its LAST key qubit outside the tile)
+                bool try_halves = r3_handle && sc.n_keys >= 1 && std::max(sc.n_side[0], sc.n_side[1]) + sc.n_keys == kFusedLdsRowsBits;
                 // (thirteen virtual qubits otherwise: two 12-qubit tiles swept by the side's one workgroup -- as long as there is a key
                 // qubit to leave outside the tile and one pass does)
                 const int most_virtual = std::max(sc.n_side[0], sc.n_side[1]) + sc.n_keys;
@@ -561,7 +561,7 @@ int build_circuit(qsv_t* h, int n_ops, const qsv_op* ops, int n_params, bool fol
                     // may target them, and the swaps that brought them home at the end (up to four of a side's ten) are not made
                     // (a zero-key circuit of the benchmark alone: 34.1 -> 32.5 us).
                     if (sp.n_virtual[s] <= side.tile_bits) side.lane_bits = 0;
-                    if (try_halves) {  // (the same goes for a half side: its state stays in LDS)
+                    if (try_halves && sp.n_virtual[s] == kFusedLdsRowsBits) {  // (the same goes for a half side: its state stays in LDS)
                         side.tile_bits = 12;
                         side.lane_bits = 0;
                     } else if (try_r3) {
@@ -577,10 +577,16 @@ int build_circuit(qsv_t* h, int n_ops, const qsv_op* ops, int n_params, bool fol
                     w.insert(w.end(), p.words.begin(), p.words.end());
                     if (try_r3) {
                         bool ok = p.stats.n_passes == 1;
-                        if (try_halves) {  // (the tile's qubits are 0 .. 11: the third key qubit, 12, is the tile number)
+                        if (ok && try_halves && sp.n_virtual[s] == kFusedLdsRowsBits) {  // (the tile's qubits are 0 .. 11: the last key qubit, 12, is the tile number)
                             const uint32_t* c0 = p.words.data();
                             const uint32_t* p0 = c0 + c0[kCircuitHeaderWords];
-                            for (uint32_t j = 0; j < 12 && ok; ++j) ok = p0[kPassHeaderWords + j] != uint32_t(kFusedLdsRowsBits - 1);
+                            bool last_outside = true;
+                            for (uint32_t j = 0; j < 12 && last_outside; ++j) last_outside = p0[kPassHeaderWords + j] != uint32_t(kFusedLdsRowsBits - 1);
+                            if (!last_outside) {  // (two tiles swept by the side's one workgroup, then: planned anew with that form's lanes)
+                                try_halves = false;
+                                w.resize(words_before);
+                                goto plan_sides;
+                            }
                         }
                         if (!ok) {  // (as before: the handle's geometry, one tile)
                             try_halves = try_r3 = false;
