@@ -352,8 +352,10 @@ int qsv_fitness_table_wait(const volatile uint64_t* own, int count, volatile int
  *                        place) instead of through its slot: the same sums in the same order, the same bits
  *   "sides_r3" 0|1       ... at 20 qubits and below (12-qubit tiles, fp64) the sides of that route are planned with EIGHT amplitudes per
  *                        thread instead of the handle's sixteen -- twice the waves per side: a gate phase is one wave's issue time over
- *                        its own amplitudes --, thirteen-qubit sides as two tiles, three-key sides of thirteen as two workgroups that
- *                        trade half rows through memory.  Other orders of the sums (1e-10 apart).  Applies to circuits registered afterwards.
+ *                        its own amplitudes --, and a side of thirteen virtual qubits runs as TWO workgroups, one per value of its last
+ *                        key qubit, that trade half rows through memory (where its plan does not leave that qubit outside the tile:
+ *                        as two tiles swept by one workgroup).  Other orders of the sums (1e-10 apart).  Applies to circuits
+ *                        registered afterwards.
  *   "side_diag" 0|1      ... and reads its values of D from a table of its own -- entry x of a side = D[x deposited in the side's
  *                        qubits], one run, filled when the circuit's plan is uploaded -- instead of gathering them from D, one
  *                        cache line per value: the same values, the same bits
