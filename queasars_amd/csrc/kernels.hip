@@ -870,7 +870,9 @@ __global__ void __launch_bounds__(512, (Occupancy<R, XMODE, FIRST, FUSED>::waves
     bool table_lds_rows = false;
     if constexpr (FUSED && std::is_same<real, double>::value)
         table_lds_rows = through && (a.mode & kModeFusedLdsTable) && n_qubits == uint32_t(kFusedLdsRowsBits) &&
-                         plan_arena[ev.split_base] == uint32_t(kFusedLdsRowsKeys);
+                         plan_arena[ev.split_base] == uint32_t(kFusedLdsRowsKeys) &&
+                         (uint32_t(k) == uint32_t(kFusedLdsRowsBits) || half_side);  // (ONE tile of thirteen qubits, or a half side's tile of twelve:
+                                                                                    // a side swept as two tiles goes through its slot)
 
     const uint32_t tg = xor_columns(pp + kPassLoadColsOffset, tid, wave);
     const uint32_t sg = xor_columns(pp + kPassStoreColsOffset, tid, wave);

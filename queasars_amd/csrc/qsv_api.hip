@@ -538,7 +538,8 @@ int build_circuit(qsv_t* h, int n_ops, const qsv_op* ops, int n_params, bool fol
                 // (kEvalHalves).  Each form is tried and kept only if it holds; else the handle's own geometry, as before.
                 const bool r3_handle = h->sides_r3 && h->dtype == QSV_F64 && h->geo.k == 12 && h->geo.r == 4 && sc.n_keys <= 3;
                 // (half sides: every thirteen-qubit side of the circuit, if each leaves its LAST key qubit outside the tile)
-                bool try_halves = r3_handle && sc.n_keys >= 1 && std::max(sc.n_side[0], sc.n_side[1]) + sc.n_keys == kFusedLdsRowsBits;
+                bool try_halves = r3_handle && sc.n_keys >= 1 && std::max(sc.n_side[0], sc.n_side[1]) + sc.n_keys == kFusedLdsRowsBits &&
+                                  !getenv("QSV_NO_HALF_SIDES");  // (tests: the swept form, which a plan that keeps its last key inside the tile falls back to)
                 // (thirteen virtual qubits otherwise: two 12-qubit tiles swept by the side's one workgroup -- as long as there is a key
                 // qubit to leave outside the tile and one pass does)
                 const int most_virtual = std::max(sc.n_side[0], sc.n_side[1]) + sc.n_keys;

@@ -7,6 +7,7 @@ applies a few dozen butterflies to every amplitude and the reductions accumulate
 """
 
 import ctypes as C
+import os
 import json
 from pathlib import Path
 
@@ -741,6 +742,14 @@ def test_sides_of_eight_amplitudes_per_thread_and_half_sides(c_oracle, layers):
     three = [i for i, k in enumerate(keys) if k == 3][:4]
     assert [ev.evaluate_circuits([circuits[i]], [params[i]])[0] for i in three] == [got[i] for i in three]
     assert ev.evaluate_circuits(circuits * 3, params * 3) == got * 3  # (more half sides than one launch takes: several launches)
+    # the form a thirteen-qubit side falls back to when its plan keeps the last key qubit inside the tile: two tiles swept by the
+    # side's one workgroup (three keys: one tile of sixteen amplitudes per thread, as before)
+    os.environ["QSV_NO_HALF_SIDES"] = "1"
+    try:
+        swept = OperatorCircuitEvaluator(op).evaluate_circuits(circuits, params)
+    finally:
+        del os.environ["QSV_NO_HALF_SIDES"]
+    assert np.abs(np.asarray(swept) - np.asarray(want)).max() < EXP_TOL
 
 
 def test_sides_tables_of_d_survive_their_buffer_filling_up():
