@@ -1286,17 +1286,23 @@ int run_group(qsv_t* h, const std::vector<Circuit*>& circs, size_t first, size_t
         // (a launch is one instantiation of the kernel: within each kind the sides with eight amplitudes per thread come first,
         // order_split_first; half sides need their states in LDS, i.e. at most one workgroup per compute unit: four per evaluation)
         auto launch_sides_by_r = [&](size_t lo, size_t hi, uint32_t extra_mode) -> int {
-            size_t mid = lo;
-            while (mid < hi && circs[eval_of(first + mid)]->split.side_r == 3) ++mid;
-            const size_t edge[3] = {lo, mid, hi};
-            for (int part = 0; part < 2; ++part) {
+            // (runs of evaluations whose sides have the same number of amplitudes per thread: order_split_first puts the eight-
+            // amplitude ones first within each kind, but a range may hold both kinds -- every split evaluation under an operator
+            // that has no one-launch route)
+            for (size_t at = lo; at < hi;) {
+                const int r = circs[eval_of(first + at)]->split.side_r == 3 ? 3 : h->geo.r;
+                size_t end = at;
                 bool halves_here = false;
-                for (size_t i = edge[part]; i < edge[part + 1]; ++i) halves_here |= circs[eval_of(first + i)]->split.halves;
-                const size_t most = (halves_here && (extra_mode & kModeFusedFactor)) ? std::max(size_t(1), size_t(h->n_cus) / 4) : hi - lo;
-                for (size_t at = edge[part]; at < edge[part + 1]; at += most) {
-                    const int rc3 = launch_sides(at, std::min(edge[part + 1], at + most), extra_mode, part == 0 ? 3 : h->geo.r);
+                while (end < hi && (circs[eval_of(first + end)]->split.side_r == 3 ? 3 : h->geo.r) == r) {
+                    halves_here |= circs[eval_of(first + end)]->split.halves;
+                    ++end;
+                }
+                const size_t most = (halves_here && (extra_mode & kModeFusedFactor)) ? std::max(size_t(1), size_t(h->n_cus) / 4) : end - at;
+                for (size_t from = at; from < end; from += most) {
+                    const int rc3 = launch_sides(from, std::min(end, from + most), extra_mode, r);
                     if (rc3) return rc3;
                 }
+                at = end;
             }
             return QSV_OK;
         };

@@ -750,6 +750,16 @@ def test_sides_of_eight_amplitudes_per_thread_and_half_sides(c_oracle, layers):
     finally:
         del os.environ["QSV_NO_HALF_SIDES"]
     assert np.abs(np.asarray(swept) - np.asarray(want)).max() < EXP_TOL
+    # the same plans -- sides of eight amplitudes per thread, two tiles for a thirteen-qubit side -- where the route is not the
+    # one-launch one: a general operator (the sides' states go to their tables, the term kernel reads them) and sampled
+    # distributions of the same circuits (the split sampler), against a device that does not split
+    general = helpers.random_pauli_operator(n, 6, seed=4)
+    few = sorted({keys.index(k) for k in set(keys) if k >= 0})
+    sub_c, sub_p = [circuits[i] for i in few], [params[i] for i in few]
+    split = OperatorCircuitEvaluator(general, statevector_device=ev.statevector_device).evaluate_circuits(sub_c, sub_p)
+    plain = OperatorCircuitEvaluator(general)
+    plain.statevector_device.set_option("split", 0)
+    assert np.abs(np.asarray(split) - np.asarray(plain.evaluate_circuits(sub_c, sub_p))).max() < EXP_TOL
 
 
 def test_sides_tables_of_d_survive_their_buffer_filling_up():
