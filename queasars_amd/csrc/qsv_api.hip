@@ -545,8 +545,9 @@ int build_circuit(qsv_t* h, int n_ops, const qsv_op* ops, int n_params, bool fol
                 const int most_virtual = std::max(sc.n_side[0], sc.n_side[1]) + sc.n_keys;
                 bool try_r3 = try_halves || (r3_handle && (most_virtual <= 12 || (most_virtual == 13 && sc.n_keys >= 1)));
                 const size_t words_before = w.size();
-              plan_sides:
-                for (int s = 0; s < 2 && fits; ++s) {
+                for (bool planned = false; !planned;) {  // (at most three times: half sides, swept tiles, the handle's own geometry)
+                planned = true;
+                for (int s = 0; s < 2 && fits && planned; ++s) {
                     PlanConfig side = pc;
                     sp.n_virtual[s] = sc.n_side[s] + sc.n_keys;
                     // (a virtual circuit one qubit larger than the handle's tile still fits ONE workgroup when that may have
@@ -585,16 +586,16 @@ int build_circuit(qsv_t* h, int n_ops, const qsv_op* ops, int n_params, bool fol
                             for (uint32_t j = 0; j < 12 && last_outside; ++j) last_outside = p0[kPassHeaderWords + j] != uint32_t(kFusedLdsRowsBits - 1);
                             if (!last_outside) {  // (two tiles swept by the side's one workgroup, then: planned anew with that form's lanes)
                                 try_halves = false;
-                                w.resize(words_before);
-                                goto plan_sides;
+                                planned = false;
                             }
                         }
                         if (!ok) {  // (as before: the handle's geometry, one tile)
                             try_halves = try_r3 = false;
-                            w.resize(words_before);
-                            goto plan_sides;
+                            planned = false;
                         }
+                        if (!planned) w.resize(words_before);
                     }
+                }
                 }
                 sp.halves = fits && try_halves;
                 sp.side_r = try_r3 ? 3 : h->geo.r;
