@@ -1147,6 +1147,11 @@ bool factor_terms_path(const qsv_t* h) { return h->factor_enabled && !h->diagona
 // Split evaluations flagged kEvalFused are finished by the launch that runs their virtual circuits (quadratic operator).
 bool fused_route(const qsv_t* h) { return factor_path(h) && h->d_factor_count.ptr != nullptr && h->fused_factor; }
 
+// Workgroups of a one-launch evaluation that do not leave at once: one per side, two for a half side (kernels.hpp kEvalHalves).
+size_t working_workgroups(const SplitInfo& sp) {
+    return 2u + (sp.halves ? size_t(sp.n_virtual[0] == kFusedLdsRowsBits) + size_t(sp.n_virtual[1] == kFusedLdsRowsBits) : 0u);
+}
+
 // Run the gate passes of evaluations [first, first+count) of the current batch (one launch group).
 int run_group(qsv_t* h, const std::vector<Circuit*>& circs, size_t first, size_t count, uint32_t mode) {
     const qsv_handle::Batch& b = h->batch;
@@ -1267,7 +1272,9 @@ int run_group(qsv_t* h, const std::vector<Circuit*>& circs, size_t first, size_t
                 if (p == 0) need = std::max(need, kFusedPrepareLdsBytes);
                 if (p == 0 && (extra_mode & kModeFusedFactor)) need = std::max(need, kFusedFactorLdsBytes);
                 // at most one workgroup per CU in flight anyway (two per evaluation): room for the sides' states in LDS
-                if (p == 0 && (extra_mode & kModeFusedFactor) && h->dtype == QSV_F64 && (h->fused_lds_table || any_halves) && 2 * size_t(grid_x) * (hi - lo) <= size_t(h->n_cus)) {
+                size_t working = 0;
+                for (size_t i = lo; i < hi; ++i) working += working_workgroups(circs[eval_of(first + i)]->split);
+                if (p == 0 && (extra_mode & kModeFusedFactor) && h->dtype == QSV_F64 && (h->fused_lds_table || any_halves) && working <= size_t(h->n_cus)) {
                     a.mode |= kModeFusedLdsTable;
                     need = std::max(need, kFusedLdsTableEnd);
                 }
@@ -1298,10 +1305,18 @@ int run_group(qsv_t* h, const std::vector<Circuit*>& circs, size_t first, size_t
                     halves_here |= circs[eval_of(first + end)]->split.halves;
                     ++end;
                 }
-                const size_t most = (halves_here && (extra_mode & kModeFusedFactor)) ? std::max(size_t(1), size_t(h->n_cus) / 4) : end - at;
-                for (size_t from = at; from < end; from += most) {
-                    const int rc3 = launch_sides(from, std::min(end, from + most), extra_mode, r);
+                // (half sides need the launch's states in LDS: at most one working workgroup per compute unit)
+                for (size_t from = at; from < end;) {
+                    size_t to = end;
+                    if (halves_here && (extra_mode & kModeFusedFactor)) {
+                        size_t wg = 0;
+                        for (to = from; to < end && wg + working_workgroups(circs[eval_of(first + to)]->split) <= size_t(h->n_cus); ++to)
+                            wg += working_workgroups(circs[eval_of(first + to)]->split);
+                        if (to == from) to = from + 1;
+                    }
+                    const int rc3 = launch_sides(from, to, extra_mode, r);
                     if (rc3) return rc3;
+                    from = to;
                 }
                 at = end;
             }
@@ -1309,7 +1324,21 @@ int run_group(qsv_t* h, const std::vector<Circuit*>& circs, size_t first, size_t
         };
         if (n_unfused > 0 && (rc2 = launch_sides_by_r(0, n_unfused, 0u))) return rc2;
         h->work = lane_of_group;
-        if (n_split > n_unfused && (rc2 = launch_sides_by_r(n_unfused, n_split, kModeFusedFactor))) return rc2;
+        // (the one-launch kind: as one launch -- unless the group is too large for one with the sides' states in LDS and holds half
+        // sides, which lead the range: those go first, to the chain stream where the push has one free, the others follow as before)
+        size_t n_halved = 0, all_working = 0;
+        while (n_unfused + n_halved < n_split && circs[eval_of(first + n_unfused + n_halved)]->split.halves) ++n_halved;
+        for (size_t i = n_unfused; i < n_split; ++i) all_working += working_workgroups(circs[eval_of(first + i)]->split);
+        if (n_halved > 0 && n_unfused + n_halved < n_split && all_working > size_t(h->n_cus)) {
+            // (too many for one launch with the sides' states in LDS, which half sides need: those few lead the range and get a
+            // launch of their own -- on the chain stream where the push has one free --, the others follow as one launch, their
+            // states handed over through their slots as in any launch of that size.  Measured, 128 evaluations with one half-sided
+            // circuit: 56 us per step; cut into launches of one working workgroup per compute unit each: 75)
+            if (b.chain_now && h->chain_stream != -1 && n_unfused == 0) h->work = chain_st;
+            if ((rc2 = launch_sides_by_r(n_unfused, n_unfused + n_halved, kModeFusedFactor))) return rc2;
+            h->work = lane_of_group;
+            if ((rc2 = launch_sides_by_r(n_unfused + n_halved, n_split, kModeFusedFactor))) return rc2;
+        } else if (n_split > n_unfused && (rc2 = launch_sides_by_r(n_unfused, n_split, kModeFusedFactor))) return rc2;
         a.mode = mode | h->stream_mode;
         // what the side circuits move: they synthesise their input and write their final states
         for (size_t i = 0; i < n_split; ++i) {
@@ -1575,13 +1604,16 @@ size_t order_split_first(qsv_t* h, size_t first, size_t count, size_t* n_cont = 
     // finished by the launch that runs theirs --, so that each kind is one contiguous range of every launch group)
     // (... and among the kEvalFused ones first those whose sides have eight amplitudes per thread: a launch is ONE instantiation of
     // the kernel)
+    // (... and of those first the ones with half sides: a group too large for one launch with the sides' states in LDS gives them
+    // a launch of their own, run_group)
     for (int fused = 0; fused <= 1; ++fused)
       for (int r = 3; r <= 4; ++r)
+       for (int halved = 1; halved >= 0; --halved)
         for (int cls = kMaxSplitKeys; cls >= 0; --cls)
             for (size_t j = 0; j < count; ++j) {
                 if (!b.split[first + j]) continue;
                 const SplitInfo& sp = b.circs[first + j]->split;
-                if (sp.n_keys != cls || int(sp.fused) != fused || ((sp.side_r == 3) != (r == 3))) continue;
+                if (sp.n_keys != cls || int(sp.fused) != fused || ((sp.side_r == 3) != (r == 3)) || int(sp.halves) != halved) continue;
                 hd[at] = tmp[j];
                 hd[P + at] = tmp2[j];
                 b.eval_at[at] = uint32_t(first + j);
@@ -1685,6 +1717,13 @@ int eval_push(qsv_t* h, size_t first, size_t count, const double* values, const 
         size_t n_fused = 0;
         for (size_t j = 0; j < n_split; ++j) n_fused += b.circs[b.eval_at[first + j]]->split.fused ? 1 : 0;
         b.chain_now = n_fused > 0 && n_fused < n_split;
+        // (... or every split evaluation is of the first kind, too many for one launch with the sides' states in LDS, and some have
+        // half sides, which need them there: those few get a launch of their own beside the others', run_group)
+        size_t n_halved = 0;
+        for (size_t j = 0; j < n_split; ++j) n_halved += b.circs[b.eval_at[first + j]]->split.halves ? 1 : 0;
+        size_t working = 0;
+        for (size_t j = 0; j < n_split; ++j) working += working_workgroups(b.circs[b.eval_at[first + j]]->split);
+        if (n_fused == n_split && n_halved > 0 && working > size_t(h->n_cus)) b.chain_now = true;
     }
     if (b.chain_now) {
         h->chain_stream = lane == 0 ? 0 : -2;  // (-2: the handle's own stream, lane 0's)

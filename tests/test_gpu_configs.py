@@ -742,6 +742,16 @@ def test_sides_of_eight_amplitudes_per_thread_and_half_sides(c_oracle, layers):
     three = [i for i, k in enumerate(keys) if k == 3][:4]
     assert [ev.evaluate_circuits([circuits[i]], [params[i]])[0] for i in three] == [got[i] for i in three]
     assert ev.evaluate_circuits(circuits * 3, params * 3) == got * 3  # (more half sides than one launch takes: several launches)
+    if layers == 4:
+        # a push too large for one launch with the sides' states in LDS (128 evaluations, two of them with half sides): the half-sided
+        # ones get a launch of their own beside the others' -- the same bits as in pushes of 64
+        _, many_c, many_p = helpers.population_circuits(n, layers, 128, seed=0)
+        many_keys = [_keys_like_the_library(c, n) for c in many_c]
+        assert many_keys.count(3) >= 1 and len(many_c) == 128
+        together = ev.evaluate_circuits(many_c, many_p)
+        assert together == ev.evaluate_circuits(many_c[:64], many_p[:64]) + ev.evaluate_circuits(many_c[64:], many_p[64:])
+        for rep in range(50):
+            assert ev.evaluate_circuits(many_c, many_p) == together, rep
     # the form a thirteen-qubit side falls back to when its plan keeps the last key qubit inside the tile: two tiles swept by the
     # side's one workgroup (three keys: one tile of sixteen amplitudes per thread, as before)
     os.environ["QSV_NO_HALF_SIDES"] = "1"
